@@ -1,0 +1,183 @@
+/*
+ * seqwin_hip.h -- C ABI of libseqwin_hip.so, the MI355X (gfx950) implementation of Seqwin's
+ * minimizer-index hot path.
+ *
+ * The entry points are exactly what the reference's native boundary for this path binds
+ * (the pybind11 module `seqwin.graph._core`, cpp/src/bindings/python_bindings.cpp:43-169, over
+ * cpp/include/seqwin/{build,filter,graph}.hpp); each declaration cites the reference interface it
+ * replaces.  Plain pointers and sizes only -- no C++/torch types cross this boundary.
+ *
+ * Conventions
+ *   - Every function returning `int` returns SW_OK or an SW_ERR_* code; the message is available
+ *     from sw_last_error() (thread-local).  Code -> Python exception mapping mirrors pybind11's
+ *     translation of the reference's C++ exceptions: SW_ERR_RUNTIME <- std::runtime_error /
+ *     std::logic_error -> RuntimeError; SW_ERR_VALUE <- std::invalid_argument -> ValueError.
+ *   - There is NO CPU fallback: if no HIP device is usable the calls fail with SW_ERR_DEVICE.
+ *   - Wire formats are the reference's PODs, byte for byte (cpp/include/seqwin/graph.hpp:15-53):
+ *     sw_kmer 8 B, sw_node 40 B, sw_edge 24 B.
+ */
+#ifndef SEQWIN_HIP_H
+#define SEQWIN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SW_OK 0
+#define SW_ERR_RUNTIME 1 /* std::runtime_error / std::logic_error in the reference */
+#define SW_ERR_VALUE 2   /* std::invalid_argument in the reference */
+#define SW_ERR_DEVICE 3  /* no usable HIP device / HIP runtime error (no reference analogue) */
+
+/* seqwin::Kmer, cpp/include/seqwin/graph.hpp:15-20 */
+typedef struct sw_kmer {
+    uint32_t pos;
+    uint32_t record_idx;
+} sw_kmer;
+
+/* seqwin::Node, cpp/include/seqwin/graph.hpp:28-41 */
+typedef struct sw_node {
+    uint64_t hash;
+    uint64_t start;
+    uint64_t stop;
+    uint32_t n_tar;
+    uint32_t n_neg;
+    double penalty;
+} sw_node;
+
+/* seqwin::Edge, cpp/include/seqwin/graph.hpp:46-53 */
+typedef struct sw_edge {
+    uint64_t first;
+    uint64_t second;
+    uint64_t weight;
+} sw_edge;
+
+typedef struct sw_graph sw_graph; /* opaque result of sw_build (host-resident arrays) */
+typedef struct sw_batch sw_batch; /* opaque device-resident batch of 2-bit packed assemblies */
+typedef struct sw_index sw_index; /* opaque device-resident index built from a batch */
+
+/* ---- diagnostics -------------------------------------------------------------------------- */
+const char *sw_last_error(void);
+const char *sw_version(void);
+/* Number of visible HIP devices (0 when none / runtime unusable). Does not initialise a context. */
+int sw_device_count(void);
+/* Select the HIP device used by the calling thread for all later calls (default 0). */
+int sw_set_device(int device);
+
+/* ---- drop-in entry points (host arrays in, host arrays out) ------------------------------- */
+
+/*
+ * Replaces `_build_native(assembly_paths, kmerlen, windowsize, n_cpu, low_memory)`
+ * (python_bindings.cpp:50-90) = seqwin::build (cpp/include/seqwin/build.hpp:22-28,
+ * cpp/src/seqwin/build.cpp:330-394).  FASTA/gz files are read and 2-bit packed on `n_cpu` host
+ * threads, sketched and indexed on the GPU, and the result is copied back into *out.
+ * `low_memory` is accepted for interface compatibility; results are identical either way
+ * (reference tests/smoke/test_graph.py:222-245).
+ * Errors: k < 3, k > 65535, w < 1, w > SW_MAX_WINDOW -> SW_ERR_VALUE; unreadable file, FASTA
+ * without header, > 2^32-1 records or bases per record -> SW_ERR_RUNTIME (build.cpp:136-147,337-339;
+ * fasta_reader.cpp:69-71,99-102).
+ */
+int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t kmerlen, uint64_t windowsize,
+             uint64_t n_cpu, int low_memory, sw_graph **out);
+
+/* Sizes of the arrays held by a graph (the shapes `_build_native` returns). `ids_bytes` is the size of
+ * the NUL-separated record-id blob (one id per FASTA record, in global record order). */
+int sw_graph_sizes(const sw_graph *g, uint64_t *n_kmers, uint64_t *n_nodes, uint64_t *n_edges,
+                   uint64_t *n_assemblies, uint64_t *ids_bytes, uint64_t *total_bp);
+
+/* Copy the graph into caller-owned buffers (numpy arrays allocated by the Python glue):
+ * kmers[n_kmers], nodes[n_nodes] (n_tar = n_neg = 0, penalty = 0.0), edges[n_edges],
+ * record_offsets[n_assemblies + 1], ids_blob[ids_bytes].  Replaces array_to_numpy
+ * (python_bindings.cpp:21-39, 69-83) without foreign-owned memory outliving the call. */
+int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *edges,
+                    uint32_t *record_offsets, char *ids_blob);
+
+void sw_graph_free(sw_graph *g);
+
+/*
+ * Replaces `_get_penalty_native(kmers, nodes, record_offsets, is_targets, n_cpu)`
+ * (python_bindings.cpp:92-135) = seqwin::get_penalty (cpp/include/seqwin/filter.hpp:11-20,
+ * cpp/src/seqwin/filter.cpp:15-137).  Mutates nodes[].{n_tar,n_neg,penalty} in place.
+ * Unlike the reference, the kmers length is passed and node ranges are checked against it.
+ * All validation failures are SW_ERR_VALUE with the reference's messages (filter.cpp:33-60,103-123).
+ */
+int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint64_t n_nodes,
+                   const uint32_t *record_offsets, uint64_t n_record_offsets, const uint8_t *is_targets,
+                   uint64_t n_assemblies, uint64_t n_cpu);
+
+/*
+ * Replaces `_filter_kmers_native(kmers, nodes, used_hashes)` (python_bindings.cpp:137-168) =
+ * seqwin::filter_kmers (cpp/src/seqwin/filter.cpp:139-201).  Two-phase: call with kmers_out ==
+ * nodes_out == NULL to obtain the output sizes, then again with buffers of those sizes.
+ */
+int sw_filter_kmers(const sw_kmer *kmers, uint64_t n_kmers, const sw_node *nodes, uint64_t n_nodes,
+                    const uint64_t *used_hashes, uint64_t n_used, sw_kmer *kmers_out, sw_node *nodes_out,
+                    uint64_t *n_kmers_out, uint64_t *n_nodes_out);
+
+/* ---- device-resident pipeline (what sw_build is made of; used by bench.py and multi-GPU) --- */
+
+#define SW_MAX_WINDOW 4096u
+
+/* Host ingest: read + pack FASTA files (fasta_reader.cpp:207-213 semantics) into a device batch.
+ * `first_assembly` is the global index of assembly_paths[0] (for sharded builds). */
+int sw_batch_from_fasta(const char *const *assembly_paths, size_t n_assemblies, uint64_t n_cpu, sw_batch **out);
+
+/* Synthetic batch generated ON DEVICE: n_genomes assemblies x records_per_genome records of
+ * `record_len` bases each, derived from `n_ancestors` iid-uniform ancestors with per-base
+ * substitution probability snp_ppm / 1e6 (counter-based RNG, `seed`).  No host ingest. */
+int sw_batch_synthetic(uint64_t n_genomes, uint64_t records_per_genome, uint64_t record_len,
+                       uint64_t n_ancestors, uint64_t snp_ppm, uint64_t seed, sw_batch **out);
+
+/* Copy the ASCII sequence of record `record_idx` (A/C/G/T, 'N' for invalid bases) back to the host;
+ * used by tests to hand the same input to the oracle. *len_out receives the record length. */
+int sw_batch_record(const sw_batch *b, uint64_t record_idx, char *seq_out, uint64_t cap, uint64_t *len_out);
+
+int sw_batch_info(const sw_batch *b, uint64_t *n_assemblies, uint64_t *n_records, uint64_t *total_bp,
+                  uint64_t *device_bytes);
+/* record_offsets[n_assemblies + 1] and the NUL-separated id blob of a batch. */
+int sw_batch_records(const sw_batch *b, uint32_t *record_offsets, char *ids_blob, uint64_t ids_cap,
+                     uint64_t *ids_bytes);
+void sw_batch_free(sw_batch *b);
+
+/* Timings of the last sw_index_build on this index, in milliseconds (HIP events on the build stream). */
+typedef struct sw_timings {
+    double total_ms;
+    double sketch_ms;    /* the fused ntHash + window-minimum kernel (dominant kernel) */
+    double order_ms;     /* tile-order compaction of the tuple stream */
+    double nodes_ms;     /* radix sort by hash + run-length -> nodes / kmers / ranks */
+    double counts_ms;    /* per-node target / non-target assembly counts + penalty */
+    double edges_ms;     /* adjacency pairs -> sort -> weights */
+    uint64_t sketch_launches;
+    uint64_t n_tiles;
+    uint64_t total_bp;
+    uint64_t n_windows;
+} sw_timings;
+
+/*
+ * Build the index of a resident batch: sketch (ntHash + windowed minimizers, nthash_kmer.hpp /
+ * minimizer.cpp:53-90) -> nodes/kmers (build.cpp:153-253, build_internals.cpp:159-251) ->
+ * edges (build.cpp:177-189, build_internals.cpp:253-291) -> if is_targets != NULL, per-node
+ * counts and penalty (filter.cpp:62-136).  Everything stays in HBM; `stream` is a hipStream_t
+ * (0 = default stream).  The call is asynchronous only up to internal size read-backs.
+ */
+int sw_index_build(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, const uint8_t *is_targets,
+                   uint64_t n_assemblies, void *stream, sw_index **out);
+
+int sw_index_sizes(const sw_index *ix, uint64_t *n_kmers, uint64_t *n_nodes, uint64_t *n_edges);
+int sw_index_timings(const sw_index *ix, sw_timings *t);
+/* D2H copies of the final arrays (any pointer may be NULL to skip that array). */
+int sw_index_export(const sw_index *ix, sw_kmer *kmers, sw_node *nodes, sw_edge *edges);
+/* Order-independent 64-bit checksums of the three arrays, computed on device (bench validation). */
+int sw_index_checksums(const sw_index *ix, uint64_t *kmers_sum, uint64_t *nodes_sum, uint64_t *edges_sum);
+/* The sketch stage alone: (out_hash, pos, record_idx) of every minimizer in (record_idx, pos) order.
+ * Two-phase like sw_filter_kmers: pass NULL buffers to get *n_out. */
+int sw_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *stream, uint64_t *out_hash,
+              sw_kmer *kmers, uint64_t cap, uint64_t *n_out);
+void sw_index_free(sw_index *ix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEQWIN_HIP_H */

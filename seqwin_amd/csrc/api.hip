@@ -1,0 +1,545 @@
+// api.hip -- C-ABI entry points of libseqwin_hip.so (see include/seqwin_hip.h for the contract and
+// the reference interfaces each one replaces), device memory pool, batch upload / synthesis.
+#include <algorithm>
+#include <memory>
+
+#include "device.hpp"
+
+namespace sw {
+
+static thread_local std::string g_last_error;
+void set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
+
+// ---- caching allocator ---------------------------------------------------------------------------
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;  // size -> ptr
+    std::map<void *, size_t> live;              // ptr -> size
+    uint64_t total = 0;
+};
+Pool &pool()
+{
+    static Pool p;
+    return p;
+}
+size_t round_size(size_t b)
+{
+    if (b < 512) return 512;
+    if (b < (1u << 20)) return (b + 511) & ~(size_t)511;
+    return (b + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);
+}
+}  // namespace
+
+void *dev_alloc(size_t bytes)
+{
+    Pool &p = pool();
+    const size_t sz = round_size(bytes);
+    {
+        std::lock_guard<std::mutex> lock(p.mu);
+        auto it = p.free_blocks.lower_bound(sz);
+        if (it != p.free_blocks.end() && it->first <= sz + sz / 4 + (1u << 20)) {
+            void *ptr = it->second;
+            p.live[ptr] = it->first;
+            p.free_blocks.erase(it);
+            return ptr;
+        }
+    }
+    void *ptr = nullptr;
+    hipError_t e = hipMalloc(&ptr, sz);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        dev_pool_trim();  // give cached blocks back and retry once
+        e = hipMalloc(&ptr, sz);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        raise(SW_ERR_DEVICE, "hipMalloc of %zu bytes failed: %s", sz, hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lock(p.mu);
+    p.live[ptr] = sz;
+    p.total += sz;
+    return ptr;
+}
+
+void dev_free(void *ptr)
+{
+    if (!ptr) return;
+    Pool &p = pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    auto it = p.live.find(ptr);
+    if (it == p.live.end()) return;
+    p.free_blocks.emplace(it->second, ptr);
+    p.live.erase(it);
+}
+
+void dev_pool_trim()
+{
+    Pool &p = pool();
+    std::vector<std::pair<size_t, void *>> blocks;
+    {
+        std::lock_guard<std::mutex> lock(p.mu);
+        blocks.assign(p.free_blocks.begin(), p.free_blocks.end());
+        p.free_blocks.clear();
+        for (auto &b : blocks) p.total -= b.first;
+    }
+    for (auto &b : blocks) (void)hipFree(b.second);
+}
+
+uint64_t dev_pool_bytes() { return pool().total; }
+
+namespace {
+
+void require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        raise(SW_ERR_DEVICE,
+              "no usable HIP device (hipGetDeviceCount: %s); libseqwin_hip has no CPU fallback",
+              e == hipSuccess ? "0 devices" : hipGetErrorString(e));
+    }
+}
+
+// Upload a HostBatch; host.packed is released afterwards (the rest of the host tables are kept for
+// planning).
+void upload_batch(sw_batch &b)
+{
+    HostBatch &h = b.host;
+    b.n_records = h.rec_len.size();
+    b.packed_words = h.packed.size();
+    b.d_packed.alloc(b.packed_words);
+    if (b.packed_words)
+        SW_HIP(hipMemcpy(b.d_packed.p, h.packed.data(), b.packed_words * 4, hipMemcpyHostToDevice));
+    std::vector<uint32_t>().swap(h.packed);
+    b.d_rec_base.alloc(b.n_records);
+    if (b.n_records)
+        SW_HIP(hipMemcpy(b.d_rec_base.p, h.rec_base.data(), b.n_records * 8, hipMemcpyHostToDevice));
+    std::vector<uint32_t> rec_asm(b.n_records);
+    for (uint64_t a = 0; a < h.n_assemblies; ++a)
+        for (uint32_t r = h.record_offsets[a]; r < h.record_offsets[a + 1]; ++r) rec_asm[r] = (uint32_t)a;
+    b.d_rec_asm.alloc(b.n_records);
+    if (b.n_records) SW_HIP(hipMemcpy(b.d_rec_asm.p, rec_asm.data(), b.n_records * 4, hipMemcpyHostToDevice));
+}
+
+__host__ __device__ inline uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+
+// One thread = one packed word (16 bases) of one record.
+__global__ void k_synth(uint32_t *packed, uint64_t words_per_record, uint64_t n_words, uint64_t records_per_genome,
+                        uint64_t record_len, uint64_t n_ancestors, uint64_t snp_ppm, uint64_t seed)
+{
+    const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= n_words) return;
+    const uint64_t rec = wi / words_per_record, wr = wi % words_per_record;
+    const uint64_t g = rec / records_per_genome, c = rec % records_per_genome;
+    const uint64_t anc = g % n_ancestors;
+    uint32_t word = 0;
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint64_t p = wr * 16 + i;
+        if (p >= record_len) break;
+        uint32_t base = (uint32_t)(mix64(seed ^ mix64((anc * records_per_genome + c) * 0x100000001b3ULL + p * 2 + 1)) >> 62);
+        const uint64_t u = mix64((seed + 0x51ed27) ^ mix64(rec * 0x9E3779B97F4A7C15ULL + p));
+        if (u % 1000000ull < snp_ppm) base = (uint32_t)(u >> 40) & 3u;
+        word |= base << (2 * i);
+    }
+    packed[wi] = word;
+}
+
+struct GraphHost {
+    std::vector<sw_kmer> kmers;
+    std::vector<sw_node> nodes;
+    std::vector<sw_edge> edges;
+    std::vector<uint32_t> record_offsets;
+    std::string ids_blob;
+    uint64_t n_assemblies = 0, total_bp = 0;
+};
+
+void check_targets(const uint8_t *is_targets, uint64_t n, uint64_t *n_tar, uint64_t *n_neg)
+{
+    uint64_t t = 0;
+    for (uint64_t i = 0; i < n; ++i) t += is_targets[i] ? 1 : 0;
+    *n_tar = t;
+    *n_neg = n - t;
+    if (t == 0) raise(SW_ERR_VALUE, "is_targets must contain at least one target assembly");          // filter.cpp:55-57
+    if (t == n) raise(SW_ERR_VALUE, "is_targets must contain at least one non-target assembly");      // filter.cpp:58-60
+}
+
+void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targets, uint64_t n_assemblies,
+                    hipStream_t stream, sw_index &ix)
+{
+    Plan &plan = get_plan(b, k, w);
+    uint64_t n_tar = 0, n_neg = 0;
+    DevArray<uint8_t> d_tar;
+    if (is_targets) {
+        if (n_assemblies != b.host.n_assemblies)
+            raise(SW_ERR_VALUE, "len(is_targets) must equal the number of assemblies in the batch");
+        check_targets(is_targets, n_assemblies, &n_tar, &n_neg);
+        d_tar.alloc(n_assemblies);
+        SW_HIP(hipMemcpyAsync(d_tar.p, is_targets, n_assemblies, hipMemcpyHostToDevice, stream));
+    }
+    hipEvent_t e0, e1, e2;
+    SW_HIP(hipEventCreate(&e0));
+    SW_HIP(hipEventCreate(&e1));
+    SW_HIP(hipEventCreate(&e2));
+    SW_HIP(hipEventRecord(e0, stream));
+    SketchOut sk;
+    float sketch_ms = 0.f;
+    run_sketch(b, plan, stream, sk, &sketch_ms);
+    SW_HIP(hipEventRecord(e1, stream));
+    OrderedOcc occ;
+    order_tuples(sk, plan, stream, occ);
+    const uint64_t launches = sk.launches;
+    sk = SketchOut();
+    SW_HIP(hipEventRecord(e2, stream));
+    ix.device = b.device;
+    build_index(b, occ, is_targets ? d_tar.p : nullptr, n_tar, n_neg, stream, ix);
+    hipEvent_t e3;
+    SW_HIP(hipEventCreate(&e3));
+    SW_HIP(hipEventRecord(e3, stream));
+    SW_HIP(hipEventSynchronize(e3));
+    float ms = 0.f;
+    SW_HIP(hipEventElapsedTime(&ms, e0, e3));
+    ix.timings.total_ms = ms;
+    SW_HIP(hipEventElapsedTime(&ms, e1, e2));
+    ix.timings.order_ms = ms;
+    ix.timings.sketch_ms = sketch_ms;
+    ix.timings.sketch_launches = launches;
+    ix.timings.n_tiles = plan.n_tiles;
+    ix.timings.total_bp = b.host.total_bp;
+    ix.timings.n_windows = plan.n_windows;
+    SW_HIP(hipEventDestroy(e0));
+    SW_HIP(hipEventDestroy(e1));
+    SW_HIP(hipEventDestroy(e2));
+    SW_HIP(hipEventDestroy(e3));
+}
+
+}  // namespace
+}  // namespace sw
+
+using namespace sw;
+
+struct sw_graph {
+    sw::GraphHost g;
+};
+
+extern "C" {
+
+const char *sw_last_error(void) { return g_last_error.c_str(); }
+const char *sw_version(void) { return "seqwin_amd 0.1.0 (gfx950)"; }
+
+int sw_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int sw_set_device(int device)
+{
+    return guarded([&] {
+        require_device();
+        SW_HIP(hipSetDevice(device));
+    });
+}
+
+int sw_batch_from_fasta(const char *const *assembly_paths, size_t n_assemblies, uint64_t n_cpu, sw_batch **out)
+{
+    return guarded([&] {
+        require_device();
+        std::unique_ptr<sw_batch> b(new sw_batch);
+        SW_HIP(hipGetDevice(&b->device));
+        ingest_fasta(assembly_paths, n_assemblies, n_cpu, b->host);
+        upload_batch(*b);
+        *out = b.release();
+    });
+}
+
+int sw_batch_synthetic(uint64_t n_genomes, uint64_t records_per_genome, uint64_t record_len, uint64_t n_ancestors,
+                       uint64_t snp_ppm, uint64_t seed, sw_batch **out)
+{
+    return guarded([&] {
+        require_device();
+        if (n_ancestors == 0 || records_per_genome == 0) raise(SW_ERR_VALUE, "n_ancestors and records_per_genome must be >= 1");
+        if (record_len > UINT32_MAX) raise(SW_ERR_VALUE, "record_len exceeds uint32 range");
+        const uint64_t R = n_genomes * records_per_genome;
+        if (R > UINT32_MAX) raise(SW_ERR_VALUE, "number of records exceeds uint32 range");
+        std::unique_ptr<sw_batch> b(new sw_batch);
+        SW_HIP(hipGetDevice(&b->device));
+        HostBatch &h = b->host;
+        h.n_assemblies = n_genomes;
+        h.total_bp = R * record_len;
+        const uint64_t padded = (record_len + 31) / 32 * 32;
+        const uint64_t wpr = padded / 16;
+        h.record_offsets.resize(n_genomes + 1);
+        for (uint64_t g = 0; g <= n_genomes; ++g) h.record_offsets[g] = (uint32_t)(g * records_per_genome);
+        h.rec_len.assign(R, (uint32_t)record_len);
+        h.rec_base.resize(R);
+        h.rec_run_off.resize(R + 1);
+        h.run_pos.assign(record_len ? R : 0, 0);
+        h.run_len.assign(record_len ? R : 0, (uint32_t)record_len);
+        char name[64];
+        for (uint64_t r = 0; r < R; ++r) {
+            h.rec_base[r] = r * padded;
+            h.rec_run_off[r] = record_len ? (uint32_t)r : 0;
+            int len = snprintf(name, sizeof name, "g%llu_c%llu", (unsigned long long)(r / records_per_genome),
+                               (unsigned long long)(r % records_per_genome));
+            h.ids_blob.append(name, (size_t)len + 1);
+        }
+        h.rec_run_off[R] = record_len ? (uint32_t)R : 0;
+        b->n_records = R;
+        b->packed_words = R * wpr + 8;
+        b->d_packed.alloc(b->packed_words);
+        SW_HIP(hipMemset(b->d_packed.p, 0, b->packed_words * 4));
+        const uint64_t n_words = R * wpr;
+        if (n_words) {
+            hipLaunchKernelGGL(k_synth, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, 0, b->d_packed.p, wpr, n_words,
+                               records_per_genome, record_len, n_ancestors, snp_ppm, seed);
+            SW_HIP(hipGetLastError());
+            SW_HIP(hipDeviceSynchronize());
+        }
+        b->d_rec_base.alloc(R);
+        if (R) SW_HIP(hipMemcpy(b->d_rec_base.p, h.rec_base.data(), R * 8, hipMemcpyHostToDevice));
+        std::vector<uint32_t> rec_asm(R);
+        for (uint64_t r = 0; r < R; ++r) rec_asm[r] = (uint32_t)(r / records_per_genome);
+        b->d_rec_asm.alloc(R);
+        if (R) SW_HIP(hipMemcpy(b->d_rec_asm.p, rec_asm.data(), R * 4, hipMemcpyHostToDevice));
+        *out = b.release();
+    });
+}
+
+int sw_batch_record(const sw_batch *b, uint64_t record_idx, char *seq_out, uint64_t cap, uint64_t *len_out)
+{
+    return guarded([&] {
+        if (record_idx >= b->n_records) raise(SW_ERR_VALUE, "record index out of range");
+        const HostBatch &h = b->host;
+        const uint64_t len = h.rec_len[record_idx];
+        *len_out = len;
+        if (!seq_out || cap < len) return;
+        const uint64_t w0 = h.rec_base[record_idx] / 16, nw = (len + 15) / 16;
+        std::vector<uint32_t> words(nw);
+        if (nw) SW_HIP(hipMemcpy(words.data(), b->d_packed.p + w0, nw * 4, hipMemcpyDeviceToHost));
+        memset(seq_out, 'N', len);
+        for (uint32_t q = h.rec_run_off[record_idx]; q < h.rec_run_off[record_idx + 1]; ++q)
+            for (uint64_t p = h.run_pos[q]; p < (uint64_t)h.run_pos[q] + h.run_len[q]; ++p)
+                seq_out[p] = "ACGT"[(words[p / 16] >> (2 * (p % 16))) & 3u];
+    });
+}
+
+int sw_batch_info(const sw_batch *b, uint64_t *n_assemblies, uint64_t *n_records, uint64_t *total_bp,
+                  uint64_t *device_bytes)
+{
+    return guarded([&] {
+        if (n_assemblies) *n_assemblies = b->host.n_assemblies;
+        if (n_records) *n_records = b->n_records;
+        if (total_bp) *total_bp = b->host.total_bp;
+        if (device_bytes) *device_bytes = b->d_packed.bytes() + b->d_rec_base.bytes() + b->d_rec_asm.bytes();
+    });
+}
+
+int sw_batch_records(const sw_batch *b, uint32_t *record_offsets, char *ids_blob, uint64_t ids_cap, uint64_t *ids_bytes)
+{
+    return guarded([&] {
+        const HostBatch &h = b->host;
+        if (record_offsets) memcpy(record_offsets, h.record_offsets.data(), (h.n_assemblies + 1) * 4);
+        if (ids_bytes) *ids_bytes = h.ids_blob.size();
+        if (ids_blob && ids_cap >= h.ids_blob.size()) memcpy(ids_blob, h.ids_blob.data(), h.ids_blob.size());
+    });
+}
+
+void sw_batch_free(sw_batch *b) { delete b; }
+
+int sw_index_build(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, const uint8_t *is_targets,
+                   uint64_t n_assemblies, void *stream, sw_index **out)
+{
+    return guarded([&] {
+        std::unique_ptr<sw_index> ix(new sw_index);
+        do_index_build(*const_cast<sw_batch *>(b), kmerlen, windowsize, is_targets, n_assemblies, (hipStream_t)stream, *ix);
+        *out = ix.release();
+    });
+}
+
+int sw_index_sizes(const sw_index *ix, uint64_t *n_kmers, uint64_t *n_nodes, uint64_t *n_edges)
+{
+    return guarded([&] {
+        *n_kmers = ix->n_kmers;
+        *n_nodes = ix->n_nodes;
+        *n_edges = ix->n_edges;
+    });
+}
+
+int sw_index_timings(const sw_index *ix, sw_timings *t)
+{
+    return guarded([&] { *t = ix->timings; });
+}
+
+int sw_index_export(const sw_index *ix, sw_kmer *kmers, sw_node *nodes, sw_edge *edges)
+{
+    return guarded([&] {
+        if (kmers && ix->n_kmers) SW_HIP(hipMemcpy(kmers, ix->kmers.p, ix->n_kmers * sizeof(sw_kmer), hipMemcpyDeviceToHost));
+        if (nodes && ix->n_nodes) SW_HIP(hipMemcpy(nodes, ix->nodes.p, ix->n_nodes * sizeof(sw_node), hipMemcpyDeviceToHost));
+        if (edges && ix->n_edges) SW_HIP(hipMemcpy(edges, ix->edges.p, ix->n_edges * sizeof(sw_edge), hipMemcpyDeviceToHost));
+    });
+}
+
+int sw_index_checksums(const sw_index *ix, uint64_t *kmers_sum, uint64_t *nodes_sum, uint64_t *edges_sum)
+{
+    return guarded([&] {
+        uint64_t s[3];
+        device_checksums(*ix, 0, s);
+        *kmers_sum = s[0];
+        *nodes_sum = s[1];
+        *edges_sum = s[2];
+    });
+}
+
+void sw_index_free(sw_index *ix) { delete ix; }
+
+int sw_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *stream, uint64_t *out_hash, sw_kmer *kmers,
+              uint64_t cap, uint64_t *n_out)
+{
+    return guarded([&] {
+        sw_batch &bb = *const_cast<sw_batch *>(b);
+        Plan &plan = get_plan(bb, kmerlen, windowsize);
+        SketchOut sk;
+        run_sketch(bb, plan, (hipStream_t)stream, sk, nullptr);
+        *n_out = sk.n_occ;
+        if (!out_hash || !kmers || cap < sk.n_occ) return;
+        OrderedOcc occ;
+        order_tuples(sk, plan, (hipStream_t)stream, occ);
+        if (occ.n) {
+            SW_HIP(hipMemcpy(out_hash, occ.hash.p, occ.n * 8, hipMemcpyDeviceToHost));
+            SW_HIP(hipMemcpy(kmers, occ.kmer.p, occ.n * 8, hipMemcpyDeviceToHost));  // pos | rec << 32 == sw_kmer layout
+        }
+    });
+}
+
+int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t kmerlen, uint64_t windowsize, uint64_t n_cpu,
+             int low_memory, sw_graph **out)
+{
+    (void)low_memory;  // same result either way (reference test_graph.py:222-245); HBM holds the whole batch
+    return guarded([&] {
+        check_kw(kmerlen, windowsize);
+        require_device();
+        std::unique_ptr<sw_batch> b(new sw_batch);
+        SW_HIP(hipGetDevice(&b->device));
+        ingest_fasta(assembly_paths, n_assemblies, n_cpu, b->host);
+        upload_batch(*b);
+        sw_index ix;
+        do_index_build(*b, kmerlen, windowsize, nullptr, 0, 0, ix);
+        std::unique_ptr<sw_graph> g(new sw_graph);
+        g->g.kmers.resize(ix.n_kmers);
+        g->g.nodes.resize(ix.n_nodes);
+        g->g.edges.resize(ix.n_edges);
+        if (ix.n_kmers) SW_HIP(hipMemcpy(g->g.kmers.data(), ix.kmers.p, ix.n_kmers * sizeof(sw_kmer), hipMemcpyDeviceToHost));
+        if (ix.n_nodes) SW_HIP(hipMemcpy(g->g.nodes.data(), ix.nodes.p, ix.n_nodes * sizeof(sw_node), hipMemcpyDeviceToHost));
+        if (ix.n_edges) SW_HIP(hipMemcpy(g->g.edges.data(), ix.edges.p, ix.n_edges * sizeof(sw_edge), hipMemcpyDeviceToHost));
+        g->g.record_offsets = b->host.record_offsets;
+        g->g.ids_blob = b->host.ids_blob;
+        g->g.n_assemblies = b->host.n_assemblies;
+        g->g.total_bp = b->host.total_bp;
+        *out = g.release();
+    });
+}
+
+int sw_graph_sizes(const sw_graph *g, uint64_t *n_kmers, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *n_assemblies,
+                   uint64_t *ids_bytes, uint64_t *total_bp)
+{
+    return guarded([&] {
+        *n_kmers = g->g.kmers.size();
+        *n_nodes = g->g.nodes.size();
+        *n_edges = g->g.edges.size();
+        *n_assemblies = g->g.n_assemblies;
+        *ids_bytes = g->g.ids_blob.size();
+        if (total_bp) *total_bp = g->g.total_bp;
+    });
+}
+
+int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *edges, uint32_t *record_offsets,
+                    char *ids_blob)
+{
+    return guarded([&] {
+        const GraphHost &h = g->g;
+        if (!h.kmers.empty()) memcpy(kmers, h.kmers.data(), h.kmers.size() * sizeof(sw_kmer));
+        if (!h.nodes.empty()) memcpy(nodes, h.nodes.data(), h.nodes.size() * sizeof(sw_node));
+        if (!h.edges.empty()) memcpy(edges, h.edges.data(), h.edges.size() * sizeof(sw_edge));
+        memcpy(record_offsets, h.record_offsets.data(), h.record_offsets.size() * 4);
+        if (!h.ids_blob.empty()) memcpy(ids_blob, h.ids_blob.data(), h.ids_blob.size());
+    });
+}
+
+void sw_graph_free(sw_graph *g) { delete g; }
+
+int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint64_t n_nodes, const uint32_t *record_offsets,
+                   uint64_t n_record_offsets, const uint8_t *is_targets, uint64_t n_assemblies, uint64_t n_cpu)
+{
+    (void)n_cpu;
+    return guarded([&] {
+        // argument validation, messages as in filter.cpp:33-60
+        if (n_record_offsets != n_assemblies + 1) raise(SW_ERR_VALUE, "len(record_offsets) must equal len(is_targets) + 1");
+        if (n_record_offsets == 0 || record_offsets[0] != 0) raise(SW_ERR_VALUE, "record_offsets must start with 0");
+        if (n_assemblies > UINT32_MAX) raise(SW_ERR_VALUE, "Number of assemblies exceeds uint32 range");
+        for (uint64_t i = 0; i < n_assemblies; ++i)
+            if (record_offsets[i + 1] < record_offsets[i]) raise(SW_ERR_VALUE, "record_offsets must be nondecreasing");
+        uint64_t n_tar = 0, n_neg = 0;
+        check_targets(is_targets, n_assemblies, &n_tar, &n_neg);
+        if (n_kmers >= 0xFFFFFFFFull) raise(SW_ERR_VALUE, "more than 2^32-2 k-mers are not supported on one device");
+        require_device();
+        if (n_nodes == 0) return;
+
+        const uint32_t n_records = record_offsets[n_assemblies];
+        std::vector<uint32_t> rec_asm(n_records);
+        for (uint64_t a = 0; a < n_assemblies; ++a)  // filter.cpp:68-87
+            for (uint32_t r = record_offsets[a]; r < record_offsets[a + 1]; ++r) rec_asm[r] = (uint32_t)a;
+        DevArray<sw_kmer> d_kmers(n_kmers);
+        DevArray<sw_node> d_nodes(n_nodes);
+        DevArray<uint32_t> d_rec_asm(n_records);
+        DevArray<uint8_t> d_tar(n_assemblies);
+        if (n_kmers) SW_HIP(hipMemcpy(d_kmers.p, kmers, n_kmers * sizeof(sw_kmer), hipMemcpyHostToDevice));
+        SW_HIP(hipMemcpy(d_nodes.p, nodes, n_nodes * sizeof(sw_node), hipMemcpyHostToDevice));
+        if (n_records) SW_HIP(hipMemcpy(d_rec_asm.p, rec_asm.data(), (size_t)n_records * 4, hipMemcpyHostToDevice));
+        SW_HIP(hipMemcpy(d_tar.p, is_targets, n_assemblies, hipMemcpyHostToDevice));
+        uint64_t err = 0;
+        device_get_penalty(d_kmers.p, n_kmers, d_nodes.p, n_nodes, d_rec_asm.p, n_records, d_tar.p, n_tar, n_neg, 0, &err);
+        if (err & 1) raise(SW_ERR_VALUE, "node range is outside kmers");
+        if (err & 2) raise(SW_ERR_VALUE, "record_idx is outside record_offsets range");                    // filter.cpp:104-106,120-122
+        if (err & 4) raise(SW_ERR_VALUE, "record_idx must be nondecreasing within each node range");        // filter.cpp:113-115
+        SW_HIP(hipMemcpy(nodes, d_nodes.p, n_nodes * sizeof(sw_node), hipMemcpyDeviceToHost));
+    });
+}
+
+int sw_filter_kmers(const sw_kmer *kmers, uint64_t n_kmers, const sw_node *nodes, uint64_t n_nodes,
+                    const uint64_t *used_hashes, uint64_t n_used, sw_kmer *kmers_out, sw_node *nodes_out,
+                    uint64_t *n_kmers_out, uint64_t *n_nodes_out)
+{
+    return guarded([&] {
+        require_device();
+        for (uint64_t i = 0; i < n_nodes; ++i)
+            if (nodes[i].start > nodes[i].stop || nodes[i].stop > n_kmers) raise(SW_ERR_VALUE, "node range is outside kmers");
+        std::vector<uint64_t> used(used_hashes, used_hashes + n_used);
+        std::sort(used.begin(), used.end());  // filter.cpp:145
+        DevArray<sw_kmer> d_kmers(n_kmers), d_kout;
+        DevArray<sw_node> d_nodes(n_nodes), d_nout;
+        DevArray<uint64_t> d_used(n_used);
+        if (n_kmers) SW_HIP(hipMemcpy(d_kmers.p, kmers, n_kmers * sizeof(sw_kmer), hipMemcpyHostToDevice));
+        if (n_nodes) SW_HIP(hipMemcpy(d_nodes.p, nodes, n_nodes * sizeof(sw_node), hipMemcpyHostToDevice));
+        if (n_used) SW_HIP(hipMemcpy(d_used.p, used.data(), n_used * 8, hipMemcpyHostToDevice));
+        uint64_t nk = 0, nn = 0;
+        device_filter_kmers(d_kmers.p, n_kmers, d_nodes.p, n_nodes, d_used.p, n_used, 0, d_kout, d_nout, &nk, &nn);
+        *n_kmers_out = nk;
+        *n_nodes_out = nn;
+        if (kmers_out && nk) SW_HIP(hipMemcpy(kmers_out, d_kout.p, nk * sizeof(sw_kmer), hipMemcpyDeviceToHost));
+        if (nodes_out && nn) SW_HIP(hipMemcpy(nodes_out, d_nout.p, nn * sizeof(sw_node), hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"

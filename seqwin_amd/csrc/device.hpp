@@ -1,0 +1,132 @@
+// device.hpp -- device-side objects shared by sketch.hip / index.hip / api.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+
+namespace sw {
+
+#define SW_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            ::sw::raise(SW_ERR_DEVICE, "HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e), \
+                        __FILE__, __LINE__, #expr);                                                    \
+    } while (0)
+
+// ---- caching device allocator (steady-state index builds do no hipMalloc) --------------------
+void *dev_alloc(size_t bytes);
+void dev_free(void *p);
+void dev_pool_trim();
+uint64_t dev_pool_bytes();
+
+template <class T> struct DevArray {
+    T *p = nullptr;
+    size_t n = 0;
+    DevArray() = default;
+    explicit DevArray(size_t count) { alloc(count); }
+    DevArray(const DevArray &) = delete;
+    DevArray &operator=(const DevArray &) = delete;
+    DevArray(DevArray &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevArray &operator=(DevArray &&o) noexcept
+    {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevArray() { release(); }
+    void alloc(size_t count)
+    {
+        release();
+        n = count;
+        p = (T *)dev_alloc((count ? count : 1) * sizeof(T));
+    }
+    void release()
+    {
+        if (p) dev_free(p);
+        p = nullptr;
+        n = 0;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+// ---- per-(k, w) launch plan of a batch ---------------------------------------------------------
+// Valid k-mers of a record are numbered 0..n_valid-1 in increasing position ("idx space",
+// minimizer.cpp:69-70).  A segment is a maximal run of valid bases of length >= k; it contributes
+// run_len-k+1 consecutive idx values.  A tile is TW consecutive window ends of one record.
+struct Plan {
+    uint32_t k = 0, w = 0;
+    uint32_t L = 0;        // k-mers hashed per thread (odd, <= w)
+    uint32_t NE = 0;       // elements per tile = 256 * L
+    uint32_t TW = 0;       // window ends per tile = NE - w
+    uint32_t n_tiles = 0;
+    uint64_t n_windows = 0;
+    uint64_t n_valid = 0;
+    size_t lds_bytes = 0;
+    DevArray<uint32_t> rec_seg_off;   // [R + 1]
+    DevArray<uint32_t> rec_nvalid;    // [R]
+    DevArray<uint32_t> rec_tile_off;  // [R + 1]
+    DevArray<uint32_t> seg_pos;       // [S]
+    DevArray<uint32_t> seg_idx;       // [S]
+    DevArray<uint64_t> lut;           // [40] roll tables, see sketch.hip
+    uint64_t mult = 0;                // 1 ^ (k * MULTISEED)
+};
+
+}  // namespace sw
+
+struct sw_batch {
+    int device = 0;
+    sw::HostBatch host;               // host.packed is released after upload
+    uint64_t n_records = 0;
+    uint64_t packed_words = 0;
+    sw::DevArray<uint32_t> d_packed;
+    sw::DevArray<uint64_t> d_rec_base;
+    sw::DevArray<uint32_t> d_rec_asm;  // assembly index of each record
+    std::mutex plan_mu;
+    std::map<std::pair<uint32_t, uint32_t>, sw::Plan> plans;
+};
+
+struct sw_index {
+    int device = 0;
+    uint64_t n_kmers = 0, n_nodes = 0, n_edges = 0;
+    sw::DevArray<sw_kmer> kmers;
+    sw::DevArray<sw_node> nodes;
+    sw::DevArray<sw_edge> edges;
+    sw_timings timings{};
+};
+
+namespace sw {
+
+Plan &get_plan(sw_batch &b, uint64_t k, uint64_t w);
+
+// sketch.hip: runs the fused ntHash + window-minimum kernel over every tile of the plan.
+// Output: tuples in TILE-ALLOCATION order in (stage_hash, stage_kmer) plus per-tile (offset, count).
+struct SketchOut {
+    DevArray<uint64_t> stage_hash;
+    DevArray<uint64_t> stage_kmer;   // pos | record_idx << 32
+    DevArray<uint32_t> tile_count;
+    DevArray<uint64_t> tile_offset;
+    uint64_t n_occ = 0;
+    uint64_t launches = 0;
+};
+void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchOut &out, float *sketch_ms);
+
+// index.hip
+struct OrderedOcc {
+    DevArray<uint64_t> hash;   // out_hash in (record_idx, pos) order
+    DevArray<uint64_t> kmer;   // pos | record_idx << 32
+    uint64_t n = 0;
+};
+void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out);
+void build_index(const sw_batch &b, const OrderedOcc &occ, const uint8_t *d_is_target, uint64_t n_targets,
+                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix);
+void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
+                        const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,
+                        uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, uint64_t *err_flags_host);
+void device_filter_kmers(const sw_kmer *d_kmers, uint64_t n_kmers, const sw_node *d_nodes, uint64_t n_nodes,
+                         const uint64_t *d_used_sorted, uint64_t n_used, hipStream_t stream,
+                         DevArray<sw_kmer> &kmers_out, DevArray<sw_node> &nodes_out, uint64_t *n_kmers_out,
+                         uint64_t *n_nodes_out);
+void device_checksums(const sw_index &ix, hipStream_t stream, uint64_t *sums3);
+
+}  // namespace sw

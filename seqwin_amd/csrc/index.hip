@@ -1,0 +1,551 @@
+// index.hip -- device-side index build: tuple ordering, nodes / kmers, per-node assembly counts,
+// adjacency edges, filter.  Replaces (reference paths relative to /root/reference):
+//   node map + grouped scatter     cpp/src/seqwin/build.cpp:153-168, 196-253
+//   edge map with per-assembly +1  cpp/src/seqwin/build.cpp:177-189
+//   radix sort + run-length merge  cpp/src/seqwin/build_internals.cpp:76-144, 159-291
+//   get_penalty                    cpp/src/seqwin/filter.cpp:15-137
+//   filter_kmers                   cpp/src/seqwin/filter.cpp:139-201
+// The reference builds per-thread ankerl hash maps and erases their iteration order with a stable
+// LSD radix sort; here the tuple stream is already in (record_idx, pos) order, so ONE stable device
+// radix sort by out_hash yields `kmers` in the reference's (hash, record_idx, pos) order and a
+// run-length pass yields `nodes`.  Edges are sorted as (rank_lo, rank_hi) pairs of dense node ranks
+// (rank order == hash order), stably, so equal pairs stay in assembly order and the number of
+// assemblies containing a pair is a count of assembly changes inside its run.
+// Device-wide sort / scan come from rocPRIM (a plain library primitive); every kernel in this file
+// is domain-specific glue around them.
+#include <cstring>  // rocprim's texture iterator needs ::memset declared first
+
+#include <rocprim/rocprim.hpp>
+
+#include "device.hpp"
+
+namespace sw {
+
+namespace {
+
+constexpr int TPB = 256;
+inline unsigned blocks_for(uint64_t n, int per = TPB) { return (unsigned)((n + per - 1) / per); }
+
+// ---- rocPRIM wrappers (temp storage from the caching allocator) ------------------------------
+template <class K, class V>
+void sort_pairs(K *&keys, K *&keys_alt, V *&vals, V *&vals_alt, size_t n, unsigned begin_bit, unsigned end_bit,
+                hipStream_t stream)
+{
+    rocprim::double_buffer<K> dk(keys, keys_alt);
+    rocprim::double_buffer<V> dv(vals, vals_alt);
+    size_t tmp_bytes = 0;
+    SW_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, dk, dv, n, begin_bit, end_bit, stream));
+    DevArray<unsigned char> tmp(tmp_bytes);
+    SW_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, dk, dv, n, begin_bit, end_bit, stream));
+    keys = dk.current();
+    keys_alt = dk.alternate();
+    vals = dv.current();
+    vals_alt = dv.alternate();
+}
+
+template <class InIt, class OutIt, class T>
+void inclusive_sum(InIt in, OutIt out, size_t n, T, hipStream_t stream)
+{
+    size_t tmp_bytes = 0;
+    SW_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, in, out, n, rocprim::plus<T>(), stream));
+    DevArray<unsigned char> tmp(tmp_bytes);
+    SW_HIP(rocprim::inclusive_scan(tmp.p, tmp_bytes, in, out, n, rocprim::plus<T>(), stream));
+}
+
+template <class InIt, class OutIt, class T>
+void exclusive_sum(InIt in, OutIt out, size_t n, T init, hipStream_t stream)
+{
+    size_t tmp_bytes = 0;
+    SW_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, init, n, rocprim::plus<T>(), stream));
+    DevArray<unsigned char> tmp(tmp_bytes);
+    SW_HIP(rocprim::exclusive_scan(tmp.p, tmp_bytes, in, out, init, n, rocprim::plus<T>(), stream));
+}
+
+struct U32ToU64 {
+    __host__ __device__ uint64_t operator()(uint32_t v) const { return v; }
+};
+
+// head-of-run flag of a sorted key array, evaluated on the fly
+struct HeadFlag {
+    const uint64_t *keys;
+    uint64_t n_valid;  // keys at >= n_valid are sentinels
+    __host__ __device__ uint32_t operator()(uint64_t s) const
+    {
+        if (s >= n_valid) return 0u;
+        return (s == 0 || keys[s] != keys[s - 1]) ? 1u : 0u;
+    }
+};
+
+// ---- tuple ordering -----------------------------------------------------------------------------
+__global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t *__restrict__ stage_kmer,
+                        const uint32_t *__restrict__ tile_count, const uint64_t *__restrict__ tile_offset,
+                        const uint64_t *__restrict__ dst_off, uint32_t n_tiles, uint64_t *__restrict__ hash,
+                        uint64_t *__restrict__ kmer)
+{
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (wave >= n_tiles) return;
+    const uint32_t c = tile_count[wave];
+    const uint64_t src = tile_offset[wave], dst = dst_off[wave];
+    for (uint32_t i = lane; i < c; i += 64) {
+        hash[dst + i] = stage_hash[src + i];
+        kmer[dst + i] = stage_kmer[src + i];
+    }
+}
+
+__global__ void k_iota(uint32_t *v, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+
+// ---- nodes / kmers / ranks ------------------------------------------------------------------------
+__global__ void k_nodes(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ perm,
+                        const uint32_t *__restrict__ cum, const uint64_t *__restrict__ kmer_in, uint64_t n,
+                        sw_kmer *__restrict__ kmers, sw_node *__restrict__ nodes, uint32_t *__restrict__ rank)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t nid = cum[s] - 1;
+    const uint32_t src = perm[s];
+    const uint64_t km = kmer_in[src];
+    kmers[s].pos = (uint32_t)km;
+    kmers[s].record_idx = (uint32_t)(km >> 32);
+    rank[src] = nid;
+    const uint64_t key = skeys[s];
+    const bool head = (s == 0) || key != skeys[s - 1];
+    if (head) {
+        nodes[nid].hash = key;
+        nodes[nid].start = s;
+        nodes[nid].n_tar = 0;
+        nodes[nid].n_neg = 0;
+        nodes[nid].penalty = 0.0;
+        if (s) nodes[nid - 1].stop = s;
+    }
+    if (s == n - 1) nodes[nid].stop = n;
+}
+
+// ---- get_penalty ------------------------------------------------------------------------------------
+// X[s] = (target-assembly change << 32) | non-target-assembly change, between occurrence s-1 and s.
+// Y[s] = (record_idx decreased << 32) | record_idx out of range.
+__global__ void k_pen_flags(const sw_kmer *__restrict__ kmers, uint64_t n, const uint32_t *__restrict__ rec_asm,
+                            uint64_t n_records, const uint8_t *__restrict__ is_target, uint64_t *__restrict__ X,
+                            uint64_t *__restrict__ Y)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    const uint32_t r = kmers[s].record_idx;
+    const bool oob = r >= n_records;
+    uint64_t x = 0, y = oob ? 1ull : 0ull;
+    if (s) {
+        const uint32_t rp = kmers[s - 1].record_idx;
+        if (r < rp) y |= 1ull << 32;
+        if (!oob) {
+            const uint32_t a = rec_asm[r];
+            const uint32_t ap = (rp < n_records) ? rec_asm[rp] : 0xFFFFFFFFu;
+            if (a != ap) x = is_target[a] ? (1ull << 32) : 1ull;
+        }
+    }
+    X[s] = x;
+    Y[s] = y;
+}
+
+__global__ void k_pen_nodes(const sw_kmer *__restrict__ kmers, uint64_t n_kmers, sw_node *__restrict__ nodes,
+                            uint64_t n_nodes, const uint32_t *__restrict__ rec_asm, uint64_t n_records,
+                            const uint8_t *__restrict__ is_target, const uint64_t *__restrict__ XS,
+                            const uint64_t *__restrict__ YS, double inv_tar, double inv_neg,
+                            uint32_t *__restrict__ err)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint64_t start = nodes[i].start, stop = nodes[i].stop;
+    if (start == stop) {  // filter.cpp:95-100
+        nodes[i].n_tar = 0;
+        nodes[i].n_neg = 0;
+        nodes[i].penalty = 1.0;
+        return;
+    }
+    if (start > stop || stop > n_kmers) {
+        atomicOr(err, 1u);
+        return;
+    }
+    const uint64_t y = YS[stop - 1] - (start ? YS[start - 1] : 0ull);
+    // out-of-range anywhere in [start, stop); decreasing strictly inside (start, stop)
+    if ((uint32_t)y) {
+        atomicOr(err, 2u);
+        return;
+    }
+    const uint64_t dec = (YS[stop - 1] - YS[start]) >> 32;
+    if (dec) {
+        atomicOr(err, 4u);
+        return;
+    }
+    const uint32_t a0 = rec_asm[kmers[start].record_idx];
+    const uint64_t x = XS[stop - 1] - XS[start];
+    const uint32_t t0 = is_target[a0] ? 1u : 0u;
+    const uint32_t n_tar = t0 + (uint32_t)(x >> 32);
+    const uint32_t n_neg = (1u - t0) + (uint32_t)x;
+    nodes[i].n_tar = n_tar;
+    nodes[i].n_neg = n_neg;
+    {
+// filter.cpp:132-134 evaluated with separate IEEE multiply / add / sqrt (no FMA contraction)
+#pragma clang fp contract(off)
+        const double ft = (double)n_tar * inv_tar;
+        const double fn = (double)n_neg * inv_neg;
+        const double omf = 1.0 - ft;
+        const double a = omf * omf;
+        const double b = fn * fn;
+        const double sum = a + b;
+        nodes[i].penalty = __dsqrt_rn(sum);
+    }
+}
+
+// ---- edges --------------------------------------------------------------------------------------------
+__global__ void k_adj(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ rank,
+                      const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, uint64_t sentinel,
+                      uint64_t *__restrict__ key, uint32_t *__restrict__ val,
+                      unsigned long long *__restrict__ n_invalid)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool invalid = false;
+    if (i + 1 < n) {
+        const uint32_t r0 = (uint32_t)(kmer[i] >> 32), r1 = (uint32_t)(kmer[i + 1] >> 32);
+        if (r0 == r1) {  // consecutive minimizers of one record (build.cpp:177-189)
+            uint32_t u = rank[i], v = rank[i + 1];
+            if (v < u) { const uint32_t t = u; u = v; v = t; }
+            key[i] = ((uint64_t)u << nb) | v;
+            val[i] = rec_asm[r0];
+        } else {
+            key[i] = sentinel;
+            val[i] = 0xFFFFFFFFu;
+            invalid = true;
+        }
+    }
+    const unsigned long long m = __ballot(invalid);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_invalid, (unsigned long long)__popcll(m));
+}
+
+// c[s] = 1 at the first pair of every (edge, assembly) combination
+struct AsmChangeFlag {
+    const uint64_t *keys;
+    const uint32_t *vals;
+    uint64_t n_valid;
+    __host__ __device__ uint32_t operator()(uint64_t s) const
+    {
+        if (s >= n_valid) return 0u;
+        return (s == 0 || keys[s] != keys[s - 1] || vals[s] != vals[s - 1]) ? 1u : 0u;
+    }
+};
+
+__global__ void k_edge_heads(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ ecum, uint64_t n_valid,
+                             uint64_t *__restrict__ edge_start)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_valid) return;
+    if (s == 0 || skeys[s] != skeys[s - 1]) edge_start[ecum[s] - 1] = s;
+}
+
+__global__ void k_edges(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ ccum,
+                        const uint64_t *__restrict__ edge_start, uint64_t n_edges, uint64_t n_valid, unsigned nb,
+                        const sw_node *__restrict__ nodes, sw_edge *__restrict__ edges)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const uint64_t s = edge_start[e];
+    const uint64_t s1 = (e + 1 < n_edges) ? edge_start[e + 1] : n_valid;
+    const uint64_t key = skeys[s];
+    const uint32_t u = (uint32_t)(key >> nb), v = (uint32_t)(key & ((1ull << nb) - 1ull));
+    edges[e].first = nodes[u].hash;
+    edges[e].second = nodes[v].hash;
+    edges[e].weight = (uint64_t)(ccum[s1 - 1] - ccum[s]) + 1ull;
+}
+
+// ---- filter_kmers -----------------------------------------------------------------------------------
+__global__ void k_filter_keep(const sw_node *__restrict__ nodes, uint64_t n_nodes, const uint64_t *__restrict__ used,
+                              uint64_t n_used, uint32_t *__restrict__ keep, uint64_t *__restrict__ size)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint64_t h = nodes[i].hash;
+    uint64_t lo = 0, hi = n_used;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (used[mid] < h) lo = mid + 1; else hi = mid;
+    }
+    const bool k = lo < n_used && used[lo] == h;
+    keep[i] = k ? 1u : 0u;
+    size[i] = k ? nodes[i].stop - nodes[i].start : 0ull;
+}
+
+__global__ void k_filter_nodes(const sw_node *__restrict__ nodes, uint64_t n_nodes, const uint32_t *__restrict__ keep,
+                               const uint32_t *__restrict__ kcum, const uint64_t *__restrict__ scum,
+                               sw_node *__restrict__ nodes_out, uint64_t *__restrict__ src_start,
+                               uint64_t *__restrict__ dst_start)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes || !keep[i]) return;
+    const uint32_t o = kcum[i] - 1;
+    const uint64_t sz = nodes[i].stop - nodes[i].start;
+    const uint64_t ns = scum[i] - sz;
+    sw_node nd = nodes[i];
+    src_start[o] = nd.start;
+    dst_start[o] = ns;
+    nd.start = ns;
+    nd.stop = ns + sz;
+    nodes_out[o] = nd;
+}
+
+__global__ void k_filter_kmers(const sw_kmer *__restrict__ kmers, const uint64_t *__restrict__ src_start,
+                               const uint64_t *__restrict__ dst_start, uint64_t n_kept, uint64_t n_out,
+                               sw_kmer *__restrict__ out)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_out) return;
+    uint64_t lo = 0, hi = n_kept;  // last kept node with dst_start <= j
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (dst_start[mid] <= j) lo = mid; else hi = mid;
+    }
+    out[j] = kmers[src_start[lo] + (j - dst_start[lo])];
+}
+
+// ---- checksums ------------------------------------------------------------------------------------------
+__host__ __device__ inline uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+
+__global__ void k_checksum(const sw_kmer *kmers, uint64_t nk, const sw_node *nodes, uint64_t nn, const sw_edge *edges,
+                           uint64_t ne, unsigned long long *sums)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t G = 0x9E3779B97F4A7C15ULL;
+    uint64_t a = 0, b = 0, c = 0;
+    if (i < nk) a = mix64(i * G + ((uint64_t)kmers[i].pos | ((uint64_t)kmers[i].record_idx << 32)));
+    if (i < nn)
+        b = mix64(i * G + nodes[i].hash) + mix64(nodes[i].start * 3 + 1) + mix64(nodes[i].stop * 5 + 2) +
+            mix64(((uint64_t)nodes[i].n_tar << 32 | nodes[i].n_neg) + 7);
+    if (i < ne) c = mix64(i * G + edges[i].first) + mix64(edges[i].second * 3 + 1) + mix64(edges[i].weight * 5 + 2);
+    for (int d = 32; d; d >>= 1) {
+        a += __shfl_down(a, d, 64);
+        b += __shfl_down(b, d, 64);
+        c += __shfl_down(c, d, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (a) atomicAdd(&sums[0], (unsigned long long)a);
+        if (b) atomicAdd(&sums[1], (unsigned long long)b);
+        if (c) atomicAdd(&sums[2], (unsigned long long)c);
+    }
+}
+
+}  // namespace
+
+void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out)
+{
+    out.n = sk.n_occ;
+    out.hash.alloc(out.n);
+    out.kmer.alloc(out.n);
+    if (plan.n_tiles == 0 || out.n == 0) return;
+    DevArray<uint64_t> dst_off(plan.n_tiles);
+    exclusive_sum(rocprim::make_transform_iterator(sk.tile_count.p, U32ToU64()), dst_off.p, plan.n_tiles,
+                  (uint64_t)0, stream);
+    const uint64_t threads = (uint64_t)plan.n_tiles * 64;
+    hipLaunchKernelGGL(k_order, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
+                       sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, out.hash.p, out.kmer.p);
+    SW_HIP(hipGetLastError());
+    SW_HIP(hipStreamSynchronize(stream));  // dst_off is released on return
+}
+
+void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
+                        const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,
+                        uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, uint64_t *err_flags_host)
+{
+    *err_flags_host = 0;
+    if (n_nodes == 0) return;
+    DevArray<uint64_t> X(n_kmers), Y(n_kmers);
+    DevArray<uint32_t> err(1);
+    SW_HIP(hipMemsetAsync(err.p, 0, 4, stream));
+    if (n_kmers) {
+        hipLaunchKernelGGL(k_pen_flags, dim3(blocks_for(n_kmers)), dim3(TPB), 0, stream, d_kmers, n_kmers, d_rec_asm,
+                           n_records, d_is_target, X.p, Y.p);
+        SW_HIP(hipGetLastError());
+        inclusive_sum(X.p, X.p, n_kmers, (uint64_t)0, stream);
+        inclusive_sum(Y.p, Y.p, n_kmers, (uint64_t)0, stream);
+    }
+    const double inv_tar = 1.0 / (double)n_targets;        // filter.cpp:89-90
+    const double inv_neg = 1.0 / (double)n_non_targets;
+    hipLaunchKernelGGL(k_pen_nodes, dim3(blocks_for(n_nodes)), dim3(TPB), 0, stream, d_kmers, n_kmers, d_nodes, n_nodes,
+                       d_rec_asm, n_records, d_is_target, X.p, Y.p, inv_tar, inv_neg, err.p);
+    SW_HIP(hipGetLastError());
+    uint32_t e = 0;
+    SW_HIP(hipMemcpyAsync(&e, err.p, 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    *err_flags_host = e;
+}
+
+void build_index(const sw_batch &b, const OrderedOcc &occ, const uint8_t *d_is_target, uint64_t n_targets,
+                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix)
+{
+    const uint64_t n = occ.n;
+    if (n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
+    hipEvent_t ev[4];
+    for (auto &e : ev) SW_HIP(hipEventCreate(&e));
+    SW_HIP(hipEventRecord(ev[0], stream));
+
+    ix.n_kmers = n;
+    ix.kmers.alloc(n);
+    DevArray<uint32_t> rank(n);
+    // -- nodes: stable radix sort of (out_hash -> original index), run-length heads ------------------
+    if (n) {
+        DevArray<uint64_t> k0(n), k1(n);
+        DevArray<uint32_t> v0(n), v1(n);
+        SW_HIP(hipMemcpyAsync(k0.p, occ.hash.p, n * 8, hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(k_iota, dim3(blocks_for(n)), dim3(TPB), 0, stream, v0.p, n);
+        uint64_t *keys = k0.p, *keys_alt = k1.p;
+        uint32_t *vals = v0.p, *vals_alt = v1.p;
+        sort_pairs(keys, keys_alt, vals, vals_alt, n, 0, 64, stream);
+        uint32_t *cum = vals_alt;  // reuse the spare value buffer for the inclusive head count
+        inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
+                                                       HeadFlag{keys, n}),
+                      cum, n, (uint32_t)0, stream);
+        uint32_t n_nodes = 0;
+        SW_HIP(hipMemcpyAsync(&n_nodes, cum + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));
+        ix.n_nodes = n_nodes;
+        ix.nodes.alloc(n_nodes);
+        hipLaunchKernelGGL(k_nodes, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, cum, occ.kmer.p, n,
+                           ix.kmers.p, ix.nodes.p, rank.p);
+        SW_HIP(hipGetLastError());
+        SW_HIP(hipStreamSynchronize(stream));  // sort buffers are released here
+    } else {
+        ix.n_nodes = 0;
+        ix.nodes.alloc(0);
+    }
+    SW_HIP(hipEventRecord(ev[1], stream));
+
+    // -- per-node target / non-target assembly counts + penalty (filter.cpp:62-136) -------------------
+    if (d_is_target && ix.n_nodes) {
+        uint64_t err = 0;
+        device_get_penalty(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, b.d_rec_asm.p, b.n_records, d_is_target, n_targets,
+                           n_non_targets, stream, &err);
+        if (err) raise(SW_ERR_RUNTIME, "internal error: inconsistent occurrence order in device index (%llu)",
+                       (unsigned long long)err);
+    }
+    SW_HIP(hipEventRecord(ev[2], stream));
+
+    // -- edges -----------------------------------------------------------------------------------------
+    ix.n_edges = 0;
+    if (n >= 2) {
+        const uint64_t m = n - 1;
+        unsigned nb = 1;
+        while (((1ull << nb) - 1ull) < ix.n_nodes) ++nb;  // n_nodes <= 2^nb - 1, so (2^nb-1, 2^nb-1) is free
+        const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
+        DevArray<uint64_t> k0(m), k1(m);
+        DevArray<uint32_t> v0(m), v1(m);
+        DevArray<unsigned long long> n_invalid(1);
+        SW_HIP(hipMemsetAsync(n_invalid.p, 0, 8, stream));
+        hipLaunchKernelGGL(k_adj, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, b.d_rec_asm.p, n, nb,
+                           sentinel, k0.p, v0.p, n_invalid.p);
+        SW_HIP(hipGetLastError());
+        uint64_t *keys = k0.p, *keys_alt = k1.p;
+        uint32_t *vals = v0.p, *vals_alt = v1.p;
+        sort_pairs(keys, keys_alt, vals, vals_alt, m, 0, 2 * nb, stream);
+        unsigned long long inv = 0;
+        SW_HIP(hipMemcpyAsync(&inv, n_invalid.p, 8, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));
+        const uint64_t n_valid = m - inv;
+        if (n_valid) {
+            DevArray<uint32_t> ecum(n_valid), ccum(n_valid);
+            inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
+                                                           HeadFlag{keys, n_valid}),
+                          ecum.p, n_valid, (uint32_t)0, stream);
+            inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
+                                                           AsmChangeFlag{keys, vals, n_valid}),
+                          ccum.p, n_valid, (uint32_t)0, stream);
+            uint32_t n_edges = 0;
+            SW_HIP(hipMemcpyAsync(&n_edges, ecum.p + (n_valid - 1), 4, hipMemcpyDeviceToHost, stream));
+            SW_HIP(hipStreamSynchronize(stream));
+            ix.n_edges = n_edges;
+            ix.edges.alloc(n_edges);
+            DevArray<uint64_t> edge_start(n_edges);
+            hipLaunchKernelGGL(k_edge_heads, dim3(blocks_for(n_valid)), dim3(TPB), 0, stream, keys, ecum.p, n_valid,
+                               edge_start.p);
+            hipLaunchKernelGGL(k_edges, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, keys, ccum.p, edge_start.p,
+                               (uint64_t)n_edges, n_valid, nb, ix.nodes.p, ix.edges.p);
+            SW_HIP(hipGetLastError());
+            SW_HIP(hipStreamSynchronize(stream));
+        }
+    }
+    if (ix.n_edges == 0) ix.edges.alloc(0);
+    SW_HIP(hipEventRecord(ev[3], stream));
+    SW_HIP(hipEventSynchronize(ev[3]));
+    float ms = 0.f;
+    SW_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    ix.timings.nodes_ms = ms;
+    SW_HIP(hipEventElapsedTime(&ms, ev[1], ev[2]));
+    ix.timings.counts_ms = ms;
+    SW_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
+    ix.timings.edges_ms = ms;
+    for (auto &e : ev) SW_HIP(hipEventDestroy(e));
+}
+
+void device_filter_kmers(const sw_kmer *d_kmers, uint64_t n_kmers, const sw_node *d_nodes, uint64_t n_nodes,
+                         const uint64_t *d_used_sorted, uint64_t n_used, hipStream_t stream,
+                         DevArray<sw_kmer> &kmers_out, DevArray<sw_node> &nodes_out, uint64_t *n_kmers_out,
+                         uint64_t *n_nodes_out)
+{
+    (void)n_kmers;
+    *n_kmers_out = 0;
+    *n_nodes_out = 0;
+    if (n_nodes == 0 || n_used == 0) {
+        kmers_out.alloc(0);
+        nodes_out.alloc(0);
+        return;
+    }
+    DevArray<uint32_t> keep(n_nodes), kcum(n_nodes);
+    DevArray<uint64_t> size(n_nodes), scum(n_nodes);
+    hipLaunchKernelGGL(k_filter_keep, dim3(blocks_for(n_nodes)), dim3(TPB), 0, stream, d_nodes, n_nodes, d_used_sorted,
+                       n_used, keep.p, size.p);
+    SW_HIP(hipGetLastError());
+    inclusive_sum(keep.p, kcum.p, n_nodes, (uint32_t)0, stream);
+    inclusive_sum(size.p, scum.p, n_nodes, (uint64_t)0, stream);
+    uint32_t n_kept = 0;
+    uint64_t n_out = 0;
+    SW_HIP(hipMemcpyAsync(&n_kept, kcum.p + (n_nodes - 1), 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipMemcpyAsync(&n_out, scum.p + (n_nodes - 1), 8, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    nodes_out.alloc(n_kept);
+    kmers_out.alloc(n_out);
+    *n_nodes_out = n_kept;
+    *n_kmers_out = n_out;
+    if (n_kept == 0) return;
+    DevArray<uint64_t> src_start(n_kept), dst_start(n_kept);
+    hipLaunchKernelGGL(k_filter_nodes, dim3(blocks_for(n_nodes)), dim3(TPB), 0, stream, d_nodes, n_nodes, keep.p, kcum.p,
+                       scum.p, nodes_out.p, src_start.p, dst_start.p);
+    if (n_out)
+        hipLaunchKernelGGL(k_filter_kmers, dim3(blocks_for(n_out)), dim3(TPB), 0, stream, d_kmers, src_start.p,
+                           dst_start.p, (uint64_t)n_kept, n_out, kmers_out.p);
+    SW_HIP(hipGetLastError());
+    SW_HIP(hipStreamSynchronize(stream));
+}
+
+void device_checksums(const sw_index &ix, hipStream_t stream, uint64_t *sums3)
+{
+    DevArray<unsigned long long> sums(3);
+    SW_HIP(hipMemsetAsync(sums.p, 0, 24, stream));
+    const uint64_t n = std::max(ix.n_kmers, std::max(ix.n_nodes, ix.n_edges));
+    if (n) {
+        hipLaunchKernelGGL(k_checksum, dim3(blocks_for(n)), dim3(TPB), 0, stream, ix.kmers.p, ix.n_kmers, ix.nodes.p,
+                           ix.n_nodes, ix.edges.p, ix.n_edges, sums.p);
+        SW_HIP(hipGetLastError());
+    }
+    unsigned long long h[3];
+    SW_HIP(hipMemcpyAsync(h, sums.p, 24, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    for (int i = 0; i < 3; ++i) sums3[i] = h[i];
+}
+
+}  // namespace sw

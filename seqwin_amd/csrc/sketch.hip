@@ -1,0 +1,494 @@
+// sketch.hip -- fused ntHash + sliding-window-minimizer kernel for gfx950 (wave64, LDS-staged).
+//
+// Replaces, for a whole batch of 2-bit packed records resident in HBM, the reference's per-record
+//   btllib::minimize_sequence   cpp/vendor/btllib/minimizer.cpp:53-90  (calc_minimizer :14-49)
+//   btllib::NtHash::roll/init   cpp/vendor/btllib/nthash_kmer.hpp:315-333, 491-511
+//   next_forward/reverse_hash   cpp/vendor/btllib/nthash_kmer.hpp:65-75, 145-155
+//   srol / sror / extend_hashes cpp/vendor/btllib/hashing_internals.hpp:29-35, 69-74, 89-103
+// and emits (out_hash, pos, record_idx) of every minimizer, the tuples build_worker consumes
+// (cpp/src/seqwin/build.cpp:151-168).
+//
+// Formulation.  Valid k-mers of a record are numbered idx = 0..n_valid-1 in
+// increasing position; windows are w consecutive idx values (they span N gaps exactly as the
+// reference's ring buffer does).  The reference emits the rightmost minimum of every window whenever its
+// position advances; because that position is monotone in the window index this equals "the set of
+// elements that are the rightmost minimum of at least one window", in position order.  A workgroup
+// owns one TILE = TW consecutive window ends of one record plus a halo of w earlier elements:
+//   phase 1  each of the 256 threads rolls ntHash over its own run of L consecutive k-mers
+//            (k-1 warm-up steps, then one LDS LUT lookup + ~35 integer VALU ops per base) and stores
+//            the 64-bit canonical hash of every element in LDS; it also keeps its run minimum and,
+//            walking back, the offset of the suffix minimum of its run from every element (1 byte).
+//   phase 2  every window [x, e] is (suffix of an earlier run from x) + (whole runs) + (prefix of the
+//            owning thread's run up to e): the thread streams its prefix minimum in registers, takes
+//            the whole-run part from <= w/L run minima and the suffix part from two LDS reads, and
+//            sets a bit for the winner (ds_or, idempotent -> duplicates vanish).
+//   phase 3  the bit of the minimizer of the window just before the tile is cleared (the previous
+//            tile owns it), bits are counted (workgroup scan), one 64-bit atomicAdd reserves the
+//            tile's output range and the tuples are written in position order.
+// Tiles land in allocation order; index.hip's order pass restores (record_idx, pos) order.
+#include <algorithm>
+
+#include "device.hpp"
+
+namespace sw {
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr uint32_t L_MAX = 33;  // 256*33 elements * 8 B = 66 KiB of hashes -> two workgroups per CU
+
+// hashing_internals.hpp:128-131
+constexpr uint64_t SEED_A = 0x3c8bfbb395c60474ULL, SEED_C = 0x3193c18562a02b4cULL,
+                   SEED_G = 0x20323ed082572324ULL, SEED_T = 0x295549f54be24456ULL;
+constexpr uint64_t MULTISEED = 0x90b45d39fb6da1faULL;  // :79
+
+uint64_t host_srol1(uint64_t x)  // hashing_internals.hpp:29-35
+{
+    uint64_t m = ((x & 0x8000000000000000ULL) >> 30) | ((x & 0x100000000ULL) >> 32);
+    return ((x << 1) & 0xFFFFFFFDFFFFFFFFULL) | m;
+}
+uint64_t host_srol(uint64_t x, unsigned d)
+{
+    for (d %= 1023u; d; --d) x = host_srol1(x);  // periods 33 and 31
+    return x;
+}
+
+struct SketchArgs {
+    const uint32_t *packed;
+    const uint64_t *rec_base;
+    const uint32_t *rec_seg_off;
+    const uint32_t *rec_nvalid;
+    const uint32_t *rec_tile_off;
+    const uint32_t *seg_pos;
+    const uint32_t *seg_idx;
+    const uint64_t *lut;
+    uint32_t n_records, k, w, L, TW, n_tiles;
+    uint64_t mult;
+    uint64_t *stage_hash;
+    uint64_t *stage_kmer;
+    unsigned long long *cursor;
+    uint64_t cap;
+    uint32_t *tile_count;
+    uint64_t *tile_offset;
+};
+
+// 2-bit base reader over the packed stream (16 bases per 32-bit word).
+struct BaseStream {
+    const uint32_t *wp;
+    uint32_t win;
+    uint32_t nleft;
+    __device__ __forceinline__ void init(const uint32_t *packed, uint64_t base)
+    {
+        wp = packed + (base >> 4);
+        const uint32_t ph = (uint32_t)base & 15u;
+        win = *wp++ >> (2u * ph);
+        nleft = 16u - ph;
+    }
+    __device__ __forceinline__ uint32_t next()
+    {
+        if (nleft == 0) {
+            win = *wp++;
+            nleft = 16;
+        }
+        const uint32_t c = win & 3u;
+        win >>= 2;
+        --nleft;
+        return c;
+    }
+};
+
+// Split-rotate the 64-bit value (hi:lo) left by one: bits [0,32] and [33,63] rotate separately
+// (hashing_internals.hpp:29-35), in 32-bit halves: 5 VALU ops.
+__device__ __forceinline__ void srol1(uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 31);  // (hi << 1) | (lo >> 31)
+    const uint32_t nlo = (lo << 1) | (hi & 1u);                 // old bit 32 -> bit 0
+    hi = (t & ~2u) | ((hi >> 30) & 2u);                         // old bit 63 -> bit 33
+    lo = nlo;
+}
+// Inverse (hashing_internals.hpp:69-74).
+__device__ __forceinline__ void sror1(uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t nlo = __builtin_amdgcn_alignbit(hi, lo, 1);  // (lo >> 1) | (hi << 31)
+    uint32_t t = hi >> 1;
+    t = (t & ~1u) | (lo & 1u);                                  // old bit 0 -> bit 32
+    hi = (t & 0x7FFFFFFFu) | ((hi << 30) & 0x80000000u);        // old bit 33 -> bit 63
+    lo = nlo;
+}
+
+__device__ __forceinline__ uint64_t make64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+__global__ __launch_bounds__(BLOCK, 2) void sketch_kernel(const SketchArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t L = A.L, NE = BLOCK * L, w = A.w, k = A.k;
+    uint64_t *H = reinterpret_cast<uint64_t *>(smem);         // [NE]    canonical hash of every element
+    uint64_t *RMh = H + NE;                                    // [BLOCK] run minimum (hash)
+    uint64_t *LUT = RMh + BLOCK;                               // [40]    roll tables, {F,R} interleaved
+    uint32_t *EM = reinterpret_cast<uint32_t *>(LUT + 40);     // [NE/32 + 2] emit bitmap
+    uint32_t *MISC = EM + (NE / 32 + 2);                       // [16]
+    uint16_t *RMp = reinterpret_cast<uint16_t *>(MISC + 16);   // [BLOCK] run minimum (element index)
+    uint8_t *SP = reinterpret_cast<uint8_t *>(RMp + BLOCK);    // [NE]    offset of the run-suffix minimum
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+
+    // ---- which record / which window range (uniform; scalar loads) ---------------------------
+    uint32_t lo = 0, hi = A.n_records;  // last r with rec_tile_off[r] <= tile
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (A.rec_tile_off[mid] <= tile) lo = mid; else hi = mid;
+    }
+    const uint32_t rec = lo;
+    const uint32_t t = tile - A.rec_tile_off[rec];
+    const uint32_t nvalid = A.rec_nvalid[rec];
+    const uint32_t I0 = (w - 1) + t * A.TW;                   // first window end (idx space)
+    const uint32_t I1 = min(I0 + A.TW, nvalid);               // one past the last window end
+    const uint32_t E0 = (t == 0) ? 0u : I0 - w;               // first element held by this tile
+    const uint32_t ne = I1 - E0;                              // elements held (<= NE)
+    const uint32_t e_first = I0 - E0;                         // tile-local index of the first owned window end
+    const uint32_t slo = A.rec_seg_off[rec], shi = A.rec_seg_off[rec + 1];
+    const uint64_t rbase = A.rec_base[rec];
+
+    for (uint32_t i = tid; i < NE / 32 + 2; i += BLOCK) EM[i] = 0;
+    if (tid < 40) LUT[tid] = A.lut[tid];
+    __syncthreads();
+
+    // ---- phase 1: roll ntHash over this thread's run of L elements ------------------------------
+    const uint32_t e0 = tid * L;
+    const uint32_t n = (e0 < ne) ? min(L, ne - e0) : 0u;
+    uint64_t rmin_h = ~0ull;
+    uint32_t rmin_e = e0;
+    if (n) {
+        uint32_t g = E0 + e0;
+        uint32_t s = slo;
+        {
+            uint32_t a = slo, b = shi;  // last segment with seg_idx <= g
+            while (b - a > 1) {
+                const uint32_t mid = (a + b) >> 1;
+                if (A.seg_idx[mid] <= g) a = mid; else b = mid;
+            }
+            s = a;
+        }
+        uint32_t e = e0, rem = n;
+        while (rem) {
+            const uint32_t sidx = A.seg_idx[s];
+            const uint32_t send = (s + 1 < shi) ? A.seg_idx[s + 1] : nvalid;
+            const uint32_t pos = A.seg_pos[s] + (g - sidx);
+            const uint32_t cnt = min(rem, send - g);
+            if (cnt == 0) break;  // cannot happen with a well-formed plan; never spin
+            const uint64_t b0 = rbase + pos;
+            BaseStream in;
+            in.init(A.packed, b0);
+            uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0;
+            // warm-up: k steps without an outgoing base (base_forward/reverse_hash, nthash_kmer.hpp:22-54,104-133)
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint32_t idx = 16u | in.next();
+                const uint64_t lf = LUT[2 * idx], lr = LUT[2 * idx + 1];
+                srol1(flo, fhi);
+                flo ^= (uint32_t)lf;
+                fhi ^= (uint32_t)(lf >> 32);
+                rlo ^= (uint32_t)lr;
+                rhi ^= (uint32_t)(lr >> 32);
+                sror1(rlo, rhi);
+            }
+            {
+                const uint64_t h = make64(flo, fhi) + make64(rlo, rhi);  // canonical(), hashing_internals.hpp:12-17
+                H[e] = h;
+                if (h <= rmin_h) { rmin_h = h; rmin_e = e; }
+            }
+            if (cnt > 1) {
+                BaseStream out;
+                out.init(A.packed, b0);
+                for (uint32_t j = 1; j < cnt; ++j) {
+                    // next_forward_hash / next_reverse_hash (nthash_kmer.hpp:65-75,145-155) with the
+                    // (in, out) seed pair folded into one 16-entry LUT by XOR-linearity
+                    const uint32_t idx = in.next() | (out.next() << 2);
+                    const uint64_t lf = LUT[2 * idx], lr = LUT[2 * idx + 1];
+                    srol1(flo, fhi);
+                    flo ^= (uint32_t)lf;
+                    fhi ^= (uint32_t)(lf >> 32);
+                    rlo ^= (uint32_t)lr;
+                    rhi ^= (uint32_t)(lr >> 32);
+                    sror1(rlo, rhi);
+                    const uint64_t h = make64(flo, fhi) + make64(rlo, rhi);
+                    H[e + j] = h;
+                    if (h <= rmin_h) { rmin_h = h; rmin_e = e + j; }
+                }
+            }
+            g += cnt;
+            e += cnt;
+            rem -= cnt;
+            ++s;
+        }
+        // suffix minima of the run, rightmost on ties (strict '<' walking right to left)
+        uint64_t cur = 0;
+        uint32_t off = 0;
+        for (uint32_t j = n; j-- > 0;) {
+            const uint64_t h = H[e0 + j];
+            if (j == n - 1 || h < cur) { cur = h; off = j; }
+            SP[e0 + j] = (uint8_t)off;
+        }
+    }
+    RMh[tid] = rmin_h;
+    RMp[tid] = (uint16_t)rmin_e;
+    __syncthreads();
+
+    // ---- phase 2: rightmost minimum of every window ending in this thread's run ------------------
+    if (n && e0 + n > w - 1) {
+        const uint32_t j0 = (e0 >= w - 1) ? 0u : (w - 1 - e0);
+        const uint32_t x0 = e0 + j0 - (w - 1);
+        const uint32_t rxA = x0 / L;
+        const uint32_t bnd = (rxA + 1) * L;
+        uint64_t mA_h = ~0ull, mB_h = ~0ull;
+        uint32_t mA_e = 0, mB_e = 0;
+        if (rxA < tid) {
+            for (uint32_t r = tid; r-- > rxA + 2;) {  // whole runs rxA+2 .. tid-1, right to left
+                const uint64_t h = RMh[r];
+                if (h < mB_h) { mB_h = h; mB_e = RMp[r]; }
+            }
+            mA_h = mB_h;
+            mA_e = mB_e;
+            if (rxA + 1 < tid) {
+                const uint64_t h = RMh[rxA + 1];
+                if (h < mA_h) { mA_h = h; mA_e = RMp[rxA + 1]; }
+            }
+        }
+        uint64_t pre_h = ~0ull;
+        uint32_t pre_e = e0;
+        uint32_t prev_arg = 0xFFFFFFFFu;
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t e = e0 + j;
+            const uint64_t h = H[e];
+            if (h <= pre_h) { pre_h = h; pre_e = e; }   // '<=': rightmost wins (minimizer.cpp:36,40)
+            if (j < j0) continue;
+            const uint32_t x = e - (w - 1);
+            uint64_t ch = pre_h;
+            uint32_t ce = pre_e;
+            if (x < e0) {
+                const bool inB = x >= bnd;
+                const uint64_t mh = inB ? mB_h : mA_h;
+                const uint32_t me = inB ? mB_e : mA_e;
+                if (mh < ch) { ch = mh; ce = me; }       // parts further left win only if strictly smaller
+                const uint32_t se = (inB ? bnd : bnd - L) + SP[x];
+                const uint64_t sh = H[se];
+                if (sh < ch) { ch = sh; ce = se; }
+            }
+            if (e < e_first) {
+                MISC[0] = ce;  // minimizer of the window just before this tile: owned by the previous tile
+            } else if (ce != prev_arg && ch != ~0ull) {  // minimizer.cpp:44-45
+                atomicOr(&EM[ce >> 5], 1u << (ce & 31u));
+            }
+            prev_arg = ce;
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && t != 0) {
+        const uint32_t sarg = MISC[0];
+        EM[sarg >> 5] &= ~(1u << (sarg & 31u));
+    }
+    __syncthreads();
+
+    // ---- phase 3: compact the set bits in position order ------------------------------------------
+    uint64_t bits = 0;
+    if (n) {
+        const uint32_t wd = e0 >> 5, sh = e0 & 31u;
+        const uint64_t two = (uint64_t)EM[wd] | ((uint64_t)EM[wd + 1] << 32);
+        bits = (two >> sh) & ((n >= 64) ? ~0ull : ((1ull << n) - 1ull));
+    }
+    const uint32_t cnt = (uint32_t)__popcll(bits);
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t incl = cnt;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) MISC[4 + wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+    for (uint32_t i = 0; i < BLOCK / 64; ++i) {
+        const uint32_t v = MISC[4 + i];
+        if (i < wave) wave_off += v;
+        total += v;
+    }
+    if (tid == 0) {
+        const unsigned long long base = atomicAdd(A.cursor, (unsigned long long)total);
+        A.tile_count[tile] = total;
+        A.tile_offset[tile] = base;
+        MISC[8] = (uint32_t)base;
+        MISC[9] = (uint32_t)(base >> 32);
+    }
+    __syncthreads();
+    const uint64_t base = make64(MISC[8], MISC[9]);
+    if (cnt && base + total <= A.cap) {
+        uint64_t o = base + wave_off + (incl - cnt);
+        while (bits) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(bits);
+            bits &= bits - 1;
+            const uint32_t e = e0 + j;
+            const uint32_t g = E0 + e;
+            uint32_t a = slo, b = shi;
+            while (b - a > 1) {
+                const uint32_t mid = (a + b) >> 1;
+                if (A.seg_idx[mid] <= g) a = mid; else b = mid;
+            }
+            const uint32_t pos = A.seg_pos[a] + (g - A.seg_idx[a]);
+            uint64_t oh = H[e] * A.mult;  // extend_hashes, hashing_internals.hpp:89-103
+            oh ^= oh >> 27;
+            A.stage_hash[o] = oh;
+            A.stage_kmer[o] = (uint64_t)pos | ((uint64_t)rec << 32);
+            ++o;
+        }
+    }
+}
+
+size_t lds_bytes_for(uint32_t L)
+{
+    const size_t NE = (size_t)BLOCK * L;
+    return NE * 8 + BLOCK * 8 + 40 * 8 + (NE / 32 + 2) * 4 + 16 * 4 + BLOCK * 2 + NE;
+}
+
+}  // namespace
+
+Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
+{
+    check_kw(k64, w64);
+    const uint32_t k = (uint32_t)k64, w = (uint32_t)w64;
+    std::lock_guard<std::mutex> lock(b.plan_mu);
+    auto key = std::make_pair(k, w);
+    auto it = b.plans.find(key);
+    if (it != b.plans.end()) return it->second;
+
+    Plan p;
+    p.k = k;
+    p.w = w;
+    uint32_t L = std::min<uint32_t>(w, L_MAX);
+    if ((L & 1u) == 0) --L;  // odd: conflict-free 64-bit LDS accesses at stride L
+    p.L = L;
+    p.NE = BLOCK * L;
+    p.TW = p.NE - w;
+    p.lds_bytes = lds_bytes_for(L);
+    p.mult = 1ULL ^ ((uint64_t)k * MULTISEED);
+
+    const HostBatch &h = b.host;
+    const size_t R = h.rec_len.size();
+    std::vector<uint32_t> rec_seg_off(R + 1, 0), rec_nvalid(R, 0), rec_tile_off(R + 1, 0), seg_pos, seg_idx;
+    uint64_t tiles = 0;
+    for (size_t r = 0; r < R; ++r) {
+        rec_seg_off[r] = (uint32_t)seg_pos.size();
+        rec_tile_off[r] = (uint32_t)tiles;
+        uint64_t nv = 0;
+        for (uint32_t q = h.rec_run_off[r]; q < h.rec_run_off[r + 1]; ++q) {
+            if (h.run_len[q] < k) continue;
+            seg_pos.push_back(h.run_pos[q]);
+            seg_idx.push_back((uint32_t)nv);
+            nv += h.run_len[q] - k + 1;
+        }
+        rec_nvalid[r] = (uint32_t)nv;
+        p.n_valid += nv;
+        // minimize_sequence's guard (minimizer.cpp:56-58) is implied: n_valid <= len-k+1
+        if (nv >= w) {
+            const uint64_t windows = nv - w + 1;
+            p.n_windows += windows;
+            tiles += (windows + p.TW - 1) / p.TW;
+        }
+        if (tiles > 0x7FFFFFFFull) raise(SW_ERR_RUNTIME, "batch too large: more than 2^31-1 tiles");
+    }
+    rec_seg_off[R] = (uint32_t)seg_pos.size();
+    rec_tile_off[R] = (uint32_t)tiles;
+    p.n_tiles = (uint32_t)tiles;
+
+    uint64_t lut[40];
+    const uint64_t S[4] = {SEED_A, SEED_C, SEED_G, SEED_T};
+    uint64_t Sk[4];
+    for (int c = 0; c < 4; ++c) Sk[c] = host_srol(S[c], k);  // srol_table(c, k), hashing_internals.hpp:347-352
+    for (int out = 0; out < 5; ++out)
+        for (int in = 0; in < 4; ++in) {
+            const int idx = in | (out << 2);
+            lut[2 * idx] = S[in] ^ (out < 4 ? Sk[out] : 0);              // forward: + S[in] + srol^k(S[out])
+            lut[2 * idx + 1] = Sk[3 - in] ^ (out < 4 ? S[3 - out] : 0);  // reverse, before the sror
+        }
+
+    auto up32 = [](DevArray<uint32_t> &d, const std::vector<uint32_t> &v) {
+        d.alloc(v.size());
+        if (!v.empty()) SW_HIP(hipMemcpy(d.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    };
+    up32(p.rec_seg_off, rec_seg_off);
+    up32(p.rec_nvalid, rec_nvalid);
+    up32(p.rec_tile_off, rec_tile_off);
+    up32(p.seg_pos, seg_pos);
+    up32(p.seg_idx, seg_idx);
+    p.lut.alloc(40);
+    SW_HIP(hipMemcpy(p.lut.p, lut, sizeof lut, hipMemcpyHostToDevice));
+    return b.plans.emplace(key, std::move(p)).first->second;
+}
+
+void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchOut &out, float *sketch_ms)
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        SW_HIP(hipFuncSetAttribute((const void *)sketch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_bytes_for(L_MAX)));
+    });
+    out.n_occ = 0;
+    out.launches = 0;
+    if (sketch_ms) *sketch_ms = 0.f;
+    out.tile_count.alloc(plan.n_tiles);
+    out.tile_offset.alloc(plan.n_tiles);
+    if (plan.n_tiles == 0) return;
+
+    DevArray<unsigned long long> cursor(1);
+    // expected density 2/(w+1) per window; grow and re-run in the (rare) overflow case
+    uint64_t cap = std::min<uint64_t>(plan.n_windows,
+                                      plan.n_windows / (plan.w + 1) * 3 + (uint64_t)plan.n_tiles * 4 + 4096);
+    hipEvent_t ev0, ev1;
+    SW_HIP(hipEventCreate(&ev0));
+    SW_HIP(hipEventCreate(&ev1));
+    for (;;) {
+        out.stage_hash.alloc(cap);
+        out.stage_kmer.alloc(cap);
+        SW_HIP(hipMemsetAsync(cursor.p, 0, sizeof(unsigned long long), stream));
+        SketchArgs a;
+        a.packed = b.d_packed.p;
+        a.rec_base = b.d_rec_base.p;
+        a.rec_seg_off = plan.rec_seg_off.p;
+        a.rec_nvalid = plan.rec_nvalid.p;
+        a.rec_tile_off = plan.rec_tile_off.p;
+        a.seg_pos = plan.seg_pos.p;
+        a.seg_idx = plan.seg_idx.p;
+        a.lut = plan.lut.p;
+        a.n_records = (uint32_t)b.n_records;
+        a.k = plan.k;
+        a.w = plan.w;
+        a.L = plan.L;
+        a.TW = plan.TW;
+        a.n_tiles = plan.n_tiles;
+        a.mult = plan.mult;
+        a.stage_hash = out.stage_hash.p;
+        a.stage_kmer = out.stage_kmer.p;
+        a.cursor = cursor.p;
+        a.cap = cap;
+        a.tile_count = out.tile_count.p;
+        a.tile_offset = out.tile_offset.p;
+        SW_HIP(hipEventRecord(ev0, stream));
+        hipLaunchKernelGGL(sketch_kernel, dim3(plan.n_tiles), dim3(BLOCK), plan.lds_bytes, stream, a);
+        SW_HIP(hipGetLastError());
+        SW_HIP(hipEventRecord(ev1, stream));
+        unsigned long long total = 0;
+        SW_HIP(hipMemcpyAsync(&total, cursor.p, sizeof total, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));
+        float ms = 0.f;
+        SW_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        if (sketch_ms) *sketch_ms += ms;
+        ++out.launches;
+        if (total <= cap) {
+            out.n_occ = total;
+            break;
+        }
+        cap = total;  // exact size is now known
+    }
+    SW_HIP(hipEventDestroy(ev0));
+    SW_HIP(hipEventDestroy(ev1));
+}
+
+}  // namespace sw

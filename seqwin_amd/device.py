@@ -1,0 +1,168 @@
+"""Device-resident pipeline: batches of 2-bit packed assemblies in HBM and indexes built from them.
+
+Thin object wrappers over the ``sw_batch_*`` / ``sw_index_*`` / ``sw_sketch`` entry points of
+include/seqwin_hip.h.  This is what ``sw_build`` is made of; bench.py and the multi-GPU driver use it
+directly so that the timed region starts with inputs already resident in HBM.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from ._core import EDGE_DTYPE, KMER_DTYPE, NODE_DTYPE, _ptr, _split_ids
+from ._lib import Timings, c_u64, c_vp, check, lib
+
+
+def device_count() -> int:
+    return int(lib.sw_device_count())
+
+
+def set_device(device: int) -> None:
+    check(lib.sw_set_device(ctypes.c_int(device)))
+
+
+class Batch:
+    """A set of assemblies, 2-bit packed and resident on the current device."""
+
+    def __init__(self, handle: c_vp):
+        self._h = handle
+
+    @classmethod
+    def from_fasta(cls, assembly_paths, n_cpu: int = 1) -> "Batch":
+        paths = [os.fsencode(str(p)) for p in assembly_paths]
+        arr = (ctypes.c_char_p * max(len(paths), 1))(*paths)
+        h = c_vp()
+        check(lib.sw_batch_from_fasta(arr, ctypes.c_size_t(len(paths)), c_u64(n_cpu), ctypes.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def synthetic(cls, n_genomes: int, records_per_genome: int, record_len: int, n_ancestors: int = 1,
+                  snp_ppm: int = 10000, seed: int = 1) -> "Batch":
+        h = c_vp()
+        check(lib.sw_batch_synthetic(c_u64(n_genomes), c_u64(records_per_genome), c_u64(record_len),
+                                     c_u64(n_ancestors), c_u64(snp_ppm), c_u64(seed), ctypes.byref(h)))
+        return cls(h)
+
+    def info(self) -> dict:
+        v = [c_u64() for _ in range(4)]
+        check(lib.sw_batch_info(self._h, *[ctypes.byref(x) for x in v]))
+        return dict(n_assemblies=v[0].value, n_records=v[1].value, total_bp=v[2].value, device_bytes=v[3].value)
+
+    def records(self):
+        """(record_offsets, ids_by_assembly)"""
+        na = self.info()["n_assemblies"]
+        offs = np.empty(na + 1, np.uint32)
+        nb = c_u64()
+        check(lib.sw_batch_records(self._h, _ptr(offs), None, c_u64(0), ctypes.byref(nb)))
+        blob = ctypes.create_string_buffer(max(nb.value, 1))
+        check(lib.sw_batch_records(self._h, _ptr(offs), blob, c_u64(nb.value), ctypes.byref(nb)))
+        return offs, _split_ids(blob.raw[:nb.value], offs)
+
+    def record(self, record_idx: int) -> bytes:
+        n = c_u64()
+        check(lib.sw_batch_record(self._h, c_u64(record_idx), None, c_u64(0), ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(max(n.value, 1))
+        check(lib.sw_batch_record(self._h, c_u64(record_idx), buf, c_u64(n.value), ctypes.byref(n)))
+        return buf.raw[:n.value]
+
+    def sketch(self, kmerlen: int, windowsize: int, stream: int = 0):
+        """All minimizers in (record_idx, pos) order: (out_hash[u64], kmers[KMER_DTYPE])."""
+        n = c_u64()
+        check(lib.sw_sketch(self._h, c_u64(kmerlen), c_u64(windowsize), c_vp(stream), None, None, c_u64(0),
+                            ctypes.byref(n)))
+        oh = np.empty(n.value, np.uint64)
+        km = np.empty(n.value, KMER_DTYPE)
+        check(lib.sw_sketch(self._h, c_u64(kmerlen), c_u64(windowsize), c_vp(stream), _ptr(oh), _ptr(km),
+                            c_u64(n.value), ctypes.byref(n)))
+        return oh, km
+
+    def build_index(self, kmerlen: int, windowsize: int, is_targets=None, stream: int = 0) -> "Index":
+        h = c_vp()
+        if is_targets is None:
+            tar, n = None, 0
+        else:
+            t = np.ascontiguousarray(np.asarray(is_targets, np.bool_)).view(np.uint8)
+            tar, n = _ptr(t), len(t)
+        check(lib.sw_index_build(self._h, c_u64(kmerlen), c_u64(windowsize), tar, c_u64(n), c_vp(stream),
+                                 ctypes.byref(h)))
+        return Index(h)
+
+    def close(self) -> None:
+        if self._h:
+            lib.sw_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Index:
+    """kmers / nodes / edges of a batch, resident on the device."""
+
+    def __init__(self, handle: c_vp):
+        self._h = handle
+
+    def sizes(self):
+        v = [c_u64() for _ in range(3)]
+        check(lib.sw_index_sizes(self._h, *[ctypes.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def timings(self) -> dict:
+        t = Timings()
+        check(lib.sw_index_timings(self._h, ctypes.byref(t)))
+        return {name: getattr(t, name) for name, _ in Timings._fields_}
+
+    def export(self):
+        nk, nn, ne = self.sizes()
+        kmers = np.empty(nk, KMER_DTYPE)
+        nodes = np.empty(nn, NODE_DTYPE)
+        edges = np.empty(ne, EDGE_DTYPE)
+        check(lib.sw_index_export(self._h, _ptr(kmers), _ptr(nodes), _ptr(edges)))
+        return kmers, nodes, edges
+
+    def checksums(self):
+        v = [c_u64() for _ in range(3)]
+        check(lib.sw_index_checksums(self._h, *[ctypes.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def close(self) -> None:
+        if self._h:
+            lib.sw_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_G = np.uint64(0x9E3779B97F4A7C15)
+
+
+def _mix64(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint64, copy=True)
+    x ^= x >> np.uint64(30); x *= np.uint64(0xbf58476d1ce4e5b9)
+    x ^= x >> np.uint64(27); x *= np.uint64(0x94d049bb133111eb)
+    x ^= x >> np.uint64(31)
+    return x
+
+
+def host_checksums(kmers, nodes, edges):
+    """numpy restatement of sw_index_checksums (index.hip:k_checksum) for host arrays."""
+    with np.errstate(over="ignore"):
+        i = np.arange(len(kmers), dtype=np.uint64)
+        a = _mix64(i * _G + (kmers["pos"].astype(np.uint64) | (kmers["record_idx"].astype(np.uint64) << np.uint64(32)))).sum(dtype=np.uint64)
+        i = np.arange(len(nodes), dtype=np.uint64)
+        b = (_mix64(i * _G + nodes["hash"]) + _mix64(nodes["start"].astype(np.uint64) * np.uint64(3) + np.uint64(1)) +
+             _mix64(nodes["stop"].astype(np.uint64) * np.uint64(5) + np.uint64(2)) +
+             _mix64(((nodes["n_tar"].astype(np.uint64) << np.uint64(32)) | nodes["n_neg"].astype(np.uint64)) + np.uint64(7))).sum(dtype=np.uint64)
+        i = np.arange(len(edges), dtype=np.uint64)
+        c = (_mix64(i * _G + edges["first"]) + _mix64(edges["second"] * np.uint64(3) + np.uint64(1)) +
+             _mix64(edges["weight"].astype(np.uint64) * np.uint64(5) + np.uint64(2))).sum(dtype=np.uint64)
+    return int(a), int(b), int(c)

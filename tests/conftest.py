@@ -1,0 +1,49 @@
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir() -> Path:
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def manifest() -> dict:
+    return json.loads((GOLDEN / "manifest.json").read_text())
+
+
+@pytest.fixture(scope="session")
+def smoke_paths() -> list[Path]:
+    s = GOLDEN / "smoke"
+    return [s / "targets/target-1.fasta", s / "targets/target-2.fasta",
+            s / "non-targets/non-target-1.fasta", s / "non-targets/non-target-2.fasta"]
+
+
+def load_case(case: dict):
+    z = np.load(GOLDEN / "vectors" / f"{case['name']}.npz")
+    paths = [GOLDEN / p for p in case["paths"]]
+    return paths, z
+
+
+def assert_graph_equal(got, exp_npz, ids=None):
+    kmers, nodes, edges, offs, rec_ids = got
+    assert kmers.dtype == exp_npz["kmers"].dtype and np.array_equal(kmers, exp_npz["kmers"])
+    assert nodes.dtype == exp_npz["nodes"].dtype and np.array_equal(nodes, exp_npz["nodes"])
+    assert edges.dtype == exp_npz["edges"].dtype and np.array_equal(edges, exp_npz["edges"])
+    assert offs.dtype == np.uint32 and np.array_equal(offs, exp_npz["record_offsets"])
+    if ids is not None:
+        assert [list(t) for t in rec_ids] == ids
