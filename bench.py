@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- Gbp/s of the minimizer-index build on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over the synthetic genome set, with the 2-bit packed
+contigs and record tables already resident in HBM: fused ntHash + window-minimizer sketch -> tuple
+ordering -> nodes / kmers (radix sort + run-length) -> per-node target / non-target assembly counts
+and penalty -> adjacency edges; for N > 1 additionally the merge of the per-GPU partial graphs over
+RCCL (seqwin_amd/dist.py).  Default workload = BASELINE.json configs[1]'s stand-in:
+512 genomes x 4.8 Mbp (50 contigs each) from 5 ancestors with 1 % substitutions, k=21, w=200, per GPU
+(weak scaling).  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WORKLOADS = {
+    # name: (genomes per GPU, records per genome, record length, ancestors, snp ppm)
+    "salmonella500": (512, 50, 96_000, 5, 10_000),       # configs[1] stand-in, 2.46 Gbp per GPU
+    "bacteria15k": (15_000, 50, 100_000, 30, 10_000),    # configs[2], 75 Gbp on one GPU
+    "random": (2_000, 1, 5_000_000, 2_000, 0),           # configs[4] slice: iid-uniform genomes, 10 Gbp
+    "tiny": (16, 4, 50_000, 2, 10_000),
+}
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(batch, k, w, n_genomes_sample, is_targets):
+    """Time the reference CPU path (oracle/_ref, kind 'reference'; else the C restatement, kind 'port') on a
+    bounded sample of the same workload, FASTA files on local disk -> final arrays incl. get_penalty."""
+    import numpy as np
+
+    import oracle
+    offs, ids = batch.records()
+    n = min(n_genomes_sample, len(offs) - 1)
+    tmp = tempfile.mkdtemp(prefix="seqwin_cpu_")
+    paths, bp = [], 0
+    for a in range(n):
+        p = os.path.join(tmp, f"g{a}.fa")
+        with open(p, "wb") as f:
+            for r in range(int(offs[a]), int(offs[a + 1])):
+                seq = batch.record(r)
+                bp += len(seq)
+                f.write(b">" + ids[a][r - int(offs[a])].encode() + b"\n" + seq + b"\n")
+        paths.append(p)
+    tar = np.asarray(is_targets[:n], np.bool_).copy()
+    if tar.all() or not tar.any():
+        tar[: n // 2] = True
+        tar[n // 2:] = False
+    cores = os.cpu_count() or 1
+    ref = oracle.load_ref()
+    t0 = time.perf_counter()
+    if ref is not None:
+        kind, used = "reference", min(cores, n)
+        kmers, nodes, edges, ro, _ = ref._build_native(paths, k, w, cores, False)
+        ref._get_penalty_native(kmers, nodes, ro, tar, cores)
+    else:
+        kind, used = "port", 1
+        kmers, nodes, edges, ro, _ = oracle.build(paths, k, w)
+        oracle.get_penalty(kmers, nodes, ro, tar)
+    dt = time.perf_counter() - t0
+    for p in paths:
+        os.unlink(p)
+    os.rmdir(tmp)
+    return {"value": round(bp / dt / 1e9, 4), "unit": "Gbp/s", "cores": used, "kind": kind,
+            "sample": f"first {n} genomes of the workload ({bp / 1e6:.0f} Mbp) as plain FASTA on local disk -> "
+                      f"kmers/nodes/edges + get_penalty, wall {dt:.2f} s, n_cpu={cores}",
+            "n_kmers": int(len(kmers)), "n_nodes": int(len(nodes)), "n_edges": int(len(edges))}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="salmonella500", choices=sorted(WORKLOADS))
+    ap.add_argument("-k", "--kmerlen", type=int, default=21)
+    ap.add_argument("-w", "--windowsize", type=int, default=200)
+    ap.add_argument("--cpu-sample-genomes", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from seqwin_amd.device import Batch, set_device
+    set_device(local_rank)
+
+    G, rpg, rl, anc, snp = WORKLOADS[args.workload]
+    k, w = args.kmerlen, args.windowsize
+    # weak scaling: every rank holds its own G genomes (assemblies [rank*G, (rank+1)*G) of the job)
+    batch = Batch.synthetic(G, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=20260821 + rank)
+    is_targets_global = np.arange(G * world) % 2 == 0
+    my_targets = is_targets_global[rank * G:(rank + 1) * G]
+    bp_rank = G * rpg * rl
+
+    if world > 1:
+        from seqwin_amd import dist as swdist
+        shard = swdist.Shard(batch, first_assembly=rank * G, n_assemblies_total=G * world)
+
+        def step():
+            return swdist.build_sharded_index(shard, k, w, is_targets_global)
+    else:
+        def step():
+            return batch.build_index(k, w, my_targets)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ix = None
+    for _ in range(args.warmup):
+        ix = step()
+    fence()
+    stage = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ix = step()
+        for key, v in ix.timings().items():
+            if key.endswith("_ms"):
+                stage[key] = stage.get(key, 0.0) + v
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    nk, nn, ne = ix.sizes()
+    tm = ix.timings()
+    counts = torch.tensor([nk, nn, ne], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counts)
+    n_occ_local = tm.get("n_occ_local", nk) if world > 1 else nk
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        total_bp = bp_rank * world
+        value = total_bp / (dt / args.steps) / 1e9
+        stage = {key: v / args.steps for key, v in stage.items()}
+        # dominant kernel = sketch_kernel (one launch per step per GPU).  Algorithmic bytes per launch
+        # (DESIGN.md section 5): read the 2-bit input once + write one 16 B tuple per minimizer.
+        sk_bytes = 0.25 * bp_rank + 16.0 * n_occ_local
+        sk_ms = stage["sketch_ms"]
+        achieved = sk_bytes / (sk_ms * 1e-3) / 1e9
+        # whole path, SURVEY 8d: 0.25 N_bp + 40 N_occ + 40 N_adj + 40 N_node + 24 N_edge  (N_adj ~= N_occ)
+        tot = counts.tolist()
+        path_bytes = 0.25 * total_bp + 80.0 * tot[0] + 40.0 * tot[1] + 24.0 * tot[2]
+        out = {
+            "metric": "Gbp/s minimizer-indexed", "value": round(value, 3), "unit": "Gbp/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {G} genomes/GPU x {rpg} contigs x {rl} bp "
+                                   f"({anc} ancestors, {snp / 1e4:g}% substitutions), on-device generator",
+                       "genomes": G * world, "mean_bp": rpg * rl, "k": k, "w": w,
+                       "parallelism": f"assembly-sharded x{world}" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "sketch_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(sk_bytes), "avg_launch_ms": round(sk_ms, 4),
+                         "note": "integer-VALU bound at w=200 (DESIGN.md section 5); measured HBM traffic is in profiles/",
+                         "path_achieved_GBs": round(path_bytes / world / (dt / args.steps) / 1e9, 2),
+                         "sketch_Gbp_per_s_per_gpu": round(bp_rank / (sk_ms * 1e-3) / 1e9, 2)},
+            "stages_ms": {key: round(v, 4) for key, v in stage.items()},
+            "counts": {"kmers": tot[0], "nodes": tot[1], "edges": tot[2]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(batch, k, w, args.cpu_sample_genomes, my_targets)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,19 @@ int sw_filter_kmers(const sw_kmer *kmers, uint64_t n_kmers, const sw_node *nodes
                     const uint64_t *used_hashes, uint64_t n_used, sw_kmer *kmers_out, sw_node *nodes_out,
                     uint64_t *n_kmers_out, uint64_t *n_nodes_out);
 
+/* ---- host ingest only (no GPU needed; used by the CPU test-suite to check the FASTA reader / packer) */
+typedef struct sw_hostbatch sw_hostbatch;
+/* Read + 2-bit pack FASTA / .gz files exactly as sw_build / sw_batch_from_fasta do
+ * (replaces read_fasta, cpp/src/utils/fasta_reader.cpp:207-213), without uploading. */
+int sw_host_ingest(const char *const *assembly_paths, size_t n_assemblies, uint64_t n_cpu, sw_hostbatch **out);
+int sw_hostbatch_info(const sw_hostbatch *hb, uint64_t *n_assemblies, uint64_t *n_records, uint64_t *total_bp,
+                      uint64_t *ids_bytes, uint64_t *n_runs);
+/* record_offsets[n_assemblies + 1], ids blob, rec_len[n_records] (any may be NULL) */
+int sw_hostbatch_tables(const sw_hostbatch *hb, uint32_t *record_offsets, char *ids_blob, uint32_t *rec_len);
+/* Decode record `record_idx` back to ASCII (A/C/G/T; 'N' for every invalid base). */
+int sw_hostbatch_record(const sw_hostbatch *hb, uint64_t record_idx, char *seq_out, uint64_t cap, uint64_t *len_out);
+void sw_hostbatch_free(sw_hostbatch *hb);
+
 /* ---- device-resident pipeline (what sw_build is made of; used by bench.py and multi-GPU) --- */
 
 #define SW_MAX_WINDOW 4096u

@@ -160,3 +160,16 @@ def filter_kmers(kmers, nodes, used_hashes):
     _check(lib().so_filter_kmers(*args, ko.ctypes.data_as(ctypes.c_void_p), no.ctypes.data_as(ctypes.c_void_p),
                                  ctypes.byref(nk), ctypes.byref(nn)))
     return ko, no
+
+
+def read_fasta(path):
+    """read_fasta (cpp/src/utils/fasta_reader.cpp:207-213): list of (id, sequence bytes).
+    Sequences containing NUL bytes are not representable through this helper."""
+    blob = ctypes.c_void_p(); n = ctypes.c_size_t(); nrec = ctypes.c_size_t()
+    _check(lib().so_read_fasta(os.fsencode(str(path)), ctypes.byref(blob), ctypes.byref(n), ctypes.byref(nrec)))
+    try:
+        raw = ctypes.string_at(blob, n.value)
+    finally:
+        lib().so_free(blob)
+    parts = raw.split(b"\0")[:-1] if n.value else []
+    return [(parts[2 * i].decode("utf-8", "replace"), parts[2 * i + 1]) for i in range(nrec.value)]

@@ -501,6 +501,34 @@ static int read_fasta(const char *path, recvec_t *out)
     return rc;
 }
 
+/* C-ABI: parse one FASTA file; returns NUL-terminated ids and sequences back to back
+ * (id0 \0 seq0 \0 id1 \0 seq1 \0 ...) in a malloc'd blob the caller frees with so_free. */
+int so_read_fasta(const char *path, char **blob_out, size_t *blob_len, size_t *n_records)
+{
+    recvec_t recs = {0};
+    int rc = read_fasta(path, &recs);
+    if (rc) { recvec_free(&recs); return rc; }
+    size_t total = 0;
+    for (size_t i = 0; i < recs.n; ++i) total += strlen(recs.v[i].id) + 1 + recs.v[i].len + 1;
+    char *blob = (char *)malloc(total ? total : 1);
+    if (!blob) { recvec_free(&recs); return fail(SO_ERR_RUNTIME, "out of memory"); }
+    size_t o = 0;
+    for (size_t i = 0; i < recs.n; ++i) {
+        size_t il = strlen(recs.v[i].id);
+        memcpy(blob + o, recs.v[i].id, il + 1); o += il + 1;
+        if (recs.v[i].len) memcpy(blob + o, recs.v[i].seq, recs.v[i].len);
+        o += recs.v[i].len;
+        blob[o++] = 0;
+    }
+    *blob_out = blob;
+    *blob_len = total;
+    *n_records = recs.n;
+    recvec_free(&recs);
+    return SO_OK;
+}
+
+void so_free(void *p) { free(p); }
+
 /* ------------------------------------------------------------------------------------------
  * Graph build (cpp/src/seqwin/build.cpp + build_internals.cpp), restated as sort + run-length.
  * ---------------------------------------------------------------------------------------- */

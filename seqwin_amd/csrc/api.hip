@@ -229,6 +229,10 @@ struct sw_graph {
     sw::GraphHost g;
 };
 
+struct sw_hostbatch {
+    sw::HostBatch h;
+};
+
 extern "C" {
 
 const char *sw_last_error(void) { return g_last_error.c_str(); }
@@ -357,6 +361,57 @@ int sw_batch_records(const sw_batch *b, uint32_t *record_offsets, char *ids_blob
 }
 
 void sw_batch_free(sw_batch *b) { delete b; }
+
+int sw_host_ingest(const char *const *assembly_paths, size_t n_assemblies, uint64_t n_cpu, sw_hostbatch **out)
+{
+    return guarded([&] {
+        std::unique_ptr<sw_hostbatch> hb(new sw_hostbatch);
+        ingest_fasta(assembly_paths, n_assemblies, n_cpu, hb->h);
+        *out = hb.release();
+    });
+}
+
+int sw_hostbatch_info(const sw_hostbatch *hb, uint64_t *n_assemblies, uint64_t *n_records, uint64_t *total_bp,
+                      uint64_t *ids_bytes, uint64_t *n_runs)
+{
+    return guarded([&] {
+        *n_assemblies = hb->h.n_assemblies;
+        *n_records = hb->h.rec_len.size();
+        *total_bp = hb->h.total_bp;
+        *ids_bytes = hb->h.ids_blob.size();
+        *n_runs = hb->h.run_pos.size();
+    });
+}
+
+int sw_hostbatch_tables(const sw_hostbatch *hb, uint32_t *record_offsets, char *ids_blob, uint32_t *rec_len)
+{
+    return guarded([&] {
+        const HostBatch &h = hb->h;
+        if (record_offsets) memcpy(record_offsets, h.record_offsets.data(), h.record_offsets.size() * 4);
+        if (ids_blob && !h.ids_blob.empty()) memcpy(ids_blob, h.ids_blob.data(), h.ids_blob.size());
+        if (rec_len && !h.rec_len.empty()) memcpy(rec_len, h.rec_len.data(), h.rec_len.size() * 4);
+    });
+}
+
+int sw_hostbatch_record(const sw_hostbatch *hb, uint64_t record_idx, char *seq_out, uint64_t cap, uint64_t *len_out)
+{
+    return guarded([&] {
+        const HostBatch &h = hb->h;
+        if (record_idx >= h.rec_len.size()) raise(SW_ERR_VALUE, "record index out of range");
+        const uint64_t len = h.rec_len[record_idx];
+        *len_out = len;
+        if (!seq_out || cap < len) return;
+        memset(seq_out, 'N', len);
+        const uint64_t b0 = h.rec_base[record_idx];
+        for (uint32_t q = h.rec_run_off[record_idx]; q < h.rec_run_off[record_idx + 1]; ++q)
+            for (uint64_t p = h.run_pos[q]; p < (uint64_t)h.run_pos[q] + h.run_len[q]; ++p) {
+                const uint64_t b = b0 + p;
+                seq_out[p] = "ACGT"[(h.packed[b / 16] >> (2 * (b % 16))) & 3u];
+            }
+    });
+}
+
+void sw_hostbatch_free(sw_hostbatch *hb) { delete hb; }
 
 int sw_index_build(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, const uint8_t *is_targets,
                    uint64_t n_assemblies, void *stream, sw_index **out)

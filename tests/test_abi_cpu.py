@@ -1,0 +1,145 @@
+"""CPU: the C-ABI library loads, exports every symbol include/seqwin_hip.h declares, keeps the
+reference's wire formats, validates arguments before touching a device, refuses to run without one,
+and its host FASTA reader / 2-bit packer agrees with the oracle's reader byte for byte."""
+import ctypes
+import gzip
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, ROOT
+from seqwin_amd import EDGE_DTYPE, KMER_DTYPE, NODE_DTYPE, KmerGraph, _core, _get_penalty, _filter_kmers
+from seqwin_amd._lib import c_u64, c_vp, check, lib
+
+HEADER = (ROOT / "include" / "seqwin_hip.h").read_text()
+NO_GPU = lib.sw_device_count() == 0
+
+
+def test_every_declared_symbol_is_exported():
+    names = sorted(set(re.findall(r"\b(sw_[a-z_0-9]+)\s*\(", HEADER)))
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/seqwin_hip.h but not exported"
+    assert b"gfx950" in lib.sw_version()
+
+
+def test_dtype_layouts():
+    # reference tests/smoke/test_graph.py:45-64
+    assert KMER_DTYPE.itemsize == 8 and KMER_DTYPE.names == ("pos", "record_idx")
+    assert NODE_DTYPE.itemsize == 40 and NODE_DTYPE.names == ("hash", "start", "stop", "n_tar", "n_neg", "penalty")
+    assert NODE_DTYPE["start"] == np.dtype(np.uintp) and NODE_DTYPE["n_tar"] == np.dtype(np.uint32)
+    assert EDGE_DTYPE.itemsize == 24 and [EDGE_DTYPE.fields[f][1] for f in ("first", "second", "weight")] == [0, 8, 16]
+
+
+def test_argument_validation_happens_without_a_device(smoke_paths):
+    with pytest.raises(ValueError):
+        KmerGraph(smoke_paths, kmerlen=2, windowsize=10)
+    with pytest.raises(ValueError):
+        KmerGraph(smoke_paths, kmerlen=21, windowsize=0)
+    with pytest.raises(ValueError):
+        KmerGraph(smoke_paths, kmerlen=21, windowsize=5000)
+    with pytest.raises(TypeError):
+        KmerGraph(smoke_paths, kmerlen=7, windowsize=10, is_targets=[True, False])   # test_graph.py:130-141
+    with pytest.raises(TypeError):
+        _core._build_native("not-a-list", 7, 10)
+    with pytest.raises(TypeError):
+        _core._build_native([], 7.5, 10)
+    kmers = np.zeros(3, KMER_DTYPE); nodes = np.zeros(1, NODE_DTYPE); nodes["stop"] = 3
+    offs = np.array([0, 1, 2], np.uint32)
+    ro = nodes.copy(); ro.flags.writeable = False
+    with pytest.raises(ValueError, match="writable"):
+        _get_penalty(kmers, ro, offs, [True, False])
+    with pytest.raises(TypeError):
+        _get_penalty(kmers, nodes, offs.astype(np.uint64), [True, False])          # test_graph.py:318-321
+    with pytest.raises(TypeError):
+        _get_penalty(kmers.astype([("pos", "<u8"), ("record_idx", "<u8")]), nodes, offs, [True, False])
+    with pytest.raises(ValueError):
+        _get_penalty(kmers, nodes, offs[:-1], [True, False])
+    with pytest.raises(ValueError):
+        _get_penalty(kmers, nodes, np.array([1, 2, 3], np.uint32), [True, False])
+    with pytest.raises(ValueError):
+        _get_penalty(kmers, nodes, np.array([0, 3, 2], np.uint32), [True, False])
+    with pytest.raises(ValueError):
+        _get_penalty(kmers, nodes, offs, [True, True])
+    with pytest.raises(ValueError):
+        _get_penalty(kmers, nodes, offs, [False, False])
+    with pytest.raises(ValueError):
+        _get_penalty(kmers, nodes, offs, np.array([[True, False, True]]))    # shape[0] != len(offsets) - 1
+
+
+@pytest.mark.skipif(not NO_GPU, reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback(smoke_paths):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        KmerGraph(smoke_paths, kmerlen=21, windowsize=200)
+    kmers = np.zeros(1, KMER_DTYPE); nodes = np.zeros(1, NODE_DTYPE); nodes["stop"] = 1
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _get_penalty(kmers, nodes, np.array([0, 1, 1], np.uint32), [True, False])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _filter_kmers(kmers, nodes, {1})
+
+
+def _host_ingest(paths, n_cpu=1):
+    arr = (ctypes.c_char_p * max(len(paths), 1))(*[str(p).encode() for p in paths])
+    hb = c_vp()
+    check(lib.sw_host_ingest(arr, ctypes.c_size_t(len(paths)), c_u64(n_cpu), ctypes.byref(hb)))
+    try:
+        v = [c_u64() for _ in range(5)]
+        check(lib.sw_hostbatch_info(hb, *[ctypes.byref(x) for x in v]))
+        na, nr, bp, nb, _ = (x.value for x in v)
+        offs = np.empty(na + 1, np.uint32); lens = np.empty(nr, np.uint32); blob = ctypes.create_string_buffer(max(nb, 1))
+        check(lib.sw_hostbatch_tables(hb, offs.ctypes.data_as(c_vp), blob, lens.ctypes.data_as(c_vp)))
+        ids = blob.raw[:nb].split(b"\0")[:-1] if nb else []
+        seqs = []
+        for r in range(nr):
+            buf = ctypes.create_string_buffer(max(int(lens[r]), 1)); n = c_u64()
+            check(lib.sw_hostbatch_record(hb, c_u64(r), buf, c_u64(int(lens[r])), ctypes.byref(n)))
+            seqs.append(buf.raw[:n.value])
+        return offs, [i.decode() for i in ids], seqs, bp
+    finally:
+        lib.sw_hostbatch_free(hb)
+
+
+def _canon(seq: bytes) -> bytes:
+    t = bytearray(b"N" * 256)
+    for a, b in zip(b"ACGTUacgtu", b"ACGTTACGTT"):
+        t[a] = b
+    return seq.translate(bytes(t))
+
+
+def test_host_ingest_matches_oracle_reader(tmp_path):
+    files = sorted((GOLDEN / "synth").glob("*")) + sorted((GOLDEN / "smoke").glob("*/*.fasta"))
+    tricky = tmp_path / "tricky.fa"
+    tricky.write_bytes(b"\n  \n>id1 desc more\r\nACGT acgt\tNN\r\n\r\n>id2\n>id3\tx\nAC\x0bGT\n  GG  \n>id4\nACGTNRYKMacgtnU-*\nTTTT")
+    gz = tmp_path / "t.fa.gz"
+    with gzip.open(gz, "wb") as f:
+        f.write(b">g1\nACGTACGTAC\nGGGG\n>g2\nNNNN\n")
+    files += [tricky, gz]
+    for n_cpu in (1, 3):
+        offs, ids, seqs, bp = _host_ingest(files, n_cpu)
+        exp_ids, exp_seqs, exp_offs = [], [], [0]
+        for f in files:
+            recs = oracle.read_fasta(f)
+            exp_ids += [r[0] for r in recs]; exp_seqs += [_canon(r[1]) for r in recs]
+            exp_offs.append(len(exp_ids))
+        assert ids == exp_ids and offs.tolist() == exp_offs
+        assert seqs == exp_seqs
+        assert bp == sum(len(s) for s in exp_seqs)
+
+
+def test_host_ingest_errors(tmp_path):
+    with pytest.raises(RuntimeError, match="Unable to open FASTA"):
+        _host_ingest([tmp_path / "missing.fa"])
+    with pytest.raises(RuntimeError, match="Unable to open gzip FASTA"):
+        _host_ingest([tmp_path / "missing.fa.gz"])
+    bad = tmp_path / "bad.fa"; bad.write_text("ACGT\n>r\nACGT\n")
+    with pytest.raises(RuntimeError, match="sequence encountered before header"):
+        _host_ingest([bad])
+    ctl = tmp_path / "ctl.fa"; ctl.write_bytes(b">r\nACGT\x01ACGT\n")
+    with pytest.raises(ValueError, match="control byte"):
+        _host_ingest([ctl])
+    assert _host_ingest([])[0].tolist() == [0]
+    empty = tmp_path / "empty.fa"; empty.write_text("")
+    assert _host_ingest([empty])[0].tolist() == [0, 0]

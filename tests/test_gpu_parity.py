@@ -1,0 +1,354 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracle and the golden vectors.
+
+Structured like the reference's tests/smoke/test_graph.py (same helper names and assertions where the
+reference has a test), plus golden-vector, fuzz and full-size property tests.  Integer / index results
+are compared bit-for-bit; the one floating-point field (penalty, f64) is also required to be
+bit-identical (tolerance 0) because the reference's own thread-invariance test compares whole node
+rows with np.array_equal (test_graph.py:281-291).
+"""
+import gzip
+import random
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, assert_graph_equal, load_case
+from seqwin_amd import EDGE_DTYPE, KMER_DTYPE, NODE_DTYPE, KmerGraph, _filter_kmers, _get_penalty
+from seqwin_amd.device import Batch, host_checksums
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(*args, **kwargs):
+    graph = KmerGraph(*args, **kwargs)
+    return graph.kmers, graph.nodes, graph.edges, graph.record_offsets, graph.record_ids
+
+
+def _sorted_edges(edges: np.ndarray) -> np.ndarray:
+    edge_values = edges.view(np.uint64).reshape(-1, 3)
+    idx = np.lexsort((edge_values[:, 2], edge_values[:, 1], edge_values[:, 0]))
+    return edge_values[idx]
+
+
+def _assert_node_ranges(kmers: np.ndarray, nodes: np.ndarray) -> None:
+    assert np.all(nodes["start"] <= nodes["stop"]) and (len(nodes) == 0 or nodes["stop"][-1] == len(kmers))
+    assert np.array_equal(nodes["start"][1:], nodes["stop"][:-1])
+    if len(nodes):
+        assert nodes["start"][0] == 0
+    rec = kmers["record_idx"].astype(np.int64)
+    inner = np.ones(len(kmers), bool)
+    inner[nodes["start"][nodes["start"] < len(kmers)]] = False
+    assert np.all((np.diff(rec) >= 0) | ~inner[1:])
+    assert int((nodes["stop"] - nodes["start"]).sum()) == len(kmers)
+
+
+# ---- golden vectors ---------------------------------------------------------------------------------
+
+def test_reference_golden_graph(smoke_paths):
+    exp = np.load(GOLDEN / "smoke" / "expected_graph_k17_w10.npz")
+    assert_graph_equal(_build(smoke_paths, 17, 10, n_cpu=1), exp)
+    assert_graph_equal(_build(smoke_paths, 17, 10, n_cpu=2, low_memory=True), exp)
+
+
+def test_all_reference_vectors(manifest):
+    for case in manifest["cases"]:
+        paths, z = load_case(case)
+        got = _build(paths, case["k"], case["w"], n_cpu=2)
+        assert_graph_equal(got, z, case["ids"])
+        if case["is_targets"] is not None and len(got[1]):
+            assert _get_penalty(got[0], got[1], got[3], case["is_targets"]) is None
+            assert np.array_equal(got[1], z["nodes_scored"]), case["name"]   # penalty bit-exact (tolerance 0)
+
+
+def test_operator_vectors():
+    z = np.load(GOLDEN / "vectors" / "operators.npz")
+    nodes = z["pen_nodes"].copy()
+    _get_penalty(z["pen_kmers"], nodes, z["pen_offsets"], z["pen_targets"])
+    assert np.array_equal(nodes, z["pen_scored"])
+    k2, n2 = _filter_kmers(z["flt_kmers"], z["flt_nodes"], frozenset(np.uint64(h) for h in z["flt_used"]))
+    assert np.array_equal(k2, z["flt_kmers_out"]) and np.array_equal(n2, z["flt_nodes_out"])
+
+
+# ---- mirrors of the reference's test_graph.py ---------------------------------------------------------
+
+def test_build_threading_equivalence(smoke_paths):   # test_graph.py:67-127
+    a = _build(smoke_paths, kmerlen=7, windowsize=10, n_cpu=1)
+    b = _build(smoke_paths, kmerlen=7, windowsize=10, n_cpu=2)
+    c = _build(smoke_paths, kmerlen=7, windowsize=10, n_cpu=99)
+    kmers_1, nodes_1, edges_1, offs_1, ids_1 = a
+    assert kmers_1.dtype == KMER_DTYPE and nodes_1.dtype == NODE_DTYPE and edges_1.dtype == EDGE_DTYPE
+    assert offs_1.dtype == np.uint32 and np.array_equal(offs_1, [0, 1, 2, 3, 4])
+    assert np.array_equal(np.unique(kmers_1["record_idx"]), np.arange(4, dtype=np.uint32))
+    assert np.all(nodes_1["n_tar"] == 0) and np.all(nodes_1["n_neg"] == 0) and np.all(nodes_1["penalty"] == 0.0)
+    ev = edges_1.view(np.uint64).reshape(-1, 3)
+    assert np.array_equal(ev[:, 0], edges_1["first"]) and np.array_equal(ev[:, 2], edges_1["weight"])
+    assert nodes_1.flags.writeable and kmers_1.flags.c_contiguous
+    for g in (a, b, c):
+        _assert_node_ranges(g[0], g[1])
+    for other in (b, c):
+        assert np.array_equal(kmers_1, other[0]) and np.array_equal(nodes_1, other[1])
+        assert np.array_equal(_sorted_edges(edges_1), _sorted_edges(other[2]))
+        assert np.array_equal(offs_1, other[3]) and ids_1 == other[4]
+    assert len(ids_1) == 4
+    assert_graph_equal(a, dict(zip(("kmers", "nodes", "edges", "record_offsets"), oracle.build(smoke_paths, 7, 10)[:4])))
+
+
+def test_multi_record_offsets_and_global_record_indices(tmp_path: Path):   # test_graph.py:144-165
+    seq = "ACGT" * 20
+    paths = []
+    for i, n_records in enumerate([2, 1, 3, 1]):
+        p = tmp_path / f"a{i}.fasta"
+        p.write_text("".join(f">r{j}\n{seq}\n" for j in range(n_records)))
+        paths.append(p)
+    kmers, _, _, offs, ids = _build(paths, kmerlen=7, windowsize=10, n_cpu=2)
+    assert [len(t) for t in ids] == [2, 1, 3, 1]
+    assert np.array_equal(offs, np.array([0, 2, 3, 6, 7], dtype=np.uint32))
+    assert np.array_equal(np.unique(kmers["record_idx"]), np.arange(7, dtype=np.uint32))
+
+
+def test_build_empty_record_offsets(tmp_path: Path):   # test_graph.py:168-187
+    empty = tmp_path / "empty.fasta"
+    empty.write_text("")
+    for paths, expected in (([], [0]), ([empty], [0, 0])):
+        for low_memory in (False, True):
+            kmers, nodes, edges, offs, ids = _build(paths, kmerlen=7, windowsize=10, n_cpu=2, low_memory=low_memory)
+            assert len(kmers) == 0 and len(nodes) == 0 and len(edges) == 0
+            assert offs.dtype == np.uint32 and np.array_equal(offs, expected)
+            assert ids == [()] * len(paths)
+
+
+def test_filter_kmers():   # test_graph.py:190-219
+    kmers = np.array([(10, 0), (11, 0), (20, 1), (30, 2), (31, 2), (32, 2)], dtype=KMER_DTYPE)
+    nodes = np.array([(10, 0, 2, 1, 0, 0.1), (20, 2, 3, 1, 0, 0.2), (30, 3, 6, 1, 1, 0.3)], dtype=NODE_DTYPE)
+    kmers_new, nodes_new = _filter_kmers(kmers, nodes, {30, 10})
+    assert np.array_equal(nodes_new["hash"], np.array([10, 30], dtype=np.uint64))
+    assert np.array_equal(nodes_new["start"], [0, 2]) and np.array_equal(nodes_new["stop"], [2, 5])
+    assert np.array_equal(nodes_new["penalty"], [0.1, 0.3]) and np.array_equal(nodes_new["n_neg"], [0, 1])
+    assert np.array_equal(kmers_new, np.array([(10, 0), (11, 0), (30, 2), (31, 2), (32, 2)], dtype=KMER_DTYPE))
+    e = _filter_kmers(kmers, nodes, set())
+    assert len(e[0]) == 0 and len(e[1]) == 0
+    e = _filter_kmers(kmers, nodes, [99, 30, 30])
+    assert np.array_equal(e[1]["hash"], [30]) and len(e[0]) == 3
+
+
+def _synthetic_penalty_inputs():   # test_graph.py:248-266
+    kmers = np.array([(0, 0), (1, 0), (2, 1), (3, 2), (4, 4), (5, 2), (6, 3), (7, 5), (8, 6), (9, 4)], dtype=KMER_DTYPE)
+    nodes = np.array([(10, 0, 5, 0, 0, 0.0), (20, 5, 7, 0, 0, 0.0), (30, 7, 9, 0, 0, 0.0), (40, 9, 10, 0, 0, 0.0),
+                      (50, 10, 10, 9, 9, 9.0), (60, 5, 9, 0, 0, 0.0)], dtype=NODE_DTYPE)
+    return kmers, nodes, np.array([0, 2, 4, 5, 7], dtype=np.uint32), np.array([True, False, True, False])
+
+
+def test_get_penalty_exact_scoring():   # test_graph.py:269-278
+    kmers, nodes, offs, tar = _synthetic_penalty_inputs()
+    assert _get_penalty(kmers, nodes, offs, tar, n_cpu=1) is None
+    assert np.array_equal(nodes["n_tar"], [2, 0, 0, 1, 0, 0]) and np.array_equal(nodes["n_neg"], [1, 1, 1, 0, 0, 2])
+    np.testing.assert_allclose(nodes["penalty"], [0.5, np.hypot(1.0, 0.5), np.hypot(1.0, 0.5), 0.5, 1.0, np.sqrt(2.0)])
+    ref = _synthetic_penalty_inputs()[1]
+    oracle.get_penalty(kmers, ref, offs, tar)
+    assert np.array_equal(nodes, ref)
+    many = _synthetic_penalty_inputs()[1]
+    _get_penalty(kmers, many, offs, tar, n_cpu=99)   # test_graph.py:281-291
+    assert np.array_equal(nodes, many)
+
+
+def test_get_penalty_skips_zero_record_assemblies():   # test_graph.py:294-304
+    kmers = np.array([(0, 0), (1, 1)], dtype=KMER_DTYPE)
+    nodes = np.array([(10, 0, 2, 0, 0, 0.0)], dtype=NODE_DTYPE)
+    _get_penalty(kmers, nodes, np.array([0, 1, 1, 1, 2], dtype=np.uint32), [True, False, True, False], n_cpu=2)
+    assert nodes[0]["n_tar"] == 1 and nodes[0]["n_neg"] == 1 and nodes[0]["penalty"] == np.sqrt(0.5)
+
+
+def test_get_penalty_validation():   # test_graph.py:307-341 (device-side checks; host-side ones are in test_abi_cpu.py)
+    kmers, nodes, offs, tar = _synthetic_penalty_inputs()
+    bad_nodes = nodes.copy(); bad_nodes[0]["stop"] = len(kmers) + 1
+    with pytest.raises(ValueError):
+        _get_penalty(kmers, bad_nodes, offs, tar)
+    bad_kmers = kmers.copy(); bad_kmers[0]["record_idx"] = 7
+    with pytest.raises(ValueError):
+        _get_penalty(bad_kmers, nodes.copy(), offs, tar)
+    descending = kmers.copy(); descending[3]["record_idx"] = 0
+    with pytest.raises(ValueError):
+        _get_penalty(descending, nodes.copy(), offs, tar)
+
+
+def test_penalty_f64_bit_exact_over_all_counts():
+    """Every (n_tar, n_neg) pair for several (T, NT): the device's mul/add/sqrt sequence must round like x86-64."""
+    for T, NT in [(1, 1), (3, 7), (72, 99), (256, 256), (13, 1000)]:
+        A = T + NT
+        # node i has one occurrence in each of the first a targets and first b non-targets
+        combos = [(a, b) for a in range(T + 1) for b in range(NT + 1) if a + b > 0]
+        if len(combos) > 30000:
+            combos = combos[::len(combos) // 30000 + 1]
+        recs, starts = [], [0]
+        for a, b in combos:
+            recs += list(range(a)) + list(range(T, T + b))
+            starts.append(len(recs))
+        kmers = np.zeros(len(recs), KMER_DTYPE); kmers["record_idx"] = recs
+        nodes = np.zeros(len(combos), NODE_DTYPE)
+        nodes["hash"] = np.arange(len(combos)); nodes["start"] = starts[:-1]; nodes["stop"] = starts[1:]
+        offs = np.arange(A + 1, dtype=np.uint32)
+        tar = np.array([True] * T + [False] * NT)
+        exp = nodes.copy()
+        oracle.get_penalty(kmers, exp, offs, tar)
+        _get_penalty(kmers, nodes, offs, tar)
+        assert np.array_equal(nodes["n_tar"], [c[0] for c in combos]) and np.array_equal(nodes["n_neg"], [c[1] for c in combos])
+        assert np.array_equal(nodes["penalty"].view(np.uint64), exp["penalty"].view(np.uint64)), (T, NT)
+
+
+# ---- fuzz against the oracle --------------------------------------------------------------------------
+
+def _randseq(rng, n):
+    mode = rng.random()
+    s = []
+    for _ in range(n):
+        r = rng.random()
+        if r < 0.01:
+            s.append(rng.choice("NnRYKMxX-*"))
+        elif r < 0.03:
+            s.append(rng.choice("acgtuU"))
+        else:
+            s.append(rng.choice("ACGT" if mode < 0.8 else "AC"))
+    s = "".join(s)
+    if rng.random() < 0.3:
+        p = rng.randrange(0, max(1, n))
+        s = s[:p] + "N" * rng.randrange(1, 300) + s[p:]
+    return s
+
+
+def test_fuzz_build_matches_oracle(tmp_path):
+    rng = random.Random(2)
+    for it in range(40):
+        ps = []
+        for a in range(rng.randrange(1, 5)):
+            txt = ""
+            for r in range(rng.randrange(0, 4)):
+                s = _randseq(rng, rng.choice([0, 5, 30, 100, 400, 1500, 9000, 30000]))
+                txt += f">r{r} desc\n"
+                width = rng.choice([60, 80, 7, 1000])
+                for i in range(0, len(s), width):
+                    txt += s[i:i + width] + rng.choice(["\n", "\r\n", " \n"])
+            gz = rng.random() < 0.3
+            p = tmp_path / (f"{it}_{a}.fa" + (".gz" if gz else ""))
+            if gz:
+                with gzip.open(p, "wt") as f:
+                    f.write(txt)
+            else:
+                p.write_text(txt)
+            ps.append(p)
+        k = rng.choice([3, 4, 5, 7, 15, 16, 17, 18, 19, 21, 31, 32, 33, 40, 100])
+        w = rng.choice([1, 2, 3, 5, 10, 25, 32, 33, 34, 50, 66, 200, 1000, 4096])
+        got = _build(ps, k, w, n_cpu=rng.choice([1, 3]))
+        exp = oracle.build(ps, k, w)
+        assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])), [list(t) for t in exp[4]])
+        if len(got[1]) and len(ps) >= 2:
+            tar = [i % 2 == 0 for i in range(len(ps))]
+            oracle.get_penalty(exp[0], exp[1], exp[3], tar)
+            _get_penalty(got[0], got[1], got[3], tar)
+            assert np.array_equal(got[1], exp[1])
+            used = frozenset(np.uint64(h) for h in exp[1]["hash"][::3])
+            f1 = _filter_kmers(got[0], got[1], used); f2 = oracle.filter_kmers(exp[0], exp[1], used)
+            assert np.array_equal(f1[0], f2[0]) and np.array_equal(f1[1], f2[1])
+
+
+def test_low_complexity_and_ties(tmp_path):
+    """Homopolymers / tandem repeats: every window is a tie, so the rightmost-minimum rule is all that decides."""
+    p = tmp_path / "lc.fa"
+    p.write_text(">polyA\n" + "A" * 20000 + "\n>at\n" + "AT" * 9000 + "\n>rep7\n" + "ACGGTCA" * 3000 + "\n>mix\n" +
+                 "A" * 500 + "N" + "C" * 700 + "ACGT" * 300 + "\n")
+    for k, w in [(21, 200), (5, 33), (15, 10), (31, 1000)]:
+        got = _build([p], k, w)
+        exp = oracle.build([p], k, w)
+        assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
+
+
+def test_tile_seams_and_many_gaps(tmp_path):
+    """Records spanning many tiles, with valid stretches of every length around k (idx space != pos space)."""
+    rng = np.random.default_rng(11)
+    s = "".join(rng.choice(list("ACGT"), 120000))
+    cuts = sorted(rng.choice(len(s), 400, replace=False).tolist())
+    arr = list(s)
+    for c in cuts:
+        for j in range(c, min(len(arr), c + int(rng.integers(1, 40)))):
+            arr[j] = "N"
+    gap = "".join(arr)
+    p = tmp_path / "seams.fa"
+    p.write_text(f">long\n{s}\n>gappy\n{gap}\n>dense_gaps\n" + "N".join(s[i:i + 23] for i in range(0, 60000, 23)) + "\n")
+    for k, w in [(21, 200), (21, 50), (23, 7), (24, 3), (17, 4096)]:
+        got = _build([p], k, w)
+        exp = oracle.build([p], k, w)
+        assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
+
+
+# ---- device-resident pipeline ---------------------------------------------------------------------------
+
+def _oracle_for_batch(b: Batch, k, w, tar, tmp_path):
+    offs, ids = b.records()
+    paths = []
+    for a in range(len(offs) - 1):
+        p = tmp_path / f"syn{a}.fa"
+        with open(p, "wb") as f:
+            for r in range(int(offs[a]), int(offs[a + 1])):
+                f.write(b">" + ids[a][r - int(offs[a])].encode() + b"\n" + b.record(r) + b"\n")
+        paths.append(p)
+    exp = oracle.build(paths, k, w)
+    if tar is not None:
+        oracle.get_penalty(exp[0], exp[1], exp[3], tar)
+    return exp
+
+
+@pytest.mark.parametrize("shape,k,w", [((12, 5, 60000), 21, 200), ((5, 2, 150000), 15, 200), ((4, 1, 200000), 31, 200),
+                                       ((6, 3, 20000), 19, 10)])
+def test_synthetic_batch_index_matches_oracle(tmp_path, shape, k, w):
+    ng, rpg, rl = shape
+    b = Batch.synthetic(ng, rpg, rl, n_ancestors=3, snp_ppm=10000, seed=20260821)
+    tar = [i < ng // 2 for i in range(ng)]
+    exp = _oracle_for_batch(b, k, w, tar, tmp_path)
+    oh, km = b.sketch(k, w)
+    order = np.lexsort((exp[0]["pos"], exp[0]["record_idx"]))
+    assert np.array_equal(km, exp[0][order])                      # the tuple stream in (record_idx, pos) order
+    node_of = np.repeat(np.arange(len(exp[1])), (exp[1]["stop"] - exp[1]["start"]).astype(np.int64))
+    assert np.array_equal(oh, exp[1]["hash"][node_of][order])
+    ix = b.build_index(k, w, tar)
+    K, N, E = ix.export()
+    assert np.array_equal(K, exp[0]) and np.array_equal(N, exp[1]) and np.array_equal(E, exp[2])
+    assert ix.checksums() == host_checksums(exp[0], exp[1], exp[2])
+    t = ix.timings()
+    assert t["total_bp"] == ng * rpg * rl and t["sketch_launches"] == 1
+    # idempotence: a second build of the same batch is identical
+    assert b.build_index(k, w, tar).checksums() == ix.checksums()
+
+
+def test_full_size_properties():
+    """configs[1]-sized synthetic batch (2.4 Gbp): size-independent properties + shard-sum identities."""
+    ng, rpg, rl, k, w = 512, 50, 96000, 21, 200
+    b = Batch.synthetic(ng, rpg, rl, n_ancestors=5, snp_ppm=10000, seed=20260821)
+    tar = np.arange(ng) < ng // 2
+    ix = b.build_index(k, w, tar)
+    K, N, E = ix.export()
+    nk, nn, ne = ix.sizes()
+    assert (nk, nn, ne) == (len(K), len(N), len(E))
+    assert ix.checksums() == host_checksums(K, N, E)
+    assert 0.0097 < nk / (ng * rpg * rl) < 0.0102                  # minimizer density ~ 2/(w+1)
+    assert np.all(N["hash"][1:] > N["hash"][:-1])                  # nodes strictly sorted by hash
+    _assert_node_ranges(K, N)
+    ev = E.view(np.uint64).reshape(-1, 3)
+    assert np.all(ev[:, 0] <= ev[:, 1])
+    key = ev[:, 0].astype(object) * (1 << 64) + ev[:, 1].astype(object) if len(ev) < 1000 else None
+    lex = np.lexsort((ev[:, 1], ev[:, 0]))
+    assert np.array_equal(lex, np.arange(len(ev)))                 # edges sorted by (first, second), no duplicates
+    assert np.all((ev[1:, 0] != ev[:-1, 0]) | (ev[1:, 1] != ev[:-1, 1]))
+    assert np.all(np.isin(ev[:, 0], N["hash"])) and np.all(np.isin(ev[:, 1], N["hash"]))
+    assert E["weight"].min() >= 1 and E["weight"].max() <= ng
+    assert np.all(N["n_tar"] <= ng // 2) and np.all(N["n_neg"] <= ng - ng // 2) and np.all(N["n_tar"] + N["n_neg"] >= 1)
+    # host recomputation of the counts from the exported occurrences (numpy, independent of both C paths)
+    asm = K["record_idx"] // rpg
+    first = np.ones(len(K), bool); first[1:] = asm[1:] != asm[:-1]; first[N["start"].astype(np.int64)] = True
+    node_of = np.repeat(np.arange(len(N)), (N["stop"] - N["start"]).astype(np.int64))
+    assert np.array_equal(np.bincount(node_of[first & tar[asm]], minlength=len(N)), N["n_tar"])
+    assert np.array_equal(np.bincount(node_of[first & ~tar[asm]], minlength=len(N)), N["n_neg"])
+    ft = N["n_tar"] * (1.0 / (ng // 2)); fn = N["n_neg"] * (1.0 / (ng - ng // 2))
+    assert np.array_equal(N["penalty"], np.sqrt((1.0 - ft) * (1.0 - ft) + fn * fn))
+    # sum of edge weights == number of distinct (pair, assembly) combinations among adjacent occurrences
+    assert int(E["weight"].sum()) <= nk - ng * rpg
