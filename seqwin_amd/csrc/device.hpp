@@ -59,13 +59,16 @@ struct Plan {
     uint32_t L = 0;        // k-mers hashed per thread (odd, <= w)
     uint32_t NE = 0;       // elements per tile = 256 * L
     uint32_t TW = 0;       // window ends per tile = NE - w
-    uint32_t n_tiles = 0;
+    uint32_t Lf = 0, TWf = 0;  // fast class (single-segment records): run length 32 / 16 / 0 = unavailable
+    uint32_t n_tiles = 0, n_tiles_fast = 0, n_tiles_gen = 0;
     uint64_t n_windows = 0;
     uint64_t n_valid = 0;
     size_t lds_bytes = 0;
     DevArray<uint32_t> rec_seg_off;   // [R + 1]
     DevArray<uint32_t> rec_nvalid;    // [R]
-    DevArray<uint32_t> rec_tile_off;  // [R + 1]
+    DevArray<uint32_t> rec_tile_off;  // [R + 1] global tile numbering
+    DevArray<uint32_t> fast_tile_off; // [R + 1] tiles of the fast class
+    DevArray<uint32_t> gen_tile_off;  // [R + 1] tiles of the generic class
     DevArray<uint32_t> seg_pos;       // [S]
     DevArray<uint32_t> seg_idx;       // [S]
     DevArray<uint64_t> lut;           // [40] roll tables, see sketch.hip

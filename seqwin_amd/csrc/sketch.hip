@@ -27,6 +27,8 @@
 //            tile's output range and the tuples are written in position order.
 // Tiles land in allocation order; index.hip's order pass restores (record_idx, pos) order.
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 
 #include "device.hpp"
 
@@ -58,11 +60,13 @@ struct SketchArgs {
     const uint64_t *rec_base;
     const uint32_t *rec_seg_off;
     const uint32_t *rec_nvalid;
-    const uint32_t *rec_tile_off;
+    const uint32_t *rec_tile_off;   // [R+1] global tile numbering (record-major)
+    const uint32_t *cls_tile_off;   // [R+1] tile numbering of the class this launch covers
     const uint32_t *seg_pos;
     const uint32_t *seg_idx;
     const uint64_t *lut;
     uint32_t n_records, k, w, L, TW, n_tiles;
+    uint64_t packed_words;
     uint64_t mult;
     uint64_t *stage_hash;
     uint64_t *stage_kmer;
@@ -118,7 +122,7 @@ __device__ __forceinline__ void sror1(uint32_t &lo, uint32_t &hi)
 
 __device__ __forceinline__ uint64_t make64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
-__global__ __launch_bounds__(BLOCK, 2) void sketch_kernel(const SketchArgs A)
+__global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t L = A.L, NE = BLOCK * L, w = A.w, k = A.k;
@@ -131,16 +135,16 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_kernel(const SketchArgs A)
     uint8_t *SP = reinterpret_cast<uint8_t *>(RMp + BLOCK);    // [NE]    offset of the run-suffix minimum
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
 
     // ---- which record / which window range (uniform; scalar loads) ---------------------------
-    uint32_t lo = 0, hi = A.n_records;  // last r with rec_tile_off[r] <= tile
+    uint32_t lo = 0, hi = A.n_records;  // last r with cls_tile_off[r] <= blockIdx.x
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (A.rec_tile_off[mid] <= tile) lo = mid; else hi = mid;
+        if (A.cls_tile_off[mid] <= blockIdx.x) lo = mid; else hi = mid;
     }
     const uint32_t rec = lo;
-    const uint32_t t = tile - A.rec_tile_off[rec];
+    const uint32_t t = blockIdx.x - A.cls_tile_off[rec];
+    const uint32_t tile = A.rec_tile_off[rec] + t;  // global tile id (order pass)
     const uint32_t nvalid = A.rec_nvalid[rec];
     const uint32_t I0 = (w - 1) + t * A.TW;                   // first window end (idx space)
     const uint32_t I1 = min(I0 + A.TW, nvalid);               // one past the last window end
@@ -342,6 +346,265 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_kernel(const SketchArgs A)
     }
 }
 
+// ================================================================================================
+// Fast path: tiles of records that are ONE valid segment (no invalid base inside the tile's reach),
+// k <= KF, run length L a power of two (32, or 16 for 16 <= w < 32).
+//  * the tile's 2-bit words are staged in LDS with coalesced loads; every lane starts on the same
+//    bit phase (L is a multiple of 16 bases = one word), so word refills are WAVE-UNIFORM (scalar
+//    branch, no divergence) and are fetched one word ahead of use;
+//  * the roll LUT read of step j+1 is issued before the arithmetic of step j (software pipeline);
+//  * the L hashes of a lane stay in registers: the suffix-minimum pass and the prefix part of the
+//    window pass never re-read LDS; LDS keeps one copy of every hash (XOR-swizzled rows, conflict
+//    free) only for the other lanes' suffix lookups.
+// ================================================================================================
+constexpr uint32_t KF = 256;
+
+template <int L> struct FastCfg {
+    static constexpr int NE = BLOCK * L;
+    static constexpr int LSP = L + 4;  // SP row stride in bytes: multiple of 4 with LSP/4 odd
+    static constexpr int NSTG = NE / 16 + KF / 16 + 4;
+    static constexpr int NEM = NE / 32 + 2;
+    static constexpr size_t off_H = 0;
+    static constexpr size_t off_RMh = off_H + (size_t)NE * 8;
+    static constexpr size_t off_LUT = off_RMh + BLOCK * 8;
+    static constexpr size_t off_STG = off_LUT + 40 * 8;
+    static constexpr size_t off_EM = off_STG + (size_t)NSTG * 4;
+    static constexpr size_t off_MISC = off_EM + (size_t)NEM * 4;
+    static constexpr size_t off_RMp = off_MISC + 16 * 4;
+    static constexpr size_t off_SP = off_RMp + BLOCK * 2;
+    static constexpr size_t bytes = off_SP + (size_t)BLOCK * LSP;
+};
+
+template <int L> __global__ __launch_bounds__(BLOCK, 2) void sketch_fast_kernel(const SketchArgs A)
+{
+    using C = FastCfg<L>;
+    constexpr uint32_t LM = L - 1;
+    constexpr uint32_t LSH = (L == 32) ? 5 : 4;
+    static_assert(L == 32 || L == 16, "run length must be 16 or 32");
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint64_t *H = reinterpret_cast<uint64_t *>(smem + C::off_H);
+    uint64_t *RMh = reinterpret_cast<uint64_t *>(smem + C::off_RMh);
+    uint64_t *LUT = reinterpret_cast<uint64_t *>(smem + C::off_LUT);
+    uint32_t *STG = reinterpret_cast<uint32_t *>(smem + C::off_STG);
+    uint32_t *EM = reinterpret_cast<uint32_t *>(smem + C::off_EM);
+    uint32_t *MISC = reinterpret_cast<uint32_t *>(smem + C::off_MISC);
+    uint16_t *RMp = reinterpret_cast<uint16_t *>(smem + C::off_RMp);
+    uint8_t *SP = reinterpret_cast<uint8_t *>(smem + C::off_SP);
+    uint32_t *SPw = reinterpret_cast<uint32_t *>(smem + C::off_SP);
+
+    const uint32_t tid = threadIdx.x, w = A.w, k = A.k;
+
+    uint32_t lo = 0, hi = A.n_records;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (A.cls_tile_off[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const uint32_t rec = lo;
+    const uint32_t t = blockIdx.x - A.cls_tile_off[rec];
+    const uint32_t tile = A.rec_tile_off[rec] + t;
+    const uint32_t nvalid = A.rec_nvalid[rec];
+    const uint32_t I0 = (w - 1) + t * A.TW;
+    const uint32_t I1 = min(I0 + A.TW, nvalid);
+    const uint32_t E0 = (t == 0) ? 0u : I0 - w;
+    const uint32_t ne = I1 - E0;
+    const uint32_t e_first = I0 - E0;
+    const uint32_t pos0 = A.seg_pos[A.rec_seg_off[rec]];   // single segment: idx g <-> pos0 + g
+    const uint64_t b_first = A.rec_base[rec] + pos0 + E0;
+    const uint32_t ph = (uint32_t)b_first & 15u;
+    const uint64_t word0 = b_first >> 4;
+
+    {   // stage the tile's packed words (coalesced), clear the emit bitmap, load the LUT
+        const uint32_t nw = (ph + ne + k + 14) / 16 + 2;
+        for (uint32_t i = tid; i < nw; i += BLOCK) {
+            const uint64_t gw = word0 + i;
+            STG[i] = (gw < A.packed_words) ? A.packed[gw] : 0u;
+        }
+        for (uint32_t i = tid; i < (uint32_t)C::NEM; i += BLOCK) EM[i] = 0;
+        if (tid < 40) LUT[tid] = A.lut[tid];
+    }
+    __syncthreads();
+
+    const uint32_t e0 = tid * L;
+    const uint32_t n = (e0 < ne) ? min((uint32_t)L, ne - e0) : 0u;
+    const uint32_t swz = tid & LM;           // H row swizzle of this lane
+    uint64_t h[L];
+    uint64_t rmin_h = ~0ull;
+    uint32_t rmin_j = 0;
+
+    if (n) {
+        // ---- phase 1: ntHash over this lane's L k-mers -------------------------------------------
+        const uint32_t *wp = STG + tid * (L / 16);
+        uint32_t icur = wp[0] >> (2u * ph), inxt = wp[1], inl = 16u - ph;
+        const uint32_t *iwp = wp + 2;
+        uint32_t ocur = icur, onxt = inxt, onl = inl;
+        const uint32_t *owp = iwp;
+        auto next_in = [&]() -> uint32_t {
+            if (inl == 0) { icur = inxt; inxt = *iwp++; inl = 16; }
+            const uint32_t c = icur & 3u;
+            icur >>= 2;
+            --inl;
+            return c;
+        };
+        auto next_out = [&]() -> uint32_t {
+            if (onl == 0) { ocur = onxt; onxt = *owp++; onl = 16; }
+            const uint32_t c = ocur & 3u;
+            ocur >>= 2;
+            --onl;
+            return c;
+        };
+        uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0;
+        auto apply = [&](uint64_t lf, uint64_t lr) {
+            srol1(flo, fhi);
+            flo ^= (uint32_t)lf;
+            fhi ^= (uint32_t)(lf >> 32);
+            rlo ^= (uint32_t)lr;
+            rhi ^= (uint32_t)(lr >> 32);
+            sror1(rlo, rhi);
+        };
+        uint32_t idx = 16u | next_in();
+        uint64_t lf = LUT[2 * idx], lr = LUT[2 * idx + 1];
+        for (uint32_t j = 1; j < k; ++j) {          // warm-up entries 0 .. k-2 applied here
+            idx = 16u | next_in();
+            const uint64_t nlf = LUT[2 * idx], nlr = LUT[2 * idx + 1];
+            apply(lf, lr);
+            lf = nlf;
+            lr = nlr;
+        }
+        uint64_t *Hrow = H + e0;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            uint64_t nlf = 0, nlr = 0;
+            if (j + 1 < L) {                        // LUT entry of the NEXT roll, issued before this step's math
+                idx = next_in() | (next_out() << 2);
+                nlf = LUT[2 * idx];
+                nlr = LUT[2 * idx + 1];
+            }
+            apply(lf, lr);                          // j == 0: last warm-up entry; j > 0: roll
+            h[j] = make64(flo, fhi) + make64(rlo, rhi);
+            Hrow[(uint32_t)j ^ swz] = h[j];
+            if ((uint32_t)j < n && h[j] <= rmin_h) { rmin_h = h[j]; rmin_j = j; }
+            lf = nlf;
+            lr = nlr;
+        }
+        // ---- suffix minima of the run (registers only), 4 offsets per 32-bit LDS store -----------
+        uint64_t cur = 0;
+        uint32_t off = 0, pk = 0;
+#pragma unroll
+        for (int j = L - 1; j >= 0; --j) {
+            const bool take = ((uint32_t)j < n) && ((uint32_t)j == n - 1 || h[j] < cur);
+            cur = take ? h[j] : cur;
+            off = take ? (uint32_t)j : off;
+            pk = (pk << 8) | off;
+            if ((j & 3) == 0) SPw[tid * (C::LSP / 4) + j / 4] = pk;
+        }
+    }
+    RMh[tid] = rmin_h;
+    RMp[tid] = (uint16_t)(e0 + rmin_j);
+    __syncthreads();
+
+    // ---- phase 2: rightmost minimum of every window ending in this lane's run -------------------
+    if (n && e0 + n > w - 1) {
+        const uint32_t j0 = (e0 >= w - 1) ? 0u : (w - 1 - e0);
+        const uint32_t x0 = e0 + j0 - (w - 1);
+        const uint32_t rxA = x0 >> LSH;
+        const uint32_t bnd = (rxA + 1) << LSH;
+        uint64_t mA_h = ~0ull, mB_h = ~0ull;
+        uint32_t mA_e = 0, mB_e = 0;
+        if (rxA < tid) {
+            for (uint32_t r = tid; r-- > rxA + 2;) {
+                const uint64_t hh = RMh[r];
+                if (hh < mB_h) { mB_h = hh; mB_e = RMp[r]; }
+            }
+            mA_h = mB_h;
+            mA_e = mB_e;
+            if (rxA + 1 < tid) {
+                const uint64_t hh = RMh[rxA + 1];
+                if (hh < mA_h) { mA_h = hh; mA_e = RMp[rxA + 1]; }
+            }
+        }
+        uint64_t pre_h = ~0ull;
+        uint32_t pre_e = e0;
+        uint32_t prev_arg = 0xFFFFFFFFu;
+        const uint32_t xb = e0 - (w - 1);   // x of step j is xb + j (mod 2^32; only used when j >= j0)
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const uint32_t e = e0 + j;
+            if ((uint32_t)j < n && h[j] <= pre_h) { pre_h = h[j]; pre_e = e; }
+            if ((uint32_t)j >= j0 && (uint32_t)j < n) {
+                const uint32_t x = xb + j;
+                uint64_t ch = pre_h;
+                uint32_t ce = pre_e;
+                if (x < e0) {
+                    const bool inB = x >= bnd;
+                    const uint64_t mh = inB ? mB_h : mA_h;
+                    const uint32_t me = inB ? mB_e : mA_e;
+                    if (mh < ch) { ch = mh; ce = me; }
+                    const uint32_t rx = x >> LSH, xr = x & ~LM;
+                    const uint32_t sp = SP[rx * C::LSP + (x & LM)];
+                    const uint64_t sh = H[xr + (sp ^ (rx & LM))];
+                    if (sh < ch) { ch = sh; ce = xr + sp; }
+                }
+                if (e < e_first) {
+                    MISC[0] = ce;
+                } else if (ce != prev_arg && ch != ~0ull) {
+                    atomicOr(&EM[ce >> 5], 1u << (ce & 31u));
+                }
+                prev_arg = ce;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && t != 0) {
+        const uint32_t sarg = MISC[0];
+        EM[sarg >> 5] &= ~(1u << (sarg & 31u));
+    }
+    __syncthreads();
+
+    // ---- phase 3: compact the set bits in position order --------------------------------------
+    uint64_t bits = 0;
+    if (n) {
+        const uint32_t wd = e0 >> 5, sh = e0 & 31u;
+        const uint64_t two = (uint64_t)EM[wd] | ((uint64_t)EM[wd + 1] << 32);
+        bits = (two >> sh) & ((1ull << n) - 1ull);
+    }
+    const uint32_t cnt = (uint32_t)__popcll(bits);
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    uint32_t incl = cnt;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) MISC[4 + wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0, total = 0;
+    for (uint32_t i = 0; i < BLOCK / 64; ++i) {
+        const uint32_t v = MISC[4 + i];
+        if (i < wave) wave_off += v;
+        total += v;
+    }
+    if (tid == 0) {
+        const unsigned long long base = atomicAdd(A.cursor, (unsigned long long)total);
+        A.tile_count[tile] = total;
+        A.tile_offset[tile] = base;
+        MISC[8] = (uint32_t)base;
+        MISC[9] = (uint32_t)(base >> 32);
+    }
+    __syncthreads();
+    const uint64_t base = make64(MISC[8], MISC[9]);
+    if (cnt && base + total <= A.cap) {
+        uint64_t o = base + wave_off + (incl - cnt);
+        while (bits) {
+            const uint32_t j = (uint32_t)__builtin_ctzll(bits);
+            bits &= bits - 1;
+            uint64_t oh = H[e0 + (j ^ swz)] * A.mult;   // extend_hashes, hashing_internals.hpp:89-103
+            oh ^= oh >> 27;
+            A.stage_hash[o] = oh;
+            A.stage_kmer[o] = (uint64_t)(pos0 + E0 + e0 + j) | ((uint64_t)rec << 32);
+            ++o;
+        }
+    }
+}
+
 size_t lds_bytes_for(uint32_t L)
 {
     const size_t NE = (size_t)BLOCK * L;
@@ -362,27 +625,37 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     Plan p;
     p.k = k;
     p.w = w;
+    // generic class: any record; run length odd (conflict-free 64-bit LDS accesses at stride L)
     uint32_t L = std::min<uint32_t>(w, L_MAX);
-    if ((L & 1u) == 0) --L;  // odd: conflict-free 64-bit LDS accesses at stride L
+    if ((L & 1u) == 0) --L;
     p.L = L;
     p.NE = BLOCK * L;
     p.TW = p.NE - w;
     p.lds_bytes = lds_bytes_for(L);
+    // fast class: single-segment records, k <= KF, power-of-two run length
+    const char *force = getenv("SEQWIN_AMD_SKETCH");   // "generic" disables the fast path (debug / A-B)
+    p.Lf = (k <= KF && !(force && !strcmp(force, "generic"))) ? (w >= 32 ? 32u : (w >= 16 ? 16u : 0u)) : 0u;
+    p.TWf = p.Lf ? BLOCK * p.Lf - w : 0;
     p.mult = 1ULL ^ ((uint64_t)k * MULTISEED);
 
     const HostBatch &h = b.host;
     const size_t R = h.rec_len.size();
-    std::vector<uint32_t> rec_seg_off(R + 1, 0), rec_nvalid(R, 0), rec_tile_off(R + 1, 0), seg_pos, seg_idx;
-    uint64_t tiles = 0;
+    std::vector<uint32_t> rec_seg_off(R + 1, 0), rec_nvalid(R, 0), rec_tile_off(R + 1, 0), fast_off(R + 1, 0),
+        gen_off(R + 1, 0), seg_pos, seg_idx;
+    uint64_t tiles = 0, tiles_f = 0, tiles_g = 0;
     for (size_t r = 0; r < R; ++r) {
         rec_seg_off[r] = (uint32_t)seg_pos.size();
         rec_tile_off[r] = (uint32_t)tiles;
+        fast_off[r] = (uint32_t)tiles_f;
+        gen_off[r] = (uint32_t)tiles_g;
         uint64_t nv = 0;
+        uint32_t nseg = 0;
         for (uint32_t q = h.rec_run_off[r]; q < h.rec_run_off[r + 1]; ++q) {
             if (h.run_len[q] < k) continue;
             seg_pos.push_back(h.run_pos[q]);
             seg_idx.push_back((uint32_t)nv);
             nv += h.run_len[q] - k + 1;
+            ++nseg;
         }
         rec_nvalid[r] = (uint32_t)nv;
         p.n_valid += nv;
@@ -390,13 +663,25 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
         if (nv >= w) {
             const uint64_t windows = nv - w + 1;
             p.n_windows += windows;
-            tiles += (windows + p.TW - 1) / p.TW;
+            if (p.Lf && nseg == 1) {
+                const uint64_t nt = (windows + p.TWf - 1) / p.TWf;
+                tiles_f += nt;
+                tiles += nt;
+            } else {
+                const uint64_t nt = (windows + p.TW - 1) / p.TW;
+                tiles_g += nt;
+                tiles += nt;
+            }
         }
         if (tiles > 0x7FFFFFFFull) raise(SW_ERR_RUNTIME, "batch too large: more than 2^31-1 tiles");
     }
     rec_seg_off[R] = (uint32_t)seg_pos.size();
     rec_tile_off[R] = (uint32_t)tiles;
+    fast_off[R] = (uint32_t)tiles_f;
+    gen_off[R] = (uint32_t)tiles_g;
     p.n_tiles = (uint32_t)tiles;
+    p.n_tiles_fast = (uint32_t)tiles_f;
+    p.n_tiles_gen = (uint32_t)tiles_g;
 
     uint64_t lut[40];
     const uint64_t S[4] = {SEED_A, SEED_C, SEED_G, SEED_T};
@@ -416,6 +701,8 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     up32(p.rec_seg_off, rec_seg_off);
     up32(p.rec_nvalid, rec_nvalid);
     up32(p.rec_tile_off, rec_tile_off);
+    up32(p.fast_tile_off, fast_off);
+    up32(p.gen_tile_off, gen_off);
     up32(p.seg_pos, seg_pos);
     up32(p.seg_idx, seg_idx);
     p.lut.alloc(40);
@@ -427,8 +714,12 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
 {
     static std::once_flag once;
     std::call_once(once, [] {
-        SW_HIP(hipFuncSetAttribute((const void *)sketch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        SW_HIP(hipFuncSetAttribute((const void *)sketch_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes_for(L_MAX)));
+        SW_HIP(hipFuncSetAttribute((const void *)sketch_fast_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)FastCfg<32>::bytes));
+        SW_HIP(hipFuncSetAttribute((const void *)sketch_fast_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)FastCfg<16>::bytes));
     });
     out.n_occ = 0;
     out.launches = 0;
@@ -460,9 +751,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         a.n_records = (uint32_t)b.n_records;
         a.k = plan.k;
         a.w = plan.w;
-        a.L = plan.L;
-        a.TW = plan.TW;
-        a.n_tiles = plan.n_tiles;
+        a.packed_words = b.packed_words;
         a.mult = plan.mult;
         a.stage_hash = out.stage_hash.p;
         a.stage_kmer = out.stage_kmer.p;
@@ -471,8 +760,25 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         a.tile_count = out.tile_count.p;
         a.tile_offset = out.tile_offset.p;
         SW_HIP(hipEventRecord(ev0, stream));
-        hipLaunchKernelGGL(sketch_kernel, dim3(plan.n_tiles), dim3(BLOCK), plan.lds_bytes, stream, a);
-        SW_HIP(hipGetLastError());
+        if (plan.n_tiles_fast) {
+            a.cls_tile_off = plan.fast_tile_off.p;
+            a.L = plan.Lf;
+            a.TW = plan.TWf;
+            a.n_tiles = plan.n_tiles_fast;
+            if (plan.Lf == 32)
+                hipLaunchKernelGGL(sketch_fast_kernel<32>, dim3(plan.n_tiles_fast), dim3(BLOCK), FastCfg<32>::bytes, stream, a);
+            else
+                hipLaunchKernelGGL(sketch_fast_kernel<16>, dim3(plan.n_tiles_fast), dim3(BLOCK), FastCfg<16>::bytes, stream, a);
+            SW_HIP(hipGetLastError());
+        }
+        if (plan.n_tiles_gen) {
+            a.cls_tile_off = plan.gen_tile_off.p;
+            a.L = plan.L;
+            a.TW = plan.TW;
+            a.n_tiles = plan.n_tiles_gen;
+            hipLaunchKernelGGL(sketch_generic_kernel, dim3(plan.n_tiles_gen), dim3(BLOCK), plan.lds_bytes, stream, a);
+            SW_HIP(hipGetLastError());
+        }
         SW_HIP(hipEventRecord(ev1, stream));
         unsigned long long total = 0;
         SW_HIP(hipMemcpyAsync(&total, cursor.p, sizeof total, hipMemcpyDeviceToHost, stream));
