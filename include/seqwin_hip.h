@@ -190,6 +190,30 @@ int sw_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *st
               sw_kmer *kmers, uint64_t cap, uint64_t *n_out);
 void sw_index_free(sw_index *ix);
 
+/* ---- multi-GPU merge (one process per GPU; the exchange itself is done by the host side with
+ *      torch.distributed / RCCL on the device buffers below).  Together these replace
+ *      merge_thread_graphs (cpp/src/seqwin/build_internals.cpp:295-392) across GPUs. -------------- */
+
+/* Device addresses of the index arrays (sw_kmer[n_kmers], sw_node[n_nodes], sw_edge[n_edges]). */
+int sw_index_device_ptrs(const sw_index *ix, void **kmers, void **nodes, void **edges);
+/* Write one row per occurrence, in the index's (hash, record_idx, pos) order, into the caller's DEVICE
+ * buffer rows[n_kmers][2] (u64): {node hash, pos | (record_idx + rec_offset) << 32}
+ * (record re-basing: build_internals.cpp:334-355, 243-246). */
+int sw_index_occ_rows(const sw_index *ix, uint64_t rec_offset, void *rows_dev, void *stream);
+/* Copy the edges, as rows[n_edges][3] (u64) = {first, second, weight}, into the caller's DEVICE buffer. */
+int sw_index_edge_rows(const sw_index *ix, void *rows_dev, void *stream);
+/* For n_bounds ascending hash bounds: occ_split[j] = number of occurrences whose node hash < node_bounds[j];
+ * edge_split[j] = number of edges whose `first` < edge_bounds[j] (host outputs). */
+int sw_index_splits(const sw_index *ix, const uint64_t *node_bounds, const uint64_t *edge_bounds, uint64_t n_bounds,
+                    uint64_t *occ_split, uint64_t *edge_split, void *stream);
+/* Build one rank's slice of the merged graph from exchanged rows (DEVICE buffers):
+ * occ_rows[n_occ][2] concatenated in source-rank order, edge_rows[n_edge_rows][3] = {first, second, weight}.
+ * Node ranges are offset by kmer_base (number of occurrences owned by lower ranks).  record_offsets /
+ * is_targets are the GLOBAL host arrays (is_targets may be NULL to skip the counts). */
+int sw_index_merge(const void *occ_rows_dev, uint64_t n_occ, const void *edge_rows_dev, uint64_t n_edge_rows,
+                   uint64_t kmer_base, const uint32_t *record_offsets, const uint8_t *is_targets,
+                   uint64_t n_assemblies, void *stream, sw_index **out);
+
 #ifdef __cplusplus
 }
 #endif

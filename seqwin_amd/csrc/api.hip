@@ -459,6 +459,79 @@ int sw_index_checksums(const sw_index *ix, uint64_t *kmers_sum, uint64_t *nodes_
 
 void sw_index_free(sw_index *ix) { delete ix; }
 
+int sw_index_device_ptrs(const sw_index *ix, void **kmers, void **nodes, void **edges)
+{
+    return guarded([&] {
+        if (kmers) *kmers = ix->kmers.p;
+        if (nodes) *nodes = ix->nodes.p;
+        if (edges) *edges = ix->edges.p;
+    });
+}
+
+int sw_index_occ_rows(const sw_index *ix, uint64_t rec_offset, void *rows_dev, void *stream)
+{
+    return guarded([&] { index_occ_rows(*ix, rec_offset, (uint64_t *)rows_dev, (hipStream_t)stream); });
+}
+
+int sw_index_edge_rows(const sw_index *ix, void *rows_dev, void *stream)
+{
+    return guarded([&] {
+        if (ix->n_edges)
+            SW_HIP(hipMemcpyAsync(rows_dev, ix->edges.p, ix->n_edges * sizeof(sw_edge), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    });
+}
+
+int sw_index_splits(const sw_index *ix, const uint64_t *node_bounds, const uint64_t *edge_bounds, uint64_t n_bounds,
+                    uint64_t *occ_split, uint64_t *edge_split, void *stream)
+{
+    return guarded([&] {
+        index_splits(*ix, node_bounds, edge_bounds, (uint32_t)n_bounds, occ_split, edge_split, (hipStream_t)stream);
+    });
+}
+
+int sw_index_merge(const void *occ_rows_dev, uint64_t n_occ, const void *edge_rows_dev, uint64_t n_edge_rows,
+                   uint64_t kmer_base, const uint32_t *record_offsets, const uint8_t *is_targets, uint64_t n_assemblies,
+                   void *stream, sw_index **out)
+{
+    return guarded([&] {
+        require_device();
+        hipStream_t st = (hipStream_t)stream;
+        std::unique_ptr<sw_index> ix(new sw_index);
+        SW_HIP(hipGetDevice(&ix->device));
+        uint64_t n_tar = 0, n_neg = 0;
+        DevArray<uint8_t> d_tar;
+        DevArray<uint32_t> d_rec_asm;
+        uint32_t n_records = 0;
+        if (is_targets) {
+            check_targets(is_targets, n_assemblies, &n_tar, &n_neg);
+            n_records = record_offsets[n_assemblies];
+            std::vector<uint32_t> rec_asm(n_records);
+            for (uint64_t a = 0; a < n_assemblies; ++a)
+                for (uint32_t r = record_offsets[a]; r < record_offsets[a + 1]; ++r) rec_asm[r] = (uint32_t)a;
+            d_rec_asm.alloc(n_records);
+            d_tar.alloc(n_assemblies);
+            if (n_records) SW_HIP(hipMemcpyAsync(d_rec_asm.p, rec_asm.data(), (size_t)n_records * 4, hipMemcpyHostToDevice, st));
+            SW_HIP(hipMemcpyAsync(d_tar.p, is_targets, n_assemblies, hipMemcpyHostToDevice, st));
+            SW_HIP(hipStreamSynchronize(st));
+        }
+        hipEvent_t e0, e1;
+        SW_HIP(hipEventCreate(&e0));
+        SW_HIP(hipEventCreate(&e1));
+        SW_HIP(hipEventRecord(e0, st));
+        merge_build((const uint64_t *)occ_rows_dev, n_occ, (const uint64_t *)edge_rows_dev, n_edge_rows, kmer_base,
+                    d_rec_asm.p, n_records, is_targets ? d_tar.p : nullptr, n_tar, n_neg, st, *ix);
+        SW_HIP(hipEventRecord(e1, st));
+        SW_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SW_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ix->timings.total_ms = ms;
+        SW_HIP(hipEventDestroy(e0));
+        SW_HIP(hipEventDestroy(e1));
+        *out = ix.release();
+    });
+}
+
 int sw_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *stream, uint64_t *out_hash, sw_kmer *kmers,
               uint64_t cap, uint64_t *n_out)
 {

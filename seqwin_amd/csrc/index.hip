@@ -101,28 +101,122 @@ __global__ void k_iota(uint32_t *v, uint64_t n)
 
 // ---- nodes / kmers / ranks ------------------------------------------------------------------------
 __global__ void k_nodes(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ perm,
-                        const uint32_t *__restrict__ cum, const uint64_t *__restrict__ kmer_in, uint64_t n,
-                        sw_kmer *__restrict__ kmers, sw_node *__restrict__ nodes, uint32_t *__restrict__ rank)
+                        const uint32_t *__restrict__ cum, const uint64_t *__restrict__ kmer_in, uint32_t kmer_stride,
+                        uint64_t n, uint64_t base, sw_kmer *__restrict__ kmers, sw_node *__restrict__ nodes,
+                        uint32_t *__restrict__ rank)
 {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const uint32_t nid = cum[s] - 1;
     const uint32_t src = perm[s];
-    const uint64_t km = kmer_in[src];
+    const uint64_t km = kmer_in[(uint64_t)src * kmer_stride];
     kmers[s].pos = (uint32_t)km;
     kmers[s].record_idx = (uint32_t)(km >> 32);
-    rank[src] = nid;
+    if (rank) rank[src] = nid;
     const uint64_t key = skeys[s];
     const bool head = (s == 0) || key != skeys[s - 1];
     if (head) {
         nodes[nid].hash = key;
-        nodes[nid].start = s;
+        nodes[nid].start = base + s;
         nodes[nid].n_tar = 0;
         nodes[nid].n_neg = 0;
         nodes[nid].penalty = 0.0;
-        if (s) nodes[nid - 1].stop = s;
+        if (s) nodes[nid - 1].stop = base + s;
     }
-    if (s == n - 1) nodes[nid].stop = n;
+    if (s == n - 1) nodes[nid].stop = base + n;
+}
+
+// ---- multi-GPU merge helpers ---------------------------------------------------------------------
+// rows[s] = (hash of the node owning occurrence s, pos | (record_idx + rec_offset) << 32)
+__global__ void k_occ_rows(const sw_kmer *__restrict__ kmers, const sw_node *__restrict__ nodes, uint64_t n_nodes,
+                           uint64_t n_kmers, uint64_t rec_offset, uint64_t *__restrict__ rows)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_kmers) return;
+    uint64_t lo = 0, hi = n_nodes;  // last node with start <= s
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (nodes[mid].start <= s) lo = mid; else hi = mid;
+    }
+    rows[2 * s] = nodes[lo].hash;
+    rows[2 * s + 1] = (uint64_t)kmers[s].pos | (((uint64_t)kmers[s].record_idx + rec_offset) << 32);
+}
+
+__global__ void k_strided_copy(const uint64_t *__restrict__ src, uint32_t stride, uint32_t col, uint64_t n,
+                               uint64_t *__restrict__ dst)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i * stride + col];
+}
+
+__global__ void k_gather_col(const uint64_t *__restrict__ rows, uint32_t stride, uint32_t col,
+                             const uint32_t *__restrict__ idx, uint64_t n, uint64_t *__restrict__ dst)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = rows[(uint64_t)idx[i] * stride + col];
+}
+
+__global__ void k_rebase_nodes(sw_node *__restrict__ nodes, uint64_t n_nodes, uint64_t base)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_nodes) {
+        nodes[i].start += base;
+        nodes[i].stop += base;
+    }
+}
+
+struct PairHeadFlag {
+    const uint64_t *a, *b;
+    __host__ __device__ uint32_t operator()(uint64_t s) const
+    {
+        return (s == 0 || a[s] != a[s - 1] || b[s] != b[s - 1]) ? 1u : 0u;
+    }
+};
+
+__global__ void k_merge_edge_heads(const uint64_t *__restrict__ f, const uint64_t *__restrict__ sd,
+                                   const uint32_t *__restrict__ ecum, uint64_t n, uint64_t *__restrict__ edge_start)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n) return;
+    if (s == 0 || f[s] != f[s - 1] || sd[s] != sd[s - 1]) edge_start[ecum[s] - 1] = s;
+}
+
+__global__ void k_merge_edges(const uint64_t *__restrict__ f, const uint64_t *__restrict__ sd,
+                              const uint64_t *__restrict__ wcum, const uint64_t *__restrict__ edge_start,
+                              uint64_t n_edges, uint64_t n, sw_edge *__restrict__ edges)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const uint64_t s = edge_start[e];
+    const uint64_t s1 = (e + 1 < n_edges) ? edge_start[e + 1] : n;
+    edges[e].first = f[s];
+    edges[e].second = sd[s];
+    edges[e].weight = wcum[s1 - 1] - (s ? wcum[s - 1] : 0ull);   // build_internals.cpp:283-285
+}
+
+__global__ void k_lower_bounds(const sw_node *__restrict__ nodes, uint64_t n_nodes, uint64_t n_kmers,
+                               const sw_edge *__restrict__ edges, uint64_t n_edges, const uint64_t *__restrict__ nb,
+                               const uint64_t *__restrict__ eb, uint32_t n_bounds, uint64_t *__restrict__ occ_split,
+                               uint64_t *__restrict__ edge_split)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_bounds) return;
+    {
+        uint64_t lo = 0, hi = n_nodes;  // first node with hash >= nb[j]
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (nodes[mid].hash < nb[j]) lo = mid + 1; else hi = mid;
+        }
+        occ_split[j] = (lo < n_nodes) ? nodes[lo].start : n_kmers;
+    }
+    {
+        uint64_t lo = 0, hi = n_edges;  // first edge with first >= eb[j]
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (edges[mid].first < eb[j]) lo = mid + 1; else hi = mid;
+        }
+        edge_split[j] = lo;
+    }
 }
 
 // ---- get_penalty ------------------------------------------------------------------------------------
@@ -416,8 +510,8 @@ void build_index(const sw_batch &b, const OrderedOcc &occ, const uint8_t *d_is_t
         SW_HIP(hipStreamSynchronize(stream));
         ix.n_nodes = n_nodes;
         ix.nodes.alloc(n_nodes);
-        hipLaunchKernelGGL(k_nodes, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, cum, occ.kmer.p, n,
-                           ix.kmers.p, ix.nodes.p, rank.p);
+        hipLaunchKernelGGL(k_nodes, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, cum, occ.kmer.p, 1u, n,
+                           (uint64_t)0, ix.kmers.p, ix.nodes.p, rank.p);
         SW_HIP(hipGetLastError());
         SW_HIP(hipStreamSynchronize(stream));  // sort buffers are released here
     } else {
@@ -490,6 +584,110 @@ void build_index(const sw_batch &b, const OrderedOcc &occ, const uint8_t *d_is_t
     SW_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
     ix.timings.edges_ms = ms;
     for (auto &e : ev) SW_HIP(hipEventDestroy(e));
+}
+
+void index_occ_rows(const sw_index &ix, uint64_t rec_offset, uint64_t *d_rows, hipStream_t stream)
+{
+    if (ix.n_kmers == 0) return;
+    hipLaunchKernelGGL(k_occ_rows, dim3(blocks_for(ix.n_kmers)), dim3(TPB), 0, stream, ix.kmers.p, ix.nodes.p, ix.n_nodes,
+                       ix.n_kmers, rec_offset, d_rows);
+    SW_HIP(hipGetLastError());
+}
+
+void index_splits(const sw_index &ix, const uint64_t *node_bounds, const uint64_t *edge_bounds, uint32_t n_bounds,
+                  uint64_t *occ_split, uint64_t *edge_split, hipStream_t stream)
+{
+    if (n_bounds == 0) return;
+    DevArray<uint64_t> nb(n_bounds), eb(n_bounds), os(n_bounds), es(n_bounds);
+    SW_HIP(hipMemcpyAsync(nb.p, node_bounds, n_bounds * 8, hipMemcpyHostToDevice, stream));
+    SW_HIP(hipMemcpyAsync(eb.p, edge_bounds, n_bounds * 8, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_lower_bounds, dim3(blocks_for(n_bounds)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, ix.n_kmers,
+                       ix.edges.p, ix.n_edges, nb.p, eb.p, n_bounds, os.p, es.p);
+    SW_HIP(hipGetLastError());
+    SW_HIP(hipMemcpyAsync(occ_split, os.p, n_bounds * 8, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipMemcpyAsync(edge_split, es.p, n_bounds * 8, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+}
+
+// Union of partial graphs (the GPU counterpart of merge_thread_graphs, build_internals.cpp:295-392):
+// occurrence rows arrive concatenated in source-rank order (each source sorted by (hash, record, pos)
+// with globally rebased record indices), edge rows as (first, second, partial weight).
+void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_rows, uint64_t m, uint64_t kmer_base,
+                 const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target, uint64_t n_targets,
+                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix)
+{
+    if (n >= 0xFFFFFFFFull || m >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 rows on one device");
+    ix.n_kmers = n;
+    ix.kmers.alloc(n);
+    ix.n_nodes = 0;
+    if (n) {
+        DevArray<uint64_t> k0(n), k1(n);
+        DevArray<uint32_t> v0(n), v1(n);
+        hipLaunchKernelGGL(k_strided_copy, dim3(blocks_for(n)), dim3(TPB), 0, stream, d_occ_rows, 2u, 0u, n, k0.p);
+        hipLaunchKernelGGL(k_iota, dim3(blocks_for(n)), dim3(TPB), 0, stream, v0.p, n);
+        uint64_t *keys = k0.p, *keys_alt = k1.p;
+        uint32_t *vals = v0.p, *vals_alt = v1.p;
+        sort_pairs(keys, keys_alt, vals, vals_alt, n, 0, 64, stream);   // stable: ties keep source-rank order
+        uint32_t *cum = vals_alt;
+        inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), HeadFlag{keys, n}),
+                      cum, n, (uint32_t)0, stream);
+        uint32_t n_nodes = 0;
+        SW_HIP(hipMemcpyAsync(&n_nodes, cum + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));
+        ix.n_nodes = n_nodes;
+        ix.nodes.alloc(n_nodes);
+        hipLaunchKernelGGL(k_nodes, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, cum, d_occ_rows + 1, 2u, n,
+                           (uint64_t)0, ix.kmers.p, ix.nodes.p, (uint32_t *)nullptr);
+        SW_HIP(hipGetLastError());
+        SW_HIP(hipStreamSynchronize(stream));
+    } else {
+        ix.nodes.alloc(0);
+    }
+    if (d_is_target && ix.n_nodes) {
+        uint64_t err = 0;   // counts on slice-local ranges; ranges are re-based afterwards
+        device_get_penalty(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, d_rec_asm, n_records, d_is_target, n_targets,
+                           n_non_targets, stream, &err);
+        if (err) raise(SW_ERR_RUNTIME, "internal error: inconsistent occurrence order in merged index (%llu)",
+                       (unsigned long long)err);
+    }
+    if (kmer_base && ix.n_nodes) {
+        hipLaunchKernelGGL(k_rebase_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes,
+                           kmer_base);
+        SW_HIP(hipGetLastError());
+    }
+    ix.n_edges = 0;
+    if (m) {
+        DevArray<uint64_t> k0(m), k1(m), f(m), sd(m), wt(m);
+        DevArray<uint32_t> v0(m), v1(m);
+        hipLaunchKernelGGL(k_strided_copy, dim3(blocks_for(m)), dim3(TPB), 0, stream, d_edge_rows, 3u, 1u, m, k0.p);
+        hipLaunchKernelGGL(k_iota, dim3(blocks_for(m)), dim3(TPB), 0, stream, v0.p, m);
+        uint64_t *keys = k0.p, *keys_alt = k1.p;
+        uint32_t *vals = v0.p, *vals_alt = v1.p;
+        sort_pairs(keys, keys_alt, vals, vals_alt, m, 0, 64, stream);   // LSD: second first ...
+        hipLaunchKernelGGL(k_gather_col, dim3(blocks_for(m)), dim3(TPB), 0, stream, d_edge_rows, 3u, 0u, vals, m, keys);
+        sort_pairs(keys, keys_alt, vals, vals_alt, m, 0, 64, stream);   // ... then first (build_internals.cpp:261)
+        hipLaunchKernelGGL(k_gather_col, dim3(blocks_for(m)), dim3(TPB), 0, stream, d_edge_rows, 3u, 0u, vals, m, f.p);
+        hipLaunchKernelGGL(k_gather_col, dim3(blocks_for(m)), dim3(TPB), 0, stream, d_edge_rows, 3u, 1u, vals, m, sd.p);
+        hipLaunchKernelGGL(k_gather_col, dim3(blocks_for(m)), dim3(TPB), 0, stream, d_edge_rows, 3u, 2u, vals, m, wt.p);
+        SW_HIP(hipGetLastError());
+        DevArray<uint32_t> ecum(m);
+        inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), PairHeadFlag{f.p, sd.p}),
+                      ecum.p, m, (uint32_t)0, stream);
+        inclusive_sum(wt.p, wt.p, m, (uint64_t)0, stream);
+        uint32_t n_edges = 0;
+        SW_HIP(hipMemcpyAsync(&n_edges, ecum.p + (m - 1), 4, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));
+        ix.n_edges = n_edges;
+        ix.edges.alloc(n_edges);
+        DevArray<uint64_t> edge_start(n_edges);
+        hipLaunchKernelGGL(k_merge_edge_heads, dim3(blocks_for(m)), dim3(TPB), 0, stream, f.p, sd.p, ecum.p, m, edge_start.p);
+        hipLaunchKernelGGL(k_merge_edges, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, f.p, sd.p, wt.p, edge_start.p,
+                           (uint64_t)n_edges, m, ix.edges.p);
+        SW_HIP(hipGetLastError());
+        SW_HIP(hipStreamSynchronize(stream));
+    } else {
+        ix.edges.alloc(0);
+    }
 }
 
 void device_filter_kmers(const sw_kmer *d_kmers, uint64_t n_kmers, const sw_node *d_nodes, uint64_t n_nodes,

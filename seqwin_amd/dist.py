@@ -1,0 +1,239 @@
+"""One process per GPU: shard the assemblies, build partial graphs, merge them over RCCL.
+
+This is the multi-GPU form of the reference's thread partition + ``merge_thread_graphs``
+(cpp/src/seqwin/build.cpp:350-367, cpp/src/seqwin/build_internals.cpp:295-392):
+
+* assemblies are split into contiguous ranges with the reference's formula (``partition_assemblies``);
+  GPU g owns the range of "thread g", so global record_idx = local + prefix of the record counts;
+* every GPU builds the partial graph of its shard (sketch -> nodes / kmers / edges, no counts);
+* occurrences are exchanged by hash range and edges by ``first`` range (order-preserving splitters,
+  quantile-shaped for edges because min(u, v) is skewed) with ``all_to_all_single`` -- backend
+  "nccl" is RCCL over xGMI; a direct all-to-all uses all seven links of a GPU at once, which is why it is
+  preferred over a ring reduce here;
+* every GPU finishes its slice: stable sort of the received runs by hash (ties keep source-rank =
+  record order), run-length -> nodes, per-node target / non-target counts, and the sum of the
+  partial edge weights (an assembly lives in exactly one shard, build_internals.cpp:283-285).
+
+The concatenation of the slices in rank order is bit-identical to the single-GPU result (shard-count
+invariance, the property the reference tests as thread-count invariance, tests/smoke/test_graph.py:67-127).
+
+The collective choreography is independent of where the per-rank compute runs: ``engine`` supplies
+local build / rows / splits / merge.  The product engine is :class:`HipEngine`; the CPU test-suite
+drives the same choreography over gloo with a numpy engine defined in tests/.
+"""
+from __future__ import annotations
+
+import math
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+
+def partition_assemblies(n_assemblies: int, n_workers: int) -> list[tuple[int, int]]:
+    """Contiguous ranges, first ``rem`` workers get one extra (cpp/src/seqwin/build.cpp:350-356)."""
+    n_workers = max(1, n_workers)
+    base, rem = divmod(n_assemblies, n_workers)
+    out = []
+    for t in range(n_workers):
+        start = t * base + min(t, rem)
+        out.append((start, start + base + (1 if t < rem else 0)))
+    return out
+
+
+def hash_bounds(n_parts: int) -> tuple[list[int], list[int]]:
+    """Order-preserving splitters in [0, 2^64]: (node_bounds, edge_bounds), n_parts - 1 values each.
+
+    Node hashes are uniform, so their splitters are j * 2^64 / P.  An edge is keyed by
+    first = min(u, v), whose CDF is 1 - (1 - x)^2, so its splitters are the quantiles
+    x_j = 1 - sqrt(1 - j / P)."""
+    nb, eb = [], []
+    for j in range(1, n_parts):
+        nb.append(-((-j << 64) // n_parts))                                   # ceil(j * 2^64 / P)
+        eb.append(min((1 << 64) - 1, (1 << 64) - math.isqrt(((n_parts - j) << 128) // n_parts)))
+    return nb, eb
+
+
+@dataclass
+class Shard:
+    """The assemblies one rank owns: a device batch plus its place in the job."""
+    batch: object
+    first_assembly: int
+    n_assemblies_total: int
+
+
+class HipEngine:
+    """Per-rank compute on the MI355X through the C ABI (include/seqwin_hip.h)."""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def _stream(self) -> int:
+        return int(self.torch.cuda.current_stream().cuda_stream)
+
+    def local_index(self, shard: Shard, k: int, w: int):
+        return shard.batch.build_index(k, w, None, stream=self._stream())
+
+    def record_offsets(self, shard: Shard) -> np.ndarray:
+        return shard.batch.records()[0]
+
+    def sizes(self, ix):
+        return ix.sizes()
+
+    def timings(self, ix) -> dict:
+        return ix.timings()
+
+    def splits(self, ix, node_bounds, edge_bounds):
+        import ctypes
+
+        from ._lib import c_u64, c_vp, check, lib
+        n = len(node_bounds)
+        nb = (c_u64 * max(n, 1))(*node_bounds)
+        eb = (c_u64 * max(n, 1))(*edge_bounds)
+        os_ = (c_u64 * max(n, 1))()
+        es_ = (c_u64 * max(n, 1))()
+        check(lib.sw_index_splits(ix._h, nb, eb, c_u64(n), os_, es_, c_vp(self._stream())))
+        return list(os_)[:n], list(es_)[:n]
+
+    def occ_rows(self, ix, rec_offset: int):
+        from ._lib import c_u64, c_vp, check, lib
+        n = ix.sizes()[0]
+        rows = self.torch.empty((n, 2), dtype=self.torch.int64, device=self.device)
+        check(lib.sw_index_occ_rows(ix._h, c_u64(rec_offset), c_vp(rows.data_ptr()), c_vp(self._stream())))
+        return rows
+
+    def edge_rows(self, ix):
+        from ._lib import c_vp, check, lib
+        m = ix.sizes()[2]
+        rows = self.torch.empty((m, 3), dtype=self.torch.int64, device=self.device)
+        check(lib.sw_index_edge_rows(ix._h, c_vp(rows.data_ptr()), c_vp(self._stream())))
+        return rows
+
+    def merge(self, occ_rows, edge_rows, kmer_base: int, record_offsets: np.ndarray, is_targets):
+        import ctypes
+
+        from ._lib import c_u64, c_vp, check, lib
+        from .device import Index
+        offs = np.ascontiguousarray(record_offsets, np.uint32)
+        if is_targets is None:
+            tar, na = None, len(offs) - 1
+        else:
+            t = np.ascontiguousarray(np.asarray(is_targets, np.bool_)).view(np.uint8)
+            tar, na = t.ctypes.data_as(c_vp), len(t)
+        self.torch.cuda.current_stream().synchronize()   # rows were produced by RCCL on its own stream
+        h = c_vp()
+        check(lib.sw_index_merge(c_vp(occ_rows.data_ptr()), c_u64(occ_rows.shape[0]), c_vp(edge_rows.data_ptr()),
+                                 c_u64(edge_rows.shape[0]), c_u64(kmer_base), offs.ctypes.data_as(c_vp), tar, c_u64(na),
+                                 c_vp(self._stream()), ctypes.byref(h)))
+        return Index(h)
+
+    def export(self, ix):
+        return ix.export()
+
+
+class ShardedIndex:
+    """This rank's slice (a hash range) of the merged graph, plus the job-wide metadata."""
+
+    def __init__(self, engine, merged, record_offsets, timings, kmer_base):
+        self.engine, self.merged = engine, merged
+        self.record_offsets, self._timings, self.kmer_base = record_offsets, timings, kmer_base
+
+    def sizes(self):
+        return self.engine.sizes(self.merged)
+
+    def timings(self) -> dict:
+        return dict(self._timings)
+
+    def export(self):
+        return self.engine.export(self.merged)
+
+    def gather(self, dst: int = 0, group=None):
+        """Concatenate all slices on rank ``dst`` -> (kmers, nodes, edges, record_offsets) or None elsewhere."""
+        import torch.distributed as dist
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, self.export(), group=group)
+        if dist.get_rank(group) != dst:
+            return None
+        return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
+                np.concatenate([p[2] for p in parts]), self.record_offsets)
+
+
+def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, group=None) -> ShardedIndex:
+    """Build this rank's partial graph, exchange by hash range, and finish this rank's slice.
+
+    ``is_targets`` is the job-wide flag vector (one per assembly, all ranks pass the same) or None."""
+    import torch
+    import torch.distributed as dist
+
+    engine = engine or HipEngine()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = engine.device
+    t0 = time.perf_counter()
+
+    ix = engine.local_index(shard, k, w)
+    tm = {key: v for key, v in engine.timings(ix).items()}
+    n_occ_local, _, n_edges_local = engine.sizes(ix)
+    local_offs = np.asarray(engine.record_offsets(shard), np.uint32)
+
+    # C0: record-count prefix (build_internals.cpp:334-355)
+    if world > 1:
+        all_offs = [None] * world
+        dist.all_gather_object(all_offs, local_offs, group=group)
+    else:
+        all_offs = [local_offs]
+    rec_base, glob = [], [np.zeros(1, np.uint32)]
+    total = 0
+    for o in all_offs:
+        rec_base.append(total)
+        glob.append((o[1:].astype(np.uint64) + total).astype(np.uint32))
+        total += int(o[-1])
+        if total > 0xFFFFFFFF:
+            raise RuntimeError("Total number of FASTA records exceeds uint32 range")
+    record_offsets = np.concatenate(glob)
+
+    occ = engine.occ_rows(ix, rec_base[rank])
+    edges = engine.edge_rows(ix)
+    t1 = time.perf_counter()
+    if world > 1:
+        # C1: all-to-all-v of occurrence rows by hash range and of edge rows by `first` range
+        nb, eb = hash_bounds(world)
+        osp, esp = engine.splits(ix, nb, eb)
+        ocut = [0] + [int(x) for x in osp] + [n_occ_local]
+        ecut = [0] + [int(x) for x in esp] + [n_edges_local]
+        send = torch.tensor([[ocut[j + 1] - ocut[j], ecut[j + 1] - ecut[j]] for j in range(world)], dtype=torch.int64, device=dev)
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=group)
+        send_l, recv_l = send.tolist(), recv.tolist()
+        r_occ = torch.empty((sum(r[0] for r in recv_l), 2), dtype=torch.int64, device=dev)
+        r_edges = torch.empty((sum(r[1] for r in recv_l), 3), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(r_occ, occ, [r[0] for r in recv_l], [s[0] for s in send_l], group=group)
+        dist.all_to_all_single(r_edges, edges, [r[1] for r in recv_l], [s[1] for s in send_l], group=group)
+        owned = torch.tensor([r_occ.shape[0]], dtype=torch.int64, device=dev)
+        owned_all = [torch.empty_like(owned) for _ in range(world)]
+        dist.all_gather(owned_all, owned, group=group)
+        kmer_base = int(sum(int(x.item()) for x in owned_all[:rank]))
+    else:
+        r_occ, r_edges, kmer_base = occ, edges, 0
+    t2 = time.perf_counter()
+    merged = engine.merge(r_occ, r_edges, kmer_base, record_offsets, is_targets)
+    t3 = time.perf_counter()
+    tm.update(n_occ_local=n_occ_local, local_build_wall_ms=(t1 - t0) * 1e3, exchange_wall_ms=(t2 - t1) * 1e3,
+              merge_wall_ms=(t3 - t2) * 1e3)
+    return ShardedIndex(engine, merged, record_offsets, tm, kmer_base)
+
+
+def build_graph_distributed(assembly_paths, k: int, w: int, is_targets=None, n_cpu: int = 1, group=None):
+    """FASTA paths -> merged graph with every rank ingesting its own shard (rank 0 returns the arrays)."""
+    import torch.distributed as dist
+
+    from .device import Batch
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    paths = [str(p) for p in assembly_paths]
+    start, end = partition_assemblies(len(paths), world)[rank]
+    shard = Shard(Batch.from_fasta(paths[start:end], n_cpu=n_cpu), start, len(paths))
+    sharded = build_sharded_index(shard, k, w, is_targets, group=group)
+    return sharded.gather(0, group=group) if world > 1 else (*sharded.export(), sharded.record_offsets)

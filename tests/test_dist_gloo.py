@@ -1,0 +1,163 @@
+"""CPU, world_size 2 over gloo: the multi-GPU choreography of seqwin_amd/dist.py (assembly partition,
+record re-basing, hash-range all-to-all of occurrence and edge rows, slice merge, gather).
+
+The per-rank compute is supplied by a numpy engine built on the oracle (test infrastructure), so what is
+under test here is exactly the code that runs between the kernels on a multi-GPU node; the HIP engine
+plugs into the same functions.  The merged result must equal the single-process result bit for bit
+(shard-count invariance, reference tests/smoke/test_graph.py:67-127)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from conftest import GOLDEN
+from seqwin_amd import dist as swdist
+
+U64 = np.uint64
+
+
+class NumpyEngine:
+    device = torch.device("cpu")
+
+    def local_index(self, shard, k, w):
+        kmers, nodes, edges, offs, _ = oracle.build(shard.batch, k, w)
+        return dict(kmers=kmers, nodes=nodes, edges=edges, offs=offs)
+
+    def record_offsets(self, shard):
+        return oracle.build(shard.batch, 3, 1)[3] if False else self._offs
+
+    def sizes(self, ix):
+        return len(ix["kmers"]), len(ix["nodes"]), len(ix["edges"])
+
+    def timings(self, ix):
+        return {}
+
+    def splits(self, ix, node_bounds, edge_bounds):
+        nodes, edges = ix["nodes"], ix["edges"]
+        osp, esp = [], []
+        for b in node_bounds:
+            i = int(np.searchsorted(nodes["hash"], U64(b), side="left"))
+            osp.append(int(nodes["start"][i]) if i < len(nodes) else len(ix["kmers"]))
+        for b in edge_bounds:
+            esp.append(int(np.searchsorted(edges["first"], U64(b), side="left")))
+        return osp, esp
+
+    def occ_rows(self, ix, rec_offset):
+        nodes, kmers = ix["nodes"], ix["kmers"]
+        h = np.repeat(nodes["hash"], (nodes["stop"] - nodes["start"]).astype(np.int64))
+        km = kmers["pos"].astype(U64) | ((kmers["record_idx"].astype(U64) + U64(rec_offset)) << U64(32))
+        return torch.from_numpy(np.stack([h, km], axis=1).view(np.int64).copy())
+
+    def edge_rows(self, ix):
+        return torch.from_numpy(ix["edges"].view(U64).reshape(-1, 3).view(np.int64).copy())
+
+    def merge(self, occ_rows, edge_rows, kmer_base, record_offsets, is_targets):
+        occ = occ_rows.numpy().view(U64)
+        order = np.argsort(occ[:, 0], kind="stable")
+        h, km = occ[order, 0], occ[order, 1]
+        kmers = np.empty(len(km), oracle.KMER_DTYPE)
+        kmers["pos"] = (km & U64(0xFFFFFFFF)).astype(np.uint32)
+        kmers["record_idx"] = (km >> U64(32)).astype(np.uint32)
+        uh, start = np.unique(h, return_index=True)
+        nodes = np.zeros(len(uh), oracle.NODE_DTYPE)
+        nodes["hash"] = uh
+        nodes["start"] = start
+        nodes["stop"] = np.append(start[1:], len(h))
+        if is_targets is not None and len(nodes):
+            oracle.get_penalty(kmers, nodes, record_offsets, is_targets)
+        nodes["start"] += U64(kmer_base)
+        nodes["stop"] += U64(kmer_base)
+        e = edge_rows.numpy().view(U64)
+        o = np.lexsort((e[:, 1], e[:, 0]))
+        e = e[o]
+        edges = np.zeros(0, oracle.EDGE_DTYPE)
+        if len(e):
+            head = np.ones(len(e), bool)
+            head[1:] = (e[1:, 0] != e[:-1, 0]) | (e[1:, 1] != e[:-1, 1])
+            idx = np.nonzero(head)[0]
+            edges = np.zeros(len(idx), oracle.EDGE_DTYPE)
+            edges["first"], edges["second"] = e[idx, 0], e[idx, 1]
+            edges["weight"] = np.add.reduceat(e[:, 2], idx)
+        return dict(kmers=kmers, nodes=nodes, edges=edges)
+
+    def export(self, ix):
+        return ix["kmers"], ix["nodes"], ix["edges"]
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, paths, k, w, tar, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        start, end = swdist.partition_assemblies(len(paths), world)[rank]
+        eng = NumpyEngine()
+        mine = paths[start:end]
+        eng._offs = oracle.build(mine, k, w)[3]
+        sharded = swdist.build_sharded_index(swdist.Shard(mine, start, len(paths)), k, w, tar, engine=eng)
+        full = sharded.gather(0)
+        if rank == 0:
+            np.savez(out_path, kmers=full[0], nodes=full[1], edges=full[2], record_offsets=full[3])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("case", ["smoke", "pan", "edge"])
+def test_sharded_build_equals_single(tmp_path, world, case):
+    if case == "smoke":
+        s = GOLDEN / "smoke"
+        paths = [s / "targets/target-1.fasta", s / "targets/target-2.fasta",
+                 s / "non-targets/non-target-1.fasta", s / "non-targets/non-target-2.fasta"]
+        k, w = 7, 10
+    elif case == "pan":
+        paths = sorted((GOLDEN / "synth").glob("pan_*.fa"))
+        k, w = 15, 20
+    else:
+        paths = sorted((GOLDEN / "synth").glob("edge_*"))
+        k, w = 11, 5
+    paths = [str(p) for p in paths]
+    tar = [i % 2 == 0 for i in range(len(paths))]
+    out = tmp_path / "merged.npz"
+    mp.spawn(_worker, nprocs=world, args=(world, _free_port(), paths, k, w, tar, str(out)), join=True)
+    got = np.load(out)
+    ek, en, ee, eo, _ = oracle.build(paths, k, w)
+    oracle.get_penalty(ek, en, eo, tar)
+    assert np.array_equal(got["kmers"], ek) and np.array_equal(got["nodes"], en)
+    assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
+
+
+def test_partition_formula():
+    # cpp/src/seqwin/build.cpp:350-356
+    assert swdist.partition_assemblies(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    assert swdist.partition_assemblies(4, 8)[:5] == [(0, 1), (1, 2), (2, 3), (3, 4), (4, 4)]
+    assert swdist.partition_assemblies(0, 2) == [(0, 0), (0, 0)]
+    for n in range(0, 40):
+        for p in range(1, 9):
+            parts = swdist.partition_assemblies(n, p)
+            assert parts[0][0] == 0 and parts[-1][1] == n and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_hash_bounds_are_monotone_and_balanced():
+    for p in (1, 2, 3, 4, 8):
+        nb, eb = swdist.hash_bounds(p)
+        assert len(nb) == len(eb) == p - 1
+        assert nb == sorted(nb) and eb == sorted(eb) and all(0 < b < 2**64 for b in nb + eb)
+    rng = np.random.default_rng(0)
+    u, v = rng.random(200000), rng.random(200000)
+    first = np.minimum(u, v)
+    nb, eb = swdist.hash_bounds(8)
+    cnt = np.histogram(first, bins=[0] + [b / 2**64 for b in eb] + [1])[0]
+    assert cnt.max() / cnt.min() < 1.15     # quantile splitters balance min(u, v)

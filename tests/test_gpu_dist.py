@@ -1,0 +1,68 @@
+"""GPU (-m gpu): the device side of the multi-GPU merge (sw_index_occ_rows / _edge_rows / _splits /
+sw_index_merge) on ONE GPU: P shard batches are built one after another, their rows are routed by
+hand exactly as all_to_all_single would route them, every owner's slice is merged, and the
+concatenation must equal the single-batch index bit for bit (shard-count invariance)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import GOLDEN
+from seqwin_amd import dist as swdist
+from seqwin_amd.device import Batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _route_and_merge(paths, world, k, w, tar):
+    eng = swdist.HipEngine()
+    parts = swdist.partition_assemblies(len(paths), world)
+    shards = [Batch.from_fasta(paths[a:b], n_cpu=2) for a, b in parts]
+    local = [s.build_index(k, w, None) for s in shards]
+    offs = [s.records()[0] for s in shards]
+    rec_base, glob, total = [], [np.zeros(1, np.uint32)], 0
+    for o in offs:
+        rec_base.append(total)
+        glob.append(o[1:] + np.uint32(total))
+        total += int(o[-1])
+    record_offsets = np.concatenate(glob)
+    nb, eb = swdist.hash_bounds(world)
+    occ, edg, ocut, ecut = [], [], [], []
+    for r, ix in enumerate(local):
+        occ.append(eng.occ_rows(ix, rec_base[r]))
+        edg.append(eng.edge_rows(ix))
+        osp, esp = eng.splits(ix, nb, eb)
+        nk, _, ne = ix.sizes()
+        ocut.append([0] + osp + [nk])
+        ecut.append([0] + esp + [ne])
+    kmers, nodes, edges, base = [], [], [], 0
+    for owner in range(world):
+        r_occ = torch.cat([occ[r][ocut[r][owner]:ocut[r][owner + 1]] for r in range(world)])
+        r_edg = torch.cat([edg[r][ecut[r][owner]:ecut[r][owner + 1]] for r in range(world)])
+        m = eng.merge(r_occ, r_edg, base, record_offsets, tar)
+        K, N, E = m.export()
+        kmers.append(K); nodes.append(N); edges.append(E)
+        base += len(K)
+    return np.concatenate(kmers), np.concatenate(nodes), np.concatenate(edges), record_offsets
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_routed_merge_equals_single_batch(world):
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa")) + sorted((GOLDEN / "synth").glob("edge_*"))]
+    tar = [i % 3 != 0 for i in range(len(paths))]
+    for k, w in [(15, 20), (21, 200), (11, 5)]:
+        got = _route_and_merge(paths, world, k, w, tar)
+        ek, en, ee, eo, _ = oracle.build(paths, k, w)
+        oracle.get_penalty(ek, en, eo, tar)
+        assert np.array_equal(got[0], ek) and np.array_equal(got[1], en), (world, k, w)
+        assert np.array_equal(got[2], ee) and np.array_equal(got[3], eo), (world, k, w)
+
+
+def test_world1_sharded_index_matches_direct():
+    b = Batch.synthetic(24, 4, 40000, n_ancestors=3, snp_ppm=10000, seed=5)
+    tar = np.arange(24) % 2 == 0
+    direct = b.build_index(21, 200, tar)
+    sharded = swdist.build_sharded_index(swdist.Shard(b, 0, 24), 21, 200, tar)
+    for x, y in zip(direct.export(), sharded.export()):
+        assert np.array_equal(x, y)
+    assert sharded.timings()["n_occ_local"] == direct.sizes()[0]
