@@ -74,6 +74,10 @@ struct SketchArgs {
     uint64_t cap;
     uint32_t *tile_count;
     uint64_t *tile_offset;
+    uint32_t *ovf_count;          // fast kernel: number of tiles handed over to the generic kernel
+    uint32_t *ovf_list;           // fast kernel: their class tile ids; generic kernel in list mode reads it
+    uint32_t rc_limit;            // fast kernel: records per run that may be consumed (RC; lower only for tests)
+    const uint32_t *list;         // generic kernel: nullptr = own class, else class tile ids of the FAST class
 };
 
 // 2-bit base reader over the packed stream (16 bases per 32-bit word).
@@ -137,13 +141,15 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
     const uint32_t tid = threadIdx.x;
 
     // ---- which record / which window range (uniform; scalar loads) ---------------------------
-    uint32_t lo = 0, hi = A.n_records;  // last r with cls_tile_off[r] <= blockIdx.x
+    // list mode: redo tiles of the fast class (same window ranges: TW = the fast class's TW <= NE - w)
+    const uint32_t ctile = A.list ? A.list[blockIdx.x] : blockIdx.x;
+    uint32_t lo = 0, hi = A.n_records;  // last r with cls_tile_off[r] <= ctile
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (A.cls_tile_off[mid] <= blockIdx.x) lo = mid; else hi = mid;
+        if (A.cls_tile_off[mid] <= ctile) lo = mid; else hi = mid;
     }
     const uint32_t rec = lo;
-    const uint32_t t = blockIdx.x - A.cls_tile_off[rec];
+    const uint32_t t = ctile - A.cls_tile_off[rec];
     const uint32_t tile = A.rec_tile_off[rec] + t;  // global tile id (order pass)
     const uint32_t nvalid = A.rec_nvalid[rec];
     const uint32_t I0 = (w - 1) + t * A.TW;                   // first window end (idx space)
@@ -353,44 +359,49 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
 //    bit phase (L is a multiple of 16 bases = one word), so word refills are WAVE-UNIFORM (scalar
 //    branch, no divergence) and are fetched one word ahead of use;
 //  * the roll LUT read of step j+1 is issued before the arithmetic of step j (software pipeline);
-//  * the L hashes of a lane stay in registers: the suffix-minimum pass and the prefix part of the
-//    window pass never re-read LDS; LDS keeps one copy of every hash (XOR-swizzled rows, conflict
-//    free) only for the other lanes' suffix lookups.
+//  * the L hashes of a lane stay in REGISTERS.  What other lanes need from a run is only its suffix
+//    minima, a step function with ~ln(L) steps ("suffix records": elements smaller than everything to
+//    their right in the run).  Each lane publishes a 32-bit position mask of its records and the
+//    hashes of the first RC records from the right (RC * 8 B instead of L * 8 B of LDS per lane);
+//    the suffix minimum from offset ox is record number popc(mask >> ox) - 1, at offset
+//    ox + ctz(mask >> ox).  A tile in which some run has more than RC records (probability ~1e-4 per
+//    run on random hashes) is not finished here: its id is appended to an overflow list and the tile
+//    is redone, exactly, by sketch_generic_kernel in list mode (run_sketch).
+//    LDS per workgroup drops from 79 KiB to ~30 KiB -> 5 workgroups (20 waves) per CU instead of 2.
 // ================================================================================================
 constexpr uint32_t KF = 256;
+constexpr uint32_t RC = 11;   // published suffix records per run (odd stride in 8-byte units)
 
 template <int L> struct FastCfg {
     static constexpr int NE = BLOCK * L;
-    static constexpr int LSP = L + 4;  // SP row stride in bytes: multiple of 4 with LSP/4 odd
     static constexpr int NSTG = NE / 16 + KF / 16 + 4;
     static constexpr int NEM = NE / 32 + 2;
-    static constexpr size_t off_H = 0;
-    static constexpr size_t off_RMh = off_H + (size_t)NE * 8;
+    static constexpr size_t off_REC = 0;
+    static constexpr size_t off_RMh = off_REC + (size_t)BLOCK * RC * 8;
     static constexpr size_t off_LUT = off_RMh + BLOCK * 8;
     static constexpr size_t off_STG = off_LUT + 40 * 8;
     static constexpr size_t off_EM = off_STG + (size_t)NSTG * 4;
-    static constexpr size_t off_MISC = off_EM + (size_t)NEM * 4;
+    static constexpr size_t off_MASK = off_EM + (size_t)NEM * 4;
+    static constexpr size_t off_MISC = off_MASK + BLOCK * 4;
     static constexpr size_t off_RMp = off_MISC + 16 * 4;
-    static constexpr size_t off_SP = off_RMp + BLOCK * 2;
-    static constexpr size_t bytes = off_SP + (size_t)BLOCK * LSP;
+    static constexpr size_t bytes = off_RMp + BLOCK * 2;
 };
 
-template <int L> __global__ __launch_bounds__(BLOCK, 2) void sketch_fast_kernel(const SketchArgs A)
+template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(const SketchArgs A)
 {
     using C = FastCfg<L>;
     constexpr uint32_t LM = L - 1;
     constexpr uint32_t LSH = (L == 32) ? 5 : 4;
     static_assert(L == 32 || L == 16, "run length must be 16 or 32");
     extern __shared__ __align__(16) unsigned char smem[];
-    uint64_t *H = reinterpret_cast<uint64_t *>(smem + C::off_H);
+    uint64_t *REC = reinterpret_cast<uint64_t *>(smem + C::off_REC);
     uint64_t *RMh = reinterpret_cast<uint64_t *>(smem + C::off_RMh);
     uint64_t *LUT = reinterpret_cast<uint64_t *>(smem + C::off_LUT);
     uint32_t *STG = reinterpret_cast<uint32_t *>(smem + C::off_STG);
     uint32_t *EM = reinterpret_cast<uint32_t *>(smem + C::off_EM);
+    uint32_t *MASK = reinterpret_cast<uint32_t *>(smem + C::off_MASK);
     uint32_t *MISC = reinterpret_cast<uint32_t *>(smem + C::off_MISC);
     uint16_t *RMp = reinterpret_cast<uint16_t *>(smem + C::off_RMp);
-    uint8_t *SP = reinterpret_cast<uint8_t *>(smem + C::off_SP);
-    uint32_t *SPw = reinterpret_cast<uint32_t *>(smem + C::off_SP);
 
     const uint32_t tid = threadIdx.x, w = A.w, k = A.k;
 
@@ -421,15 +432,13 @@ template <int L> __global__ __launch_bounds__(BLOCK, 2) void sketch_fast_kernel(
         }
         for (uint32_t i = tid; i < (uint32_t)C::NEM; i += BLOCK) EM[i] = 0;
         if (tid < 40) LUT[tid] = A.lut[tid];
+        if (tid == 0) MISC[1] = 0;
     }
     __syncthreads();
 
     const uint32_t e0 = tid * L;
     const uint32_t n = (e0 < ne) ? min((uint32_t)L, ne - e0) : 0u;
-    const uint32_t swz = tid & LM;           // H row swizzle of this lane
     uint64_t h[L];
-    uint64_t rmin_h = ~0ull;
-    uint32_t rmin_j = 0;
 
     if (n) {
         // ---- phase 1: ntHash over this lane's L k-mers -------------------------------------------
@@ -470,7 +479,6 @@ template <int L> __global__ __launch_bounds__(BLOCK, 2) void sketch_fast_kernel(
             lf = nlf;
             lr = nlr;
         }
-        uint64_t *Hrow = H + e0;
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             uint64_t nlf = 0, nlr = 0;
@@ -480,27 +488,46 @@ template <int L> __global__ __launch_bounds__(BLOCK, 2) void sketch_fast_kernel(
                 nlr = LUT[2 * idx + 1];
             }
             apply(lf, lr);                          // j == 0: last warm-up entry; j > 0: roll
-            h[j] = make64(flo, fhi) + make64(rlo, rhi);
-            Hrow[(uint32_t)j ^ swz] = h[j];
-            if ((uint32_t)j < n && h[j] <= rmin_h) { rmin_h = h[j]; rmin_j = j; }
+            uint32_t slo = flo + rlo;               // canonical(): 64-bit add with explicit carry
+            uint32_t shi = fhi + rhi + (slo < flo ? 1u : 0u);
+            asm volatile("" : "+v"(slo), "+v"(shi));   // computed here, not sunk to its first use
+            h[j] = make64(slo, shi);
             lf = nlf;
             lr = nlr;
+            // pin the rolling state here: exactly one LUT read in flight, and the arithmetic is not sunk
+            // below the (uniform) refill branches of later steps (which made the compiler spill LUT rows)
+            asm volatile("" : "+v"(flo), "+v"(fhi), "+v"(rlo), "+v"(rhi) : : "memory");
         }
-        // ---- suffix minima of the run (registers only), 4 offsets per 32-bit LDS store -----------
+        // ---- suffix records of the run, right to left (registers only) ---------------------------
         uint64_t cur = 0;
-        uint32_t off = 0, pk = 0;
+        uint32_t off = 0, mask = 0, cnt = 0;
+        uint64_t *rec = REC + tid * RC;
 #pragma unroll
         for (int j = L - 1; j >= 0; --j) {
             const bool take = ((uint32_t)j < n) && ((uint32_t)j == n - 1 || h[j] < cur);
-            cur = take ? h[j] : cur;
-            off = take ? (uint32_t)j : off;
-            pk = (pk << 8) | off;
-            if ((j & 3) == 0) SPw[tid * (C::LSP / 4) + j / 4] = pk;
+            if (take) {
+                cur = h[j];
+                off = (uint32_t)j;
+                mask |= 1u << j;
+                if (cnt < RC) rec[cnt] = cur;
+                ++cnt;
+            }
         }
+        MASK[tid] = mask;
+        RMh[tid] = cur;                              // the leftmost record is the (rightmost) run minimum
+        RMp[tid] = (uint16_t)(e0 + off);
+        if (cnt > A.rc_limit) MISC[1] = 1;                   // more records than published: redo this tile exactly
     }
-    RMh[tid] = rmin_h;
-    RMp[tid] = (uint16_t)(e0 + rmin_j);
     __syncthreads();
+    if (MISC[1]) {                                   // uniform: hand the tile to the generic kernel (list mode)
+        if (tid == 0) {
+            const uint32_t slot = atomicAdd(A.ovf_count, 1u);
+            A.ovf_list[slot] = blockIdx.x;
+            A.tile_count[tile] = 0;
+            A.tile_offset[tile] = 0;
+        }
+        return;
+    }
 
     // ---- phase 2: rightmost minimum of every window ending in this lane's run -------------------
     if (n && e0 + n > w - 1) {
@@ -509,7 +536,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 2) void sketch_fast_kernel(
         const uint32_t rxA = x0 >> LSH;
         const uint32_t bnd = (rxA + 1) << LSH;
         uint64_t mA_h = ~0ull, mB_h = ~0ull;
-        uint32_t mA_e = 0, mB_e = 0;
+        uint32_t mA_e = 0, mB_e = 0, maskA = 0, maskB = 0;
         if (rxA < tid) {
             for (uint32_t r = tid; r-- > rxA + 2;) {
                 const uint64_t hh = RMh[r];
@@ -517,9 +544,11 @@ template <int L> __global__ __launch_bounds__(BLOCK, 2) void sketch_fast_kernel(
             }
             mA_h = mB_h;
             mA_e = mB_e;
+            maskA = MASK[rxA];
             if (rxA + 1 < tid) {
                 const uint64_t hh = RMh[rxA + 1];
                 if (hh < mA_h) { mA_h = hh; mA_e = RMp[rxA + 1]; }
+                maskB = MASK[rxA + 1];
             }
         }
         uint64_t pre_h = ~0ull;
@@ -539,10 +568,13 @@ template <int L> __global__ __launch_bounds__(BLOCK, 2) void sketch_fast_kernel(
                     const uint64_t mh = inB ? mB_h : mA_h;
                     const uint32_t me = inB ? mB_e : mA_e;
                     if (mh < ch) { ch = mh; ce = me; }
-                    const uint32_t rx = x >> LSH, xr = x & ~LM;
-                    const uint32_t sp = SP[rx * C::LSP + (x & LM)];
-                    const uint64_t sh = H[xr + (sp ^ (rx & LM))];
-                    if (sh < ch) { ch = sh; ce = xr + sp; }
+                    const uint32_t rx = inB ? rxA + 1 : rxA;
+                    const uint32_t ox = x & LM;
+                    const uint32_t tb = (inB ? maskB : maskA) >> ox;     // records at offsets >= ox (never 0)
+                    const uint32_t slot = (uint32_t)__popc(tb) - 1u;     // records to the right of the answer
+                    const uint32_t se = (rx << LSH) + ox + (uint32_t)__builtin_ctz(tb);
+                    const uint64_t sh = REC[rx * RC + slot];             // slot < RC: overflow tiles left above
+                    if (sh < ch) { ch = sh; ce = se; }
                 }
                 if (e < e_first) {
                     MISC[0] = ce;
@@ -551,6 +583,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 2) void sketch_fast_kernel(
                 }
                 prev_arg = ce;
             }
+            if ((j & 3) == 3) asm volatile("" ::: "memory");   // keep at most 4 iterations of LDS reads in flight (VGPR budget)
         }
     }
     __syncthreads();
@@ -560,14 +593,17 @@ template <int L> __global__ __launch_bounds__(BLOCK, 2) void sketch_fast_kernel(
     }
     __syncthreads();
 
-    // ---- phase 3: compact the set bits in position order --------------------------------------
-    uint64_t bits = 0;
+    // ---- phase 3: compact the set bits in position order (hashes come from registers) -----------
+    uint32_t bits = 0;
     if (n) {
-        const uint32_t wd = e0 >> 5, sh = e0 & 31u;
-        const uint64_t two = (uint64_t)EM[wd] | ((uint64_t)EM[wd + 1] << 32);
-        bits = (two >> sh) & ((1ull << n) - 1ull);
+        if (L == 32) {
+            bits = EM[tid];
+        } else {
+            bits = (EM[tid >> 1] >> ((tid & 1u) * 16u)) & 0xFFFFu;
+        }
+        if (n < (uint32_t)L) bits &= (1u << n) - 1u;
     }
-    const uint32_t cnt = (uint32_t)__popcll(bits);
+    const uint32_t cnt = (uint32_t)__popc(bits);
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     uint32_t incl = cnt;
     for (uint32_t d = 1; d < 64; d <<= 1) {
@@ -593,14 +629,17 @@ template <int L> __global__ __launch_bounds__(BLOCK, 2) void sketch_fast_kernel(
     const uint64_t base = make64(MISC[8], MISC[9]);
     if (cnt && base + total <= A.cap) {
         uint64_t o = base + wave_off + (incl - cnt);
-        while (bits) {
-            const uint32_t j = (uint32_t)__builtin_ctzll(bits);
-            bits &= bits - 1;
-            uint64_t oh = H[e0 + (j ^ swz)] * A.mult;   // extend_hashes, hashing_internals.hpp:89-103
-            oh ^= oh >> 27;
-            A.stage_hash[o] = oh;
-            A.stage_kmer[o] = (uint64_t)(pos0 + E0 + e0 + j) | ((uint64_t)rec << 32);
-            ++o;
+        const uint64_t kmer0 = (uint64_t)(pos0 + E0 + e0) | ((uint64_t)rec << 32);
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            if ((bits >> j) & 1u) {
+                asm volatile("" ::: "memory");   // keep this a real (rarely taken) branch: no speculative 64-bit multiplies
+                uint64_t oh = h[j] * A.mult;   // extend_hashes, hashing_internals.hpp:89-103
+                oh ^= oh >> 27;
+                A.stage_hash[o] = oh;
+                A.stage_kmer[o] = kmer0 + (uint32_t)j;
+                ++o;
+            }
         }
     }
 }
@@ -635,7 +674,9 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     // fast class: single-segment records, k <= KF, power-of-two run length
     const char *force = getenv("SEQWIN_AMD_SKETCH");   // "generic" disables the fast path (debug / A-B)
     p.Lf = (k <= KF && !(force && !strcmp(force, "generic"))) ? (w >= 32 ? 32u : (w >= 16 ? 16u : 0u)) : 0u;
+    if (p.Lf == 32 && force && !strcmp(force, "fast16")) p.Lf = 16;   // A/B: half the LDS per workgroup
     p.TWf = p.Lf ? BLOCK * p.Lf - w : 0;
+    p.Lg_list = p.Lf ? p.Lf + 1 : 0;   // odd run length (<= w) whose tile of 256 * Lg elements holds a fast tile
     p.mult = 1ULL ^ ((uint64_t)k * MULTISEED);
 
     const HostBatch &h = b.host;
@@ -729,6 +770,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
     if (plan.n_tiles == 0) return;
 
     DevArray<unsigned long long> cursor(1);
+    DevArray<uint32_t> ovf_count(1), ovf_list(plan.n_tiles_fast);
     // expected density 2/(w+1) per window; grow and re-run in the (rare) overflow case
     uint64_t cap = std::min<uint64_t>(plan.n_windows,
                                       plan.n_windows / (plan.w + 1) * 3 + (uint64_t)plan.n_tiles * 4 + 4096);
@@ -759,6 +801,14 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         a.cap = cap;
         a.tile_count = out.tile_count.p;
         a.tile_offset = out.tile_offset.p;
+        a.ovf_count = ovf_count.p;
+        a.ovf_list = ovf_list.p;
+        a.list = nullptr;
+        {
+            const char *rc = getenv("SEQWIN_AMD_RC");   // test hook: force the overflow (list-mode) path
+            a.rc_limit = rc ? std::min<uint32_t>(RC, (uint32_t)atoi(rc)) : RC;
+        }
+        SW_HIP(hipMemsetAsync(ovf_count.p, 0, 4, stream));
         SW_HIP(hipEventRecord(ev0, stream));
         if (plan.n_tiles_fast) {
             a.cls_tile_off = plan.fast_tile_off.p;
@@ -781,12 +831,30 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         }
         SW_HIP(hipEventRecord(ev1, stream));
         unsigned long long total = 0;
+        uint32_t n_ovf = 0;
         SW_HIP(hipMemcpyAsync(&total, cursor.p, sizeof total, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipMemcpyAsync(&n_ovf, ovf_count.p, 4, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipStreamSynchronize(stream));
         float ms = 0.f;
         SW_HIP(hipEventElapsedTime(&ms, ev0, ev1));
         if (sketch_ms) *sketch_ms += ms;
         ++out.launches;
+        if (n_ovf) {   // tiles the fast kernel handed over: redo them exactly with the generic kernel
+            a.cls_tile_off = plan.fast_tile_off.p;
+            a.L = plan.Lg_list;
+            a.TW = plan.TWf;
+            a.n_tiles = n_ovf;
+            a.list = ovf_list.p;
+            SW_HIP(hipEventRecord(ev0, stream));
+            hipLaunchKernelGGL(sketch_generic_kernel, dim3(n_ovf), dim3(BLOCK), lds_bytes_for(plan.Lg_list), stream, a);
+            SW_HIP(hipGetLastError());
+            SW_HIP(hipEventRecord(ev1, stream));
+            SW_HIP(hipMemcpyAsync(&total, cursor.p, sizeof total, hipMemcpyDeviceToHost, stream));
+            SW_HIP(hipStreamSynchronize(stream));
+            SW_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+            if (sketch_ms) *sketch_ms += ms;
+            out.n_ovf_tiles += n_ovf;
+        }
         if (total <= cap) {
             out.n_occ = total;
             break;
