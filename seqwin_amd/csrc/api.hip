@@ -1,6 +1,7 @@
 // api.hip -- C-ABI entry points of libseqwin_hip.so (see include/seqwin_hip.h for the contract and
 // the reference interfaces each one replaces), device memory pool, batch upload / synthesis.
 #include <algorithm>
+#include <cstdlib>
 #include <memory>
 
 #include "device.hpp"
@@ -45,6 +46,7 @@ void *dev_alloc(size_t bytes)
             return ptr;
         }
     }
+    if (getenv("SEQWIN_AMD_DEBUG_ALLOC") && sz >= (1ull << 28)) fprintf(stderr, "[seqwin_amd] hipMalloc %.3f GiB\n", sz / 1073741824.0);
     void *ptr = nullptr;
     hipError_t e = hipMalloc(&ptr, sz);
     if (e != hipSuccess) {
@@ -133,9 +135,9 @@ __host__ __device__ inline uint64_t mix64(uint64_t x)
 
 // One thread = one packed word (16 bases) of one record.
 __global__ void k_synth(uint32_t *packed, uint64_t words_per_record, uint64_t n_words, uint64_t records_per_genome,
-                        uint64_t record_len, uint64_t n_ancestors, uint64_t snp_ppm, uint64_t seed)
+                        uint64_t record_len, uint64_t n_ancestors, uint64_t snp_ppm, uint64_t seed, uint64_t word_base)
 {
-    const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t wi = word_base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (wi >= n_words) return;
     const uint64_t rec = wi / words_per_record, wr = wi % words_per_record;
     const uint64_t g = rec / records_per_genome, c = rec % records_per_genome;
@@ -305,12 +307,14 @@ int sw_batch_synthetic(uint64_t n_genomes, uint64_t records_per_genome, uint64_t
         b->d_packed.alloc(b->packed_words);
         SW_HIP(hipMemset(b->d_packed.p, 0, b->packed_words * 4));
         const uint64_t n_words = R * wpr;
-        if (n_words) {
-            hipLaunchKernelGGL(k_synth, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, 0, b->d_packed.p, wpr, n_words,
-                               records_per_genome, record_len, n_ancestors, snp_ppm, seed);
+        // a HIP grid is limited to 2^32 - 1 work-items per dimension: launch in chunks of 2^30 words
+        for (uint64_t base = 0; base < n_words; base += (1ull << 30)) {
+            const uint64_t cnt = std::min<uint64_t>(n_words - base, 1ull << 30);
+            hipLaunchKernelGGL(k_synth, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, b->d_packed.p, wpr, base + cnt,
+                               records_per_genome, record_len, n_ancestors, snp_ppm, seed, base);
             SW_HIP(hipGetLastError());
-            SW_HIP(hipDeviceSynchronize());
         }
+        SW_HIP(hipDeviceSynchronize());
         b->d_rec_base.alloc(R);
         if (R) SW_HIP(hipMemcpy(b->d_rec_base.p, h.rec_base.data(), R * 8, hipMemcpyHostToDevice));
         std::vector<uint32_t> rec_asm(R);

@@ -37,6 +37,7 @@ namespace sw {
 namespace {
 
 constexpr int BLOCK = 256;
+constexpr uint32_t MAX_TILES_PER_LAUNCH = 1u << 23;  // x 256 threads stays below the 2^32 work-item grid limit
 constexpr uint32_t L_MAX = 33;  // 256*33 elements * 8 B = 66 KiB of hashes -> two workgroups per CU
 
 // hashing_internals.hpp:128-131
@@ -66,6 +67,7 @@ struct SketchArgs {
     const uint32_t *seg_idx;
     const uint64_t *lut;
     uint32_t n_records, k, w, L, TW, n_tiles;
+    uint32_t tile_base;           // class tile id of blockIdx.x == 0 (launches are chunked: 2^32 work-item grid limit)
     uint64_t packed_words;
     uint64_t mult;
     uint64_t *stage_hash;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
 
     // ---- which record / which window range (uniform; scalar loads) ---------------------------
     // list mode: redo tiles of the fast class (same window ranges: TW = the fast class's TW <= NE - w)
-    const uint32_t ctile = A.list ? A.list[blockIdx.x] : blockIdx.x;
+    const uint32_t ctile = A.list ? A.list[A.tile_base + blockIdx.x] : A.tile_base + blockIdx.x;
     uint32_t lo = 0, hi = A.n_records;  // last r with cls_tile_off[r] <= ctile
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -405,13 +407,14 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
 
     const uint32_t tid = threadIdx.x, w = A.w, k = A.k;
 
+    const uint32_t ctile = A.tile_base + blockIdx.x;
     uint32_t lo = 0, hi = A.n_records;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (A.cls_tile_off[mid] <= blockIdx.x) lo = mid; else hi = mid;
+        if (A.cls_tile_off[mid] <= ctile) lo = mid; else hi = mid;
     }
     const uint32_t rec = lo;
-    const uint32_t t = blockIdx.x - A.cls_tile_off[rec];
+    const uint32_t t = ctile - A.cls_tile_off[rec];
     const uint32_t tile = A.rec_tile_off[rec] + t;
     const uint32_t nvalid = A.rec_nvalid[rec];
     const uint32_t I0 = (w - 1) + t * A.TW;
@@ -522,7 +525,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
     if (MISC[1]) {                                   // uniform: hand the tile to the generic kernel (list mode)
         if (tid == 0) {
             const uint32_t slot = atomicAdd(A.ovf_count, 1u);
-            A.ovf_list[slot] = blockIdx.x;
+            A.ovf_list[slot] = ctile;
             A.tile_count[tile] = 0;
             A.tile_offset[tile] = 0;
         }
@@ -815,19 +818,27 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
             a.L = plan.Lf;
             a.TW = plan.TWf;
             a.n_tiles = plan.n_tiles_fast;
-            if (plan.Lf == 32)
-                hipLaunchKernelGGL(sketch_fast_kernel<32>, dim3(plan.n_tiles_fast), dim3(BLOCK), FastCfg<32>::bytes, stream, a);
-            else
-                hipLaunchKernelGGL(sketch_fast_kernel<16>, dim3(plan.n_tiles_fast), dim3(BLOCK), FastCfg<16>::bytes, stream, a);
-            SW_HIP(hipGetLastError());
+            for (uint32_t tb = 0; tb < plan.n_tiles_fast; tb += MAX_TILES_PER_LAUNCH) {
+                const uint32_t nt = std::min(plan.n_tiles_fast - tb, MAX_TILES_PER_LAUNCH);
+                a.tile_base = tb;
+                if (plan.Lf == 32)
+                    hipLaunchKernelGGL(sketch_fast_kernel<32>, dim3(nt), dim3(BLOCK), FastCfg<32>::bytes, stream, a);
+                else
+                    hipLaunchKernelGGL(sketch_fast_kernel<16>, dim3(nt), dim3(BLOCK), FastCfg<16>::bytes, stream, a);
+                SW_HIP(hipGetLastError());
+            }
         }
         if (plan.n_tiles_gen) {
             a.cls_tile_off = plan.gen_tile_off.p;
             a.L = plan.L;
             a.TW = plan.TW;
             a.n_tiles = plan.n_tiles_gen;
-            hipLaunchKernelGGL(sketch_generic_kernel, dim3(plan.n_tiles_gen), dim3(BLOCK), plan.lds_bytes, stream, a);
-            SW_HIP(hipGetLastError());
+            for (uint32_t tb = 0; tb < plan.n_tiles_gen; tb += MAX_TILES_PER_LAUNCH) {
+                const uint32_t nt = std::min(plan.n_tiles_gen - tb, MAX_TILES_PER_LAUNCH);
+                a.tile_base = tb;
+                hipLaunchKernelGGL(sketch_generic_kernel, dim3(nt), dim3(BLOCK), plan.lds_bytes, stream, a);
+                SW_HIP(hipGetLastError());
+            }
         }
         SW_HIP(hipEventRecord(ev1, stream));
         unsigned long long total = 0;
@@ -846,8 +857,12 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
             a.n_tiles = n_ovf;
             a.list = ovf_list.p;
             SW_HIP(hipEventRecord(ev0, stream));
-            hipLaunchKernelGGL(sketch_generic_kernel, dim3(n_ovf), dim3(BLOCK), lds_bytes_for(plan.Lg_list), stream, a);
-            SW_HIP(hipGetLastError());
+            for (uint32_t tb = 0; tb < n_ovf; tb += MAX_TILES_PER_LAUNCH) {
+                a.tile_base = tb;
+                hipLaunchKernelGGL(sketch_generic_kernel, dim3(std::min(n_ovf - tb, MAX_TILES_PER_LAUNCH)), dim3(BLOCK),
+                                   lds_bytes_for(plan.Lg_list), stream, a);
+                SW_HIP(hipGetLastError());
+            }
             SW_HIP(hipEventRecord(ev1, stream));
             SW_HIP(hipMemcpyAsync(&total, cursor.p, sizeof total, hipMemcpyDeviceToHost, stream));
             SW_HIP(hipStreamSynchronize(stream));
