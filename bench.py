@@ -102,10 +102,15 @@ def main() -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SEQWIN_BENCH_BACKEND", "nccl")   # "gloo": smoke-test the N>1 path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from seqwin_amd.device import Batch, set_device
     set_device(local_rank)
@@ -121,9 +126,10 @@ def main() -> None:
     if world > 1:
         from seqwin_amd import dist as swdist
         shard = swdist.Shard(batch, first_assembly=rank * G, n_assemblies_total=G * world)
+        engine = swdist.HipEngine("device" if dist.get_backend() == "nccl" else "host")
 
         def step():
-            return swdist.build_sharded_index(shard, k, w, is_targets_global)
+            return swdist.build_sharded_index(shard, k, w, is_targets_global, engine=engine)
     else:
         def step():
             return batch.build_index(k, w, my_targets)
@@ -134,13 +140,20 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def release(ix):
+        # give the previous result's HBM back to the pool before the next pass (as a pipeline would)
+        if ix is not None:
+            (ix.merged if hasattr(ix, "merged") else ix).close()
+
     ix = None
     for _ in range(args.warmup):
+        release(ix)
         ix = step()
     fence()
     stage = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        release(ix)
         ix = step()
         for key, v in ix.timings().items():
             if key.endswith("_ms"):
@@ -148,13 +161,13 @@ def main() -> None:
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=engine.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     nk, nn, ne = ix.sizes()
     tm = ix.timings()
-    counts = torch.tensor([nk, nn, ne], dtype=torch.int64, device="cuda")
+    counts = torch.tensor([nk, nn, ne], dtype=torch.int64, device=engine.device if world > 1 else "cuda")
     if world > 1:
         dist.all_reduce(counts)
     n_occ_local = tm.get("n_occ_local", nk) if world > 1 else nk

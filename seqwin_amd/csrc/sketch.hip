@@ -554,31 +554,39 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
                 maskB = MASK[rxA + 1];
             }
         }
-        uint64_t pre_h = ~0ull;
-        uint32_t pre_e = e0;
+        // Window [x, e] = left region [x, e0) (earlier runs) + own prefix [e0, e].  The left region only
+        // shrinks while this lane advances, so its rightmost minimum `lc` stays valid until it leaves the
+        // window; it is recomputed (suffix records of run rx + whole-run minima) only then -- about
+        // 0.2 times per lane per tile -- instead of at every step.
+        uint64_t pre_h = ~0ull, lc_h = ~0ull;
+        uint32_t pre_e = e0, lc_e = 0;
         uint32_t prev_arg = 0xFFFFFFFFu;
         const uint32_t xb = e0 - (w - 1);   // x of step j is xb + j (mod 2^32; only used when j >= j0)
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             const uint32_t e = e0 + j;
-            if ((uint32_t)j < n && h[j] <= pre_h) { pre_h = h[j]; pre_e = e; }
+            if ((uint32_t)j < n && h[j] <= pre_h) { pre_h = h[j]; pre_e = e; }   // '<=': rightmost wins
             if ((uint32_t)j >= j0 && (uint32_t)j < n) {
                 const uint32_t x = xb + j;
-                uint64_t ch = pre_h;
-                uint32_t ce = pre_e;
-                if (x < e0) {
+                if (x >= e0) {
+                    lc_h = ~0ull;                                        // no left region (w == L): never wins
+                } else if ((uint32_t)j == j0 || lc_e < x) {
                     const bool inB = x >= bnd;
-                    const uint64_t mh = inB ? mB_h : mA_h;
-                    const uint32_t me = inB ? mB_e : mA_e;
-                    if (mh < ch) { ch = mh; ce = me; }
+                    lc_h = inB ? mB_h : mA_h;
+                    lc_e = inB ? mB_e : mA_e;
                     const uint32_t rx = inB ? rxA + 1 : rxA;
                     const uint32_t ox = x & LM;
                     const uint32_t tb = (inB ? maskB : maskA) >> ox;     // records at offsets >= ox (never 0)
                     const uint32_t slot = (uint32_t)__popc(tb) - 1u;     // records to the right of the answer
-                    const uint32_t se = (rx << LSH) + ox + (uint32_t)__builtin_ctz(tb);
                     const uint64_t sh = REC[rx * RC + slot];             // slot < RC: overflow tiles left above
-                    if (sh < ch) { ch = sh; ce = se; }
+                    if (sh < lc_h) {                                     // further left: only if strictly smaller
+                        lc_h = sh;
+                        lc_e = (rx << LSH) + ox + (uint32_t)__builtin_ctz(tb);
+                    }
                 }
+                const bool left = lc_h < pre_h;
+                const uint64_t ch = left ? lc_h : pre_h;
+                const uint32_t ce = left ? lc_e : pre_e;
                 if (e < e_first) {
                     MISC[0] = ce;
                 } else if (ce != prev_arg && ch != ~0ull) {
@@ -586,7 +594,6 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
                 }
                 prev_arg = ce;
             }
-            if ((j & 3) == 3) asm volatile("" ::: "memory");   // keep at most 4 iterations of LDS reads in flight (VGPR budget)
         }
     }
     __syncthreads();

@@ -63,12 +63,17 @@ class Shard:
 
 
 class HipEngine:
-    """Per-rank compute on the MI355X through the C ABI (include/seqwin_hip.h)."""
+    """Per-rank compute on the MI355X through the C ABI (include/seqwin_hip.h).
 
-    def __init__(self):
+    ``staging="device"`` (default) exchanges device buffers directly (backend "nccl" = RCCL over xGMI).
+    ``staging="host"`` stages the exchanged rows through host memory so that the same choreography can run
+    over gloo (used to test the multi-process path on a box with a single GPU)."""
+
+    def __init__(self, staging: str = "device"):
         import torch
         self.torch = torch
-        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.gpu = torch.device("cuda", torch.cuda.current_device())
+        self.device = self.gpu if staging == "device" else torch.device("cpu")
 
     def _stream(self) -> int:
         return int(self.torch.cuda.current_stream().cuda_stream)
@@ -100,16 +105,16 @@ class HipEngine:
     def occ_rows(self, ix, rec_offset: int):
         from ._lib import c_u64, c_vp, check, lib
         n = ix.sizes()[0]
-        rows = self.torch.empty((n, 2), dtype=self.torch.int64, device=self.device)
+        rows = self.torch.empty((n, 2), dtype=self.torch.int64, device=self.gpu)
         check(lib.sw_index_occ_rows(ix._h, c_u64(rec_offset), c_vp(rows.data_ptr()), c_vp(self._stream())))
-        return rows
+        return rows.to(self.device)
 
     def edge_rows(self, ix):
         from ._lib import c_vp, check, lib
         m = ix.sizes()[2]
-        rows = self.torch.empty((m, 3), dtype=self.torch.int64, device=self.device)
+        rows = self.torch.empty((m, 3), dtype=self.torch.int64, device=self.gpu)
         check(lib.sw_index_edge_rows(ix._h, c_vp(rows.data_ptr()), c_vp(self._stream())))
-        return rows
+        return rows.to(self.device)
 
     def merge(self, occ_rows, edge_rows, kmer_base: int, record_offsets: np.ndarray, is_targets):
         import ctypes
@@ -122,6 +127,8 @@ class HipEngine:
         else:
             t = np.ascontiguousarray(np.asarray(is_targets, np.bool_)).view(np.uint8)
             tar, na = t.ctypes.data_as(c_vp), len(t)
+        occ_rows = occ_rows.to(self.gpu).contiguous()
+        edge_rows = edge_rows.to(self.gpu).contiguous()
         self.torch.cuda.current_stream().synchronize()   # rows were produced by RCCL on its own stream
         h = c_vp()
         check(lib.sw_index_merge(c_vp(occ_rows.data_ptr()), c_u64(occ_rows.shape[0]), c_vp(edge_rows.data_ptr()),

@@ -66,3 +66,44 @@ def test_world1_sharded_index_matches_direct():
     for x, y in zip(direct.export(), sharded.export()):
         assert np.array_equal(x, y)
     assert sharded.timings()["n_occ_local"] == direct.sizes()[0]
+
+
+def _gloo_worker(rank, world, port, paths, k, w, tar, out_path):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seqwin_amd.device import set_device
+        set_device(0)
+        start, end = swdist.partition_assemblies(len(paths), world)[rank]
+        shard = swdist.Shard(Batch.from_fasta(paths[start:end], n_cpu=2), start, len(paths))
+        sharded = swdist.build_sharded_index(shard, k, w, tar, engine=swdist.HipEngine("host"))
+        full = sharded.gather(0)
+        if rank == 0:
+            np.savez(out_path, kmers=full[0], nodes=full[1], edges=full[2], record_offsets=full[3])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_processes_one_gpu_real_collectives(tmp_path, world):
+    """The full multi-process path -- HIP engine in every process, real all_to_all_single / all_gather
+    (over gloo with host staging, since this box has one GPU) -- must reproduce the single-process result."""
+    import socket
+
+    import torch.multiprocessing as mp
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa")) + sorted((GOLDEN / "synth").glob("edge_*"))]
+    tar = [i % 2 == 0 for i in range(len(paths))]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "merged.npz"
+    mp.spawn(_gloo_worker, nprocs=world, args=(world, port, paths, 15, 20, tar, str(out)), join=True)
+    got = np.load(out)
+    ek, en, ee, eo, _ = oracle.build(paths, 15, 20)
+    oracle.get_penalty(ek, en, eo, tar)
+    assert np.array_equal(got["kmers"], ek) and np.array_equal(got["nodes"], en)
+    assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
