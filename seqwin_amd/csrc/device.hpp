@@ -72,6 +72,7 @@ struct Plan {
     DevArray<uint32_t> seg_pos;       // [S]
     DevArray<uint32_t> seg_idx;       // [S]
     DevArray<uint64_t> lut;           // [40] roll tables, see sketch.hip
+    DevArray<uint64_t> t4;            // [256][2] 4-base warm-up table
     uint64_t mult = 0;                // 1 ^ (k * MULTISEED)
 };
 

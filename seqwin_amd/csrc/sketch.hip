@@ -66,6 +66,7 @@ struct SketchArgs {
     const uint32_t *seg_pos;
     const uint32_t *seg_idx;
     const uint64_t *lut;
+    const uint64_t *t4;           // [256][2] warm-up table: 4 bases per step (forward, reverse), fast kernel
     uint32_t n_records, k, w, L, TW, n_tiles;
     uint32_t tile_base;           // class tile id of blockIdx.x == 0 (launches are chunked: 2^32 work-item grid limit)
     uint64_t packed_words;
@@ -124,6 +125,26 @@ __device__ __forceinline__ void sror1(uint32_t &lo, uint32_t &hi)
     t = (t & ~1u) | (lo & 1u);                                  // old bit 0 -> bit 32
     hi = (t & 0x7FFFFFFFu) | ((hi << 30) & 0x80000000u);        // old bit 33 -> bit 63
     lo = nlo;
+}
+
+// srol / sror applied N times (1 <= N <= 30) in one go: rotate the low 33 and the high 31 bits by N.
+template <int N> __device__ __forceinline__ void srolN(uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t b32 = hi & 1u, h31 = hi >> 1;
+    const uint32_t nlo = (lo << N) | (lo >> (33 - N)) | (b32 << (N - 1));
+    const uint32_t nb32 = (lo >> (32 - N)) & 1u;
+    const uint32_t nh = ((h31 << N) | (h31 >> (31 - N))) & 0x7FFFFFFFu;
+    lo = nlo;
+    hi = (nh << 1) | nb32;
+}
+template <int N> __device__ __forceinline__ void srorN(uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t b32 = hi & 1u, h31 = hi >> 1;
+    const uint32_t nlo = (lo >> N) | (b32 << (32 - N)) | (lo << (33 - N));
+    const uint32_t nb32 = (lo >> (N - 1)) & 1u;
+    const uint32_t nh = ((h31 >> N) | (h31 << (31 - N))) & 0x7FFFFFFFu;
+    lo = nlo;
+    hi = (nh << 1) | nb32;
 }
 
 __device__ __forceinline__ uint64_t make64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
@@ -473,33 +494,67 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
             rhi ^= (uint32_t)(lr >> 32);
             sror1(rlo, rhi);
         };
-        uint32_t idx = 16u | next_in();
-        uint64_t lf = LUT[2 * idx], lr = LUT[2 * idx + 1];
-        for (uint32_t j = 1; j < k; ++j) {          // warm-up entries 0 .. k-2 applied here
+        // warm-up (first k-mer of the run): k = r + 4q bases; r single-base steps through the roll LUT,
+        // then q steps of 4 bases through the 256-entry table t4 (F' = srol^4(F) ^ F4[b], R' = sror^4(R) ^ R4[b]),
+        // gathered from global memory (4 KiB, L1/L2 resident) one step ahead of use
+        uint32_t idx;
+        for (uint32_t s4 = 0; s4 < (k & 3u); ++s4) {
             idx = 16u | next_in();
-            const uint64_t nlf = LUT[2 * idx], nlr = LUT[2 * idx + 1];
-            apply(lf, lr);
-            lf = nlf;
-            lr = nlr;
+            apply(LUT[2 * idx], LUT[2 * idx + 1]);
         }
+        {
+            auto next4 = [&]() -> uint32_t {             // next 4 bases as one byte (uniform control flow)
+                uint32_t b;
+                if (inl >= 4) {
+                    b = icur & 0xFFu;
+                    icur >>= 8;
+                    inl -= 4;
+                } else {
+                    b = (icur | (inxt << (2u * inl))) & 0xFFu;
+                    icur = inxt >> (2u * (4u - inl));
+                    inl += 12;
+                    inxt = *iwp++;
+                }
+                return b;
+            };
+            const uint32_t q = k >> 2;
+            const ulonglong2 *T4 = reinterpret_cast<const ulonglong2 *>(A.t4);
+            ulonglong2 te = make_ulonglong2(0, 0);
+            if (q) te = T4[next4()];
+            for (uint32_t s4 = 0; s4 < q; ++s4) {
+                ulonglong2 tn = te;
+                if (s4 + 1 < q) tn = T4[next4()];
+                srolN<4>(flo, fhi);
+                flo ^= (uint32_t)te.x;
+                fhi ^= (uint32_t)(te.x >> 32);
+                srorN<4>(rlo, rhi);
+                rlo ^= (uint32_t)te.y;
+                rhi ^= (uint32_t)(te.y >> 32);
+                te = tn;
+            }
+        }
+        idx = next_in() | (next_out() << 2);
+        uint64_t lf = LUT[2 * idx], lr = LUT[2 * idx + 1];     // entry of roll 1
 #pragma unroll
         for (int j = 0; j < L; ++j) {
-            uint64_t nlf = 0, nlr = 0;
-            if (j + 1 < L) {                        // LUT entry of the NEXT roll, issued before this step's math
-                idx = next_in() | (next_out() << 2);
-                nlf = LUT[2 * idx];
-                nlr = LUT[2 * idx + 1];
-            }
-            apply(lf, lr);                          // j == 0: last warm-up entry; j > 0: roll
             uint32_t slo = flo + rlo;               // canonical(): 64-bit add with explicit carry
             uint32_t shi = fhi + rhi + (slo < flo ? 1u : 0u);
             asm volatile("" : "+v"(slo), "+v"(shi));   // computed here, not sunk to its first use
             h[j] = make64(slo, shi);
-            lf = nlf;
-            lr = nlr;
-            // pin the rolling state here: exactly one LUT read in flight, and the arithmetic is not sunk
-            // below the (uniform) refill branches of later steps (which made the compiler spill LUT rows)
-            asm volatile("" : "+v"(flo), "+v"(fhi), "+v"(rlo), "+v"(rhi) : : "memory");
+            if (j + 1 < L) {
+                uint64_t nlf = 0, nlr = 0;
+                if (j + 2 < L) {                    // LUT entry of the roll after next, issued before this roll's math
+                    idx = next_in() | (next_out() << 2);
+                    nlf = LUT[2 * idx];
+                    nlr = LUT[2 * idx + 1];
+                }
+                apply(lf, lr);
+                lf = nlf;
+                lr = nlr;
+                // pin the rolling state here: exactly one LUT read in flight, and the arithmetic is not sunk
+                // below the (uniform) refill branches of later steps (which made the compiler spill LUT rows)
+                asm volatile("" : "+v"(flo), "+v"(fhi), "+v"(rlo), "+v"(rhi) : : "memory");
+            }
         }
         // ---- suffix records of the run, right to left (registers only) ---------------------------
         uint64_t cur = 0;
@@ -758,6 +813,22 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     up32(p.seg_idx, seg_idx);
     p.lut.alloc(40);
     SW_HIP(hipMemcpy(p.lut.p, lut, sizeof lut, hipMemcpyHostToDevice));
+    {   // 4-base warm-up table; byte b = c0 | c1 << 2 | c2 << 4 | c3 << 6 with c0 the earliest base
+        std::vector<uint64_t> t4(512);
+        auto host_sror = [&](uint64_t x, unsigned d) { return host_srol(x, 1023u - (d % 1023u)); };
+        for (int b = 0; b < 256; ++b) {
+            uint64_t f = 0, r = 0;
+            for (int i = 0; i < 4; ++i) {
+                const int c = (b >> (2 * i)) & 3;
+                f = host_srol1(f) ^ S[c];              // F' = srol(F) ^ S[c]
+                r = host_sror(r ^ Sk[3 - c], 1);       // R' = sror(R ^ srol^k(S[~c]))
+            }
+            t4[2 * b] = f;
+            t4[2 * b + 1] = r;
+        }
+        p.t4.alloc(512);
+        SW_HIP(hipMemcpy(p.t4.p, t4.data(), 512 * 8, hipMemcpyHostToDevice));
+    }
     return b.plans.emplace(key, std::move(p)).first->second;
 }
 
@@ -800,6 +871,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         a.seg_pos = plan.seg_pos.p;
         a.seg_idx = plan.seg_idx.p;
         a.lut = plan.lut.p;
+        a.t4 = plan.t4.p;
         a.n_records = (uint32_t)b.n_records;
         a.k = plan.k;
         a.w = plan.w;
