@@ -617,37 +617,59 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         uint32_t pre_e = e0, lc_e = 0;
         uint32_t prev_arg = 0xFFFFFFFFu;
         const uint32_t xb = e0 - (w - 1);   // x of step j is xb + j (mod 2^32; only used when j >= j0)
+        auto recompute = [&](uint32_t x) {
+            const bool inB = x >= bnd;
+            lc_h = inB ? mB_h : mA_h;
+            lc_e = inB ? mB_e : mA_e;
+            const uint32_t rx = inB ? rxA + 1 : rxA;
+            const uint32_t ox = x & LM;
+            const uint32_t tb = (inB ? maskB : maskA) >> ox;     // records at offsets >= ox (never 0)
+            const uint32_t slot = (uint32_t)__popc(tb) - 1u;     // records to the right of the answer
+            const uint64_t sh = REC[rx * RC + slot];             // slot < RC: overflow tiles left above
+            if (sh < lc_h) {                                     // further left: only if strictly smaller
+                lc_h = sh;
+                lc_e = (rx << LSH) + ox + (uint32_t)__builtin_ctz(tb);
+            }
+        };
+        auto mark = [&](bool left, uint32_t ce) {                 // rarely taken: the minimizer changed
+            const uint64_t ch = left ? lc_h : pre_h;
+            if (ch != ~0ull) atomicOr(&EM[ce >> 5], 1u << (ce & 31u));   // minimizer.cpp:44-45
+        };
+        // wave-uniform fast variant: every lane of the wave has a full run, all its windows exist and are
+        // owned by this tile, and the left region is never empty -> no per-step edge predicates
+        const bool wave_full = __all(n == (uint32_t)L && e0 >= e_first) && w > (uint32_t)L;
+        if (wave_full) {
+            recompute(xb);
 #pragma unroll
-        for (int j = 0; j < L; ++j) {
-            const uint32_t e = e0 + j;
-            if ((uint32_t)j < n && h[j] <= pre_h) { pre_h = h[j]; pre_e = e; }   // '<=': rightmost wins
-            if ((uint32_t)j >= j0 && (uint32_t)j < n) {
-                const uint32_t x = xb + j;
-                if (x >= e0) {
-                    lc_h = ~0ull;                                        // no left region (w == L): never wins
-                } else if ((uint32_t)j == j0 || lc_e < x) {
-                    const bool inB = x >= bnd;
-                    lc_h = inB ? mB_h : mA_h;
-                    lc_e = inB ? mB_e : mA_e;
-                    const uint32_t rx = inB ? rxA + 1 : rxA;
-                    const uint32_t ox = x & LM;
-                    const uint32_t tb = (inB ? maskB : maskA) >> ox;     // records at offsets >= ox (never 0)
-                    const uint32_t slot = (uint32_t)__popc(tb) - 1u;     // records to the right of the answer
-                    const uint64_t sh = REC[rx * RC + slot];             // slot < RC: overflow tiles left above
-                    if (sh < lc_h) {                                     // further left: only if strictly smaller
-                        lc_h = sh;
-                        lc_e = (rx << LSH) + ox + (uint32_t)__builtin_ctz(tb);
-                    }
-                }
+            for (int j = 0; j < L; ++j) {
+                if (h[j] <= pre_h) { pre_h = h[j]; pre_e = e0 + j; }      // '<=': rightmost wins
+                if (j && lc_e < xb + j) recompute(xb + j);
                 const bool left = lc_h < pre_h;
-                const uint64_t ch = left ? lc_h : pre_h;
                 const uint32_t ce = left ? lc_e : pre_e;
-                if (e < e_first) {
-                    MISC[0] = ce;
-                } else if (ce != prev_arg && ch != ~0ull) {
-                    atomicOr(&EM[ce >> 5], 1u << (ce & 31u));
-                }
+                if (ce != prev_arg) mark(left, ce);
                 prev_arg = ce;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+                const uint32_t e = e0 + j;
+                if ((uint32_t)j < n && h[j] <= pre_h) { pre_h = h[j]; pre_e = e; }
+                if ((uint32_t)j >= j0 && (uint32_t)j < n) {
+                    const uint32_t x = xb + j;
+                    if (x >= e0) {
+                        lc_h = ~0ull;                                    // no left region (w == L): never wins
+                    } else if ((uint32_t)j == j0 || lc_e < x) {
+                        recompute(x);
+                    }
+                    const bool left = lc_h < pre_h;
+                    const uint32_t ce = left ? lc_e : pre_e;
+                    if (e < e_first) {
+                        MISC[0] = ce;
+                    } else if (ce != prev_arg) {
+                        mark(left, ce);
+                    }
+                    prev_arg = ce;
+                }
             }
         }
     }
