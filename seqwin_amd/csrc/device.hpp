@@ -120,10 +120,11 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
 struct OrderedOcc {
     DevArray<uint64_t> hash;   // out_hash in (record_idx, pos) order
     DevArray<uint64_t> kmer;   // pos | record_idx << 32
+    DevArray<uint32_t> idx;    // identity permutation (consumed by the node sort)
     uint64_t n = 0;
 };
 void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out);
-void build_index(const sw_batch &b, const OrderedOcc &occ, const uint8_t *d_is_target, uint64_t n_targets,
+void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target, uint64_t n_targets,
                  uint64_t n_non_targets, hipStream_t stream, sw_index &ix);
 void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
                         const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,

@@ -80,7 +80,7 @@ struct HeadFlag {
 __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t *__restrict__ stage_kmer,
                         const uint32_t *__restrict__ tile_count, const uint64_t *__restrict__ tile_offset,
                         const uint64_t *__restrict__ dst_off, uint32_t n_tiles, uint64_t *__restrict__ hash,
-                        uint64_t *__restrict__ kmer)
+                        uint64_t *__restrict__ kmer, uint32_t *__restrict__ idx)
 {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
@@ -90,6 +90,7 @@ __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t 
     for (uint32_t i = lane; i < c; i += 64) {
         hash[dst + i] = stage_hash[src + i];
         kmer[dst + i] = stage_kmer[src + i];
+        idx[dst + i] = (uint32_t)(dst + i);   // identity permutation for the sort that follows
     }
 }
 
@@ -440,27 +441,42 @@ __global__ void k_checksum(const sw_kmer *kmers, uint64_t nk, const sw_node *nod
 void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out)
 {
     out.n = sk.n_occ;
+    if (out.n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
     out.hash.alloc(out.n);
     out.kmer.alloc(out.n);
+    out.idx.alloc(out.n);
     if (plan.n_tiles == 0 || out.n == 0) return;
     DevArray<uint64_t> dst_off(plan.n_tiles);
     exclusive_sum(rocprim::make_transform_iterator(sk.tile_count.p, U32ToU64()), dst_off.p, plan.n_tiles,
                   (uint64_t)0, stream);
     const uint64_t threads = (uint64_t)plan.n_tiles * 64;
     hipLaunchKernelGGL(k_order, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
-                       sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, out.hash.p, out.kmer.p);
+                       sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, out.hash.p, out.kmer.p, out.idx.p);
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));  // dst_off is released on return
 }
 
-void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
-                        const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,
-                        uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, uint64_t *err_flags_host)
+namespace {
+struct PenaltyJob {   // buffers of an in-flight get_penalty (asynchronous on `stream`)
+    DevArray<uint64_t> X, Y;
+    DevArray<uint32_t> err;
+    hipStream_t stream = nullptr;
+    bool active = false;
+    ~PenaltyJob() { if (active) (void)hipStreamSynchronize(stream); }   // never release buffers of running kernels
+};
+
+void penalty_launch(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
+                    const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target, uint64_t n_targets,
+                    uint64_t n_non_targets, hipStream_t stream, PenaltyJob &job)
 {
-    *err_flags_host = 0;
-    if (n_nodes == 0) return;
-    DevArray<uint64_t> X(n_kmers), Y(n_kmers);
-    DevArray<uint32_t> err(1);
+    job.stream = stream;
+    job.active = n_nodes != 0;
+    if (!job.active) return;
+    job.X.alloc(n_kmers);
+    job.Y.alloc(n_kmers);
+    job.err.alloc(1);
+    DevArray<uint64_t> &X = job.X, &Y = job.Y;
+    DevArray<uint32_t> &err = job.err;
     SW_HIP(hipMemsetAsync(err.p, 0, 4, stream));
     if (n_kmers) {
         hipLaunchKernelGGL(k_pen_flags, dim3(blocks_for(n_kmers)), dim3(TPB), 0, stream, d_kmers, n_kmers, d_rec_asm,
@@ -474,18 +490,42 @@ void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nod
     hipLaunchKernelGGL(k_pen_nodes, dim3(blocks_for(n_nodes)), dim3(TPB), 0, stream, d_kmers, n_kmers, d_nodes, n_nodes,
                        d_rec_asm, n_records, d_is_target, X.p, Y.p, inv_tar, inv_neg, err.p);
     SW_HIP(hipGetLastError());
-    uint32_t e = 0;
-    SW_HIP(hipMemcpyAsync(&e, err.p, 4, hipMemcpyDeviceToHost, stream));
-    SW_HIP(hipStreamSynchronize(stream));
-    *err_flags_host = e;
 }
 
-void build_index(const sw_batch &b, const OrderedOcc &occ, const uint8_t *d_is_target, uint64_t n_targets,
+uint64_t penalty_finish(PenaltyJob &job)
+{
+    if (!job.active) return 0;
+    uint32_t e = 0;
+    SW_HIP(hipMemcpyAsync(&e, job.err.p, 4, hipMemcpyDeviceToHost, job.stream));
+    SW_HIP(hipStreamSynchronize(job.stream));
+    job.active = false;
+    return e;
+}
+
+hipStream_t side_stream()
+{
+    static thread_local hipStream_t s = nullptr;
+    if (!s) SW_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
+}  // namespace
+
+void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
+                        const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,
+                        uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, uint64_t *err_flags_host)
+{
+    PenaltyJob job;
+    penalty_launch(d_kmers, n_kmers, d_nodes, n_nodes, d_rec_asm, n_records, d_is_target, n_targets, n_non_targets,
+                   stream, job);
+    *err_flags_host = penalty_finish(job);
+}
+
+void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target, uint64_t n_targets,
                  uint64_t n_non_targets, hipStream_t stream, sw_index &ix)
 {
     const uint64_t n = occ.n;
     if (n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
-    hipEvent_t ev[4];
+    hipEvent_t ev[6];
     for (auto &e : ev) SW_HIP(hipEventCreate(&e));
     SW_HIP(hipEventRecord(ev[0], stream));
 
@@ -494,12 +534,11 @@ void build_index(const sw_batch &b, const OrderedOcc &occ, const uint8_t *d_is_t
     DevArray<uint32_t> rank(n);
     // -- nodes: stable radix sort of (out_hash -> original index), run-length heads ------------------
     if (n) {
-        DevArray<uint64_t> k0(n), k1(n);
-        DevArray<uint32_t> v0(n), v1(n);
-        SW_HIP(hipMemcpyAsync(k0.p, occ.hash.p, n * 8, hipMemcpyDeviceToDevice, stream));
-        hipLaunchKernelGGL(k_iota, dim3(blocks_for(n)), dim3(TPB), 0, stream, v0.p, n);
-        uint64_t *keys = k0.p, *keys_alt = k1.p;
-        uint32_t *vals = v0.p, *vals_alt = v1.p;
+        // the ordered hash / identity-index arrays are consumed in place as the sort's first buffers
+        DevArray<uint64_t> k1(n);
+        DevArray<uint32_t> v1(n);
+        uint64_t *keys = occ.hash.p, *keys_alt = k1.p;
+        uint32_t *vals = occ.idx.p, *vals_alt = v1.p;
         sort_pairs(keys, keys_alt, vals, vals_alt, n, 0, 64, stream);
         uint32_t *cum = vals_alt;  // reuse the spare value buffer for the inclusive head count
         inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
@@ -520,13 +559,16 @@ void build_index(const sw_batch &b, const OrderedOcc &occ, const uint8_t *d_is_t
     }
     SW_HIP(hipEventRecord(ev[1], stream));
 
-    // -- per-node target / non-target assembly counts + penalty (filter.cpp:62-136) -------------------
+    // -- per-node target / non-target assembly counts + penalty (filter.cpp:62-136), on a second stream
+    //    so that it overlaps the edge stage (both only read kmers / ranks; nodes fields are disjoint) -----
+    PenaltyJob pen;
+    hipStream_t side = side_stream();
     if (d_is_target && ix.n_nodes) {
-        uint64_t err = 0;
-        device_get_penalty(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, b.d_rec_asm.p, b.n_records, d_is_target, n_targets,
-                           n_non_targets, stream, &err);
-        if (err) raise(SW_ERR_RUNTIME, "internal error: inconsistent occurrence order in device index (%llu)",
-                       (unsigned long long)err);
+        SW_HIP(hipStreamWaitEvent(side, ev[1], 0));
+        SW_HIP(hipEventRecord(ev[4], side));
+        penalty_launch(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, b.d_rec_asm.p, b.n_records, d_is_target, n_targets,
+                       n_non_targets, side, pen);
+        SW_HIP(hipEventRecord(ev[5], side));
     }
     SW_HIP(hipEventRecord(ev[2], stream));
 
@@ -574,13 +616,23 @@ void build_index(const sw_batch &b, const OrderedOcc &occ, const uint8_t *d_is_t
         }
     }
     if (ix.n_edges == 0) ix.edges.alloc(0);
+    const bool had_pen = pen.active;
+    if (had_pen) {
+        const uint64_t err = penalty_finish(pen);
+        SW_HIP(hipStreamWaitEvent(stream, ev[5], 0));   // the build is complete on `stream` only after the counts
+        if (err) raise(SW_ERR_RUNTIME, "internal error: inconsistent occurrence order in device index (%llu)",
+                       (unsigned long long)err);
+    }
     SW_HIP(hipEventRecord(ev[3], stream));
     SW_HIP(hipEventSynchronize(ev[3]));
     float ms = 0.f;
     SW_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
     ix.timings.nodes_ms = ms;
-    SW_HIP(hipEventElapsedTime(&ms, ev[1], ev[2]));
-    ix.timings.counts_ms = ms;
+    ix.timings.counts_ms = 0;
+    if (had_pen) {
+        SW_HIP(hipEventElapsedTime(&ms, ev[4], ev[5]));
+        ix.timings.counts_ms = ms;                       // overlaps edges_ms
+    }
     SW_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
     ix.timings.edges_ms = ms;
     for (auto &e : ev) SW_HIP(hipEventDestroy(e));
