@@ -123,10 +123,11 @@ def main() -> None:
     my_targets = is_targets_global[rank * G:(rank + 1) * G]
     bp_rank = G * rpg * rl
 
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SEQWIN_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: cost of the sharded path at N=1
+    if use_dist:
         from seqwin_amd import dist as swdist
         shard = swdist.Shard(batch, first_assembly=rank * G, n_assemblies_total=G * world)
-        engine = swdist.HipEngine("device" if dist.get_backend() == "nccl" else "host")
+        engine = swdist.HipEngine("device" if world == 1 or dist.get_backend() == "nccl" else "host")
 
         def step():
             return swdist.build_sharded_index(shard, k, w, is_targets_global, engine=engine)
@@ -170,7 +171,7 @@ def main() -> None:
     counts = torch.tensor([nk, nn, ne], dtype=torch.int64, device=engine.device if world > 1 else "cuda")
     if world > 1:
         dist.all_reduce(counts)
-    n_occ_local = tm.get("n_occ_local", nk) if world > 1 else nk
+    n_occ_local = tm.get("n_occ_local", nk)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3

@@ -214,6 +214,38 @@ int sw_index_merge(const void *occ_rows_dev, uint64_t n_occ, const void *edge_ro
                    uint64_t kmer_base, const uint32_t *record_offsets, const uint8_t *is_targets,
                    uint64_t n_assemblies, void *stream, sw_index **out);
 
+/* ---- multi-GPU, tuple-exchange form (what bench.py --gpus N times; seqwin_amd/dist.py drives it) ---------
+ * Instead of building a partial graph per GPU and merging (above), every GPU sketches its shard and the TUPLES are
+ * exchanged by hash range, so each occurrence is sorted exactly once, by its owner:
+ *   sw_occ_sketch -> sw_occ_partition -> [all_to_all rows] -> sw_slice_build (nodes / kmers / counts + rank of every
+ *   received row) -> [all_to_all ranks back] -> sw_occ_adjacency -> [all_to_all adjacency rows] -> sw_slice_edges. */
+typedef struct sw_occ sw_occ; /* device-resident (out_hash, pos|record) stream of one shard in (record_idx, pos) order */
+int sw_occ_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *stream, sw_occ **out);
+int sw_occ_size(const sw_occ *o, uint64_t *n, double *sketch_ms);
+void sw_occ_free(sw_occ *o);
+/* Stable partition by owner = number of ascending bounds <= out_hash.  DEVICE outputs: rows[n][2] =
+ * {out_hash, pos | (record_idx + rec_offset) << 32} grouped by owner, perm[n] (u32: original index of row j).
+ * HOST output: counts[n_bounds + 1]. */
+int sw_occ_partition(const sw_occ *o, const uint64_t *bounds, uint64_t n_bounds, uint64_t rec_offset, void *rows_dev,
+                     void *perm_dev, uint64_t *counts, void *stream);
+/* Owner: nodes / kmers (+ counts and penalty if is_targets) of its hash range from received rows (concatenated in
+ * source-rank order = global (record_idx, pos) order).  ranks_dev[n] (u32, DEVICE) receives the slice-local node rank
+ * of every received row.  Node ranges are offset by kmer_base.  The index has no edges yet. */
+int sw_slice_build(const void *rows_dev, uint64_t n, uint64_t kmer_base, const uint32_t *record_offsets,
+                   const uint8_t *is_targets, uint64_t n_assemblies, void *ranks_dev, void *stream, sw_index **out);
+/* Copy the node hashes (u64[n_nodes]) of an index into a DEVICE buffer. */
+int sw_index_node_hashes(const sw_index *ix, void *dst_dev, void *stream);
+/* Source: adjacency rows {(rank_lo << n_bits) | rank_hi, global assembly} of consecutive minimizers of a record, from
+ * the GLOBAL node rank of every partitioned row (rank_by_row_dev, u32[n]) and perm; grouped by edge owner = number of
+ * ascending rank_bounds <= rank_lo.  DEVICE output rows[<= n-1][2]; HOST output counts[n_bounds + 1]. */
+int sw_occ_adjacency(const sw_occ *o, const void *perm_dev, const void *rank_by_row_dev, uint64_t n_bits,
+                     uint64_t asm_base, const uint64_t *rank_bounds, uint64_t n_bounds, void *rows_dev, uint64_t *counts,
+                     void *stream);
+/* Owner: edges of its rank range from received adjacency rows (source-rank order), hashes looked up in the job-wide
+ * rank -> hash table (DEVICE u64[total nodes]).  Attaches the edges to `ix`. */
+int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t n_bits, const void *rank_hash_dev,
+                   void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -227,6 +227,8 @@ void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targe
 
 using namespace sw;
 
+sw_occ::~sw_occ() { delete occ; }
+
 struct sw_graph {
     sw::GraphHost g;
 };
@@ -463,6 +465,76 @@ int sw_index_checksums(const sw_index *ix, uint64_t *kmers_sum, uint64_t *nodes_
 
 void sw_index_free(sw_index *ix) { delete ix; }
 
+int sw_occ_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *stream, sw_occ **out)
+{
+    return guarded([&] {
+        sw_batch &bb = *const_cast<sw_batch *>(b);
+        Plan &plan = get_plan(bb, kmerlen, windowsize);
+        std::unique_ptr<sw_occ> o(new sw_occ);
+        o->batch = b;
+        o->occ = new OrderedOcc;
+        SketchOut sk;
+        run_sketch(bb, plan, (hipStream_t)stream, sk, &o->sketch_ms);
+        order_tuples(sk, plan, (hipStream_t)stream, *o->occ);
+        *out = o.release();
+    });
+}
+
+int sw_occ_size(const sw_occ *o, uint64_t *n, double *sketch_ms)
+{
+    return guarded([&] {
+        *n = o->occ->n;
+        if (sketch_ms) *sketch_ms = o->sketch_ms;
+    });
+}
+
+void sw_occ_free(sw_occ *o) { delete o; }
+
+int sw_occ_partition(const sw_occ *o, const uint64_t *bounds, uint64_t n_bounds, uint64_t rec_offset, void *rows_dev,
+                     void *perm_dev, uint64_t *counts, void *stream)
+{
+    return guarded([&] {
+        occ_partition(*o->occ, bounds, (uint32_t)n_bounds, rec_offset, (uint64_t *)rows_dev, (uint32_t *)perm_dev, counts,
+                      (hipStream_t)stream);
+    });
+}
+
+int sw_occ_adjacency(const sw_occ *o, const void *perm_dev, const void *rank_by_row_dev, uint64_t n_bits, uint64_t asm_base,
+                     const uint64_t *rank_bounds, uint64_t n_bounds, void *rows_dev, uint64_t *counts, void *stream)
+{
+    return guarded([&] {
+        if (n_bits < 1 || n_bits > 32) raise(SW_ERR_VALUE, "n_bits must be in [1, 32]");
+        occ_adjacency(*o->occ, o->batch->d_rec_asm.p, (const uint32_t *)perm_dev, (const uint32_t *)rank_by_row_dev,
+                      (unsigned)n_bits, asm_base, rank_bounds, (uint32_t)n_bounds, (uint64_t *)rows_dev, counts,
+                      (hipStream_t)stream);
+    });
+}
+
+int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t n_bits, const void *rank_hash_dev,
+                   void *stream)
+{
+    return guarded([&] {
+        hipEvent_t e0, e1;
+        SW_HIP(hipEventCreate(&e0));
+        SW_HIP(hipEventCreate(&e1));
+        SW_HIP(hipEventRecord(e0, (hipStream_t)stream));
+        slice_edges(*ix, (const uint64_t *)adj_rows_dev, m, (unsigned)n_bits, (const uint64_t *)rank_hash_dev,
+                    (hipStream_t)stream);
+        SW_HIP(hipEventRecord(e1, (hipStream_t)stream));
+        SW_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SW_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ix->timings.edges_ms = ms;
+        SW_HIP(hipEventDestroy(e0));
+        SW_HIP(hipEventDestroy(e1));
+    });
+}
+
+int sw_index_node_hashes(const sw_index *ix, void *dst_dev, void *stream)
+{
+    return guarded([&] { index_node_hashes(*ix, (uint64_t *)dst_dev, (hipStream_t)stream); });
+}
+
 int sw_index_device_ptrs(const sw_index *ix, void **kmers, void **nodes, void **edges)
 {
     return guarded([&] {
@@ -494,11 +566,34 @@ int sw_index_splits(const sw_index *ix, const uint64_t *node_bounds, const uint6
     });
 }
 
+static void merge_like(const void *occ_rows_dev, uint64_t n_occ, const void *edge_rows_dev, uint64_t n_edge_rows,
+                       uint64_t kmer_base, const uint32_t *record_offsets, const uint8_t *is_targets, uint64_t n_assemblies,
+                       void *stream, uint32_t *d_rank_out, sw_index **out);
+
 int sw_index_merge(const void *occ_rows_dev, uint64_t n_occ, const void *edge_rows_dev, uint64_t n_edge_rows,
                    uint64_t kmer_base, const uint32_t *record_offsets, const uint8_t *is_targets, uint64_t n_assemblies,
                    void *stream, sw_index **out)
 {
     return guarded([&] {
+        merge_like(occ_rows_dev, n_occ, edge_rows_dev, n_edge_rows, kmer_base, record_offsets, is_targets, n_assemblies,
+                   stream, nullptr, out);
+    });
+}
+
+int sw_slice_build(const void *rows_dev, uint64_t n, uint64_t kmer_base, const uint32_t *record_offsets,
+                   const uint8_t *is_targets, uint64_t n_assemblies, void *ranks_dev, void *stream, sw_index **out)
+{
+    return guarded([&] {
+        merge_like(rows_dev, n, nullptr, 0, kmer_base, record_offsets, is_targets, n_assemblies, stream,
+                   (uint32_t *)ranks_dev, out);
+    });
+}
+
+static void merge_like(const void *occ_rows_dev, uint64_t n_occ, const void *edge_rows_dev, uint64_t n_edge_rows,
+                       uint64_t kmer_base, const uint32_t *record_offsets, const uint8_t *is_targets, uint64_t n_assemblies,
+                       void *stream, uint32_t *d_rank_out, sw_index **out)
+{
+    {
         require_device();
         hipStream_t st = (hipStream_t)stream;
         std::unique_ptr<sw_index> ix(new sw_index);
@@ -524,7 +619,7 @@ int sw_index_merge(const void *occ_rows_dev, uint64_t n_occ, const void *edge_ro
         SW_HIP(hipEventCreate(&e1));
         SW_HIP(hipEventRecord(e0, st));
         merge_build((const uint64_t *)occ_rows_dev, n_occ, (const uint64_t *)edge_rows_dev, n_edge_rows, kmer_base,
-                    d_rec_asm.p, n_records, is_targets ? d_tar.p : nullptr, n_tar, n_neg, st, *ix);
+                    d_rec_asm.p, n_records, is_targets ? d_tar.p : nullptr, n_tar, n_neg, st, *ix, d_rank_out);
         SW_HIP(hipEventRecord(e1, st));
         SW_HIP(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -533,7 +628,7 @@ int sw_index_merge(const void *occ_rows_dev, uint64_t n_occ, const void *edge_ro
         SW_HIP(hipEventDestroy(e0));
         SW_HIP(hipEventDestroy(e1));
         *out = ix.release();
-    });
+    }
 }
 
 int sw_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *stream, uint64_t *out_hash, sw_kmer *kmers,

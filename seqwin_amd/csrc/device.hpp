@@ -90,6 +90,15 @@ struct sw_batch {
     std::map<std::pair<uint32_t, uint32_t>, sw::Plan> plans;
 };
 
+namespace sw { struct OrderedOcc; }
+
+struct sw_occ {   // ordered tuple stream of one shard (tuple-exchange form of the multi-GPU build)
+    const sw_batch *batch = nullptr;
+    sw::OrderedOcc *occ = nullptr;
+    float sketch_ms = 0.f;
+    ~sw_occ();
+};
+
 struct sw_index {
     int device = 0;
     uint64_t n_kmers = 0, n_nodes = 0, n_edges = 0;
@@ -139,6 +148,14 @@ void index_splits(const sw_index &ix, const uint64_t *node_bounds, const uint64_
                   uint64_t *occ_split, uint64_t *edge_split, hipStream_t stream);
 void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_rows, uint64_t m, uint64_t kmer_base,
                  const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target, uint64_t n_targets,
-                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix);
+                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix, uint32_t *d_rank_out = nullptr);
+void occ_partition(const OrderedOcc &occ, const uint64_t *bounds, uint32_t n_bounds, uint64_t rec_offset, uint64_t *d_rows,
+                   uint32_t *d_perm, uint64_t *counts_host, hipStream_t stream);
+void occ_adjacency(const OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_perm, const uint32_t *d_rank_by_row,
+                   unsigned nb, uint64_t asm_base, const uint64_t *rank_bounds, uint32_t n_bounds, uint64_t *d_rows_out,
+                   uint64_t *counts_host, hipStream_t stream);
+void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned nb, const uint64_t *d_rank_hash,
+                 hipStream_t stream);
+void index_node_hashes(const sw_index &ix, uint64_t *d_out, hipStream_t stream);
 
 }  // namespace sw

@@ -129,15 +129,22 @@ __global__ void k_nodes(const uint64_t *__restrict__ skeys, const uint32_t *__re
 
 // ---- multi-GPU merge helpers ---------------------------------------------------------------------
 // rows[s] = (hash of the node owning occurrence s, pos | (record_idx + rec_offset) << 32)
-__global__ void k_occ_rows(const sw_kmer *__restrict__ kmers, const sw_node *__restrict__ nodes, uint64_t n_nodes,
-                           uint64_t n_kmers, uint64_t rec_offset, uint64_t *__restrict__ rows)
+__global__ void k_node_starts(const sw_node *__restrict__ nodes, uint64_t n_nodes, uint32_t *__restrict__ start)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_nodes) start[i] = (uint32_t)nodes[i].start;
+}
+
+__global__ void k_occ_rows(const sw_kmer *__restrict__ kmers, const sw_node *__restrict__ nodes,
+                           const uint32_t *__restrict__ start, uint64_t n_nodes, uint64_t n_kmers, uint64_t rec_offset,
+                           uint64_t *__restrict__ rows)
 {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_kmers) return;
-    uint64_t lo = 0, hi = n_nodes;  // last node with start <= s
+    uint64_t lo = 0, hi = n_nodes;  // last node with start <= s (compact 4-byte starts: cache resident)
     while (hi - lo > 1) {
         const uint64_t mid = (lo + hi) >> 1;
-        if (nodes[mid].start <= s) lo = mid; else hi = mid;
+        if (start[mid] <= s) lo = mid; else hi = mid;
     }
     rows[2 * s] = nodes[lo].hash;
     rows[2 * s + 1] = (uint64_t)kmers[s].pos | (((uint64_t)kmers[s].record_idx + rec_offset) << 32);
@@ -342,7 +349,8 @@ __global__ void k_edge_heads(const uint64_t *__restrict__ skeys, const uint32_t 
 
 __global__ void k_edges(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ ccum,
                         const uint64_t *__restrict__ edge_start, uint64_t n_edges, uint64_t n_valid, unsigned nb,
-                        const sw_node *__restrict__ nodes, sw_edge *__restrict__ edges)
+                        const sw_node *__restrict__ nodes, const uint64_t *__restrict__ rank_hash,
+                        sw_edge *__restrict__ edges)
 {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
@@ -350,9 +358,94 @@ __global__ void k_edges(const uint64_t *__restrict__ skeys, const uint32_t *__re
     const uint64_t s1 = (e + 1 < n_edges) ? edge_start[e + 1] : n_valid;
     const uint64_t key = skeys[s];
     const uint32_t u = (uint32_t)(key >> nb), v = (uint32_t)(key & ((1ull << nb) - 1ull));
-    edges[e].first = nodes[u].hash;
-    edges[e].second = nodes[v].hash;
+    edges[e].first = rank_hash ? rank_hash[u] : nodes[u].hash;
+    edges[e].second = rank_hash ? rank_hash[v] : nodes[v].hash;
     edges[e].weight = (uint64_t)(ccum[s1 - 1] - ccum[s]) + 1ull;
+}
+
+// ---- tuple-exchange form of the multi-GPU build (dist.py) ---------------------------------------------
+// owner of a key = number of ascending bounds <= key; rows with key == drop_key go to bucket n_bounds + 1
+__global__ void k_owner(const uint64_t *__restrict__ key, uint32_t stride, uint64_t n, const uint64_t *__restrict__ bounds,
+                        uint32_t n_bounds, uint64_t drop_key, bool has_drop, uint32_t *__restrict__ owner,
+                        uint32_t *__restrict__ idx, unsigned long long *__restrict__ counts)
+{
+    __shared__ unsigned int hist[18];
+    if (threadIdx.x < 18) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint64_t kx = key[i * stride];
+        uint32_t o = 0;
+        for (uint32_t j = 0; j < n_bounds; ++j) o += (bounds[j] <= kx) ? 1u : 0u;
+        if (has_drop && kx == drop_key) o = n_bounds + 1;
+        owner[i] = o;
+        idx[i] = (uint32_t)i;
+        atomicAdd(&hist[o], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < n_bounds + 2 && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+__global__ void k_tuple_rows(const uint64_t *__restrict__ hash, const uint64_t *__restrict__ kmer,
+                             const uint32_t *__restrict__ perm, uint64_t n, uint64_t rec_offset, uint64_t *__restrict__ rows)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t i = perm[j];
+    rows[2 * j] = hash[i];
+    rows[2 * j + 1] = kmer[i] + (rec_offset << 32);
+}
+
+__global__ void k_unpermute(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ by_row, uint64_t n,
+                            uint32_t *__restrict__ orig)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) orig[perm[j]] = by_row[j];
+}
+
+// (key, assembly) of consecutive minimizers of a record, from GLOBAL node ranks; sentinel otherwise
+__global__ void k_adj_rows(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ rank,
+                           const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, uint64_t sentinel,
+                           uint64_t asm_base, uint64_t *__restrict__ rows)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 >= n) return;
+    const uint32_t r0 = (uint32_t)(kmer[i] >> 32), r1 = (uint32_t)(kmer[i + 1] >> 32);
+    if (r0 == r1) {
+        uint32_t u = rank[i], v = rank[i + 1];
+        if (v < u) { const uint32_t t = u; u = v; v = t; }
+        rows[2 * i] = ((uint64_t)u << nb) | v;
+        rows[2 * i + 1] = asm_base + rec_asm[r0];
+    } else {
+        rows[2 * i] = sentinel;
+        rows[2 * i + 1] = 0;
+    }
+}
+
+__global__ void k_gather_rows2(const uint64_t *__restrict__ src, const uint32_t *__restrict__ perm, uint64_t n,
+                               uint64_t *__restrict__ dst)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t i = perm[j];
+    dst[2 * j] = src[2 * (uint64_t)i];
+    dst[2 * j + 1] = src[2 * (uint64_t)i + 1];
+}
+
+__global__ void k_split_rows2(const uint64_t *__restrict__ rows, uint64_t n, uint64_t *__restrict__ key,
+                              uint32_t *__restrict__ val)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        key[i] = rows[2 * i];
+        val[i] = (uint32_t)rows[2 * i + 1];
+    }
+}
+
+__global__ void k_node_hashes(const sw_node *__restrict__ nodes, uint64_t n_nodes, uint64_t *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_nodes) out[i] = nodes[i].hash;
 }
 
 // ---- filter_kmers -----------------------------------------------------------------------------------
@@ -510,6 +603,35 @@ hipStream_t side_stream()
 }
 }  // namespace
 
+namespace {
+// keys[m] = (rank_lo << nb) | rank_hi (sentinels sort last), vals[m] = assembly; stable sort keeps equal
+// pairs in assembly order, so weight = number of assembly changes inside a run (+1).
+void edges_from_adjacency(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt, uint64_t m,
+                          uint64_t n_valid, unsigned nb, const uint64_t *rank_hash, hipStream_t stream, sw_index &ix)
+{
+    ix.n_edges = 0;
+    if (m == 0 || n_valid == 0) return;
+    sort_pairs(keys, keys_alt, vals, vals_alt, m, 0, 2 * nb, stream);
+    DevArray<uint32_t> ecum(n_valid), ccum(n_valid);
+    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), HeadFlag{keys, n_valid}),
+                  ecum.p, n_valid, (uint32_t)0, stream);
+    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
+                                                   AsmChangeFlag{keys, vals, n_valid}),
+                  ccum.p, n_valid, (uint32_t)0, stream);
+    uint32_t n_edges = 0;
+    SW_HIP(hipMemcpyAsync(&n_edges, ecum.p + (n_valid - 1), 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    ix.n_edges = n_edges;
+    ix.edges.alloc(n_edges);
+    DevArray<uint64_t> edge_start(n_edges);
+    hipLaunchKernelGGL(k_edge_heads, dim3(blocks_for(n_valid)), dim3(TPB), 0, stream, keys, ecum.p, n_valid, edge_start.p);
+    hipLaunchKernelGGL(k_edges, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, keys, ccum.p, edge_start.p,
+                       (uint64_t)n_edges, n_valid, nb, ix.nodes.p, rank_hash, ix.edges.p);
+    SW_HIP(hipGetLastError());
+    SW_HIP(hipStreamSynchronize(stream));
+}
+}  // namespace
+
 void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
                         const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,
                         uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, uint64_t *err_flags_host)
@@ -586,34 +708,10 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
         hipLaunchKernelGGL(k_adj, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, b.d_rec_asm.p, n, nb,
                            sentinel, k0.p, v0.p, n_invalid.p);
         SW_HIP(hipGetLastError());
-        uint64_t *keys = k0.p, *keys_alt = k1.p;
-        uint32_t *vals = v0.p, *vals_alt = v1.p;
-        sort_pairs(keys, keys_alt, vals, vals_alt, m, 0, 2 * nb, stream);
         unsigned long long inv = 0;
         SW_HIP(hipMemcpyAsync(&inv, n_invalid.p, 8, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipStreamSynchronize(stream));
-        const uint64_t n_valid = m - inv;
-        if (n_valid) {
-            DevArray<uint32_t> ecum(n_valid), ccum(n_valid);
-            inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
-                                                           HeadFlag{keys, n_valid}),
-                          ecum.p, n_valid, (uint32_t)0, stream);
-            inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
-                                                           AsmChangeFlag{keys, vals, n_valid}),
-                          ccum.p, n_valid, (uint32_t)0, stream);
-            uint32_t n_edges = 0;
-            SW_HIP(hipMemcpyAsync(&n_edges, ecum.p + (n_valid - 1), 4, hipMemcpyDeviceToHost, stream));
-            SW_HIP(hipStreamSynchronize(stream));
-            ix.n_edges = n_edges;
-            ix.edges.alloc(n_edges);
-            DevArray<uint64_t> edge_start(n_edges);
-            hipLaunchKernelGGL(k_edge_heads, dim3(blocks_for(n_valid)), dim3(TPB), 0, stream, keys, ecum.p, n_valid,
-                               edge_start.p);
-            hipLaunchKernelGGL(k_edges, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, keys, ccum.p, edge_start.p,
-                               (uint64_t)n_edges, n_valid, nb, ix.nodes.p, ix.edges.p);
-            SW_HIP(hipGetLastError());
-            SW_HIP(hipStreamSynchronize(stream));
-        }
+        edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, m - inv, nb, nullptr, stream, ix);
     }
     if (ix.n_edges == 0) ix.edges.alloc(0);
     const bool had_pen = pen.active;
@@ -641,9 +739,12 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
 void index_occ_rows(const sw_index &ix, uint64_t rec_offset, uint64_t *d_rows, hipStream_t stream)
 {
     if (ix.n_kmers == 0) return;
-    hipLaunchKernelGGL(k_occ_rows, dim3(blocks_for(ix.n_kmers)), dim3(TPB), 0, stream, ix.kmers.p, ix.nodes.p, ix.n_nodes,
-                       ix.n_kmers, rec_offset, d_rows);
+    DevArray<uint32_t> start(ix.n_nodes);
+    hipLaunchKernelGGL(k_node_starts, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, start.p);
+    hipLaunchKernelGGL(k_occ_rows, dim3(blocks_for(ix.n_kmers)), dim3(TPB), 0, stream, ix.kmers.p, ix.nodes.p, start.p,
+                       ix.n_nodes, ix.n_kmers, rec_offset, d_rows);
     SW_HIP(hipGetLastError());
+    SW_HIP(hipStreamSynchronize(stream));   // `start` is released on return
 }
 
 void index_splits(const sw_index &ix, const uint64_t *node_bounds, const uint64_t *edge_bounds, uint32_t n_bounds,
@@ -666,7 +767,7 @@ void index_splits(const sw_index &ix, const uint64_t *node_bounds, const uint64_
 // with globally rebased record indices), edge rows as (first, second, partial weight).
 void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_rows, uint64_t m, uint64_t kmer_base,
                  const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target, uint64_t n_targets,
-                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix)
+                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix, uint32_t *d_rank_out)
 {
     if (n >= 0xFFFFFFFFull || m >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 rows on one device");
     ix.n_kmers = n;
@@ -689,7 +790,7 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
         ix.n_nodes = n_nodes;
         ix.nodes.alloc(n_nodes);
         hipLaunchKernelGGL(k_nodes, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, cum, d_occ_rows + 1, 2u, n,
-                           (uint64_t)0, ix.kmers.p, ix.nodes.p, (uint32_t *)nullptr);
+                           (uint64_t)0, ix.kmers.p, ix.nodes.p, d_rank_out);
         SW_HIP(hipGetLastError());
         SW_HIP(hipStreamSynchronize(stream));
     } else {
@@ -740,6 +841,105 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
     } else {
         ix.edges.alloc(0);
     }
+}
+
+// Stable partition of n rows by owner (number of bounds <= key).  Returns perm (row j of the grouped order is
+// original row perm[j]) and the per-owner counts; rows whose key equals drop_key are moved past the last owner.
+static void partition_by_owner(const uint64_t *d_key, uint32_t key_stride, uint64_t n, const uint64_t *bounds,
+                               uint32_t n_bounds, bool has_drop, uint64_t drop_key, hipStream_t stream,
+                               DevArray<uint32_t> &perm_store, uint32_t *&perm, uint64_t *counts_host)
+{
+    if (n_bounds > 15) raise(SW_ERR_VALUE, "at most 16 owners are supported");
+    for (uint32_t j = 0; j < n_bounds + 2; ++j) counts_host[j] = 0;
+    if (n == 0) { perm = nullptr; return; }
+    DevArray<uint64_t> d_bounds(n_bounds ? n_bounds : 1);
+    DevArray<unsigned long long> d_counts(18);
+    DevArray<uint32_t> o0(n), o1(n), i1(n);
+    perm_store.alloc(n);
+    if (n_bounds) SW_HIP(hipMemcpyAsync(d_bounds.p, bounds, n_bounds * 8, hipMemcpyHostToDevice, stream));
+    SW_HIP(hipMemsetAsync(d_counts.p, 0, 18 * 8, stream));
+    hipLaunchKernelGGL(k_owner, dim3(blocks_for(n)), dim3(TPB), 0, stream, d_key, key_stride, n, d_bounds.p, n_bounds,
+                       drop_key, has_drop, o0.p, perm_store.p, d_counts.p);
+    SW_HIP(hipGetLastError());
+    uint32_t *ok = o0.p, *ok_alt = o1.p, *iv = perm_store.p, *iv_alt = i1.p;
+    unsigned bits = 1;
+    while ((1u << bits) < n_bounds + 2) ++bits;
+    sort_pairs(ok, ok_alt, iv, iv_alt, n, 0, bits, stream);   // one stable pass: groups by owner, keeps order
+    if (iv != perm_store.p) SW_HIP(hipMemcpyAsync(perm_store.p, iv, n * 4, hipMemcpyDeviceToDevice, stream));
+    perm = perm_store.p;
+    unsigned long long h[18];
+    SW_HIP(hipMemcpyAsync(h, d_counts.p, 18 * 8, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    for (uint32_t j = 0; j < n_bounds + 2; ++j) counts_host[j] = h[j];
+}
+
+void occ_partition(const OrderedOcc &occ, const uint64_t *bounds, uint32_t n_bounds, uint64_t rec_offset, uint64_t *d_rows,
+                   uint32_t *d_perm, uint64_t *counts_host, hipStream_t stream)
+{
+    DevArray<uint32_t> store;
+    uint32_t *perm = nullptr;
+    uint64_t counts[18];
+    partition_by_owner(occ.hash.p, 1, occ.n, bounds, n_bounds, false, 0, stream, store, perm, counts);
+    for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = counts[j];
+    if (occ.n == 0) return;
+    hipLaunchKernelGGL(k_tuple_rows, dim3(blocks_for(occ.n)), dim3(TPB), 0, stream, occ.hash.p, occ.kmer.p, perm, occ.n,
+                       rec_offset, d_rows);
+    SW_HIP(hipMemcpyAsync(d_perm, perm, occ.n * 4, hipMemcpyDeviceToDevice, stream));
+    SW_HIP(hipGetLastError());
+    SW_HIP(hipStreamSynchronize(stream));
+}
+
+void occ_adjacency(const OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_perm, const uint32_t *d_rank_by_row,
+                   unsigned nb, uint64_t asm_base, const uint64_t *rank_bounds, uint32_t n_bounds, uint64_t *d_rows_out,
+                   uint64_t *counts_host, hipStream_t stream)
+{
+    for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = 0;
+    const uint64_t n = occ.n;
+    if (n < 2) return;
+    const uint64_t m = n - 1;
+    const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
+    DevArray<uint32_t> rank(n);
+    DevArray<uint64_t> rows(2 * m);
+    hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(n)), dim3(TPB), 0, stream, d_perm, d_rank_by_row, n, rank.p);
+    hipLaunchKernelGGL(k_adj_rows, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, d_rec_asm, n, nb, sentinel,
+                       asm_base, rows.p);
+    SW_HIP(hipGetLastError());
+    std::vector<uint64_t> kb(n_bounds);
+    for (uint32_t j = 0; j < n_bounds; ++j) kb[j] = rank_bounds[j] << nb;   // key is monotone in rank_lo
+    DevArray<uint32_t> store;
+    uint32_t *perm = nullptr;
+    uint64_t counts[18];
+    partition_by_owner(rows.p, 2, m, kb.data(), n_bounds, true, sentinel, stream, store, perm, counts);
+    for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = counts[j];
+    uint64_t keep = 0;
+    for (uint32_t j = 0; j <= n_bounds; ++j) keep += counts[j];
+    if (keep) {
+        hipLaunchKernelGGL(k_gather_rows2, dim3(blocks_for(keep)), dim3(TPB), 0, stream, rows.p, perm, keep, d_rows_out);
+        SW_HIP(hipGetLastError());
+    }
+    SW_HIP(hipStreamSynchronize(stream));
+}
+
+void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned nb, const uint64_t *d_rank_hash,
+                 hipStream_t stream)
+{
+    ix.n_edges = 0;
+    if (m >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 adjacency rows on one device");
+    if (m) {
+        DevArray<uint64_t> k0(m), k1(m);
+        DevArray<uint32_t> v0(m), v1(m);
+        hipLaunchKernelGGL(k_split_rows2, dim3(blocks_for(m)), dim3(TPB), 0, stream, d_adj_rows, m, k0.p, v0.p);
+        SW_HIP(hipGetLastError());
+        edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, m, nb, d_rank_hash, stream, ix);
+    }
+    if (ix.n_edges == 0) ix.edges.alloc(0);
+}
+
+void index_node_hashes(const sw_index &ix, uint64_t *d_out, hipStream_t stream)
+{
+    if (ix.n_nodes == 0) return;
+    hipLaunchKernelGGL(k_node_hashes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, d_out);
+    SW_HIP(hipGetLastError());
 }
 
 void device_filter_kmers(const sw_kmer *d_kmers, uint64_t n_kmers, const sw_node *d_nodes, uint64_t n_nodes,

@@ -5,14 +5,18 @@ This is the multi-GPU form of the reference's thread partition + ``merge_thread_
 
 * assemblies are split into contiguous ranges with the reference's formula (``partition_assemblies``);
   GPU g owns the range of "thread g", so global record_idx = local + prefix of the record counts;
-* every GPU builds the partial graph of its shard (sketch -> nodes / kmers / edges, no counts);
-* occurrences are exchanged by hash range and edges by ``first`` range (order-preserving splitters,
-  quantile-shaped for edges because min(u, v) is skewed) with ``all_to_all_single`` -- backend
-  "nccl" is RCCL over xGMI; a direct all-to-all uses all seven links of a GPU at once, which is why it is
-  preferred over a ring reduce here;
-* every GPU finishes its slice: stable sort of the received runs by hash (ties keep source-rank =
-  record order), run-length -> nodes, per-node target / non-target counts, and the sum of the
-  partial edge weights (an assembly lives in exactly one shard, build_internals.cpp:283-285).
+* ``build_sharded_index`` (tuple exchange, what bench.py times): every GPU sketches its shard; the
+  (out_hash, pos|record) tuples are exchanged by hash range with ``all_to_all_single`` (backend "nccl" is
+  RCCL over xGMI; a direct all-to-all uses all seven links of a GPU at once, which is why it is preferred
+  over a ring reduce here); the owner of a hash range sorts its tuples ONCE (stable, so ties keep
+  source-rank = record order), run-lengths them into nodes / kmers, counts target / non-target
+  assemblies, and returns the node rank of every tuple to its source; sources turn consecutive
+  minimizers into (rank_lo, rank_hi, assembly) rows, which are exchanged by rank range (quantile-shaped
+  splitters, because min(u, v) is skewed) and reduced to weighted edges by their owner;
+* ``build_sharded_index_merge`` (graph merge, the literal analogue of merge_thread_graphs): every GPU
+  builds the complete partial graph of its shard, occurrence rows and partial edges are exchanged by
+  hash range, owners re-sort and sum the partial edge weights (an assembly lives in exactly one shard,
+  build_internals.cpp:283-285).  Kept as a cross-check; it sorts every occurrence twice.
 
 The concatenation of the slices in rank order is bit-identical to the single-GPU result (shard-count
 invariance, the property the reference tests as thread-count invariance, tests/smoke/test_graph.py:67-127).
@@ -136,8 +140,103 @@ class HipEngine:
                                  c_vp(self._stream()), ctypes.byref(h)))
         return Index(h)
 
+    # ---- tuple-exchange form ------------------------------------------------------------------------
+    def sketch(self, shard: Shard, k: int, w: int):
+        import ctypes
+
+        from ._lib import c_u64, c_vp, check, lib
+        h = c_vp()
+        check(lib.sw_occ_sketch(shard.batch._h, c_u64(k), c_u64(w), c_vp(self._stream()), ctypes.byref(h)))
+        n, ms = c_u64(), ctypes.c_double()
+        check(lib.sw_occ_size(h, ctypes.byref(n), ctypes.byref(ms)))
+        return _Occ(h, n.value, ms.value)
+
+    def partition(self, occ, bounds, rec_offset: int):
+        from ._lib import c_u64, c_vp, check, lib
+        t = self.torch
+        rows = t.empty((occ.n, 2), dtype=t.int64, device=self.gpu)
+        perm = t.empty((occ.n,), dtype=t.int32, device=self.gpu)
+        nb = len(bounds)
+        b = (c_u64 * max(nb, 1))(*bounds)
+        cnt = (c_u64 * (nb + 1))()
+        check(lib.sw_occ_partition(occ._h, b, c_u64(nb), c_u64(rec_offset), c_vp(rows.data_ptr()), c_vp(perm.data_ptr()),
+                                   cnt, c_vp(self._stream())))
+        return rows.to(self.device), perm, [int(x) for x in cnt]
+
+    def slice_build(self, rows, kmer_base: int, record_offsets: np.ndarray, is_targets):
+        import ctypes
+
+        from ._lib import c_u64, c_vp, check, lib
+        from .device import Index
+        t = self.torch
+        rows = rows.to(self.gpu).contiguous()
+        ranks = t.empty((rows.shape[0],), dtype=t.int32, device=self.gpu)
+        offs = np.ascontiguousarray(record_offsets, np.uint32)
+        if is_targets is None:
+            tar, na = None, len(offs) - 1
+        else:
+            tt = np.ascontiguousarray(np.asarray(is_targets, np.bool_)).view(np.uint8)
+            tar, na = tt.ctypes.data_as(c_vp), len(tt)
+        t.cuda.current_stream().synchronize()
+        h = c_vp()
+        check(lib.sw_slice_build(c_vp(rows.data_ptr()), c_u64(rows.shape[0]), c_u64(kmer_base), offs.ctypes.data_as(c_vp),
+                                 tar, c_u64(na), c_vp(ranks.data_ptr()), c_vp(self._stream()), ctypes.byref(h)))
+        return Index(h), ranks.to(self.device)
+
+    def node_hashes(self, ix):
+        from ._lib import c_vp, check, lib
+        t = self.torch
+        out = t.empty((ix.sizes()[1],), dtype=t.int64, device=self.gpu)
+        check(lib.sw_index_node_hashes(ix._h, c_vp(out.data_ptr()), c_vp(self._stream())))
+        t.cuda.current_stream().synchronize()
+        return out.to(self.device)
+
+    def adjacency(self, occ, perm, ranks_by_row, n_bits: int, asm_base: int, rank_bounds):
+        from ._lib import c_u64, c_vp, check, lib
+        t = self.torch
+        ranks_by_row = ranks_by_row.to(self.gpu).contiguous()
+        rows = t.empty((max(occ.n - 1, 0), 2), dtype=t.int64, device=self.gpu)
+        nb = len(rank_bounds)
+        b = (c_u64 * max(nb, 1))(*rank_bounds)
+        cnt = (c_u64 * (nb + 1))()
+        t.cuda.current_stream().synchronize()
+        check(lib.sw_occ_adjacency(occ._h, c_vp(perm.data_ptr()), c_vp(ranks_by_row.data_ptr()), c_u64(n_bits),
+                                   c_u64(asm_base), b, c_u64(nb), c_vp(rows.data_ptr()), cnt, c_vp(self._stream())))
+        counts = [int(x) for x in cnt]
+        return rows[:sum(counts)].to(self.device), counts
+
+    def slice_edges(self, ix, adj_rows, n_bits: int, rank_hash) -> None:
+        from ._lib import c_u64, c_vp, check, lib
+        adj_rows = adj_rows.to(self.gpu).contiguous()
+        rank_hash = rank_hash.to(self.gpu).contiguous()
+        self.torch.cuda.current_stream().synchronize()
+        check(lib.sw_slice_edges(ix._h, c_vp(adj_rows.data_ptr()), c_u64(adj_rows.shape[0]), c_u64(n_bits),
+                                 c_vp(rank_hash.data_ptr()), c_vp(self._stream())))
+
+    def free_occ(self, occ) -> None:
+        occ.close()
+
     def export(self, ix):
         return ix.export()
+
+
+class _Occ:
+    """Handle of a device-resident ordered tuple stream (sw_occ)."""
+
+    def __init__(self, h, n, sketch_ms):
+        self._h, self.n, self.sketch_ms = h, n, sketch_ms
+
+    def close(self):
+        from ._lib import lib
+        if self._h:
+            lib.sw_occ_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ShardedIndex:
@@ -167,8 +266,8 @@ class ShardedIndex:
                 np.concatenate([p[2] for p in parts]), self.record_offsets)
 
 
-def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, group=None) -> ShardedIndex:
-    """Build this rank's partial graph, exchange by hash range, and finish this rank's slice.
+def build_sharded_index_merge(shard: Shard, k: int, w: int, is_targets, engine=None, group=None) -> ShardedIndex:
+    """Graph-merge form: build this rank's partial graph, exchange by hash range, finish this rank's slice.
 
     ``is_targets`` is the job-wide flag vector (one per assembly, all ranks pass the same) or None."""
     import torch
@@ -230,6 +329,115 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     tm.update(n_occ_local=n_occ_local, local_build_wall_ms=(t1 - t0) * 1e3, exchange_wall_ms=(t2 - t1) * 1e3,
               merge_wall_ms=(t3 - t2) * 1e3)
     return ShardedIndex(engine, merged, record_offsets, tm, kmer_base)
+
+
+def rank_bounds(n_parts: int, total_nodes: int) -> list[int]:
+    """Order-preserving splitters of the node-rank space for edges keyed by rank_lo = min(rank_u, rank_v):
+    the j/P quantile of min(u, v) for uniform u, v is 1 - sqrt(1 - j/P)."""
+    return [total_nodes - math.isqrt(((n_parts - j) * total_nodes * total_nodes) // n_parts) for j in range(1, n_parts)]
+
+
+def _exchange_rows(rows, counts, dev, group):
+    """all_to_all_single of rows grouped by destination; returns (received rows, per-source counts)."""
+    import torch
+    import torch.distributed as dist
+    send = torch.tensor(counts, dtype=torch.int64, device=dev)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    recv_l = [int(x) for x in recv.tolist()]
+    out = torch.empty((sum(recv_l),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
+    dist.all_to_all_single(out, rows.contiguous(), recv_l, [int(c) for c in counts], group=group)
+    return out, recv_l
+
+
+def _gather_ints(value: int, dev, group) -> list[int]:
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.int64, device=dev)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, t, group=group)
+    return [int(p.item()) for p in parts]
+
+
+def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, group=None) -> ShardedIndex:
+    """Tuple-exchange form: sketch the shard, exchange tuples by hash range, build this rank's slice of
+    nodes / kmers / counts, return ranks to the sources, exchange adjacency rows, build this rank's edges.
+
+    ``is_targets`` is the job-wide flag vector (one per assembly, all ranks pass the same) or None."""
+    import torch
+    import torch.distributed as dist
+
+    engine = engine or HipEngine()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = engine.device
+    t0 = time.perf_counter()
+
+    occ = engine.sketch(shard, k, w)
+    local_offs = np.asarray(engine.record_offsets(shard), np.uint32)
+    t1 = time.perf_counter()
+
+    # C0: record-count prefix (build_internals.cpp:334-355)
+    if world > 1:
+        all_offs = [None] * world
+        dist.all_gather_object(all_offs, local_offs, group=group)
+    else:
+        all_offs = [local_offs]
+    rec_base, glob, total = [], [np.zeros(1, np.uint32)], 0
+    for o in all_offs:
+        rec_base.append(total)
+        glob.append((o[1:].astype(np.uint64) + total).astype(np.uint32))
+        total += int(o[-1])
+        if total > 0xFFFFFFFF:
+            raise RuntimeError("Total number of FASTA records exceeds uint32 range")
+    record_offsets = np.concatenate(glob)
+
+    # C1: tuples to the owner of their hash range
+    nb, _ = hash_bounds(world)
+    rows, perm, cnt = engine.partition(occ, nb, rec_base[rank])
+    if world > 1:
+        r_rows, recv_cnt = _exchange_rows(rows, cnt, dev, group)
+        kmer_base = sum(_gather_ints(int(r_rows.shape[0]), dev, group)[:rank])
+    else:
+        r_rows, recv_cnt, kmer_base = rows, cnt, 0
+    t2 = time.perf_counter()
+    ix, r_ranks = engine.slice_build(r_rows, kmer_base, record_offsets, is_targets)
+    tm = dict(engine.timings(ix))
+    n_nodes = engine.sizes(ix)[1]
+    t3 = time.perf_counter()
+
+    # C2: node ranks back to the sources; C3: rank -> hash table everywhere
+    if world > 1:
+        node_cnt = _gather_ints(n_nodes, dev, group)
+        node_base, total_nodes = sum(node_cnt[:rank]), sum(node_cnt)
+        if total_nodes >= 0xFFFFFFFF:
+            raise RuntimeError("more than 2^32-2 nodes")
+        r_ranks = (r_ranks.to(torch.int64) + node_base).to(torch.int32)   # uint32 bit pattern (wraps above 2^31)
+        ranks_by_row = torch.empty((occ.n,), dtype=torch.int32, device=dev)
+        dist.all_to_all_single(ranks_by_row, r_ranks.contiguous(), [int(c) for c in cnt], recv_cnt, group=group)
+        hashes = engine.node_hashes(ix)
+        pad = max(node_cnt)
+        mine = torch.zeros((pad,), dtype=torch.int64, device=dev)
+        mine[:n_nodes] = hashes
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        rank_hash = torch.cat([p[:c] for p, c in zip(parts, node_cnt)])
+    else:
+        total_nodes, ranks_by_row, rank_hash = n_nodes, r_ranks, engine.node_hashes(ix)
+    n_bits = max(1, (total_nodes).bit_length())     # total_nodes <= 2^n_bits - 1
+    adj, acnt = engine.adjacency(occ, perm, ranks_by_row, n_bits, shard.first_assembly, rank_bounds(world, total_nodes))
+    if world > 1:
+        r_adj, _ = _exchange_rows(adj, acnt, dev, group)
+    else:
+        r_adj = adj
+    t4 = time.perf_counter()
+    engine.slice_edges(ix, r_adj, n_bits, rank_hash)
+    tm.update(engine.timings(ix))
+    t5 = time.perf_counter()
+    tm.update(sketch_ms=occ.sketch_ms, n_occ_local=occ.n, sketch_wall_ms=(t1 - t0) * 1e3, tuple_exchange_wall_ms=(t2 - t1) * 1e3,
+              slice_build_wall_ms=(t3 - t2) * 1e3, rank_adj_exchange_wall_ms=(t4 - t3) * 1e3, slice_edges_wall_ms=(t5 - t4) * 1e3)
+    engine.free_occ(occ)
+    return ShardedIndex(engine, ix, record_offsets, tm, kmer_base)
 
 
 def build_graph_distributed(assembly_paths, k: int, w: int, is_targets=None, n_cpu: int = 1, group=None):

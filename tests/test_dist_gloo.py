@@ -88,6 +88,71 @@ class NumpyEngine:
     def export(self, ix):
         return ix["kmers"], ix["nodes"], ix["edges"]
 
+    # ---- tuple-exchange form (same interface as seqwin_amd.dist.HipEngine) -------------------------------
+    def sketch(self, shard, k, w):
+        from types import SimpleNamespace
+        hs, km, rec_asm, rec = [np.zeros(0, U64)], [np.zeros(0, U64)], [], 0
+        for a, path in enumerate(shard.batch):
+            for _id, seq in oracle.read_fasta(path):
+                _, oh, pos = oracle.minimize(seq, k, w)
+                hs.append(oh)
+                km.append(pos.astype(U64) | (U64(rec) << U64(32)))
+                rec_asm.append(a)
+                rec += 1
+        h = np.concatenate(hs)
+        return SimpleNamespace(n=len(h), hash=h, kmer=np.concatenate(km), rec_asm=np.array(rec_asm, np.int64), sketch_ms=0.0)
+
+    def partition(self, occ, bounds, rec_offset):
+        b = np.array(bounds, dtype=U64)
+        owner = np.searchsorted(b, occ.hash, side="right")
+        perm = np.argsort(owner, kind="stable")
+        rows = np.stack([occ.hash[perm], occ.kmer[perm] + (U64(rec_offset) << U64(32))], axis=1)
+        counts = np.bincount(owner, minlength=len(bounds) + 1).tolist()
+        return torch.from_numpy(rows.view(np.int64).copy()), torch.from_numpy(perm.astype(np.int32)), counts
+
+    def slice_build(self, rows, kmer_base, record_offsets, is_targets):
+        ix = self.merge(rows, torch.zeros((0, 3), dtype=torch.int64), kmer_base, record_offsets, is_targets)
+        ranks = np.searchsorted(ix["nodes"]["hash"], rows.numpy().view(U64)[:, 0]).astype(np.uint32)
+        return ix, torch.from_numpy(ranks.view(np.int32).copy())
+
+    def node_hashes(self, ix):
+        return torch.from_numpy(ix["nodes"]["hash"].view(np.int64).copy())
+
+    def adjacency(self, occ, perm, ranks_by_row, n_bits, asm_base, rank_bounds):
+        rank = np.zeros(occ.n, U64)
+        rank[perm.numpy()] = ranks_by_row.numpy().view(np.uint32).astype(U64)
+        rec = (occ.kmer >> U64(32)).astype(np.int64)
+        ok = rec[1:] == rec[:-1] if occ.n > 1 else np.zeros(0, bool)
+        u, v = rank[:-1][ok], rank[1:][ok]
+        key = (np.minimum(u, v) << U64(n_bits)) | np.maximum(u, v)
+        asm = (occ.rec_asm[rec[:-1][ok]] + asm_base).astype(U64)
+        kb = np.array([b << n_bits for b in rank_bounds], dtype=U64)
+        owner = np.searchsorted(kb, key, side="right")
+        p = np.argsort(owner, kind="stable")
+        rows = np.stack([key[p], asm[p]], axis=1) if len(key) else np.zeros((0, 2), U64)
+        return torch.from_numpy(rows.view(np.int64).copy()), np.bincount(owner, minlength=len(rank_bounds) + 1).tolist()
+
+    def slice_edges(self, ix, adj_rows, n_bits, rank_hash):
+        r = adj_rows.numpy().view(U64)
+        table = rank_hash.numpy().view(U64)
+        edges = np.zeros(0, oracle.EDGE_DTYPE)
+        if len(r):
+            o = np.argsort(r[:, 0], kind="stable")
+            key, asm = r[o, 0], r[o, 1]
+            head = np.ones(len(key), bool)
+            head[1:] = key[1:] != key[:-1]
+            change = head.copy()
+            change[1:] |= asm[1:] != asm[:-1]
+            idx = np.nonzero(head)[0]
+            edges = np.zeros(len(idx), oracle.EDGE_DTYPE)
+            edges["first"] = table[(key[idx] >> U64(n_bits)).astype(np.int64)]
+            edges["second"] = table[(key[idx] & U64((1 << n_bits) - 1)).astype(np.int64)]
+            edges["weight"] = np.add.reduceat(change.astype(np.uint64), idx)
+        ix["edges"] = edges
+
+    def free_occ(self, occ):
+        pass
+
 
 def _free_port() -> int:
     with socket.socket() as s:
@@ -95,7 +160,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, paths, k, w, tar, out_path):
+def _worker(rank, world, port, paths, k, w, tar, out_path, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -104,7 +169,8 @@ def _worker(rank, world, port, paths, k, w, tar, out_path):
         eng = NumpyEngine()
         mine = paths[start:end]
         eng._offs = oracle.build(mine, k, w)[3]
-        sharded = swdist.build_sharded_index(swdist.Shard(mine, start, len(paths)), k, w, tar, engine=eng)
+        build = swdist.build_sharded_index if mode == "tuples" else swdist.build_sharded_index_merge
+        sharded = build(swdist.Shard(mine, start, len(paths)), k, w, tar, engine=eng)
         full = sharded.gather(0)
         if rank == 0:
             np.savez(out_path, kmers=full[0], nodes=full[1], edges=full[2], record_offsets=full[3])
@@ -112,9 +178,10 @@ def _worker(rank, world, port, paths, k, w, tar, out_path):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["tuples", "merge"])
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("case", ["smoke", "pan", "edge"])
-def test_sharded_build_equals_single(tmp_path, world, case):
+def test_sharded_build_equals_single(tmp_path, world, case, mode):
     if case == "smoke":
         s = GOLDEN / "smoke"
         paths = [s / "targets/target-1.fasta", s / "targets/target-2.fasta",
@@ -129,7 +196,7 @@ def test_sharded_build_equals_single(tmp_path, world, case):
     paths = [str(p) for p in paths]
     tar = [i % 2 == 0 for i in range(len(paths))]
     out = tmp_path / "merged.npz"
-    mp.spawn(_worker, nprocs=world, args=(world, _free_port(), paths, k, w, tar, str(out)), join=True)
+    mp.spawn(_worker, nprocs=world, args=(world, _free_port(), paths, k, w, tar, str(out), mode), join=True)
     got = np.load(out)
     ek, en, ee, eo, _ = oracle.build(paths, k, w)
     oracle.get_penalty(ek, en, eo, tar)
@@ -148,6 +215,25 @@ def test_partition_formula():
             assert parts[0][0] == 0 and parts[-1][1] == n and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_single_process_tuple_form_equals_oracle():
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa"))]
+    eng = NumpyEngine()
+    eng._offs = oracle.build(paths, 15, 20)[3]
+    tar = [True, False, True, False, True, False]
+    sharded = swdist.build_sharded_index(swdist.Shard(paths, 0, len(paths)), 15, 20, tar, engine=eng)
+    ek, en, ee, eo, _ = oracle.build(paths, 15, 20)
+    oracle.get_penalty(ek, en, eo, tar)
+    k, n, e = sharded.export()
+    assert np.array_equal(k, ek) and np.array_equal(n, en) and np.array_equal(e, ee)
+
+
+def test_rank_bounds():
+    for p in (1, 2, 4, 8):
+        for total in (0, 1, 7, 1000, 3_831_468, 2**32 - 2):
+            rb = swdist.rank_bounds(p, total)
+            assert len(rb) == p - 1 and rb == sorted(rb) and all(0 <= b <= total for b in rb)
 
 
 def test_hash_bounds_are_monotone_and_balanced():

@@ -62,13 +62,14 @@ def test_world1_sharded_index_matches_direct():
     b = Batch.synthetic(24, 4, 40000, n_ancestors=3, snp_ppm=10000, seed=5)
     tar = np.arange(24) % 2 == 0
     direct = b.build_index(21, 200, tar)
-    sharded = swdist.build_sharded_index(swdist.Shard(b, 0, 24), 21, 200, tar)
-    for x, y in zip(direct.export(), sharded.export()):
-        assert np.array_equal(x, y)
-    assert sharded.timings()["n_occ_local"] == direct.sizes()[0]
+    for build in (swdist.build_sharded_index, swdist.build_sharded_index_merge):
+        sharded = build(swdist.Shard(b, 0, 24), 21, 200, tar)
+        for x, y in zip(direct.export(), sharded.export()):
+            assert np.array_equal(x, y)
+        assert sharded.timings()["n_occ_local"] == direct.sizes()[0]
 
 
-def _gloo_worker(rank, world, port, paths, k, w, tar, out_path):
+def _gloo_worker(rank, world, port, paths, k, w, tar, out_path, mode):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -80,7 +81,8 @@ def _gloo_worker(rank, world, port, paths, k, w, tar, out_path):
         set_device(0)
         start, end = swdist.partition_assemblies(len(paths), world)[rank]
         shard = swdist.Shard(Batch.from_fasta(paths[start:end], n_cpu=2), start, len(paths))
-        sharded = swdist.build_sharded_index(shard, k, w, tar, engine=swdist.HipEngine("host"))
+        build = swdist.build_sharded_index if mode == "tuples" else swdist.build_sharded_index_merge
+        sharded = build(shard, k, w, tar, engine=swdist.HipEngine("host"))
         full = sharded.gather(0)
         if rank == 0:
             np.savez(out_path, kmers=full[0], nodes=full[1], edges=full[2], record_offsets=full[3])
@@ -88,8 +90,9 @@ def _gloo_worker(rank, world, port, paths, k, w, tar, out_path):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["tuples", "merge"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_two_processes_one_gpu_real_collectives(tmp_path, world):
+def test_two_processes_one_gpu_real_collectives(tmp_path, world, mode):
     """The full multi-process path -- HIP engine in every process, real all_to_all_single / all_gather
     (over gloo with host staging, since this box has one GPU) -- must reproduce the single-process result."""
     import socket
@@ -101,7 +104,7 @@ def test_two_processes_one_gpu_real_collectives(tmp_path, world):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out = tmp_path / "merged.npz"
-    mp.spawn(_gloo_worker, nprocs=world, args=(world, port, paths, 15, 20, tar, str(out)), join=True)
+    mp.spawn(_gloo_worker, nprocs=world, args=(world, port, paths, 15, 20, tar, str(out), mode), join=True)
     got = np.load(out)
     ek, en, ee, eo, _ = oracle.build(paths, 15, 20)
     oracle.get_penalty(ek, en, eo, tar)
