@@ -364,37 +364,7 @@ __global__ void k_edges(const uint64_t *__restrict__ skeys, const uint32_t *__re
 }
 
 // ---- tuple-exchange form of the multi-GPU build (dist.py) ---------------------------------------------
-// owner of a key = number of ascending bounds <= key; rows with key == drop_key go to bucket n_bounds + 1
-__global__ void k_owner(const uint64_t *__restrict__ key, uint32_t stride, uint64_t n, const uint64_t *__restrict__ bounds,
-                        uint32_t n_bounds, uint64_t drop_key, bool has_drop, uint32_t *__restrict__ owner,
-                        uint32_t *__restrict__ idx, unsigned long long *__restrict__ counts)
-{
-    __shared__ unsigned int hist[18];
-    if (threadIdx.x < 18) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const uint64_t kx = key[i * stride];
-        uint32_t o = 0;
-        for (uint32_t j = 0; j < n_bounds; ++j) o += (bounds[j] <= kx) ? 1u : 0u;
-        if (has_drop && kx == drop_key) o = n_bounds + 1;
-        owner[i] = o;
-        idx[i] = (uint32_t)i;
-        atomicAdd(&hist[o], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < n_bounds + 2 && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
-}
 
-__global__ void k_tuple_rows(const uint64_t *__restrict__ hash, const uint64_t *__restrict__ kmer,
-                             const uint32_t *__restrict__ perm, uint64_t n, uint64_t rec_offset, uint64_t *__restrict__ rows)
-{
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const uint32_t i = perm[j];
-    rows[2 * j] = hash[i];
-    rows[2 * j + 1] = kmer[i] + (rec_offset << 32);
-}
 
 __global__ void k_unpermute(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ by_row, uint64_t n,
                             uint32_t *__restrict__ orig)
@@ -422,15 +392,6 @@ __global__ void k_adj_rows(const uint64_t *__restrict__ kmer, const uint32_t *__
     }
 }
 
-__global__ void k_gather_rows2(const uint64_t *__restrict__ src, const uint32_t *__restrict__ perm, uint64_t n,
-                               uint64_t *__restrict__ dst)
-{
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    const uint32_t i = perm[j];
-    dst[2 * j] = src[2 * (uint64_t)i];
-    dst[2 * j + 1] = src[2 * (uint64_t)i + 1];
-}
 
 __global__ void k_split_rows2(const uint64_t *__restrict__ rows, uint64_t n, uint64_t *__restrict__ key,
                               uint32_t *__restrict__ val)
@@ -796,17 +757,19 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
     } else {
         ix.nodes.alloc(0);
     }
+    // counts on slice-local ranges, on the side stream so that they overlap the partial-edge merge below;
+    // ranges are re-based after both are done
+    PenaltyJob pen;
+    hipEvent_t ev_nodes = nullptr, ev_pen = nullptr;
     if (d_is_target && ix.n_nodes) {
-        uint64_t err = 0;   // counts on slice-local ranges; ranges are re-based afterwards
-        device_get_penalty(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, d_rec_asm, n_records, d_is_target, n_targets,
-                           n_non_targets, stream, &err);
-        if (err) raise(SW_ERR_RUNTIME, "internal error: inconsistent occurrence order in merged index (%llu)",
-                       (unsigned long long)err);
-    }
-    if (kmer_base && ix.n_nodes) {
-        hipLaunchKernelGGL(k_rebase_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes,
-                           kmer_base);
-        SW_HIP(hipGetLastError());
+        hipStream_t side = side_stream();
+        SW_HIP(hipEventCreate(&ev_nodes));
+        SW_HIP(hipEventCreate(&ev_pen));
+        SW_HIP(hipEventRecord(ev_nodes, stream));
+        SW_HIP(hipStreamWaitEvent(side, ev_nodes, 0));
+        penalty_launch(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, d_rec_asm, n_records, d_is_target, n_targets, n_non_targets,
+                       side, pen);
+        SW_HIP(hipEventRecord(ev_pen, side));
     }
     ix.n_edges = 0;
     if (m) {
@@ -841,52 +804,161 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
     } else {
         ix.edges.alloc(0);
     }
+    if (pen.active) {
+        const uint64_t err = penalty_finish(pen);
+        SW_HIP(hipStreamWaitEvent(stream, ev_pen, 0));
+        if (err) raise(SW_ERR_RUNTIME, "internal error: inconsistent occurrence order in merged index (%llu)",
+                       (unsigned long long)err);
+    }
+    if (ev_nodes) (void)hipEventDestroy(ev_nodes);
+    if (ev_pen) (void)hipEventDestroy(ev_pen);
+    if (kmer_base && ix.n_nodes) {
+        hipLaunchKernelGGL(k_rebase_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes,
+                           kmer_base);
+        SW_HIP(hipGetLastError());
+        SW_HIP(hipStreamSynchronize(stream));
+    }
 }
 
-// Stable partition of n rows by owner (number of bounds <= key).  Returns perm (row j of the grouped order is
-// original row perm[j]) and the per-owner counts; rows whose key equals drop_key are moved past the last owner.
-static void partition_by_owner(const uint64_t *d_key, uint32_t key_stride, uint64_t n, const uint64_t *bounds,
-                               uint32_t n_bounds, bool has_drop, uint64_t drop_key, hipStream_t stream,
-                               DevArray<uint32_t> &perm_store, uint32_t *&perm, uint64_t *counts_host)
+// ---- stable multi-way partition (tuple exchange) ----------------------------------------------------
+// One wave owns PART_ROWS x 64 consecutive elements and walks them row by row; inside a row the lanes
+// with the same owner are found with 5 ballots (owner < 32), so the position of every element inside its
+// (wave, owner) group is exact and the partition is stable.  Pass A counts, a scan turns the
+// (owner-major, wave-minor) counts into offsets, pass B recomputes the owners and writes the rows.
+namespace {
+constexpr int PART_ROWS = 32;
+constexpr uint32_t PART_BUCKETS = 32;
+
+struct TupleSrc {   // rows from the ordered tuple stream
+    const uint64_t *hash, *kmer;
+    uint64_t rec_off;
+    __device__ uint64_t key(uint64_t i) const { return hash[i]; }
+    __device__ void row(uint64_t i, uint64_t &r0, uint64_t &r1) const { r0 = hash[i]; r1 = kmer[i] + (rec_off << 32); }
+};
+struct RowSrc {     // rows[n][2], key = column 0
+    const uint64_t *rows;
+    __device__ uint64_t key(uint64_t i) const { return rows[2 * i]; }
+    __device__ void row(uint64_t i, uint64_t &r0, uint64_t &r1) const { r0 = rows[2 * i]; r1 = rows[2 * i + 1]; }
+};
+
+struct PartArgs {
+    uint64_t n;
+    uint64_t bounds[16];
+    uint32_t n_bounds;
+    uint64_t drop_key;
+    uint32_t has_drop;
+    uint32_t n_waves;
+};
+
+__device__ __forceinline__ uint32_t owner_of(const PartArgs &P, uint64_t kx)
+{
+    uint32_t o = 0;
+    for (uint32_t j = 0; j < P.n_bounds; ++j) o += (P.bounds[j] <= kx) ? 1u : 0u;
+    if (P.has_drop && kx == P.drop_key) o = P.n_bounds + 1;
+    return o;
+}
+
+// mask of lanes (among `active`) whose 5-bit value equals this lane's
+__device__ __forceinline__ uint64_t match5(uint32_t v, uint64_t active)
+{
+    uint64_t m = active;
+    for (int b = 0; b < 5; ++b) {
+        const uint64_t bal = __ballot((v >> b) & 1u);
+        m &= ((v >> b) & 1u) ? bal : ~bal;
+    }
+    return m;
+}
+
+template <class Src, bool WRITE>
+__global__ __launch_bounds__(256) void k_partition(const Src src, const PartArgs P, uint32_t *__restrict__ hist,
+                                                   const uint32_t *__restrict__ offsets, uint64_t *__restrict__ rows_out,
+                                                   uint32_t *__restrict__ perm_out)
+{
+    __shared__ uint32_t cnt[4][PART_BUCKETS];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4 + wv;
+    if (lane < PART_BUCKETS) cnt[wv][lane] = (WRITE && wave < P.n_waves) ? offsets[(uint64_t)lane * P.n_waves + wave] : 0u;
+    __syncthreads();
+    if (wave >= P.n_waves) return;
+    const uint64_t base = wave * (uint64_t)(PART_ROWS * 64);
+    for (int r = 0; r < PART_ROWS; ++r) {
+        const uint64_t i = base + (uint64_t)r * 64 + lane;
+        const bool live = i < P.n;
+        const uint64_t active = __ballot(live);
+        if (!active) break;
+        uint32_t o = 0;
+        if (live) o = owner_of(P, src.key(i));
+        const uint64_t same = match5(o, active);
+        if (live) {
+            const uint32_t before = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            const uint32_t start = cnt[wv][o];               // all lanes of a group read before the leader adds
+            if (WRITE) {
+                const uint64_t dst = (uint64_t)start + before;
+                uint64_t r0, r1;
+                src.row(i, r0, r1);
+                rows_out[2 * dst] = r0;
+                rows_out[2 * dst + 1] = r1;
+                if (perm_out) perm_out[dst] = (uint32_t)i;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (before == 0) cnt[wv][o] = start + (uint32_t)__popcll(same);   // leader of the group
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!WRITE && lane < PART_BUCKETS) hist[(uint64_t)lane * P.n_waves + wave] = cnt[wv][lane];
+}
+
+__global__ void k_part_counts(const uint32_t *__restrict__ offsets, const uint32_t *__restrict__ hist, uint32_t n_waves,
+                              unsigned long long *__restrict__ counts)
+{
+    const uint32_t o = threadIdx.x;
+    if (o >= PART_BUCKETS) return;
+    const uint64_t last = (uint64_t)o * n_waves + (n_waves - 1);
+    const uint64_t first = (uint64_t)o * n_waves;
+    counts[o] = (unsigned long long)(offsets[last] + hist[last]) - offsets[first];
+}
+
+template <class Src>
+void stable_partition(const Src &src, uint64_t n, const uint64_t *bounds, uint32_t n_bounds, bool has_drop, uint64_t drop_key,
+                      uint64_t *d_rows_out, uint32_t *d_perm_out, uint64_t *counts_host, hipStream_t stream)
 {
     if (n_bounds > 15) raise(SW_ERR_VALUE, "at most 16 owners are supported");
     for (uint32_t j = 0; j < n_bounds + 2; ++j) counts_host[j] = 0;
-    if (n == 0) { perm = nullptr; return; }
-    DevArray<uint64_t> d_bounds(n_bounds ? n_bounds : 1);
-    DevArray<unsigned long long> d_counts(18);
-    DevArray<uint32_t> o0(n), o1(n), i1(n);
-    perm_store.alloc(n);
-    if (n_bounds) SW_HIP(hipMemcpyAsync(d_bounds.p, bounds, n_bounds * 8, hipMemcpyHostToDevice, stream));
-    SW_HIP(hipMemsetAsync(d_counts.p, 0, 18 * 8, stream));
-    hipLaunchKernelGGL(k_owner, dim3(blocks_for(n)), dim3(TPB), 0, stream, d_key, key_stride, n, d_bounds.p, n_bounds,
-                       drop_key, has_drop, o0.p, perm_store.p, d_counts.p);
+    if (n == 0) return;
+    if (n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 rows on one device");
+    PartArgs P{};
+    P.n = n;
+    P.n_bounds = n_bounds;
+    for (uint32_t j = 0; j < n_bounds; ++j) P.bounds[j] = bounds[j];
+    P.drop_key = drop_key;
+    P.has_drop = has_drop ? 1u : 0u;
+    P.n_waves = (uint32_t)((n + PART_ROWS * 64 - 1) / (PART_ROWS * 64));
+    const uint64_t nh = (uint64_t)PART_BUCKETS * P.n_waves;
+    DevArray<uint32_t> hist(nh), offs(nh);
+    DevArray<unsigned long long> counts(PART_BUCKETS);
+    const unsigned blocks = (P.n_waves + 3) / 4;
+    hipLaunchKernelGGL((k_partition<Src, false>), dim3(blocks), dim3(256), 0, stream, src, P, hist.p, (const uint32_t *)nullptr,
+                       (uint64_t *)nullptr, (uint32_t *)nullptr);
     SW_HIP(hipGetLastError());
-    uint32_t *ok = o0.p, *ok_alt = o1.p, *iv = perm_store.p, *iv_alt = i1.p;
-    unsigned bits = 1;
-    while ((1u << bits) < n_bounds + 2) ++bits;
-    sort_pairs(ok, ok_alt, iv, iv_alt, n, 0, bits, stream);   // one stable pass: groups by owner, keeps order
-    if (iv != perm_store.p) SW_HIP(hipMemcpyAsync(perm_store.p, iv, n * 4, hipMemcpyDeviceToDevice, stream));
-    perm = perm_store.p;
-    unsigned long long h[18];
-    SW_HIP(hipMemcpyAsync(h, d_counts.p, 18 * 8, hipMemcpyDeviceToHost, stream));
+    exclusive_sum(hist.p, offs.p, nh, (uint32_t)0, stream);
+    hipLaunchKernelGGL((k_partition<Src, true>), dim3(blocks), dim3(256), 0, stream, src, P, (uint32_t *)nullptr, offs.p,
+                       d_rows_out, d_perm_out);
+    hipLaunchKernelGGL(k_part_counts, dim3(1), dim3(64), 0, stream, offs.p, hist.p, P.n_waves, counts.p);
+    SW_HIP(hipGetLastError());
+    unsigned long long h[PART_BUCKETS];
+    SW_HIP(hipMemcpyAsync(h, counts.p, sizeof h, hipMemcpyDeviceToHost, stream));
     SW_HIP(hipStreamSynchronize(stream));
     for (uint32_t j = 0; j < n_bounds + 2; ++j) counts_host[j] = h[j];
 }
+}  // namespace
 
 void occ_partition(const OrderedOcc &occ, const uint64_t *bounds, uint32_t n_bounds, uint64_t rec_offset, uint64_t *d_rows,
                    uint32_t *d_perm, uint64_t *counts_host, hipStream_t stream)
 {
-    DevArray<uint32_t> store;
-    uint32_t *perm = nullptr;
     uint64_t counts[18];
-    partition_by_owner(occ.hash.p, 1, occ.n, bounds, n_bounds, false, 0, stream, store, perm, counts);
+    stable_partition(TupleSrc{occ.hash.p, occ.kmer.p, rec_offset}, occ.n, bounds, n_bounds, false, 0, d_rows, d_perm, counts,
+                     stream);
     for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = counts[j];
-    if (occ.n == 0) return;
-    hipLaunchKernelGGL(k_tuple_rows, dim3(blocks_for(occ.n)), dim3(TPB), 0, stream, occ.hash.p, occ.kmer.p, perm, occ.n,
-                       rec_offset, d_rows);
-    SW_HIP(hipMemcpyAsync(d_perm, perm, occ.n * 4, hipMemcpyDeviceToDevice, stream));
-    SW_HIP(hipGetLastError());
-    SW_HIP(hipStreamSynchronize(stream));
 }
 
 void occ_adjacency(const OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_perm, const uint32_t *d_rank_by_row,
@@ -906,18 +978,10 @@ void occ_adjacency(const OrderedOcc &occ, const uint32_t *d_rec_asm, const uint3
     SW_HIP(hipGetLastError());
     std::vector<uint64_t> kb(n_bounds);
     for (uint32_t j = 0; j < n_bounds; ++j) kb[j] = rank_bounds[j] << nb;   // key is monotone in rank_lo
-    DevArray<uint32_t> store;
-    uint32_t *perm = nullptr;
     uint64_t counts[18];
-    partition_by_owner(rows.p, 2, m, kb.data(), n_bounds, true, sentinel, stream, store, perm, counts);
+    // dropped (sentinel) rows land after the last owner; the output buffer holds all m rows
+    stable_partition(RowSrc{rows.p}, m, kb.data(), n_bounds, true, sentinel, d_rows_out, (uint32_t *)nullptr, counts, stream);
     for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = counts[j];
-    uint64_t keep = 0;
-    for (uint32_t j = 0; j <= n_bounds; ++j) keep += counts[j];
-    if (keep) {
-        hipLaunchKernelGGL(k_gather_rows2, dim3(blocks_for(keep)), dim3(TPB), 0, stream, rows.p, perm, keep, d_rows_out);
-        SW_HIP(hipGetLastError());
-    }
-    SW_HIP(hipStreamSynchronize(stream));
 }
 
 void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned nb, const uint64_t *d_rank_hash,

@@ -50,6 +50,12 @@ class Batch:
         check(lib.sw_batch_info(self._h, *[ctypes.byref(x) for x in v]))
         return dict(n_assemblies=v[0].value, n_records=v[1].value, total_bp=v[2].value, device_bytes=v[3].value)
 
+    def record_offsets(self) -> np.ndarray:
+        offs = np.empty(self.info()["n_assemblies"] + 1, np.uint32)
+        nb = c_u64()
+        check(lib.sw_batch_records(self._h, _ptr(offs), None, c_u64(0), ctypes.byref(nb)))
+        return offs
+
     def records(self):
         """(record_offsets, ids_by_assembly)"""
         na = self.info()["n_assemblies"]

@@ -64,6 +64,7 @@ class Shard:
     batch: object
     first_assembly: int
     n_assemblies_total: int
+    _offs: object = None
 
 
 class HipEngine:
@@ -86,7 +87,9 @@ class HipEngine:
         return shard.batch.build_index(k, w, None, stream=self._stream())
 
     def record_offsets(self, shard: Shard) -> np.ndarray:
-        return shard.batch.records()[0]
+        if getattr(shard, "_offs", None) is None:   # ids are not needed here; fetch the offsets once
+            shard._offs = shard.batch.record_offsets()
+        return shard._offs
 
     def sizes(self, ix):
         return ix.sizes()
