@@ -190,6 +190,18 @@ int sw_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *st
               sw_kmer *kmers, uint64_t cap, uint64_t *n_out);
 void sw_index_free(sw_index *ix);
 
+/* ---- next rows of the path, device-resident: what kmers.filter_graph does with the arrays ------
+ * sums[3] = { sum n_tar, sum n_tar^2, sum n_tar * n_neg } over the nodes: the exact integer sums behind the
+ * minimizer-sketch penalty threshold (src/seqwin/kmers.py:426-429). */
+int sw_index_threshold_sums(const sw_index *ix, uint64_t *sums);
+/* kmers._filter_edges_and_nodes (src/seqwin/kmers.py:132-173) without leaving HBM: *out holds the edges with
+ * weight > edge_weight_th (already floored, np.uintp(th)) and the nodes that are an endpoint of one; no kmers. */
+int sw_index_filter_graph(const sw_index *ix, uint64_t edge_weight_th, sw_index **out);
+/* seqwin::filter_kmers (filter.cpp:139-201) on a resident index: *out holds the nodes of `nodes_from` whose hash is
+ * in used_hashes (host array) and their kmers (taken from `ix`), ranges re-based; no edges. */
+int sw_index_filter_kmers(const sw_index *ix, const sw_index *nodes_from, const uint64_t *used_hashes, uint64_t n_used,
+                          sw_index **out);
+
 /* ---- multi-GPU merge (one process per GPU; the exchange itself is done by the host side with
  *      torch.distributed / RCCL on the device buffers below).  Together these replace
  *      merge_thread_graphs (cpp/src/seqwin/build_internals.cpp:295-392) across GPUs. -------------- */

@@ -465,6 +465,41 @@ int sw_index_checksums(const sw_index *ix, uint64_t *kmers_sum, uint64_t *nodes_
 
 void sw_index_free(sw_index *ix) { delete ix; }
 
+int sw_index_threshold_sums(const sw_index *ix, uint64_t *sums)
+{
+    return guarded([&] { index_threshold_sums(*ix, 0, sums); });
+}
+
+int sw_index_filter_graph(const sw_index *ix, uint64_t edge_weight_th, sw_index **out)
+{
+    return guarded([&] {
+        std::unique_ptr<sw_index> o(new sw_index);
+        index_filter_graph(*ix, edge_weight_th, 0, *o);
+        *out = o.release();
+    });
+}
+
+int sw_index_filter_kmers(const sw_index *ix, const sw_index *nodes_from, const uint64_t *used_hashes, uint64_t n_used,
+                          sw_index **out)
+{
+    return guarded([&] {
+        std::vector<uint64_t> used(used_hashes, used_hashes + n_used);
+        std::sort(used.begin(), used.end());
+        DevArray<uint64_t> d_used(n_used);
+        if (n_used) SW_HIP(hipMemcpy(d_used.p, used.data(), n_used * 8, hipMemcpyHostToDevice));
+        std::unique_ptr<sw_index> o(new sw_index);
+        o->device = ix->device;
+        uint64_t nk = 0, nn = 0;
+        device_filter_kmers(ix->kmers.p, ix->n_kmers, nodes_from->nodes.p, nodes_from->n_nodes, d_used.p, n_used, 0, o->kmers,
+                            o->nodes, &nk, &nn);
+        o->n_kmers = nk;
+        o->n_nodes = nn;
+        o->n_edges = 0;
+        o->edges.alloc(0);
+        *out = o.release();
+    });
+}
+
 int sw_occ_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *stream, sw_occ **out)
 {
     return guarded([&] {

@@ -409,6 +409,64 @@ __global__ void k_node_hashes(const sw_node *__restrict__ nodes, uint64_t n_node
     if (i < n_nodes) out[i] = nodes[i].hash;
 }
 
+// ---- next rows: threshold sums, edge / node filter on device --------------------------------
+// sums[0] = sum n_tar, sums[1] = sum n_tar^2, sums[2] = sum n_tar * n_neg  (kmers.py:426-429, exact integers)
+__global__ void k_threshold_sums(const sw_node *__restrict__ nodes, uint64_t n, unsigned long long *__restrict__ sums)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t a = 0, b = 0, c = 0;
+    if (i < n) {
+        const uint64_t t = nodes[i].n_tar, g = nodes[i].n_neg;
+        a = t;
+        b = t * t;
+        c = t * g;
+    }
+    for (int d = 32; d; d >>= 1) {
+        a += __shfl_down(a, d, 64);
+        b += __shfl_down(b, d, 64);
+        c += __shfl_down(c, d, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (a) atomicAdd(&sums[0], (unsigned long long)a);
+        if (b) atomicAdd(&sums[1], (unsigned long long)b);
+        if (c) atomicAdd(&sums[2], (unsigned long long)c);
+    }
+}
+
+struct EdgeKeepFlag {   // edges['weight'] > th  (kmers.py:152-153)
+    const sw_edge *edges;
+    uint64_t th;
+    __host__ __device__ uint32_t operator()(uint64_t e) const { return edges[e].weight > th ? 1u : 0u; }
+};
+
+__device__ __forceinline__ uint64_t node_index_of(const sw_node *nodes, uint64_t n_nodes, uint64_t h)
+{
+    uint64_t lo = 0, hi = n_nodes;   // np.searchsorted(nodes['hash'], h)
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (nodes[mid].hash < h) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_filter_edges(const sw_edge *__restrict__ edges, uint64_t n_edges, uint64_t th,
+                               const uint32_t *__restrict__ ecum, const sw_node *__restrict__ nodes, uint64_t n_nodes,
+                               sw_edge *__restrict__ out, uint32_t *__restrict__ node_keep)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges || !(edges[e].weight > th)) return;
+    out[ecum[e] - 1] = edges[e];
+    node_keep[node_index_of(nodes, n_nodes, edges[e].first)] = 1u;     // endpoints survive (kmers.py:157-161)
+    node_keep[node_index_of(nodes, n_nodes, edges[e].second)] = 1u;
+}
+
+__global__ void k_compact_nodes(const sw_node *__restrict__ nodes, uint64_t n_nodes, const uint32_t *__restrict__ keep,
+                                const uint32_t *__restrict__ kcum, sw_node *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_nodes && keep[i]) out[kcum[i] - 1] = nodes[i];
+}
+
 // ---- filter_kmers -----------------------------------------------------------------------------------
 __global__ void k_filter_keep(const sw_node *__restrict__ nodes, uint64_t n_nodes, const uint64_t *__restrict__ used,
                               uint64_t n_used, uint32_t *__restrict__ keep, uint64_t *__restrict__ size)
@@ -1004,6 +1062,58 @@ void index_node_hashes(const sw_index &ix, uint64_t *d_out, hipStream_t stream)
     if (ix.n_nodes == 0) return;
     hipLaunchKernelGGL(k_node_hashes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, d_out);
     SW_HIP(hipGetLastError());
+}
+
+void index_threshold_sums(const sw_index &ix, hipStream_t stream, uint64_t *sums3)
+{
+    DevArray<unsigned long long> sums(3);
+    SW_HIP(hipMemsetAsync(sums.p, 0, 24, stream));
+    if (ix.n_nodes) {
+        hipLaunchKernelGGL(k_threshold_sums, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, sums.p);
+        SW_HIP(hipGetLastError());
+    }
+    unsigned long long h[3];
+    SW_HIP(hipMemcpyAsync(h, sums.p, 24, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    for (int i = 0; i < 3; ++i) sums3[i] = h[i];
+}
+
+// kmers._filter_edges_and_nodes (src/seqwin/kmers.py:132-173) on device: edges with weight > th and the
+// nodes that are an endpoint of a surviving edge; kmers are shared with `ix` (not copied).
+void index_filter_graph(const sw_index &ix, uint64_t weight_th, hipStream_t stream, sw_index &out)
+{
+    out.device = ix.device;
+    out.n_kmers = 0;
+    out.kmers.alloc(0);
+    out.n_nodes = 0;
+    out.n_edges = 0;
+    if (ix.n_edges == 0 || ix.n_nodes == 0) {
+        out.nodes.alloc(0);
+        out.edges.alloc(0);
+        return;
+    }
+    DevArray<uint32_t> ecum(ix.n_edges), keep(ix.n_nodes), kcum(ix.n_nodes);
+    SW_HIP(hipMemsetAsync(keep.p, 0, ix.n_nodes * 4, stream));
+    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), EdgeKeepFlag{ix.edges.p, weight_th}),
+                  ecum.p, ix.n_edges, (uint32_t)0, stream);
+    uint32_t ne = 0;
+    SW_HIP(hipMemcpyAsync(&ne, ecum.p + (ix.n_edges - 1), 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    out.n_edges = ne;
+    out.edges.alloc(ne);
+    hipLaunchKernelGGL(k_filter_edges, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ix.edges.p, ix.n_edges, weight_th,
+                       ecum.p, ix.nodes.p, ix.n_nodes, out.edges.p, keep.p);
+    SW_HIP(hipGetLastError());
+    inclusive_sum(keep.p, kcum.p, ix.n_nodes, (uint32_t)0, stream);
+    uint32_t nn = 0;
+    SW_HIP(hipMemcpyAsync(&nn, kcum.p + (ix.n_nodes - 1), 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    out.n_nodes = nn;
+    out.nodes.alloc(nn);
+    hipLaunchKernelGGL(k_compact_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, keep.p, kcum.p,
+                       out.nodes.p);
+    SW_HIP(hipGetLastError());
+    SW_HIP(hipStreamSynchronize(stream));
 }
 
 void device_filter_kmers(const sw_kmer *d_kmers, uint64_t n_kmers, const sw_node *d_nodes, uint64_t n_nodes,

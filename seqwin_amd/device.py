@@ -131,6 +131,31 @@ class Index:
         check(lib.sw_index_export(self._h, _ptr(kmers), _ptr(nodes), _ptr(edges)))
         return kmers, nodes, edges
 
+    def threshold_sums(self):
+        """(sum n_tar, sum n_tar^2, sum n_tar*n_neg) over the nodes, computed on device (kmers.py:426-429)."""
+        v = (c_u64 * 3)()
+        check(lib.sw_index_threshold_sums(self._h, v))
+        return tuple(int(x) for x in v)
+
+    def filter_graph(self, edge_weight_th: float) -> "Index":
+        """kmers._filter_edges_and_nodes on device: edges with weight > th and their endpoint nodes (no kmers)."""
+        h = c_vp()
+        check(lib.sw_index_filter_graph(self._h, c_u64(int(np.uintp(edge_weight_th))), ctypes.byref(h)))
+        return Index(h)
+
+    def filter_kmers(self, nodes_from: "Index", used_hashes) -> "Index":
+        """filter_kmers on device: nodes of ``nodes_from`` whose hash is in ``used_hashes`` + their kmers from self."""
+        used = np.fromiter((int(x) for x in used_hashes), dtype=np.uint64)
+        h = c_vp()
+        check(lib.sw_index_filter_kmers(self._h, nodes_from._h, _ptr(used), c_u64(len(used)), ctypes.byref(h)))
+        return Index(h)
+
+    def save_npz(self, path, record_offsets) -> None:
+        """Write ``graph.npz`` exactly as ``--save-graph`` does (src/seqwin/core.py:134-145)."""
+        kmers, nodes, edges = self.export()
+        np.savez(path, allow_pickle=False, kmers=kmers, nodes=nodes, edges=edges,
+                 record_offsets=np.asarray(record_offsets, np.uint32))
+
     def checksums(self):
         v = [c_u64() for _ in range(3)]
         check(lib.sw_index_checksums(self._h, *[ctypes.byref(x) for x in v]))

@@ -219,7 +219,7 @@ def _randseq(rng, n):
 
 def test_fuzz_build_matches_oracle(tmp_path):
     rng = random.Random(2)
-    for it in range(40):
+    for it in range(60):
         ps = []
         for a in range(rng.randrange(1, 5)):
             txt = ""
@@ -237,8 +237,8 @@ def test_fuzz_build_matches_oracle(tmp_path):
             else:
                 p.write_text(txt)
             ps.append(p)
-        k = rng.choice([3, 4, 5, 7, 15, 16, 17, 18, 19, 21, 31, 32, 33, 40, 100])
-        w = rng.choice([1, 2, 3, 5, 10, 25, 32, 33, 34, 50, 66, 200, 1000, 4096])
+        k = rng.choice([3, 4, 5, 7, 15, 16, 17, 18, 19, 21, 31, 32, 33, 40, 100, 255, 256, 257, 300])
+        w = rng.choice([1, 2, 3, 5, 10, 15, 16, 17, 25, 31, 32, 33, 34, 50, 66, 200, 1000, 4096])
         got = _build(ps, k, w, n_cpu=rng.choice([1, 3]))
         exp = oracle.build(ps, k, w)
         assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])), [list(t) for t in exp[4]])
@@ -352,3 +352,38 @@ def test_full_size_properties():
     assert np.array_equal(N["penalty"], np.sqrt((1.0 - ft) * (1.0 - ft) + fn * fn))
     # sum of edge weights == number of distinct (pair, assembly) combinations among adjacent occurrences
     assert int(E["weight"].sum()) <= nk - ng * rpg
+
+
+# ---- next rows, device-resident -------------------------------------------------------------
+
+def test_device_resident_filter_pipeline_matches_reference_numpy(tmp_path, smoke_paths):
+    """threshold sums, _filter_edges_and_nodes, filter_kmers and graph.npz without leaving HBM, against the
+    numpy expressions of the reference's kmers.py:132-173, 426-429 applied to oracle arrays."""
+    paths = sorted((GOLDEN / "synth").glob("pan_*.fa")) + smoke_paths
+    tar = [i % 2 == 0 for i in range(len(paths))]
+    b = Batch.from_fasta(paths, n_cpu=2)
+    ix = b.build_index(15, 20, tar)
+    ek, en, ee, eo, _ = oracle.build(paths, 15, 20)
+    oracle.get_penalty(ek, en, eo, tar)
+    nt, ng = en["n_tar"].astype(np.uint64), en["n_neg"].astype(np.uint64)
+    assert ix.threshold_sums() == (int(nt.sum()), int((nt * nt).sum()), int((nt * ng).sum()))
+    for th in (0.0, 1.0, 1.9, 2.5, 100.0):
+        f = ix.filter_graph(th)
+        _, fn, fe = f.export()
+        e2 = ee[ee["weight"] > np.uintp(th)]                                   # kmers.py:152-153
+        keep = np.unique(e2.view(np.uint64).reshape(-1, 3)[:, :2])              # kmers.py:157
+        n2 = en[np.searchsorted(en["hash"], keep)]                              # kmers.py:158-160
+        assert np.array_equal(fe, e2) and np.array_equal(fn, n2)
+        used = frozenset(np.uint64(h) for h in n2["hash"][::2])
+        g = ix.filter_kmers(f, used)
+        gk, gn, _ = g.export()
+        rk, rn = oracle.filter_kmers(ek, n2, used)
+        assert np.array_equal(gk, rk) and np.array_equal(gn, rn)
+    out = tmp_path / "graph.npz"
+    raw = b.build_index(15, 20, None)
+    raw.save_npz(out, b.records()[0])
+    z = np.load(out)
+    ek0, en0, ee0, eo0, _ = oracle.build(paths, 15, 20)
+    assert sorted(z.files) == ["edges", "kmers", "nodes", "record_offsets"]
+    assert np.array_equal(z["kmers"], ek0) and np.array_equal(z["nodes"], en0)
+    assert np.array_equal(z["edges"], ee0) and np.array_equal(z["record_offsets"], eo0)
