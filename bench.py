@@ -186,6 +186,15 @@ def main() -> None:
         # whole path, SURVEY 8d: 0.25 N_bp + 40 N_occ + 40 N_adj + 40 N_node + 24 N_edge  (N_adj ~= N_occ)
         tot = counts.tolist()
         path_bytes = 0.25 * total_bp + 80.0 * tot[0] + 40.0 * tot[1] + 24.0 * tot[2]
+        # HBM bytes per launch of the dominant kernel from the committed PMC profile of this same command
+        # (profiles/traffic.json, written by scripts/summarize_profiles.py); null for other workloads
+        traffic, traffic_src = None, None
+        try:
+            tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+            if (tj.get("workload"), tj.get("k"), tj.get("w")) == (args.workload, k, w) and world == 1:
+                traffic, traffic_src = int(tj["hbm_bytes_per_launch"]), tj.get("source")
+        except Exception:
+            pass
         out = {
             "metric": "Gbp/s minimizer-indexed", "value": round(value, 3), "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -194,8 +203,9 @@ def main() -> None:
                                    f"({anc} ancestors, {snp / 1e4:g}% substitutions), on-device generator",
                        "genomes": G * world, "mean_bp": rpg * rl, "k": k, "w": w,
                        "parallelism": f"assembly-sharded x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "sketch_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "sketch_fast_kernel<32>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(sk_bytes), "avg_launch_ms": round(sk_ms, 4),
                          "note": "integer-VALU bound at w=200 (DESIGN.md section 5); measured HBM traffic is in profiles/",
                          "path_achieved_GBs": round(path_bytes / world / (dt / args.steps) / 1e9, 2),
