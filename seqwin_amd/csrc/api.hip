@@ -15,8 +15,8 @@ void set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
 namespace {
 struct Pool {
     std::mutex mu;
-    std::multimap<size_t, void *> free_blocks;  // size -> ptr
-    std::map<void *, size_t> live;              // ptr -> size
+    std::multimap<std::pair<int, size_t>, void *> free_blocks;  // (device, size) -> ptr
+    std::map<void *, std::pair<int, size_t>> live;              // ptr -> (device, size)
     uint64_t total = 0;
 };
 Pool &pool()
@@ -36,10 +36,12 @@ void *dev_alloc(size_t bytes)
 {
     Pool &p = pool();
     const size_t sz = round_size(bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     {
         std::lock_guard<std::mutex> lock(p.mu);
-        auto it = p.free_blocks.lower_bound(sz);
-        if (it != p.free_blocks.end() && it->first <= sz + sz / 4 + (1u << 20)) {
+        auto it = p.free_blocks.lower_bound(std::make_pair(dev, sz));
+        if (it != p.free_blocks.end() && it->first.first == dev && it->first.second <= sz + sz / 4 + (1u << 20)) {
             void *ptr = it->second;
             p.live[ptr] = it->first;
             p.free_blocks.erase(it);
@@ -59,7 +61,7 @@ void *dev_alloc(size_t bytes)
         raise(SW_ERR_DEVICE, "hipMalloc of %zu bytes failed: %s", sz, hipGetErrorString(e));
     }
     std::lock_guard<std::mutex> lock(p.mu);
-    p.live[ptr] = sz;
+    p.live[ptr] = std::make_pair(dev, sz);
     p.total += sz;
     return ptr;
 }
@@ -78,12 +80,12 @@ void dev_free(void *ptr)
 void dev_pool_trim()
 {
     Pool &p = pool();
-    std::vector<std::pair<size_t, void *>> blocks;
+    std::vector<std::pair<std::pair<int, size_t>, void *>> blocks;
     {
         std::lock_guard<std::mutex> lock(p.mu);
         blocks.assign(p.free_blocks.begin(), p.free_blocks.end());
         p.free_blocks.clear();
-        for (auto &b : blocks) p.total -= b.first;
+        for (auto &b : blocks) p.total -= b.first.second;
     }
     for (auto &b : blocks) (void)hipFree(b.second);
 }

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
     const uint32_t tile = A.rec_tile_off[rec] + t;  // global tile id (order pass)
     const uint32_t nvalid = A.rec_nvalid[rec];
     const uint32_t I0 = (w - 1) + t * A.TW;                   // first window end (idx space)
-    const uint32_t I1 = min(I0 + A.TW, nvalid);               // one past the last window end
+    const uint32_t I1 = (uint32_t)min((uint64_t)I0 + A.TW, (uint64_t)nvalid);   // no wrap near 2^32 k-mers               // one past the last window end
     const uint32_t E0 = (t == 0) ? 0u : I0 - w;               // first element held by this tile
     const uint32_t ne = I1 - E0;                              // elements held (<= NE)
     const uint32_t e_first = I0 - E0;                         // tile-local index of the first owned window end
@@ -439,7 +439,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
     const uint32_t tile = A.rec_tile_off[rec] + t;
     const uint32_t nvalid = A.rec_nvalid[rec];
     const uint32_t I0 = (w - 1) + t * A.TW;
-    const uint32_t I1 = min(I0 + A.TW, nvalid);
+    const uint32_t I1 = (uint32_t)min((uint64_t)I0 + A.TW, (uint64_t)nvalid);   // no wrap near 2^32 k-mers
     const uint32_t E0 = (t == 0) ? 0u : I0 - w;
     const uint32_t ne = I1 - E0;
     const uint32_t e_first = I0 - E0;
@@ -856,15 +856,22 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
 
 void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchOut &out, float *sketch_ms)
 {
-    static std::once_flag once;
-    std::call_once(once, [] {
-        SW_HIP(hipFuncSetAttribute((const void *)sketch_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds_bytes_for(L_MAX)));
-        SW_HIP(hipFuncSetAttribute((const void *)sketch_fast_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)FastCfg<32>::bytes));
-        SW_HIP(hipFuncSetAttribute((const void *)sketch_fast_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)FastCfg<16>::bytes));
-    });
+    {   // > 64 KiB of dynamic LDS must be opted into, once per device
+        static std::mutex mu;
+        static std::map<int, bool> done;
+        int dev = 0;
+        SW_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(mu);
+        if (!done[dev]) {
+            SW_HIP(hipFuncSetAttribute((const void *)sketch_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes_for(L_MAX)));
+            SW_HIP(hipFuncSetAttribute((const void *)sketch_fast_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)FastCfg<32>::bytes));
+            SW_HIP(hipFuncSetAttribute((const void *)sketch_fast_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)FastCfg<16>::bytes));
+            done[dev] = true;
+        }
+    }
     out.n_occ = 0;
     out.launches = 0;
     if (sketch_ms) *sketch_ms = 0.f;

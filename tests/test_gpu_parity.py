@@ -387,3 +387,15 @@ def test_device_resident_filter_pipeline_matches_reference_numpy(tmp_path, smoke
     assert sorted(z.files) == ["edges", "kmers", "nodes", "record_offsets"]
     assert np.array_equal(z["kmers"], ek0) and np.array_equal(z["nodes"], en0)
     assert np.array_equal(z["edges"], ee0) and np.array_equal(z["record_offsets"], eo0)
+
+
+def test_staging_overflow_rerun(tmp_path):
+    """Poly-A: every window emits, far above the 2/(w+1) density the staging buffer is sized for -> the sketch
+    is re-run with the exact size (run_sketch); the result must still be exact."""
+    p = tmp_path / "polyA.fa"
+    p.write_text(">a\n" + "A" * 300000 + "\n>b\n" + "ACGT" * 50000 + "\n")
+    for k, w in [(21, 200), (15, 33)]:
+        got = _build([p], k, w)
+        exp = oracle.build([p], k, w)
+        assert len(exp[0]) > 250000
+        assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
