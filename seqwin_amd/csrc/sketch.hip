@@ -558,19 +558,35 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         }
         // ---- suffix records of the run, right to left (registers only) ---------------------------
         uint64_t cur = 0;
-        uint32_t off = 0, mask = 0, cnt = 0;
+        uint32_t mask = 0, cnt = 0;
         uint64_t *rec = REC + tid * RC;
+        if (__all(n == (uint32_t)L)) {              // wave-uniform: full runs, no per-step edge predicates
+            cur = h[L - 1];
+            mask = 1u << (L - 1);
+            rec[0] = cur;
+            cnt = 1;
 #pragma unroll
-        for (int j = L - 1; j >= 0; --j) {
-            const bool take = ((uint32_t)j < n) && ((uint32_t)j == n - 1 || h[j] < cur);
-            if (take) {
-                cur = h[j];
-                off = (uint32_t)j;
-                mask |= 1u << j;
-                if (cnt < RC) rec[cnt] = cur;
-                ++cnt;
+            for (int j = L - 2; j >= 0; --j) {
+                if (h[j] < cur) {                   // strictly smaller than everything to its right
+                    cur = h[j];
+                    mask |= 1u << j;
+                    if (cnt < RC) rec[cnt] = cur;
+                    ++cnt;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = L - 1; j >= 0; --j) {
+                const bool take = ((uint32_t)j < n) && ((uint32_t)j == n - 1 || h[j] < cur);
+                if (take) {
+                    cur = h[j];
+                    mask |= 1u << j;
+                    if (cnt < RC) rec[cnt] = cur;
+                    ++cnt;
+                }
             }
         }
+        const uint32_t off = (uint32_t)__builtin_ctz(mask);   // the leftmost record is the run minimum
         MASK[tid] = mask;
         RMh[tid] = cur;                              // the leftmost record is the (rightmost) run minimum
         RMp[tid] = (uint16_t)(e0 + off);
