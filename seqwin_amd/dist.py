@@ -65,6 +65,7 @@ class Shard:
     first_assembly: int
     n_assemblies_total: int
     _offs: object = None
+    _global_offsets: object = None
 
 
 class HipEngine:
@@ -377,23 +378,30 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     t0 = time.perf_counter()
 
     occ = engine.sketch(shard, k, w)
-    local_offs = np.asarray(engine.record_offsets(shard), np.uint32)
     t1 = time.perf_counter()
 
-    # C0: record-count prefix (build_internals.cpp:334-355)
-    if world > 1:
-        all_offs = [None] * world
-        dist.all_gather_object(all_offs, local_offs, group=group)
-    else:
-        all_offs = [local_offs]
-    rec_base, glob, total = [], [np.zeros(1, np.uint32)], 0
-    for o in all_offs:
-        rec_base.append(total)
-        glob.append((o[1:].astype(np.uint64) + total).astype(np.uint32))
-        total += int(o[-1])
-        if total > 0xFFFFFFFF:
-            raise RuntimeError("Total number of FASTA records exceeds uint32 range")
-    record_offsets = np.concatenate(glob)
+    # C0: record-count prefix (build_internals.cpp:334-355); depends only on the shard, so it is cached on it
+    cached = getattr(shard, "_global_offsets", None)
+    if cached is None or cached[0] != world:
+        local_offs = np.asarray(engine.record_offsets(shard), np.uint32)
+        if world > 1:
+            all_offs = [None] * world
+            dist.all_gather_object(all_offs, local_offs, group=group)
+        else:
+            all_offs = [local_offs]
+        rec_base, glob, total = [], [np.zeros(1, np.uint32)], 0
+        for o in all_offs:
+            rec_base.append(total)
+            glob.append((o[1:].astype(np.uint64) + total).astype(np.uint32))
+            total += int(o[-1])
+            if total > 0xFFFFFFFF:
+                raise RuntimeError("Total number of FASTA records exceeds uint32 range")
+        cached = (world, rec_base, np.concatenate(glob))
+        try:
+            shard._global_offsets = cached
+        except Exception:
+            pass
+    _, rec_base, record_offsets = cached
 
     # C1: tuples to the owner of their hash range
     nb, _ = hash_bounds(world)
@@ -423,14 +431,16 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
         mine = torch.zeros((pad,), dtype=torch.int64, device=dev)
         mine[:n_nodes] = hashes
         parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
-        rank_hash = torch.cat([p[:c] for p, c in zip(parts, node_cnt)])
+        hash_work = dist.all_gather(parts, mine, group=group, async_op=True)   # overlaps the adjacency build below
+        rank_hash = None
     else:
-        total_nodes, ranks_by_row, rank_hash = n_nodes, r_ranks, engine.node_hashes(ix)
+        total_nodes, ranks_by_row, rank_hash, hash_work = n_nodes, r_ranks, engine.node_hashes(ix), None
     n_bits = max(1, (total_nodes).bit_length())     # total_nodes <= 2^n_bits - 1
     adj, acnt = engine.adjacency(occ, perm, ranks_by_row, n_bits, shard.first_assembly, rank_bounds(world, total_nodes))
     if world > 1:
         r_adj, _ = _exchange_rows(adj, acnt, dev, group)
+        hash_work.wait()
+        rank_hash = torch.cat([p[:c] for p, c in zip(parts, node_cnt)])
     else:
         r_adj = adj
     t4 = time.perf_counter()
