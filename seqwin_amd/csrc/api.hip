@@ -21,8 +21,9 @@ struct Pool {
 };
 Pool &pool()
 {
-    static Pool p;
-    return p;
+    // intentionally leaked: handles may be released by Python finalizers after static destructors have run
+    static Pool *p = new Pool;
+    return *p;
 }
 size_t round_size(size_t b)
 {

@@ -873,8 +873,8 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
 void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchOut &out, float *sketch_ms)
 {
     {   // > 64 KiB of dynamic LDS must be opted into, once per device
-        static std::mutex mu;
-        static std::map<int, bool> done;
+        static std::mutex &mu = *new std::mutex;                 // leaked on purpose (see api.hip: pool())
+        static std::map<int, bool> &done = *new std::map<int, bool>;
         int dev = 0;
         SW_HIP(hipGetDevice(&dev));
         std::lock_guard<std::mutex> lock(mu);
