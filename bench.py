@@ -216,7 +216,7 @@ def main() -> None:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(batch, k, w, args.cpu_sample_genomes, my_targets)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

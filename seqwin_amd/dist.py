@@ -28,10 +28,15 @@ drives the same choreography over gloo with a numpy engine defined in tests/.
 from __future__ import annotations
 
 import math
+import os
 import time
 from dataclasses import dataclass
 
 import numpy as np
+
+
+# SEQWIN_DIST_FORCE_COLLECTIVES=1 issues every collective even at world size 1 (exercises the RCCL calls on one GPU)
+_FORCE_COLLECTIVES = os.environ.get("SEQWIN_DIST_FORCE_COLLECTIVES") == "1"
 
 
 def partition_assemblies(n_assemblies: int, n_workers: int) -> list[tuple[int, int]]:
@@ -375,6 +380,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     dev = engine.device
+    multi = world > 1 or (_FORCE_COLLECTIVES and dist.is_initialized())
     t0 = time.perf_counter()
 
     occ = engine.sketch(shard, k, w)
@@ -384,7 +390,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     cached = getattr(shard, "_global_offsets", None)
     if cached is None or cached[0] != world:
         local_offs = np.asarray(engine.record_offsets(shard), np.uint32)
-        if world > 1:
+        if multi:
             all_offs = [None] * world
             dist.all_gather_object(all_offs, local_offs, group=group)
         else:
@@ -406,7 +412,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     # C1: tuples to the owner of their hash range
     nb, _ = hash_bounds(world)
     rows, perm, cnt = engine.partition(occ, nb, rec_base[rank])
-    if world > 1:
+    if multi:
         r_rows, recv_cnt = _exchange_rows(rows, cnt, dev, group)
         kmer_base = sum(_gather_ints(int(r_rows.shape[0]), dev, group)[:rank])
     else:
@@ -418,7 +424,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     t3 = time.perf_counter()
 
     # C2: node ranks back to the sources; C3: rank -> hash table everywhere
-    if world > 1:
+    if multi:
         node_cnt = _gather_ints(n_nodes, dev, group)
         node_base, total_nodes = sum(node_cnt[:rank]), sum(node_cnt)
         if total_nodes >= 0xFFFFFFFF:
@@ -437,7 +443,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
         total_nodes, ranks_by_row, rank_hash, hash_work = n_nodes, r_ranks, engine.node_hashes(ix), None
     n_bits = max(1, (total_nodes).bit_length())     # total_nodes <= 2^n_bits - 1
     adj, acnt = engine.adjacency(occ, perm, ranks_by_row, n_bits, shard.first_assembly, rank_bounds(world, total_nodes))
-    if world > 1:
+    if multi:
         r_adj, _ = _exchange_rows(adj, acnt, dev, group)
         hash_work.wait()
         rank_hash = torch.cat([p[:c] for p, c in zip(parts, node_cnt)])

@@ -110,3 +110,46 @@ def test_two_processes_one_gpu_real_collectives(tmp_path, world, mode):
     oracle.get_penalty(ek, en, eo, tar)
     assert np.array_equal(got["kmers"], ek) and np.array_equal(got["nodes"], en)
     assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
+
+
+def _rccl_worker(rank, port, paths, k, w, tar, out_path):
+    import os
+    os.environ["SEQWIN_DIST_FORCE_COLLECTIVES"] = "1"
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import importlib
+
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import seqwin_amd.dist as d
+        importlib.reload(d)
+        from seqwin_amd.device import set_device
+        set_device(0)
+        shard = d.Shard(Batch.from_fasta(paths, n_cpu=2), 0, len(paths))
+        sharded = d.build_sharded_index(shard, k, w, tar)          # every collective is issued, over RCCL
+        kmers, nodes, edges = sharded.export()
+        np.savez(out_path, kmers=kmers, nodes=nodes, edges=edges, record_offsets=sharded.record_offsets)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_world1(tmp_path):
+    """backend "nccl" (= RCCL): all_gather_object, three all_to_all_single with split sizes (int64 rows, int32
+    ranks), the asynchronous all_gather -- issued for real at world size 1, result must equal the oracle."""
+    import socket
+
+    import torch.multiprocessing as mp
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa")) + sorted((GOLDEN / "synth").glob("edge_*"))]
+    tar = [i % 2 == 0 for i in range(len(paths))]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "rccl.npz"
+    mp.spawn(_rccl_worker, nprocs=1, args=(port, paths, 21, 200, tar, str(out)), join=True)
+    got = np.load(out)
+    ek, en, ee, eo, _ = oracle.build(paths, 21, 200)
+    oracle.get_penalty(ek, en, eo, tar)
+    assert np.array_equal(got["kmers"], ek) and np.array_equal(got["nodes"], en)
+    assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
