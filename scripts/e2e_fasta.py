@@ -25,7 +25,7 @@ for a in range(n_genomes):
     paths.append(p)
 tar = np.arange(n_genomes) % 2 == 0
 cores = os.cpu_count()
-for n_cpu in (8, cores):
+for n_cpu in (4, 8, 16, 32, 64, cores):
     _core._build_native(paths[:4], 21, 200, n_cpu, False)  # warm
     t0 = time.perf_counter()
     k, n, e, o, _ = _core._build_native(paths, 21, 200, n_cpu, False)

@@ -1,6 +1,7 @@
 // api.hip -- C-ABI entry points of libseqwin_hip.so (see include/seqwin_hip.h for the contract and
 // the reference interfaces each one replaces), device memory pool, batch upload / synthesis.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <memory>
 
@@ -157,10 +158,8 @@ __global__ void k_synth(uint32_t *packed, uint64_t words_per_record, uint64_t n_
     packed[wi] = word;
 }
 
-struct GraphHost {
-    std::vector<sw_kmer> kmers;
-    std::vector<sw_node> nodes;
-    std::vector<sw_edge> edges;
+struct GraphHost {   // result of sw_build: arrays stay in HBM until sw_graph_export copies them into caller buffers
+    sw_index ix;
     std::vector<uint32_t> record_offsets;
     std::string ids_blob;
     uint64_t n_assemblies = 0, total_bp = 0;
@@ -695,23 +694,29 @@ int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t km
     return guarded([&] {
         check_kw(kmerlen, windowsize);
         require_device();
+        const bool dbg = getenv("SEQWIN_AMD_DEBUG_TIMING") != nullptr;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double, std::milli>(b - a).count();
+        };
+        const auto t0 = now();
         std::unique_ptr<sw_batch> b(new sw_batch);
         SW_HIP(hipGetDevice(&b->device));
         ingest_fasta(assembly_paths, n_assemblies, n_cpu, b->host);
+        const auto t1 = now();
         upload_batch(*b);
-        sw_index ix;
-        do_index_build(*b, kmerlen, windowsize, nullptr, 0, 0, ix);
+        const auto t2 = now();
         std::unique_ptr<sw_graph> g(new sw_graph);
-        g->g.kmers.resize(ix.n_kmers);
-        g->g.nodes.resize(ix.n_nodes);
-        g->g.edges.resize(ix.n_edges);
-        if (ix.n_kmers) SW_HIP(hipMemcpy(g->g.kmers.data(), ix.kmers.p, ix.n_kmers * sizeof(sw_kmer), hipMemcpyDeviceToHost));
-        if (ix.n_nodes) SW_HIP(hipMemcpy(g->g.nodes.data(), ix.nodes.p, ix.n_nodes * sizeof(sw_node), hipMemcpyDeviceToHost));
-        if (ix.n_edges) SW_HIP(hipMemcpy(g->g.edges.data(), ix.edges.p, ix.n_edges * sizeof(sw_edge), hipMemcpyDeviceToHost));
+        do_index_build(*b, kmerlen, windowsize, nullptr, 0, 0, g->g.ix);
+        const auto t3 = now();
         g->g.record_offsets = b->host.record_offsets;
         g->g.ids_blob = b->host.ids_blob;
         g->g.n_assemblies = b->host.n_assemblies;
         g->g.total_bp = b->host.total_bp;
+        const auto t4 = now();
+        if (dbg)
+            fprintf(stderr, "[seqwin_amd] sw_build: ingest %.1f ms, upload %.1f ms, device %.1f ms, rest %.1f ms (%.1f Mbp)\n",
+                    ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), b->host.total_bp / 1e6);
         *out = g.release();
     });
 }
@@ -720,9 +725,9 @@ int sw_graph_sizes(const sw_graph *g, uint64_t *n_kmers, uint64_t *n_nodes, uint
                    uint64_t *ids_bytes, uint64_t *total_bp)
 {
     return guarded([&] {
-        *n_kmers = g->g.kmers.size();
-        *n_nodes = g->g.nodes.size();
-        *n_edges = g->g.edges.size();
+        *n_kmers = g->g.ix.n_kmers;
+        *n_nodes = g->g.ix.n_nodes;
+        *n_edges = g->g.ix.n_edges;
         *n_assemblies = g->g.n_assemblies;
         *ids_bytes = g->g.ids_blob.size();
         if (total_bp) *total_bp = g->g.total_bp;
@@ -734,9 +739,10 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
 {
     return guarded([&] {
         const GraphHost &h = g->g;
-        if (!h.kmers.empty()) memcpy(kmers, h.kmers.data(), h.kmers.size() * sizeof(sw_kmer));
-        if (!h.nodes.empty()) memcpy(nodes, h.nodes.data(), h.nodes.size() * sizeof(sw_node));
-        if (!h.edges.empty()) memcpy(edges, h.edges.data(), h.edges.size() * sizeof(sw_edge));
+        const sw_index &ix = h.ix;   // D2H straight into the caller's (numpy) buffers
+        if (ix.n_kmers) SW_HIP(hipMemcpy(kmers, ix.kmers.p, ix.n_kmers * sizeof(sw_kmer), hipMemcpyDeviceToHost));
+        if (ix.n_nodes) SW_HIP(hipMemcpy(nodes, ix.nodes.p, ix.n_nodes * sizeof(sw_node), hipMemcpyDeviceToHost));
+        if (ix.n_edges) SW_HIP(hipMemcpy(edges, ix.edges.p, ix.n_edges * sizeof(sw_edge), hipMemcpyDeviceToHost));
         memcpy(record_offsets, h.record_offsets.data(), h.record_offsets.size() * 4);
         if (!h.ids_blob.empty()) memcpy(ids_blob, h.ids_blob.data(), h.ids_blob.size());
     });
