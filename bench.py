@@ -188,11 +188,12 @@ def main() -> None:
         path_bytes = 0.25 * total_bp + 80.0 * tot[0] + 40.0 * tot[1] + 24.0 * tot[2]
         # HBM bytes per launch of the dominant kernel from the committed PMC profile of this same command
         # (profiles/traffic.json, written by scripts/summarize_profiles.py); null for other workloads
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu_insts = None, None, None
         try:
             tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
             if (tj.get("workload"), tj.get("k"), tj.get("w")) == (args.workload, k, w) and world == 1:
                 traffic, traffic_src = int(tj["hbm_bytes_per_launch"]), tj.get("source")
+                valu_insts = tj.get("valu_wave_insts_per_launch")
         except Exception:
             pass
         out = {
@@ -213,6 +214,13 @@ def main() -> None:
             "stages_ms": {key: round(v, 4) for key, v in stage.items()},
             "counts": {"kmers": tot[0], "nodes": tot[1], "edges": tot[2]},
         }
+        if valu_insts:
+            # explanatory (not the mandated roofline): integer VALU issue, 256 CU x 4 SIMD x 32 lanes x 2.4 GHz peak
+            lane_ops = valu_insts * 64.0
+            out["roofline"]["valu"] = {"lane_ops_per_bp": round(lane_ops / bp_rank, 1),
+                                       "achieved_Tlaneops_per_s": round(lane_ops / (sk_ms * 1e-3) / 1e12, 2),
+                                       "peak_Tlaneops_per_s": 78.64, "frac": round(lane_ops / (sk_ms * 1e-3) / 78.64e12, 3),
+                                       "source": "SQ_INSTS_VALU of the committed PMC profile (profiles/*_pmc_sketch.txt)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(batch, k, w, args.cpu_sample_genomes, my_targets)
         print(json.dumps(out), flush=True)
