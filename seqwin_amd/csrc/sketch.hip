@@ -778,8 +778,11 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     const char *force = getenv("SEQWIN_AMD_SKETCH");   // "generic" disables the fast path (debug / A-B)
     p.Lf = (k <= KF && !(force && !strcmp(force, "generic"))) ? (w >= 32 ? 32u : (w >= 16 ? 16u : 0u)) : 0u;
     if (p.Lf == 32 && force && !strcmp(force, "fast16")) p.Lf = 16;   // A/B: half the LDS per workgroup
-    p.TWf = p.Lf ? BLOCK * p.Lf - w : 0;
-    p.Lg_list = p.Lf ? p.Lf + 1 : 0;   // odd run length (<= w) whose tile of 256 * Lg elements holds a fast tile
+    // Overflow tiles of the fast class are redone by the generic kernel, whose run length must be odd and <= w and
+    // whose tile (256 * Lg elements) must hold the fast tile: Lg = Lf + 1 when w > Lf; when w == Lf the fast tiles
+    // are made one run-column smaller instead (256 * (Lf - 1) elements) and Lg = Lf - 1.
+    p.Lg_list = p.Lf ? (w > p.Lf ? p.Lf + 1 : p.Lf - 1) : 0;
+    p.TWf = p.Lf ? BLOCK * std::min(p.Lf, p.Lg_list) - w : 0;
     p.mult = 1ULL ^ ((uint64_t)k * MULTISEED);
 
     const HostBatch &h = b.host;

@@ -399,3 +399,21 @@ def test_staging_overflow_rerun(tmp_path):
         exp = oracle.build([p], k, w)
         assert len(exp[0]) > 250000
         assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
+
+
+@pytest.mark.parametrize("w", [16, 17, 31, 32, 33])
+def test_window_equal_to_run_length_and_overflow_tiles(tmp_path, w, monkeypatch):
+    """w == L (16 / 32) is the corner where the window never reaches past the previous run, and the tiles the
+    fast kernel hands to the generic kernel (more suffix records than it publishes) must still fit that kernel's
+    geometry (run length <= w).  Found by scripts/fuzz_gpu.py; SEQWIN_AMD_RC forces the hand-over for most tiles."""
+    rng = np.random.default_rng(w)
+    p = tmp_path / "long.fa"
+    p.write_text(">a\n" + "".join(rng.choice(list("ACGT"), 70000)) + "\n>b\n" + "".join(rng.choice(list("ACGT"), 8193)) + "\n")
+    exp = oracle.build([p], 21, w)
+    for rc in (None, "2"):
+        if rc is None:
+            monkeypatch.delenv("SEQWIN_AMD_RC", raising=False)
+        else:
+            monkeypatch.setenv("SEQWIN_AMD_RC", rc)
+        got = _build([p], 21, w)
+        assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
