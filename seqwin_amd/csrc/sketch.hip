@@ -782,6 +782,7 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     // whose tile (256 * Lg elements) must hold the fast tile: Lg = Lf + 1 when w > Lf; when w == Lf the fast tiles
     // are made one run-column smaller instead (256 * (Lf - 1) elements) and Lg = Lf - 1.
     p.Lg_list = p.Lf ? (w > p.Lf ? p.Lf + 1 : p.Lf - 1) : 0;
+    if (p.Lf && (uint64_t)BLOCK * std::min(p.Lf, p.Lg_list) < 2ull * w) p.Lf = 0;   // (only reachable through the fast16 A/B switch)
     p.TWf = p.Lf ? BLOCK * std::min(p.Lf, p.Lg_list) - w : 0;
     p.mult = 1ULL ^ ((uint64_t)k * MULTISEED);
 
