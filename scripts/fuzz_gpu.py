@@ -10,7 +10,11 @@ from seqwin_amd import _core
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-replay = [int(x) for x in sys.argv[3:]]          # optional: replay these exact case seeds and print the first differences
+replay = [int(x) for x in sys.argv[3:]]
+DIST = os.environ.get("FUZZ_DIST") == "1"          # also push every case through the routed multi-GPU forms (P shards on one GPU)
+if DIST:
+    sys.path.insert(0, str(ROOT / "tests"))
+    from test_gpu_dist import _route_and_merge, routed_tuple_exchange          # optional: replay these exact case seeds and print the first differences
 tmp = tempfile.mkdtemp(prefix="fuzz_")
 t_end = time.time() + budget
 n_cases = n_bad = 0
@@ -67,6 +71,16 @@ while time.time() < t_end and (not replay or it < len(replay)):
             oracle.get_penalty(exp[0], exp[1], exp[3], tar)
             _core._get_penalty_native(got[0], got[1], got[3], np.asarray(tar, np.bool_), 1)
             ok = np.array_equal(got[1], exp[1])
+        if ok and DIST and len(ps) >= 2:
+            tar = [i % 2 == 0 for i in range(len(ps))]
+            P = rng.choice([2, 3, 4, 8])
+            for fn in (routed_tuple_exchange, _route_and_merge):
+                d = fn(ps, P, k, w, tar)
+                ok = ok and np.array_equal(d[0], exp[0]) and np.array_equal(d[1], exp[1]) and np.array_equal(d[2], exp[2]) \
+                    and np.array_equal(d[3], exp[3])
+                if not ok:
+                    print("  dist form", fn.__name__, "P =", P)
+                    break
     except Exception as e:
         ok = False
         print("EXC", type(e).__name__, e)

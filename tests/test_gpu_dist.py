@@ -153,3 +153,67 @@ def test_rccl_collectives_world1(tmp_path):
     oracle.get_penalty(ek, en, eo, tar)
     assert np.array_equal(got["kmers"], ek) and np.array_equal(got["nodes"], en)
     assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
+
+
+def routed_tuple_exchange(paths, world, k, w, tar):
+    """The tuple-exchange form with the all-to-all steps done by hand on ONE GPU (P shards, one after another)."""
+    eng = swdist.HipEngine()
+    parts = swdist.partition_assemblies(len(paths), world)
+    shards = [swdist.Shard(Batch.from_fasta(paths[a:b], n_cpu=2), a, len(paths)) for a, b in parts]
+    occs = [eng.sketch(s, k, w) for s in shards]
+    offs = [s.batch.record_offsets() for s in shards]
+    rec_base, glob, total = [], [np.zeros(1, np.uint32)], 0
+    for o in offs:
+        rec_base.append(total)
+        glob.append(o[1:] + np.uint32(total))
+        total += int(o[-1])
+    record_offsets = np.concatenate(glob)
+    nb, _ = swdist.hash_bounds(world)
+    rows, perms, cnts = zip(*[eng.partition(occs[r], nb, rec_base[r]) for r in range(world)])
+    cuts = [np.concatenate([[0], np.cumsum(c)]) for c in cnts]
+    slices, ranks_back, kbase = [], [[None] * world for _ in range(world)], 0
+    for owner in range(world):
+        r_rows = torch.cat([rows[r][cuts[r][owner]:cuts[r][owner + 1]] for r in range(world)])
+        ix, r_ranks = eng.slice_build(r_rows, kbase, record_offsets, tar)
+        slices.append((ix, r_ranks))
+        kbase += r_rows.shape[0]
+    node_cnt = [s[0].sizes()[1] for s in slices]
+    total_nodes = sum(node_cnt)
+    for owner in range(world):
+        ix, r_ranks = slices[owner]
+        g = (r_ranks.to(torch.int64) + sum(node_cnt[:owner])).to(torch.int32)
+        o = 0
+        for r in range(world):
+            c = int(cnts[r][owner])
+            ranks_back[r][owner] = g[o:o + c]
+            o += c
+    rank_hash = torch.cat([eng.node_hashes(s[0]) for s in slices])
+    n_bits = max(1, total_nodes.bit_length())
+    rb = swdist.rank_bounds(world, total_nodes)
+    adj = []
+    for r in range(world):
+        by_row = torch.cat(ranks_back[r]) if occs[r].n else torch.zeros(0, dtype=torch.int32, device=eng.gpu)
+        adj.append(eng.adjacency(occs[r], perms[r], by_row, n_bits, shards[r].first_assembly, rb))
+    kmers, nodes, edges = [], [], []
+    for owner in range(world):
+        pieces = []
+        for r in range(world):
+            a_rows, a_cnt = adj[r]
+            c = np.concatenate([[0], np.cumsum(a_cnt)])
+            pieces.append(a_rows[c[owner]:c[owner + 1]])
+        eng.slice_edges(slices[owner][0], torch.cat(pieces), n_bits, rank_hash)
+        K, N, E = slices[owner][0].export()
+        kmers.append(K); nodes.append(N); edges.append(E)
+    return np.concatenate(kmers), np.concatenate(nodes), np.concatenate(edges), record_offsets
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5, 8])
+def test_routed_tuple_exchange_equals_single_batch(world):
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa")) + sorted((GOLDEN / "synth").glob("edge_*"))]
+    tar = [i % 3 != 0 for i in range(len(paths))]
+    for k, w in [(15, 20), (21, 200), (11, 5)]:
+        got = routed_tuple_exchange(paths, world, k, w, tar)
+        ek, en, ee, eo, _ = oracle.build(paths, k, w)
+        oracle.get_penalty(ek, en, eo, tar)
+        assert np.array_equal(got[0], ek) and np.array_equal(got[1], en), (world, k, w)
+        assert np.array_equal(got[2], ee) and np.array_equal(got[3], eo), (world, k, w)
