@@ -133,8 +133,8 @@ void sw_hostbatch_free(sw_hostbatch *hb);
 
 #define SW_MAX_WINDOW 4096u
 
-/* Host ingest: read + pack FASTA files (fasta_reader.cpp:207-213 semantics) into a device batch.
- * `first_assembly` is the global index of assembly_paths[0] (for sharded builds). */
+/* Host ingest: read + pack FASTA files (fasta_reader.cpp:207-213 semantics) on n_cpu host threads and upload them
+ * as one device-resident batch (assembly i of the batch = assembly_paths[i]). */
 int sw_batch_from_fasta(const char *const *assembly_paths, size_t n_assemblies, uint64_t n_cpu, sw_batch **out);
 
 /* Synthetic batch generated ON DEVICE: n_genomes assemblies x records_per_genome records of
@@ -160,12 +160,13 @@ typedef struct sw_timings {
     double sketch_ms;    /* the fused ntHash + window-minimum kernel (dominant kernel) */
     double order_ms;     /* tile-order compaction of the tuple stream */
     double nodes_ms;     /* radix sort by hash + run-length -> nodes / kmers / ranks */
-    double counts_ms;    /* per-node target / non-target assembly counts + penalty */
+    double counts_ms;    /* per-node target / non-target assembly counts + penalty (side stream, overlaps edges_ms) */
     double edges_ms;     /* adjacency pairs -> sort -> weights */
     uint64_t sketch_launches;
     uint64_t n_tiles;
     uint64_t total_bp;
     uint64_t n_windows;
+    uint64_t ovf_tiles;  /* fast-class tiles redone exactly by the generic kernel (more suffix records than published) */
 } sw_timings;
 
 /*
@@ -182,7 +183,8 @@ int sw_index_sizes(const sw_index *ix, uint64_t *n_kmers, uint64_t *n_nodes, uin
 int sw_index_timings(const sw_index *ix, sw_timings *t);
 /* D2H copies of the final arrays (any pointer may be NULL to skip that array). */
 int sw_index_export(const sw_index *ix, sw_kmer *kmers, sw_node *nodes, sw_edge *edges);
-/* Order-independent 64-bit checksums of the three arrays, computed on device (bench validation). */
+/* 64-bit checksums of the three arrays (sum over elements of a mix of the element and its index, so order matters),
+ * computed on device; seqwin_amd.device.host_checksums is the numpy restatement. */
 int sw_index_checksums(const sw_index *ix, uint64_t *kmers_sum, uint64_t *nodes_sum, uint64_t *edges_sum);
 /* The sketch stage alone: (out_hash, pos, record_idx) of every minimizer in (record_idx, pos) order.
  * Two-phase like sw_filter_kmers: pass NULL buffers to get *n_out. */

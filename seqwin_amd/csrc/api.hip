@@ -199,7 +199,7 @@ void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targe
     SW_HIP(hipEventRecord(e1, stream));
     OrderedOcc occ;
     order_tuples(sk, plan, stream, occ);
-    const uint64_t launches = sk.launches;
+    const uint64_t launches = sk.launches, ovf_tiles = sk.n_ovf_tiles;
     sk = SketchOut();
     SW_HIP(hipEventRecord(e2, stream));
     ix.device = b.device;
@@ -218,6 +218,7 @@ void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targe
     ix.timings.n_tiles = plan.n_tiles;
     ix.timings.total_bp = b.host.total_bp;
     ix.timings.n_windows = plan.n_windows;
+    ix.timings.ovf_tiles = ovf_tiles;
     SW_HIP(hipEventDestroy(e0));
     SW_HIP(hipEventDestroy(e1));
     SW_HIP(hipEventDestroy(e2));

@@ -417,3 +417,6 @@ def test_window_equal_to_run_length_and_overflow_tiles(tmp_path, w, monkeypatch)
             monkeypatch.setenv("SEQWIN_AMD_RC", rc)
         got = _build([p], 21, w)
         assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
+        if w >= 16:   # the hand-over really happens when forced, and only rarely otherwise
+            t = Batch.from_fasta([p]).build_index(21, w).timings()
+            assert (t["ovf_tiles"] >= t["n_tiles"] // 2) if rc else (t["ovf_tiles"] <= max(1, t["n_tiles"] // 4))
