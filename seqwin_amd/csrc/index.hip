@@ -13,6 +13,7 @@
 // assemblies containing a pair is a count of assembly changes inside its run.
 // Device-wide sort / scan come from rocPRIM (a plain library primitive); every kernel in this file
 // is domain-specific glue around them.
+#include <cstdlib>
 #include <cstring>  // rocprim's texture iterator needs ::memset declared first
 
 #include <rocprim/rocprim.hpp>
@@ -623,6 +624,100 @@ hipStream_t side_stream()
 }  // namespace
 
 namespace {
+// ---- packed edge keys: ((rank_lo << nb | rank_hi) << ab) | assembly in ONE 64-bit key when 2 nb + ab <= 64 ----
+// (keys-only radix sort: 16 B instead of 24 B per element and pass; equal pairs of one assembly become adjacent
+// duplicates, so weight = number of distinct keys inside a pair's run)
+__global__ void k_adj_packed(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ rank,
+                             const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, unsigned ab, uint64_t sentinel,
+                             uint64_t *__restrict__ key, unsigned long long *__restrict__ n_invalid)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool invalid = false;
+    if (i + 1 < n) {
+        const uint32_t r0 = (uint32_t)(kmer[i] >> 32), r1 = (uint32_t)(kmer[i + 1] >> 32);
+        if (r0 == r1) {
+            uint32_t u = rank[i], v = rank[i + 1];
+            if (v < u) { const uint32_t t = u; u = v; v = t; }
+            key[i] = (((((uint64_t)u << nb) | v)) << ab) | rec_asm[r0];
+        } else {
+            key[i] = sentinel;
+            invalid = true;
+        }
+    }
+    const unsigned long long m = __ballot(invalid);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_invalid, (unsigned long long)__popcll(m));
+}
+
+struct PackedHeadFlag {   // first occurrence of a pair
+    const uint64_t *keys;
+    unsigned ab;
+    __host__ __device__ uint32_t operator()(uint64_t s) const
+    {
+        return (s == 0 || (keys[s] >> ab) != (keys[s - 1] >> ab)) ? 1u : 0u;
+    }
+};
+struct PackedChangeFlag {   // first occurrence of a (pair, assembly)
+    const uint64_t *keys;
+    __host__ __device__ uint32_t operator()(uint64_t s) const { return (s == 0 || keys[s] != keys[s - 1]) ? 1u : 0u; }
+};
+
+__global__ void k_edge_heads_packed(const uint64_t *__restrict__ skeys, unsigned ab, const uint32_t *__restrict__ ecum,
+                                    uint64_t n_valid, uint64_t *__restrict__ edge_start)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_valid) return;
+    if (s == 0 || (skeys[s] >> ab) != (skeys[s - 1] >> ab)) edge_start[ecum[s] - 1] = s;
+}
+
+__global__ void k_edges_packed(const uint64_t *__restrict__ skeys, unsigned ab, const uint32_t *__restrict__ ccum,
+                               const uint64_t *__restrict__ edge_start, uint64_t n_edges, uint64_t n_valid, unsigned nb,
+                               const sw_node *__restrict__ nodes, sw_edge *__restrict__ edges)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const uint64_t s = edge_start[e];
+    const uint64_t s1 = (e + 1 < n_edges) ? edge_start[e + 1] : n_valid;
+    const uint64_t pair = skeys[s] >> ab;
+    const uint32_t u = (uint32_t)(pair >> nb), v = (uint32_t)(pair & ((1ull << nb) - 1ull));
+    edges[e].first = nodes[u].hash;
+    edges[e].second = nodes[v].hash;
+    edges[e].weight = (uint64_t)(ccum[s1 - 1] - ccum[s]) + 1ull;
+}
+
+void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t n_valid, unsigned nb, unsigned ab,
+                       hipStream_t stream, sw_index &ix)
+{
+    ix.n_edges = 0;
+    if (m == 0 || n_valid == 0) return;
+    {
+        rocprim::double_buffer<uint64_t> dk(keys, keys_alt);
+        size_t tmp_bytes = 0;
+        SW_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, dk, m, 0, 2 * nb + ab, stream));
+        DevArray<unsigned char> tmp(tmp_bytes);
+        SW_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, m, 0, 2 * nb + ab, stream));
+        keys = dk.current();
+    }
+    DevArray<uint32_t> ecum(n_valid), ccum(n_valid);
+    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), PackedHeadFlag{keys, ab}),
+                  ecum.p, n_valid, (uint32_t)0, stream);
+    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), PackedChangeFlag{keys}),
+                  ccum.p, n_valid, (uint32_t)0, stream);
+    uint32_t n_edges = 0;
+    SW_HIP(hipMemcpyAsync(&n_edges, ecum.p + (n_valid - 1), 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    ix.n_edges = n_edges;
+    ix.edges.alloc(n_edges);
+    DevArray<uint64_t> edge_start(n_edges);
+    hipLaunchKernelGGL(k_edge_heads_packed, dim3(blocks_for(n_valid)), dim3(TPB), 0, stream, keys, ab, ecum.p, n_valid,
+                       edge_start.p);
+    hipLaunchKernelGGL(k_edges_packed, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, keys, ab, ccum.p, edge_start.p,
+                       (uint64_t)n_edges, n_valid, nb, ix.nodes.p, ix.edges.p);
+    SW_HIP(hipGetLastError());
+    SW_HIP(hipStreamSynchronize(stream));
+}
+}  // namespace
+
+namespace {
 // keys[m] = (rank_lo << nb) | rank_hi (sentinels sort last), vals[m] = assembly; stable sort keeps equal
 // pairs in assembly order, so weight = number of assembly changes inside a run (+1).
 void edges_from_adjacency(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt, uint64_t m,
@@ -719,18 +814,33 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
         const uint64_t m = n - 1;
         unsigned nb = 1;
         while (((1ull << nb) - 1ull) < ix.n_nodes) ++nb;  // n_nodes <= 2^nb - 1, so (2^nb-1, 2^nb-1) is free
-        const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
-        DevArray<uint64_t> k0(m), k1(m);
-        DevArray<uint32_t> v0(m), v1(m);
+        unsigned ab = 1;
+        while ((1ull << ab) < b.host.n_assemblies) ++ab;     // assembly index < 2^ab
         DevArray<unsigned long long> n_invalid(1);
         SW_HIP(hipMemsetAsync(n_invalid.p, 0, 8, stream));
-        hipLaunchKernelGGL(k_adj, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, b.d_rec_asm.p, n, nb,
-                           sentinel, k0.p, v0.p, n_invalid.p);
-        SW_HIP(hipGetLastError());
         unsigned long long inv = 0;
-        SW_HIP(hipMemcpyAsync(&inv, n_invalid.p, 8, hipMemcpyDeviceToHost, stream));
-        SW_HIP(hipStreamSynchronize(stream));
-        edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, m - inv, nb, nullptr, stream, ix);
+        if (2 * nb + ab <= 64 && !getenv("SEQWIN_AMD_NO_PACKED_EDGES")) {
+            // pair and assembly in one 64-bit key: keys-only sort
+            const unsigned tb = 2 * nb + ab;
+            const uint64_t sentinel = (tb == 64) ? ~0ull : ((1ull << tb) - 1ull);
+            DevArray<uint64_t> k0(m), k1(m);
+            hipLaunchKernelGGL(k_adj_packed, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, b.d_rec_asm.p, n, nb,
+                               ab, sentinel, k0.p, n_invalid.p);
+            SW_HIP(hipGetLastError());
+            SW_HIP(hipMemcpyAsync(&inv, n_invalid.p, 8, hipMemcpyDeviceToHost, stream));
+            SW_HIP(hipStreamSynchronize(stream));
+            edges_from_packed(k0.p, k1.p, m, m - inv, nb, ab, stream, ix);
+        } else {
+            const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
+            DevArray<uint64_t> k0(m), k1(m);
+            DevArray<uint32_t> v0(m), v1(m);
+            hipLaunchKernelGGL(k_adj, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, b.d_rec_asm.p, n, nb,
+                               sentinel, k0.p, v0.p, n_invalid.p);
+            SW_HIP(hipGetLastError());
+            SW_HIP(hipMemcpyAsync(&inv, n_invalid.p, 8, hipMemcpyDeviceToHost, stream));
+            SW_HIP(hipStreamSynchronize(stream));
+            edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, m - inv, nb, nullptr, stream, ix);
+        }
     }
     if (ix.n_edges == 0) ix.edges.alloc(0);
     const bool had_pen = pen.active;
