@@ -249,16 +249,19 @@ int sw_slice_build(const void *rows_dev, uint64_t n, uint64_t kmer_base, const u
                    const uint8_t *is_targets, uint64_t n_assemblies, void *ranks_dev, void *stream, sw_index **out);
 /* Copy the node hashes (u64[n_nodes]) of an index into a DEVICE buffer. */
 int sw_index_node_hashes(const sw_index *ix, void *dst_dev, void *stream);
-/* Source: adjacency rows {(rank_lo << n_bits) | rank_hi, global assembly} of consecutive minimizers of a record, from
- * the GLOBAL node rank of every partitioned row (rank_by_row_dev, u32[n]) and perm; grouped by edge owner = number of
- * ascending rank_bounds <= rank_lo.  DEVICE output rows[<= n-1][2]; HOST output counts[n_bounds + 1]. */
+/* Source: adjacency rows of consecutive minimizers of a record, from the GLOBAL node rank of every partitioned row
+ * (rank_by_row_dev, u32[n]) and perm; grouped by edge owner = number of ascending rank_bounds <= rank_lo.
+ * asm_bits == 0: DEVICE rows[<= n-1][2] = {(rank_lo << n_bits) | rank_hi, global assembly};
+ * asm_bits  > 0 (requires 2 n_bits + asm_bits <= 64): DEVICE rows[<= n-1] = one packed key
+ *               (((rank_lo << n_bits) | rank_hi) << asm_bits) | global assembly  -- half the exchange volume.
+ * HOST output counts[n_bounds + 1]. */
 int sw_occ_adjacency(const sw_occ *o, const void *perm_dev, const void *rank_by_row_dev, uint64_t n_bits,
-                     uint64_t asm_base, const uint64_t *rank_bounds, uint64_t n_bounds, void *rows_dev, uint64_t *counts,
-                     void *stream);
-/* Owner: edges of its rank range from received adjacency rows (source-rank order), hashes looked up in the job-wide
- * rank -> hash table (DEVICE u64[total nodes]).  Attaches the edges to `ix`. */
-int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t n_bits, const void *rank_hash_dev,
-                   void *stream);
+                     uint64_t asm_bits, uint64_t asm_base, const uint64_t *rank_bounds, uint64_t n_bounds, void *rows_dev,
+                     uint64_t *counts, void *stream);
+/* Owner: edges of its rank range from received adjacency rows (source-rank order; same format as above), hashes
+ * looked up in the job-wide rank -> hash table (DEVICE u64[total nodes]).  Attaches the edges to `ix`. */
+int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t n_bits, uint64_t asm_bits,
+                   const void *rank_hash_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,15 @@ while time.time() < t_end and (not replay or it < len(replay)):
                     and np.array_equal(d[3], exp[3])
                 if not ok:
                     print("  dist form", fn.__name__, "P =", P)
+                    if True:
+                        d2 = fn(ps, P, k, w, tar)
+                        print("    retry equal to expected:", all(np.array_equal(a, b) for a, b in zip(d2[:4], exp[:4])),
+                              " retry equal to first:", all(np.array_equal(a, b) for a, b in zip(d2[:4], d[:4])))
+                        for name, x, y in zip(("kmers", "nodes", "edges", "offsets"), d[:4], exp[:4]):
+                            print("    ", name, len(x), len(y))
+                            if len(x) == len(y) and not np.array_equal(x, y):
+                                j = np.nonzero(x != y)[0]
+                                print("       ", len(j), "diffs; first at", j[:4], x[j[:4]], y[j[:4]])
                     break
     except Exception as e:
         ok = False

@@ -537,27 +537,29 @@ int sw_occ_partition(const sw_occ *o, const uint64_t *bounds, uint64_t n_bounds,
     });
 }
 
-int sw_occ_adjacency(const sw_occ *o, const void *perm_dev, const void *rank_by_row_dev, uint64_t n_bits, uint64_t asm_base,
-                     const uint64_t *rank_bounds, uint64_t n_bounds, void *rows_dev, uint64_t *counts, void *stream)
+int sw_occ_adjacency(const sw_occ *o, const void *perm_dev, const void *rank_by_row_dev, uint64_t n_bits, uint64_t asm_bits,
+                     uint64_t asm_base, const uint64_t *rank_bounds, uint64_t n_bounds, void *rows_dev, uint64_t *counts,
+                     void *stream)
 {
     return guarded([&] {
         if (n_bits < 1 || n_bits > 32) raise(SW_ERR_VALUE, "n_bits must be in [1, 32]");
+        if (asm_bits && 2 * n_bits + asm_bits > 64) raise(SW_ERR_VALUE, "packed adjacency keys need 2 n_bits + asm_bits <= 64");
         occ_adjacency(*o->occ, o->batch->d_rec_asm.p, (const uint32_t *)perm_dev, (const uint32_t *)rank_by_row_dev,
-                      (unsigned)n_bits, asm_base, rank_bounds, (uint32_t)n_bounds, (uint64_t *)rows_dev, counts,
-                      (hipStream_t)stream);
+                      (unsigned)n_bits, (unsigned)asm_bits, asm_base, rank_bounds, (uint32_t)n_bounds, (uint64_t *)rows_dev,
+                      counts, (hipStream_t)stream);
     });
 }
 
-int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t n_bits, const void *rank_hash_dev,
-                   void *stream)
+int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t n_bits, uint64_t asm_bits,
+                   const void *rank_hash_dev, void *stream)
 {
     return guarded([&] {
         hipEvent_t e0, e1;
         SW_HIP(hipEventCreate(&e0));
         SW_HIP(hipEventCreate(&e1));
         SW_HIP(hipEventRecord(e0, (hipStream_t)stream));
-        slice_edges(*ix, (const uint64_t *)adj_rows_dev, m, (unsigned)n_bits, (const uint64_t *)rank_hash_dev,
-                    (hipStream_t)stream);
+        slice_edges(*ix, (const uint64_t *)adj_rows_dev, m, (unsigned)n_bits, (unsigned)asm_bits,
+                    (const uint64_t *)rank_hash_dev, (hipStream_t)stream);
         SW_HIP(hipEventRecord(e1, (hipStream_t)stream));
         SW_HIP(hipEventSynchronize(e1));
         float ms = 0.f;

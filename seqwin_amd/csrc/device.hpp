@@ -154,9 +154,9 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
 void occ_partition(const OrderedOcc &occ, const uint64_t *bounds, uint32_t n_bounds, uint64_t rec_offset, uint64_t *d_rows,
                    uint32_t *d_perm, uint64_t *counts_host, hipStream_t stream);
 void occ_adjacency(const OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_perm, const uint32_t *d_rank_by_row,
-                   unsigned nb, uint64_t asm_base, const uint64_t *rank_bounds, uint32_t n_bounds, uint64_t *d_rows_out,
-                   uint64_t *counts_host, hipStream_t stream);
-void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned nb, const uint64_t *d_rank_hash,
+                   unsigned nb, unsigned ab, uint64_t asm_base, const uint64_t *rank_bounds, uint32_t n_bounds,
+                   uint64_t *d_rows_out, uint64_t *counts_host, hipStream_t stream);
+void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned nb, unsigned ab, const uint64_t *d_rank_hash,
                  hipStream_t stream);
 void index_node_hashes(const sw_index &ix, uint64_t *d_out, hipStream_t stream);
 

@@ -44,12 +44,24 @@ void sort_pairs(K *&keys, K *&keys_alt, V *&vals, V *&vals_alt, size_t n, unsign
     vals_alt = dv.alternate();
 }
 
+// NOTE: the temp storage goes back to the caching allocator when the wrapper returns, while the scan / sort may
+// still be running.  That is safe only because every later user of the block is ordered after it on the SAME
+// stream; work on a second stream must keep its temp storage alive itself (inclusive_sum_keep).
 template <class InIt, class OutIt, class T>
 void inclusive_sum(InIt in, OutIt out, size_t n, T, hipStream_t stream)
 {
     size_t tmp_bytes = 0;
     SW_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, in, out, n, rocprim::plus<T>(), stream));
     DevArray<unsigned char> tmp(tmp_bytes);
+    SW_HIP(rocprim::inclusive_scan(tmp.p, tmp_bytes, in, out, n, rocprim::plus<T>(), stream));
+}
+
+template <class InIt, class OutIt, class T>
+void inclusive_sum_keep(InIt in, OutIt out, size_t n, T, hipStream_t stream, DevArray<unsigned char> &tmp)
+{
+    size_t tmp_bytes = 0;
+    SW_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, in, out, n, rocprim::plus<T>(), stream));
+    tmp.alloc(tmp_bytes);
     SW_HIP(rocprim::inclusive_scan(tmp.p, tmp_bytes, in, out, n, rocprim::plus<T>(), stream));
 }
 
@@ -394,6 +406,22 @@ __global__ void k_adj_rows(const uint64_t *__restrict__ kmer, const uint32_t *__
 }
 
 
+__global__ void k_adj_rows_packed(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ rank,
+                                  const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, unsigned ab, uint64_t sentinel,
+                                  uint64_t asm_base, uint64_t *__restrict__ rows)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 >= n) return;
+    const uint32_t r0 = (uint32_t)(kmer[i] >> 32), r1 = (uint32_t)(kmer[i + 1] >> 32);
+    if (r0 == r1) {
+        uint32_t u = rank[i], v = rank[i + 1];
+        if (v < u) { const uint32_t t = u; u = v; v = t; }
+        rows[i] = (((((uint64_t)u << nb) | v)) << ab) | (asm_base + rec_asm[r0]);
+    } else {
+        rows[i] = sentinel;
+    }
+}
+
 __global__ void k_split_rows2(const uint64_t *__restrict__ rows, uint64_t n, uint64_t *__restrict__ key,
                               uint32_t *__restrict__ val)
 {
@@ -573,6 +601,8 @@ namespace {
 struct PenaltyJob {   // buffers of an in-flight get_penalty (asynchronous on `stream`)
     DevArray<uint64_t> X, Y;
     DevArray<uint32_t> err;
+    DevArray<unsigned char> tmp_x, tmp_y;   // scan temp storage: held until the job is finished, because the main
+                                            // stream allocates from the same pool while this job runs
     hipStream_t stream = nullptr;
     bool active = false;
     ~PenaltyJob() { if (active) (void)hipStreamSynchronize(stream); }   // never release buffers of running kernels
@@ -595,8 +625,8 @@ void penalty_launch(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, 
         hipLaunchKernelGGL(k_pen_flags, dim3(blocks_for(n_kmers)), dim3(TPB), 0, stream, d_kmers, n_kmers, d_rec_asm,
                            n_records, d_is_target, X.p, Y.p);
         SW_HIP(hipGetLastError());
-        inclusive_sum(X.p, X.p, n_kmers, (uint64_t)0, stream);
-        inclusive_sum(Y.p, Y.p, n_kmers, (uint64_t)0, stream);
+        inclusive_sum_keep(X.p, X.p, n_kmers, (uint64_t)0, stream, job.tmp_x);
+        inclusive_sum_keep(Y.p, Y.p, n_kmers, (uint64_t)0, stream, job.tmp_y);
     }
     const double inv_tar = 1.0 / (double)n_targets;        // filter.cpp:89-90
     const double inv_neg = 1.0 / (double)n_non_targets;
@@ -671,7 +701,8 @@ __global__ void k_edge_heads_packed(const uint64_t *__restrict__ skeys, unsigned
 
 __global__ void k_edges_packed(const uint64_t *__restrict__ skeys, unsigned ab, const uint32_t *__restrict__ ccum,
                                const uint64_t *__restrict__ edge_start, uint64_t n_edges, uint64_t n_valid, unsigned nb,
-                               const sw_node *__restrict__ nodes, sw_edge *__restrict__ edges)
+                               const sw_node *__restrict__ nodes, const uint64_t *__restrict__ rank_hash,
+                               sw_edge *__restrict__ edges)
 {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
@@ -679,13 +710,13 @@ __global__ void k_edges_packed(const uint64_t *__restrict__ skeys, unsigned ab, 
     const uint64_t s1 = (e + 1 < n_edges) ? edge_start[e + 1] : n_valid;
     const uint64_t pair = skeys[s] >> ab;
     const uint32_t u = (uint32_t)(pair >> nb), v = (uint32_t)(pair & ((1ull << nb) - 1ull));
-    edges[e].first = nodes[u].hash;
-    edges[e].second = nodes[v].hash;
+    edges[e].first = rank_hash ? rank_hash[u] : nodes[u].hash;
+    edges[e].second = rank_hash ? rank_hash[v] : nodes[v].hash;
     edges[e].weight = (uint64_t)(ccum[s1 - 1] - ccum[s]) + 1ull;
 }
 
 void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t n_valid, unsigned nb, unsigned ab,
-                       hipStream_t stream, sw_index &ix)
+                       const uint64_t *rank_hash, hipStream_t stream, sw_index &ix)
 {
     ix.n_edges = 0;
     if (m == 0 || n_valid == 0) return;
@@ -711,7 +742,7 @@ void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t 
     hipLaunchKernelGGL(k_edge_heads_packed, dim3(blocks_for(n_valid)), dim3(TPB), 0, stream, keys, ab, ecum.p, n_valid,
                        edge_start.p);
     hipLaunchKernelGGL(k_edges_packed, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, keys, ab, ccum.p, edge_start.p,
-                       (uint64_t)n_edges, n_valid, nb, ix.nodes.p, ix.edges.p);
+                       (uint64_t)n_edges, n_valid, nb, ix.nodes.p, rank_hash, ix.edges.p);
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));
 }
@@ -829,7 +860,7 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
             SW_HIP(hipGetLastError());
             SW_HIP(hipMemcpyAsync(&inv, n_invalid.p, 8, hipMemcpyDeviceToHost, stream));
             SW_HIP(hipStreamSynchronize(stream));
-            edges_from_packed(k0.p, k1.p, m, m - inv, nb, ab, stream, ix);
+            edges_from_packed(k0.p, k1.p, m, m - inv, nb, ab, nullptr, stream, ix);
         } else {
             const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
             DevArray<uint64_t> k0(m), k1(m);
@@ -1009,6 +1040,12 @@ struct RowSrc {     // rows[n][2], key = column 0
     __device__ void row(uint64_t i, uint64_t &r0, uint64_t &r1) const { r0 = rows[2 * i]; r1 = rows[2 * i + 1]; }
 };
 
+struct KeySrc {     // rows[n] of packed keys (one column); the second output column is unused
+    const uint64_t *rows;
+    __device__ uint64_t key(uint64_t i) const { return rows[i]; }
+    __device__ void row(uint64_t i, uint64_t &r0, uint64_t &r1) const { r0 = rows[i]; r1 = 0; }
+};
+
 struct PartArgs {
     uint64_t n;
     uint64_t bounds[16];
@@ -1016,6 +1053,7 @@ struct PartArgs {
     uint64_t drop_key;
     uint32_t has_drop;
     uint32_t n_waves;
+    uint32_t cols;       // output columns per row: 2, or 1 for packed keys
 };
 
 __device__ __forceinline__ uint32_t owner_of(const PartArgs &P, uint64_t kx)
@@ -1064,8 +1102,12 @@ __global__ __launch_bounds__(256) void k_partition(const Src src, const PartArgs
                 const uint64_t dst = (uint64_t)start + before;
                 uint64_t r0, r1;
                 src.row(i, r0, r1);
-                rows_out[2 * dst] = r0;
-                rows_out[2 * dst + 1] = r1;
+                if (P.cols == 2) {
+                    rows_out[2 * dst] = r0;
+                    rows_out[2 * dst + 1] = r1;
+                } else {
+                    rows_out[dst] = r0;
+                }
                 if (perm_out) perm_out[dst] = (uint32_t)i;
             }
             __builtin_amdgcn_wave_barrier();
@@ -1088,7 +1130,7 @@ __global__ void k_part_counts(const uint32_t *__restrict__ offsets, const uint32
 
 template <class Src>
 void stable_partition(const Src &src, uint64_t n, const uint64_t *bounds, uint32_t n_bounds, bool has_drop, uint64_t drop_key,
-                      uint64_t *d_rows_out, uint32_t *d_perm_out, uint64_t *counts_host, hipStream_t stream)
+                      uint64_t *d_rows_out, uint32_t *d_perm_out, uint64_t *counts_host, hipStream_t stream, uint32_t cols = 2)
 {
     if (n_bounds > 15) raise(SW_ERR_VALUE, "at most 16 owners are supported");
     for (uint32_t j = 0; j < n_bounds + 2; ++j) counts_host[j] = 0;
@@ -1100,6 +1142,7 @@ void stable_partition(const Src &src, uint64_t n, const uint64_t *bounds, uint32
     for (uint32_t j = 0; j < n_bounds; ++j) P.bounds[j] = bounds[j];
     P.drop_key = drop_key;
     P.has_drop = has_drop ? 1u : 0u;
+    P.cols = cols;
     P.n_waves = (uint32_t)((n + PART_ROWS * 64 - 1) / (PART_ROWS * 64));
     const uint64_t nh = (uint64_t)PART_BUCKETS * P.n_waves;
     DevArray<uint32_t> hist(nh), offs(nh);
@@ -1129,35 +1172,48 @@ void occ_partition(const OrderedOcc &occ, const uint64_t *bounds, uint32_t n_bou
     for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = counts[j];
 }
 
+// ab == 0: rows are {key, assembly} pairs; ab > 0: one packed 64-bit key per row, (key << ab) | assembly
 void occ_adjacency(const OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_perm, const uint32_t *d_rank_by_row,
-                   unsigned nb, uint64_t asm_base, const uint64_t *rank_bounds, uint32_t n_bounds, uint64_t *d_rows_out,
-                   uint64_t *counts_host, hipStream_t stream)
+                   unsigned nb, unsigned ab, uint64_t asm_base, const uint64_t *rank_bounds, uint32_t n_bounds,
+                   uint64_t *d_rows_out, uint64_t *counts_host, hipStream_t stream)
 {
     for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = 0;
     const uint64_t n = occ.n;
     if (n < 2) return;
     const uint64_t m = n - 1;
-    const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
+    const unsigned tb = 2 * nb + ab;
+    const uint64_t sentinel = (tb >= 64) ? ~0ull : ((1ull << tb) - 1ull);
     DevArray<uint32_t> rank(n);
-    DevArray<uint64_t> rows(2 * m);
+    DevArray<uint64_t> rows(ab ? m : 2 * m);
     hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(n)), dim3(TPB), 0, stream, d_perm, d_rank_by_row, n, rank.p);
-    hipLaunchKernelGGL(k_adj_rows, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, d_rec_asm, n, nb, sentinel,
-                       asm_base, rows.p);
+    if (ab)
+        hipLaunchKernelGGL(k_adj_rows_packed, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, d_rec_asm, n, nb, ab,
+                           sentinel, asm_base, rows.p);
+    else
+        hipLaunchKernelGGL(k_adj_rows, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, d_rec_asm, n, nb, sentinel,
+                           asm_base, rows.p);
     SW_HIP(hipGetLastError());
     std::vector<uint64_t> kb(n_bounds);
-    for (uint32_t j = 0; j < n_bounds; ++j) kb[j] = rank_bounds[j] << nb;   // key is monotone in rank_lo
+    for (uint32_t j = 0; j < n_bounds; ++j) kb[j] = rank_bounds[j] << (nb + ab);   // key is monotone in rank_lo
     uint64_t counts[18];
     // dropped (sentinel) rows land after the last owner; the output buffer holds all m rows
-    stable_partition(RowSrc{rows.p}, m, kb.data(), n_bounds, true, sentinel, d_rows_out, (uint32_t *)nullptr, counts, stream);
+    if (ab)
+        stable_partition(KeySrc{rows.p}, m, kb.data(), n_bounds, true, sentinel, d_rows_out, (uint32_t *)nullptr, counts, stream, 1);
+    else
+        stable_partition(RowSrc{rows.p}, m, kb.data(), n_bounds, true, sentinel, d_rows_out, (uint32_t *)nullptr, counts, stream);
     for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = counts[j];
 }
 
-void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned nb, const uint64_t *d_rank_hash,
+void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned nb, unsigned ab, const uint64_t *d_rank_hash,
                  hipStream_t stream)
 {
     ix.n_edges = 0;
     if (m >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 adjacency rows on one device");
-    if (m) {
+    if (m && ab) {
+        DevArray<uint64_t> k0(m), k1(m);
+        SW_HIP(hipMemcpyAsync(k0.p, d_adj_rows, m * 8, hipMemcpyDeviceToDevice, stream));
+        edges_from_packed(k0.p, k1.p, m, m, nb, ab, d_rank_hash, stream, ix);
+    } else if (m) {
         DevArray<uint64_t> k0(m), k1(m);
         DevArray<uint32_t> v0(m), v1(m);
         hipLaunchKernelGGL(k_split_rows2, dim3(blocks_for(m)), dim3(TPB), 0, stream, d_adj_rows, m, k0.p, v0.p);

@@ -200,27 +200,28 @@ class HipEngine:
         t.cuda.current_stream().synchronize()
         return out.to(self.device)
 
-    def adjacency(self, occ, perm, ranks_by_row, n_bits: int, asm_base: int, rank_bounds):
+    def adjacency(self, occ, perm, ranks_by_row, n_bits: int, asm_bits: int, asm_base: int, rank_bounds):
         from ._lib import c_u64, c_vp, check, lib
         t = self.torch
         ranks_by_row = ranks_by_row.to(self.gpu).contiguous()
-        rows = t.empty((max(occ.n - 1, 0), 2), dtype=t.int64, device=self.gpu)
+        m = max(occ.n - 1, 0)
+        rows = t.empty((m,) if asm_bits else (m, 2), dtype=t.int64, device=self.gpu)
         nb = len(rank_bounds)
         b = (c_u64 * max(nb, 1))(*rank_bounds)
         cnt = (c_u64 * (nb + 1))()
         t.cuda.current_stream().synchronize()
         check(lib.sw_occ_adjacency(occ._h, c_vp(perm.data_ptr()), c_vp(ranks_by_row.data_ptr()), c_u64(n_bits),
-                                   c_u64(asm_base), b, c_u64(nb), c_vp(rows.data_ptr()), cnt, c_vp(self._stream())))
+                                   c_u64(asm_bits), c_u64(asm_base), b, c_u64(nb), c_vp(rows.data_ptr()), cnt, c_vp(self._stream())))
         counts = [int(x) for x in cnt]
         return rows[:sum(counts)].to(self.device), counts
 
-    def slice_edges(self, ix, adj_rows, n_bits: int, rank_hash) -> None:
+    def slice_edges(self, ix, adj_rows, n_bits: int, asm_bits: int, rank_hash) -> None:
         from ._lib import c_u64, c_vp, check, lib
         adj_rows = adj_rows.to(self.gpu).contiguous()
         rank_hash = rank_hash.to(self.gpu).contiguous()
         self.torch.cuda.current_stream().synchronize()
         check(lib.sw_slice_edges(ix._h, c_vp(adj_rows.data_ptr()), c_u64(adj_rows.shape[0]), c_u64(n_bits),
-                                 c_vp(rank_hash.data_ptr()), c_vp(self._stream())))
+                                 c_u64(asm_bits), c_vp(rank_hash.data_ptr()), c_vp(self._stream())))
 
     def free_occ(self, occ) -> None:
         occ.close()
@@ -346,6 +347,15 @@ def rank_bounds(n_parts: int, total_nodes: int) -> list[int]:
     return [total_nodes - math.isqrt(((n_parts - j) * total_nodes * total_nodes) // n_parts) for j in range(1, n_parts)]
 
 
+def adjacency_asm_bits(n_bits: int, n_assemblies_total: int) -> int:
+    """Width of the assembly field of a packed adjacency key ((rank_lo << n_bits | rank_hi) << asm_bits | assembly),
+    or 0 when the key does not fit 64 bits and rows travel as {key, assembly} pairs."""
+    ab = max(1, int(n_assemblies_total).bit_length())
+    if os.environ.get("SEQWIN_AMD_NO_PACKED_EDGES"):
+        return 0
+    return ab if 2 * n_bits + ab <= 64 else 0
+
+
 def _exchange_rows(rows, counts, dev, group):
     """all_to_all_single of rows grouped by destination; returns (received rows, per-source counts)."""
     import torch
@@ -442,7 +452,9 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     else:
         total_nodes, ranks_by_row, rank_hash, hash_work = n_nodes, r_ranks, engine.node_hashes(ix), None
     n_bits = max(1, (total_nodes).bit_length())     # total_nodes <= 2^n_bits - 1
-    adj, acnt = engine.adjacency(occ, perm, ranks_by_row, n_bits, shard.first_assembly, rank_bounds(world, total_nodes))
+    asm_bits = adjacency_asm_bits(n_bits, shard.n_assemblies_total)
+    adj, acnt = engine.adjacency(occ, perm, ranks_by_row, n_bits, asm_bits, shard.first_assembly,
+                                 rank_bounds(world, total_nodes))
     if multi:
         r_adj, _ = _exchange_rows(adj, acnt, dev, group)
         hash_work.wait()
@@ -450,7 +462,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     else:
         r_adj = adj
     t4 = time.perf_counter()
-    engine.slice_edges(ix, r_adj, n_bits, rank_hash)
+    engine.slice_edges(ix, r_adj, n_bits, asm_bits, rank_hash)
     tm.update(engine.timings(ix))
     t5 = time.perf_counter()
     tm.update(sketch_ms=occ.sketch_ms, n_occ_local=occ.n, sketch_wall_ms=(t1 - t0) * 1e3, tuple_exchange_wall_ms=(t2 - t1) * 1e3,

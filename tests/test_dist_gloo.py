@@ -118,7 +118,7 @@ class NumpyEngine:
     def node_hashes(self, ix):
         return torch.from_numpy(ix["nodes"]["hash"].view(np.int64).copy())
 
-    def adjacency(self, occ, perm, ranks_by_row, n_bits, asm_base, rank_bounds):
+    def adjacency(self, occ, perm, ranks_by_row, n_bits, asm_bits, asm_base, rank_bounds):
         rank = np.zeros(occ.n, U64)
         rank[perm.numpy()] = ranks_by_row.numpy().view(np.uint32).astype(U64)
         rec = (occ.kmer >> U64(32)).astype(np.int64)
@@ -129,11 +129,16 @@ class NumpyEngine:
         kb = np.array([b << n_bits for b in rank_bounds], dtype=U64)
         owner = np.searchsorted(kb, key, side="right")
         p = np.argsort(owner, kind="stable")
-        rows = np.stack([key[p], asm[p]], axis=1) if len(key) else np.zeros((0, 2), U64)
+        if asm_bits:
+            rows = (key[p] << U64(asm_bits)) | asm[p]
+        else:
+            rows = np.stack([key[p], asm[p]], axis=1) if len(key) else np.zeros((0, 2), U64)
         return torch.from_numpy(rows.view(np.int64).copy()), np.bincount(owner, minlength=len(rank_bounds) + 1).tolist()
 
-    def slice_edges(self, ix, adj_rows, n_bits, rank_hash):
+    def slice_edges(self, ix, adj_rows, n_bits, asm_bits, rank_hash):
         r = adj_rows.numpy().view(U64)
+        if asm_bits:
+            r = np.stack([r >> U64(asm_bits), r & U64((1 << asm_bits) - 1)], axis=1)
         table = rank_hash.numpy().view(U64)
         edges = np.zeros(0, oracle.EDGE_DTYPE)
         if len(r):

@@ -155,7 +155,7 @@ def test_rccl_collectives_world1(tmp_path):
     assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
 
 
-def routed_tuple_exchange(paths, world, k, w, tar):
+def routed_tuple_exchange(paths, world, k, w, tar, packed=True):
     """The tuple-exchange form with the all-to-all steps done by hand on ONE GPU (P shards, one after another)."""
     eng = swdist.HipEngine()
     parts = swdist.partition_assemblies(len(paths), world)
@@ -190,10 +190,11 @@ def routed_tuple_exchange(paths, world, k, w, tar):
     rank_hash = torch.cat([eng.node_hashes(s[0]) for s in slices])
     n_bits = max(1, total_nodes.bit_length())
     rb = swdist.rank_bounds(world, total_nodes)
+    asm_bits = swdist.adjacency_asm_bits(n_bits, shards[0].n_assemblies_total) if packed else 0
     adj = []
     for r in range(world):
         by_row = torch.cat(ranks_back[r]) if occs[r].n else torch.zeros(0, dtype=torch.int32, device=eng.gpu)
-        adj.append(eng.adjacency(occs[r], perms[r], by_row, n_bits, shards[r].first_assembly, rb))
+        adj.append(eng.adjacency(occs[r], perms[r], by_row, n_bits, asm_bits, shards[r].first_assembly, rb))
     kmers, nodes, edges = [], [], []
     for owner in range(world):
         pieces = []
@@ -201,7 +202,7 @@ def routed_tuple_exchange(paths, world, k, w, tar):
             a_rows, a_cnt = adj[r]
             c = np.concatenate([[0], np.cumsum(a_cnt)])
             pieces.append(a_rows[c[owner]:c[owner + 1]])
-        eng.slice_edges(slices[owner][0], torch.cat(pieces), n_bits, rank_hash)
+        eng.slice_edges(slices[owner][0], torch.cat(pieces), n_bits, asm_bits, rank_hash)
         K, N, E = slices[owner][0].export()
         kmers.append(K); nodes.append(N); edges.append(E)
     return np.concatenate(kmers), np.concatenate(nodes), np.concatenate(edges), record_offsets
@@ -212,8 +213,9 @@ def test_routed_tuple_exchange_equals_single_batch(world):
     paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa")) + sorted((GOLDEN / "synth").glob("edge_*"))]
     tar = [i % 3 != 0 for i in range(len(paths))]
     for k, w in [(15, 20), (21, 200), (11, 5)]:
-        got = routed_tuple_exchange(paths, world, k, w, tar)
         ek, en, ee, eo, _ = oracle.build(paths, k, w)
         oracle.get_penalty(ek, en, eo, tar)
-        assert np.array_equal(got[0], ek) and np.array_equal(got[1], en), (world, k, w)
-        assert np.array_equal(got[2], ee) and np.array_equal(got[3], eo), (world, k, w)
+        for packed in (True, False):    # one 64-bit key per adjacency row, or {key, assembly} pairs
+            got = routed_tuple_exchange(paths, world, k, w, tar, packed)
+            assert np.array_equal(got[0], ek) and np.array_equal(got[1], en), (world, k, w, packed)
+            assert np.array_equal(got[2], ee) and np.array_equal(got[3], eo), (world, k, w, packed)
