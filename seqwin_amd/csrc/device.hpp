@@ -129,7 +129,8 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
 struct OrderedOcc {
     DevArray<uint64_t> hash;   // out_hash in (record_idx, pos) order
     DevArray<uint64_t> kmer;   // pos | record_idx << 32
-    DevArray<uint32_t> idx;    // identity permutation (consumed by the node sort)
+    DevArray<uint32_t> key32;  // out_hash >> 32: first-phase key of the node sort (consumed by it)
+    DevArray<uint64_t> val;    // out_hash << 32 | position in this stream: its payload (consumed by it)
     uint64_t n = 0;
 };
 void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out);

@@ -93,7 +93,7 @@ struct HeadFlag {
 __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t *__restrict__ stage_kmer,
                         const uint32_t *__restrict__ tile_count, const uint64_t *__restrict__ tile_offset,
                         const uint64_t *__restrict__ dst_off, uint32_t n_tiles, uint64_t *__restrict__ hash,
-                        uint64_t *__restrict__ kmer, uint32_t *__restrict__ idx)
+                        uint64_t *__restrict__ kmer, uint32_t *__restrict__ key32, uint64_t *__restrict__ val)
 {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
@@ -101,9 +101,11 @@ __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t 
     const uint32_t c = tile_count[wave];
     const uint64_t src = tile_offset[wave], dst = dst_off[wave];
     for (uint32_t i = lane; i < c; i += 64) {
-        hash[dst + i] = stage_hash[src + i];
+        const uint64_t h = stage_hash[src + i];
+        hash[dst + i] = h;
         kmer[dst + i] = stage_kmer[src + i];
-        idx[dst + i] = (uint32_t)(dst + i);   // identity permutation for the sort that follows
+        key32[dst + i] = (uint32_t)(h >> 32);   // first-phase sort key and payload (sort_hashes)
+        val[dst + i] = (h << 32) | (dst + i);
     }
 }
 
@@ -114,7 +116,8 @@ __global__ void k_iota(uint32_t *v, uint64_t n)
 }
 
 // ---- nodes / kmers / ranks ------------------------------------------------------------------------
-__global__ void k_nodes(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ perm,
+// sorted hashes arrive in the split form of sort_hashes: key32[s] = top half, val[s] = low half << 32 | original index
+__global__ void k_nodes(const uint32_t *__restrict__ key32, const uint64_t *__restrict__ val,
                         const uint32_t *__restrict__ cum, const uint64_t *__restrict__ kmer_in, uint32_t kmer_stride,
                         uint64_t n, uint64_t base, sw_kmer *__restrict__ kmers, sw_node *__restrict__ nodes,
                         uint32_t *__restrict__ rank)
@@ -122,13 +125,14 @@ __global__ void k_nodes(const uint64_t *__restrict__ skeys, const uint32_t *__re
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     const uint32_t nid = cum[s] - 1;
-    const uint32_t src = perm[s];
+    const uint64_t v = val[s];
+    const uint32_t src = (uint32_t)v;
     const uint64_t km = kmer_in[(uint64_t)src * kmer_stride];
     kmers[s].pos = (uint32_t)km;
     kmers[s].record_idx = (uint32_t)(km >> 32);
     if (rank) rank[src] = nid;
-    const uint64_t key = skeys[s];
-    const bool head = (s == 0) || key != skeys[s - 1];
+    const uint64_t key = ((uint64_t)key32[s] << 32) | (v >> 32);
+    const bool head = (s == 0) || key != (((uint64_t)key32[s - 1] << 32) | (val[s - 1] >> 32));
     if (head) {
         nodes[nid].hash = key;
         nodes[nid].start = base + s;
@@ -577,6 +581,236 @@ __global__ void k_checksum(const sw_kmer *kmers, uint64_t nk, const sw_node *nod
     }
 }
 
+// ---- stable sort of 64-bit hashes in two phases -------------------------------------------------------
+// Phase 1: 4 radix passes over the TOP 32 bits only, carrying (low 32 bits << 32 | original index) as a 64-bit
+// payload: 24 B per element and pass for 4 passes instead of 8.  The result stays in this split form
+// (key32[q], val[q]); consumers rebuild hash = key32 << 32 | val >> 32 and index = (u32)val on the fly.
+// Phase 2: a run of equal top halves whose low halves are out of order (two different hashes sharing 32 bits:
+// ~n_nodes^2 / 2^33 runs) is repaired: the runs are located by binary search in the sorted keys, their elements
+// are pulled into a side array, sorted by the full hash (stable) and put back into the same positions --
+// positions ascend with the top half, so the outcome is exactly the stable 64-bit sort.
+// SEQWIN_AMD_SORT_KEYBITS=b (tests) makes phase 1 look at the top b bits only.
+__global__ void k_key32(const uint64_t *__restrict__ hash, uint32_t stride, uint64_t n, uint32_t *__restrict__ key32,
+                        uint64_t *__restrict__ val)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t h = hash[i * stride];
+    key32[i] = (uint32_t)(h >> 32);
+    val[i] = (h << 32) | i;
+}
+
+__global__ void k_mask_keys(uint32_t *__restrict__ key32, uint64_t n, uint32_t mask)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key32[i] &= mask;
+}
+
+__global__ void k_restore_keys(const uint64_t *__restrict__ hash, uint32_t stride, const uint64_t *__restrict__ val,
+                               uint64_t n, uint32_t *__restrict__ key32)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) key32[i] = (uint32_t)(hash[(uint64_t)(uint32_t)val[i] * stride] >> 32);
+}
+
+// descents: q > 0 in the same phase-1 run as q-1 with a smaller full hash
+__global__ void k_find_descents(const uint32_t *__restrict__ key32, const uint64_t *__restrict__ val, uint32_t kmask,
+                                uint64_t n, uint32_t *__restrict__ bad, uint32_t cap, unsigned long long *__restrict__ n_desc)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool desc = false;
+    uint32_t kq = 0;
+    if (q > 0 && q < n) {
+        kq = key32[q];
+        const uint32_t kp = key32[q - 1];
+        if ((kq & kmask) == (kp & kmask)) {
+            const uint64_t hq = ((uint64_t)kq << 32) | (val[q] >> 32), hp = ((uint64_t)kp << 32) | (val[q - 1] >> 32);
+            desc = hq < hp;
+        }
+    }
+    const unsigned long long m = __ballot(desc);
+    if (m) {   // rare
+        const uint32_t lane = threadIdx.x & 63u;
+        const int leader = __builtin_ctzll(m);
+        unsigned long long base = 0;
+        if ((int)lane == leader) base = atomicAdd(n_desc, (unsigned long long)__popcll(m));
+        base = __shfl(base, leader);
+        if (desc) {
+            const unsigned long long slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (slot < cap) bad[slot] = kq & kmask;
+        }
+    }
+}
+
+// one thread per (sorted) bad key: the first of equal entries looks its run up in the sorted phase-1 keys
+__global__ void k_bad_runs(const uint32_t *__restrict__ bad, uint32_t n_bad, const uint32_t *__restrict__ key32,
+                           uint32_t kmask, uint64_t n, uint32_t *__restrict__ run_start, uint32_t *__restrict__ run_len)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bad) return;
+    const uint32_t k = bad[i];
+    if (i && bad[i - 1] == k) {
+        run_start[i] = 0;
+        run_len[i] = 0;
+        return;
+    }
+    uint64_t lo = 0, hi = n;   // first q with (key32[q] & kmask) >= k
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((key32[mid] & kmask) < k) lo = mid + 1; else hi = mid;
+    }
+    const uint64_t a = lo;
+    hi = n;                    // first q with (key32[q] & kmask) > k
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((key32[mid] & kmask) <= k) lo = mid + 1; else hi = mid;
+    }
+    run_start[i] = (uint32_t)a;
+    run_len[i] = (uint32_t)(lo - a);
+}
+
+// sub[t] = element t of the concatenated bad runs (run_off = exclusive sum of run_len; null: identity, everything)
+__global__ void k_gather_sub(const uint32_t *__restrict__ key32, const uint64_t *__restrict__ val,
+                             const uint32_t *__restrict__ run_start, const uint64_t *__restrict__ run_off, uint32_t n_bad,
+                             uint64_t n_sub, uint64_t *__restrict__ sub_h, uint32_t *__restrict__ sub_p,
+                             uint32_t *__restrict__ pos)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_sub) return;
+    uint64_t q = t;
+    if (run_off) {
+        uint32_t lo = 0, hi = n_bad;   // last entry with run_off <= t (zero-length entries share an offset: take the last)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (run_off[mid] <= t) lo = mid; else hi = mid;
+        }
+        q = (uint64_t)run_start[lo] + (t - run_off[lo]);
+        pos[t] = (uint32_t)q;
+    }
+    const uint64_t v = val[q];
+    sub_h[t] = ((uint64_t)key32[q] << 32) | (v >> 32);
+    sub_p[t] = (uint32_t)v;
+}
+
+__global__ void k_scatter_sub(const uint64_t *__restrict__ sub_h, const uint32_t *__restrict__ sub_p,
+                              const uint32_t *__restrict__ pos, uint64_t n_sub, uint32_t *__restrict__ key32,
+                              uint64_t *__restrict__ val)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_sub) return;
+    const uint64_t q = pos ? pos[t] : t;
+    const uint64_t h = sub_h[t];
+    key32[q] = (uint32_t)(h >> 32);
+    val[q] = (h << 32) | sub_p[t];
+}
+
+struct SplitHeadFlag {   // head-of-run flag over the split (key32, val) form of the sorted hashes
+    const uint32_t *key32;
+    const uint64_t *val;
+    __host__ __device__ uint32_t operator()(uint64_t s) const
+    {
+        return (s == 0 || key32[s] != key32[s - 1] || (val[s] >> 32) != (val[s - 1] >> 32)) ? 1u : 0u;
+    }
+};
+
+struct HashSort {
+    DevArray<uint32_t> key_a, key_b;   // phase-1 double buffers (key_a / val_a may be handed in prefilled)
+    DevArray<uint64_t> val_a, val_b;
+    const uint32_t *key32 = nullptr;   // result: top halves, ascending
+    const uint64_t *val = nullptr;     // result: low half << 32 | original index (stable)
+    uint32_t *spare = nullptr;         // n free u32 for the caller (the other key buffer)
+    uint64_t n_repaired = 0;
+};
+
+void sort_hashes(const uint64_t *hash, uint32_t stride, uint64_t n, bool prefilled, hipStream_t stream, HashSort &o)
+{
+    unsigned bits = 32;
+    if (const char *e = getenv("SEQWIN_AMD_SORT_KEYBITS")) {
+        const int b = atoi(e);
+        if (b >= 1 && b <= 32) bits = (unsigned)b;
+    }
+    const uint32_t kmask = ~0u << (32 - bits);
+    if (!prefilled) {
+        o.key_a.alloc(n);
+        o.val_a.alloc(n);
+        hipLaunchKernelGGL(k_key32, dim3(blocks_for(n)), dim3(TPB), 0, stream, hash, stride, n, o.key_a.p, o.val_a.p);
+        SW_HIP(hipGetLastError());
+    }
+    if (~kmask) {   // test knob: sort on cleared low key bits (always over 32 bits), then restore the true keys
+        hipLaunchKernelGGL(k_mask_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, o.key_a.p, n, kmask);
+        SW_HIP(hipGetLastError());
+    }
+    o.key_b.alloc(n);
+    o.val_b.alloc(n);
+    uint32_t *keys = o.key_a.p, *keys_alt = o.key_b.p;
+    uint64_t *vals = o.val_a.p, *vals_alt = o.val_b.p;
+    sort_pairs(keys, keys_alt, vals, vals_alt, n, 0, 32, stream);
+    if (~kmask) {
+        hipLaunchKernelGGL(k_restore_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, hash, stride, vals, n, keys);
+        SW_HIP(hipGetLastError());
+    }
+    o.key32 = keys;
+    o.val = vals;
+    o.spare = keys_alt;
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(1u << 16, n / 16));
+    DevArray<uint32_t> bad(cap);
+    DevArray<unsigned long long> n_desc(1);
+    SW_HIP(hipMemsetAsync(n_desc.p, 0, 8, stream));
+    hipLaunchKernelGGL(k_find_descents, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, kmask, n, bad.p, cap, n_desc.p);
+    SW_HIP(hipGetLastError());
+    unsigned long long D = 0;
+    SW_HIP(hipMemcpyAsync(&D, n_desc.p, 8, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    if (D == 0) return;
+
+    // ---- repair ----
+    uint64_t n_sub = n;
+    DevArray<uint32_t> run_start, run_len, pos;
+    DevArray<uint64_t> run_off;
+    const bool listed = D <= cap;   // otherwise: more descents than the list holds -> treat everything as one subset
+    if (listed) {
+        const uint32_t nb = (uint32_t)D;
+        {
+            DevArray<uint32_t> bad_alt(nb);
+            rocprim::double_buffer<uint32_t> db(bad.p, bad_alt.p);
+            size_t tmp_bytes = 0;
+            SW_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, db, (size_t)nb, 0, 32, stream));
+            DevArray<unsigned char> tmp(tmp_bytes);
+            SW_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, db, (size_t)nb, 0, 32, stream));
+            if (db.current() != bad.p)
+                SW_HIP(hipMemcpyAsync(bad.p, db.current(), (size_t)nb * 4, hipMemcpyDeviceToDevice, stream));
+            SW_HIP(hipStreamSynchronize(stream));   // bad_alt is released here
+        }
+        run_start.alloc(nb);
+        run_len.alloc(nb);
+        run_off.alloc((size_t)nb + 1);
+        hipLaunchKernelGGL(k_bad_runs, dim3((unsigned)blocks_for(nb)), dim3(TPB), 0, stream, bad.p, nb, keys, kmask, n,
+                           run_start.p, run_len.p);
+        SW_HIP(hipGetLastError());
+        exclusive_sum(rocprim::make_transform_iterator(run_len.p, U32ToU64()), run_off.p, nb, (uint64_t)0, stream);
+        uint64_t last_off = 0;
+        uint32_t last_len = 0;
+        SW_HIP(hipMemcpyAsync(&last_off, run_off.p + (nb - 1), 8, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipMemcpyAsync(&last_len, run_len.p + (nb - 1), 4, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));
+        n_sub = last_off + last_len;
+        pos.alloc(n_sub);
+    }
+    DevArray<uint64_t> sh0(n_sub), sh1(n_sub);
+    DevArray<uint32_t> sp0(n_sub), sp1(n_sub);
+    hipLaunchKernelGGL(k_gather_sub, dim3(blocks_for(n_sub)), dim3(TPB), 0, stream, keys, vals, run_start.p,
+                       listed ? run_off.p : (const uint64_t *)nullptr, (uint32_t)(listed ? D : 0), n_sub, sh0.p, sp0.p, pos.p);
+    SW_HIP(hipGetLastError());
+    uint64_t *sk = sh0.p, *sk_alt = sh1.p;
+    uint32_t *sv = sp0.p, *sv_alt = sp1.p;
+    sort_pairs(sk, sk_alt, sv, sv_alt, n_sub, 0, 64, stream);
+    hipLaunchKernelGGL(k_scatter_sub, dim3(blocks_for(n_sub)), dim3(TPB), 0, stream, sk, sv,
+                       listed ? pos.p : (const uint32_t *)nullptr, n_sub, keys, vals);
+    SW_HIP(hipGetLastError());
+    SW_HIP(hipStreamSynchronize(stream));   // side arrays are released on return
+    o.n_repaired = n_sub;
+}
+
 }  // namespace
 
 void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out)
@@ -585,14 +819,16 @@ void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, Ord
     if (out.n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
     out.hash.alloc(out.n);
     out.kmer.alloc(out.n);
-    out.idx.alloc(out.n);
+    out.key32.alloc(out.n);
+    out.val.alloc(out.n);
     if (plan.n_tiles == 0 || out.n == 0) return;
     DevArray<uint64_t> dst_off(plan.n_tiles);
     exclusive_sum(rocprim::make_transform_iterator(sk.tile_count.p, U32ToU64()), dst_off.p, plan.n_tiles,
                   (uint64_t)0, stream);
     const uint64_t threads = (uint64_t)plan.n_tiles * 64;
     hipLaunchKernelGGL(k_order, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
-                       sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, out.hash.p, out.kmer.p, out.idx.p);
+                       sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, out.hash.p, out.kmer.p, out.key32.p,
+                       out.val.p);
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));  // dst_off is released on return
 }
@@ -801,15 +1037,16 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
     DevArray<uint32_t> rank(n);
     // -- nodes: stable radix sort of (out_hash -> original index), run-length heads ------------------
     if (n) {
-        // the ordered hash / identity-index arrays are consumed in place as the sort's first buffers
-        DevArray<uint64_t> k1(n);
-        DevArray<uint32_t> v1(n);
-        uint64_t *keys = occ.hash.p, *keys_alt = k1.p;
-        uint32_t *vals = occ.idx.p, *vals_alt = v1.p;
-        sort_pairs(keys, keys_alt, vals, vals_alt, n, 0, 64, stream);
-        uint32_t *cum = vals_alt;  // reuse the spare value buffer for the inclusive head count
+        // the first-phase key / identity-index arrays written by k_order are consumed in place
+        HashSort hs;
+        hs.key_a = std::move(occ.key32);
+        hs.val_a = std::move(occ.val);
+        sort_hashes(occ.hash.p, 1u, n, true, stream, hs);
+        const uint32_t *keys = hs.key32;
+        const uint64_t *vals = hs.val;
+        uint32_t *cum = hs.spare;  // reuse the spare key buffer for the inclusive head count
         inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
-                                                       HeadFlag{keys, n}),
+                                                       SplitHeadFlag{keys, vals}),
                       cum, n, (uint32_t)0, stream);
         uint32_t n_nodes = 0;
         SW_HIP(hipMemcpyAsync(&n_nodes, cum + (n - 1), 4, hipMemcpyDeviceToHost, stream));
@@ -934,15 +1171,13 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
     ix.kmers.alloc(n);
     ix.n_nodes = 0;
     if (n) {
-        DevArray<uint64_t> k0(n), k1(n);
-        DevArray<uint32_t> v0(n), v1(n);
-        hipLaunchKernelGGL(k_strided_copy, dim3(blocks_for(n)), dim3(TPB), 0, stream, d_occ_rows, 2u, 0u, n, k0.p);
-        hipLaunchKernelGGL(k_iota, dim3(blocks_for(n)), dim3(TPB), 0, stream, v0.p, n);
-        uint64_t *keys = k0.p, *keys_alt = k1.p;
-        uint32_t *vals = v0.p, *vals_alt = v1.p;
-        sort_pairs(keys, keys_alt, vals, vals_alt, n, 0, 64, stream);   // stable: ties keep source-rank order
-        uint32_t *cum = vals_alt;
-        inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), HeadFlag{keys, n}),
+        HashSort hs;
+        sort_hashes(d_occ_rows, 2u, n, false, stream, hs);   // stable: ties keep source-rank order
+        const uint32_t *keys = hs.key32;
+        const uint64_t *vals = hs.val;
+        uint32_t *cum = hs.spare;
+        inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
+                                                       SplitHeadFlag{keys, vals}),
                       cum, n, (uint32_t)0, stream);
         uint32_t n_nodes = 0;
         SW_HIP(hipMemcpyAsync(&n_nodes, cum + (n - 1), 4, hipMemcpyDeviceToHost, stream));

@@ -219,3 +219,41 @@ def test_routed_tuple_exchange_equals_single_batch(world):
             got = routed_tuple_exchange(paths, world, k, w, tar, packed)
             assert np.array_equal(got[0], ek) and np.array_equal(got[1], en), (world, k, w, packed)
             assert np.array_equal(got[2], ee) and np.array_equal(got[3], eo), (world, k, w, packed)
+
+
+@pytest.mark.parametrize("case", ["few_tops_random_lows", "pairs_sharing_top", "ascending_lows", "random", "one_top_long_runs"])
+def test_two_phase_hash_sort_repairs_shared_top_halves(case):
+    """The node sort orders by the top 32 bits first and repairs runs whose low halves are out of order.  The slice
+    builder takes arbitrary (hash, kmer) rows, so crafted hashes reach every branch of the repair: none needed,
+    a sparse set of runs, and more descents than the list holds (whole-array fallback)."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(case.encode()))
+    n = 300_000
+    if case == "few_tops_random_lows":            # ~n/2 descents: more than the list capacity
+        h = (rng.integers(0, 3, n, dtype=np.uint64) << np.uint64(32)) | rng.integers(0, 2**32, n, dtype=np.uint64)
+    elif case == "pairs_sharing_top":             # 2000 tops, two full hashes each, heavily repeated
+        tops = rng.integers(0, 2**32, 2000, dtype=np.uint64)
+        lows = rng.integers(0, 2**32, (2000, 2), dtype=np.uint64)
+        t = rng.integers(0, 2000, n)
+        h = (tops[t] << np.uint64(32)) | lows[t, rng.integers(0, 2, n)]
+    elif case == "ascending_lows":                # shared tops but already in order: nothing to repair
+        h = (np.uint64(7) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    elif case == "one_top_long_runs":             # one shared top, three hashes, 100k occurrences each, interleaved
+        h = (np.uint64(0xFFFFFFFF) << np.uint64(32)) | rng.permutation(np.repeat(np.array([5, 1, 3], np.uint64), n // 3))
+        # plus a sprinkling of unrelated hashes so that most runs are clean
+        h = np.concatenate([h, rng.integers(0, 2**63, n, dtype=np.uint64)])
+        h = h[rng.permutation(len(h))]
+    else:
+        h = rng.integers(0, 2**64, n, dtype=np.uint64)
+    n = len(h)
+    kmer = np.arange(n, dtype=np.uint64) | (np.uint64(0) << np.uint64(32))     # record 0, pos = arrival index
+    rows = torch.from_numpy(np.stack([h, kmer], axis=1).view(np.int64))
+    eng = swdist.HipEngine()
+    ix, ranks = eng.slice_build(rows.to(eng.gpu), 0, np.array([0, 1], np.uint32), None)
+    K, N, E = ix.export()
+    order = np.argsort(h, kind="stable")
+    assert np.array_equal(K["pos"], order.astype(np.uint32))
+    uh, start, cnt = np.unique(h[order], return_index=True, return_counts=True)
+    assert np.array_equal(N["hash"], uh) and np.array_equal(N["start"], start.astype(np.uint64))
+    assert np.array_equal(N["stop"], (start + cnt).astype(np.uint64))
+    assert np.array_equal(ranks.cpu().numpy().view(np.uint32), np.searchsorted(uh, h).astype(np.uint32))
