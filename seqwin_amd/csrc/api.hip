@@ -108,17 +108,11 @@ void require_device()
     }
 }
 
-// Upload a HostBatch; host.packed is released afterwards (the rest of the host tables are kept for
-// planning).
-void upload_batch(sw_batch &b)
+// Record tables of a HostBatch -> device.
+void upload_tables(sw_batch &b)
 {
     HostBatch &h = b.host;
     b.n_records = h.rec_len.size();
-    b.packed_words = h.packed.size();
-    b.d_packed.alloc(b.packed_words);
-    if (b.packed_words)
-        SW_HIP(hipMemcpy(b.d_packed.p, h.packed.data(), b.packed_words * 4, hipMemcpyHostToDevice));
-    std::vector<uint32_t>().swap(h.packed);
     b.d_rec_base.alloc(b.n_records);
     if (b.n_records)
         SW_HIP(hipMemcpy(b.d_rec_base.p, h.rec_base.data(), b.n_records * 8, hipMemcpyHostToDevice));
@@ -127,6 +121,123 @@ void upload_batch(sw_batch &b)
         for (uint32_t r = h.record_offsets[a]; r < h.record_offsets[a + 1]; ++r) rec_asm[r] = (uint32_t)a;
     b.d_rec_asm.alloc(b.n_records);
     if (b.n_records) SW_HIP(hipMemcpy(b.d_rec_asm.p, rec_asm.data(), b.n_records * 4, hipMemcpyHostToDevice));
+}
+
+// Upload a HostBatch whose packed chunks are still on the host; they are released afterwards (the rest of the
+// host tables are kept for planning).
+void upload_batch(sw_batch &b)
+{
+    HostBatch &h = b.host;
+    b.packed_words = h.packed_words32();
+    b.d_packed.alloc(b.packed_words);
+    const uint64_t n_words64 = h.chunk_word0.empty() ? 0 : h.chunk_word0.back();
+    SW_HIP(hipMemsetAsync(b.d_packed.p + 2 * n_words64, 0, 8 * 4, nullptr));   // the read slack
+    for (size_t c = 0; c < h.chunks.size(); ++c)    // every assembly goes straight to its place in the stream
+        if (!h.chunks[c].empty())
+            SW_HIP(hipMemcpyAsync(b.d_packed.p + 2 * h.chunk_word0[c], h.chunks[c].data(), h.chunks[c].size() * 8,
+                                  hipMemcpyHostToDevice, nullptr));
+    SW_HIP(hipStreamSynchronize(nullptr));
+    std::vector<std::vector<uint64_t>>().swap(h.chunks);
+    upload_tables(b);
+}
+
+// ---- pipelined upload: packed chunks go to the device while later files are still being parsed ------------
+// The ingest thread that owns the sink copies each finished chunk through a small ring of pinned slots
+// (a plain memcpy into pinned memory + an asynchronous DMA: ~20 GB/s from one thread on the target host, where
+// hipMemcpy from freshly written pageable memory manages ~2-3 GB/s because it pins pages on the fly).
+struct PinnedRing {
+    static constexpr size_t SLOT = 8u << 20;
+    static constexpr int SLOTS = 4;
+    char *base = nullptr;
+    hipEvent_t ev[SLOTS];
+    hipStream_t st = nullptr;
+    std::mutex in_use;
+};
+PinnedRing &pinned_ring(int device)
+{
+    // intentionally leaked, one per device (allocating pinned memory costs ~0.25 ms per MiB)
+    static std::mutex mu;
+    static std::map<int, PinnedRing *> *rings = new std::map<int, PinnedRing *>;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = rings->find(device);
+    if (it != rings->end()) return *it->second;
+    PinnedRing *r = new PinnedRing;
+    SW_HIP(hipHostMalloc((void **)&r->base, PinnedRing::SLOT * PinnedRing::SLOTS, hipHostMallocDefault));
+    SW_HIP(hipStreamCreateWithFlags(&r->st, hipStreamNonBlocking));
+    for (auto &e : r->ev) SW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    (*rings)[device] = r;
+    return *r;
+}
+
+struct DeviceSink : ChunkSink {
+    sw_batch &b;
+    PinnedRing &ring;
+    std::unique_lock<std::mutex> hold;
+    uint64_t cap32 = 0;     // capacity of b.d_packed in 32-bit words
+    uint64_t used32 = 0;    // words written so far (a prefix)
+    unsigned next_slot = 0;
+    DeviceSink(sw_batch &batch, PinnedRing &r) : b(batch), ring(r), hold(r.in_use) {}
+    void reserve(uint64_t words32)
+    {
+        if (words32 <= cap32) return;
+        const uint64_t ncap = std::max(words32, cap32 + cap32 / 2);
+        DevArray<uint32_t> bigger(ncap);
+        SW_HIP(hipStreamSynchronize(ring.st));
+        if (used32) SW_HIP(hipMemcpy(bigger.p, b.d_packed.p, used32 * 4, hipMemcpyDeviceToDevice));
+        b.d_packed = std::move(bigger);
+        cap32 = ncap;
+    }
+    void begin(uint64_t expected_words64) override { reserve(expected_words64 * 2 + 8); }
+    void chunk(const uint64_t *data, uint64_t n_words64, uint64_t word_off) override
+    {
+        reserve((word_off + n_words64) * 2 + 8);
+        const char *src = (const char *)data;
+        size_t left = n_words64 * 8;
+        char *dst = (char *)(b.d_packed.p + 2 * word_off);
+        while (left) {
+            const size_t n = std::min(left, PinnedRing::SLOT);
+            const unsigned s = next_slot++ % PinnedRing::SLOTS;
+            SW_HIP(hipEventSynchronize(ring.ev[s]));   // the slot's previous copy has left the host
+            memcpy(ring.base + s * PinnedRing::SLOT, src, n);
+            SW_HIP(hipMemcpyAsync(dst, ring.base + s * PinnedRing::SLOT, n, hipMemcpyHostToDevice, ring.st));
+            SW_HIP(hipEventRecord(ring.ev[s], ring.st));
+            src += n;
+            dst += n;
+            left -= n;
+        }
+        used32 = (word_off + n_words64) * 2;
+    }
+    void finish()
+    {
+        const uint64_t n_words64 = b.host.chunk_word0.empty() ? 0 : b.host.chunk_word0.back();
+        reserve(n_words64 * 2 + 8);
+        SW_HIP(hipMemsetAsync(b.d_packed.p + 2 * n_words64, 0, 8 * 4, ring.st));   // the read slack
+        SW_HIP(hipStreamSynchronize(ring.st));
+        b.packed_words = n_words64 * 2 + 8;
+    }
+    ~DeviceSink() { (void)hipStreamSynchronize(ring.st); }   // nothing may still read the ring / write the buffer
+};
+
+// FASTA files -> device-resident batch
+void ingest_to_device(const char *const *paths, size_t n_paths, uint64_t n_cpu, sw_batch &b)
+{
+    if (n_paths >= 2 && !getenv("SEQWIN_AMD_NO_STREAM_UPLOAD")) {
+        const auto t0 = std::chrono::steady_clock::now();
+        DeviceSink sink(b, pinned_ring(b.device));
+        const auto t1 = std::chrono::steady_clock::now();
+        ingest_fasta(paths, n_paths, n_cpu, b.host, &sink);
+        const auto t2 = std::chrono::steady_clock::now();
+        sink.finish();
+        upload_tables(b);
+        if (getenv("SEQWIN_AMD_DEBUG_TIMING"))
+            fprintf(stderr, "[seqwin_amd] ingest_to_device: ring %.1f ms, ingest %.1f ms, finish + tables %.1f ms\n",
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                    std::chrono::duration<double, std::milli>(t2 - t1).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
+    } else {
+        ingest_fasta(paths, n_paths, n_cpu, b.host);
+        upload_batch(b);
+    }
 }
 
 __host__ __device__ inline uint64_t mix64(uint64_t x)
@@ -269,8 +380,7 @@ int sw_batch_from_fasta(const char *const *assembly_paths, size_t n_assemblies, 
         require_device();
         std::unique_ptr<sw_batch> b(new sw_batch);
         SW_HIP(hipGetDevice(&b->device));
-        ingest_fasta(assembly_paths, n_assemblies, n_cpu, b->host);
-        upload_batch(*b);
+        ingest_to_device(assembly_paths, n_assemblies, n_cpu, *b);
         *out = b.release();
     });
 }
@@ -415,7 +525,7 @@ int sw_hostbatch_record(const sw_hostbatch *hb, uint64_t record_idx, char *seq_o
         for (uint32_t q = h.rec_run_off[record_idx]; q < h.rec_run_off[record_idx + 1]; ++q)
             for (uint64_t p = h.run_pos[q]; p < (uint64_t)h.run_pos[q] + h.run_len[q]; ++p) {
                 const uint64_t b = b0 + p;
-                seq_out[p] = "ACGT"[(h.packed[b / 16] >> (2 * (b % 16))) & 3u];
+                seq_out[p] = "ACGT"[(h.word32(b / 16) >> (2 * (b % 16))) & 3u];
             }
     });
 }
@@ -705,10 +815,9 @@ int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t km
         const auto t0 = now();
         std::unique_ptr<sw_batch> b(new sw_batch);
         SW_HIP(hipGetDevice(&b->device));
-        ingest_fasta(assembly_paths, n_assemblies, n_cpu, b->host);
+        ingest_to_device(assembly_paths, n_assemblies, n_cpu, *b);
         const auto t1 = now();
-        upload_batch(*b);
-        const auto t2 = now();
+        const auto t2 = t1;
         std::unique_ptr<sw_graph> g(new sw_graph);
         do_index_build(*b, kmerlen, windowsize, nullptr, 0, 0, g->g.ix);
         const auto t3 = now();
@@ -718,7 +827,7 @@ int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t km
         g->g.total_bp = b->host.total_bp;
         const auto t4 = now();
         if (dbg)
-            fprintf(stderr, "[seqwin_amd] sw_build: ingest %.1f ms, upload %.1f ms, device %.1f ms, rest %.1f ms (%.1f Mbp)\n",
+            fprintf(stderr, "[seqwin_amd] sw_build: ingest+upload %.1f ms (+%.1f), device %.1f ms, rest %.1f ms (%.1f Mbp)\n",
                     ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), b->host.total_bp / 1e6);
         *out = g.release();
     });
@@ -743,11 +852,16 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
     return guarded([&] {
         const GraphHost &h = g->g;
         const sw_index &ix = h.ix;   // D2H straight into the caller's (numpy) buffers
+        const auto t0 = std::chrono::steady_clock::now();
         if (ix.n_kmers) SW_HIP(hipMemcpy(kmers, ix.kmers.p, ix.n_kmers * sizeof(sw_kmer), hipMemcpyDeviceToHost));
         if (ix.n_nodes) SW_HIP(hipMemcpy(nodes, ix.nodes.p, ix.n_nodes * sizeof(sw_node), hipMemcpyDeviceToHost));
         if (ix.n_edges) SW_HIP(hipMemcpy(edges, ix.edges.p, ix.n_edges * sizeof(sw_edge), hipMemcpyDeviceToHost));
         memcpy(record_offsets, h.record_offsets.data(), h.record_offsets.size() * 4);
         if (!h.ids_blob.empty()) memcpy(ids_blob, h.ids_blob.data(), h.ids_blob.size());
+        if (getenv("SEQWIN_AMD_DEBUG_TIMING"))
+            fprintf(stderr, "[seqwin_amd] sw_graph_export: %.1f ms for %.1f MB\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                    (ix.n_kmers * sizeof(sw_kmer) + ix.n_nodes * sizeof(sw_node) + ix.n_edges * sizeof(sw_edge)) / 1e6);
     });
 }
 

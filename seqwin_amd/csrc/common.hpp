@@ -8,6 +8,7 @@
 #include <map>
 #include <mutex>
 #include <stdexcept>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -63,11 +64,31 @@ struct HostBatch {
     std::vector<uint64_t> rec_base;         // [R] offset of the record's first base in the packed stream
     std::vector<uint32_t> rec_run_off;      // [R + 1] index of the record's first valid run
     std::vector<uint32_t> run_pos, run_len; // maximal runs of valid bases, in (record, pos) order
-    std::vector<uint32_t> packed;           // 2-bit stream
+    // 2-bit stream: one chunk per assembly, never concatenated on the host.  When the ingest streams to a ChunkSink
+    // the chunks are gone by the time it returns (chunks[i] empty); chunk_word0 always describes the layout.
+    std::vector<std::vector<uint64_t>> chunks;   // [n_assemblies]
+    std::vector<uint64_t> chunk_word0;           // [n_assemblies + 1] index of the chunk's first 64-bit word in the stream
+    uint64_t packed_words32() const { return (chunk_word0.empty() ? 0 : chunk_word0.back()) * 2 + 8; }   // + read slack
+    uint32_t word32(uint64_t i) const            // test / debug accessor (non-streamed batches)
+    {
+        const uint64_t w = i >> 1;
+        const size_t c = std::upper_bound(chunk_word0.begin(), chunk_word0.end(), w) - chunk_word0.begin() - 1;
+        if (c >= chunks.size() || w - chunk_word0[c] >= chunks[c].size()) return 0;
+        return (uint32_t)(chunks[c][w - chunk_word0[c]] >> (32 * (i & 1)));
+    }
 };
 
+// Receives the packed chunks in assembly order while later files are still being parsed (pipelined upload).
+struct ChunkSink {
+    virtual void begin(uint64_t expected_words64) = 0;                                   // estimate, before the first chunk
+    virtual void chunk(const uint64_t *data, uint64_t n_words64, uint64_t word_off) = 0; // word_off: place in the stream
+    virtual ~ChunkSink() {}
+};
+
+
+
 // host_ingest.cpp
-void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, HostBatch &out);
+void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, HostBatch &out, ChunkSink *sink = nullptr);
 void check_kw(uint64_t k, uint64_t w);
 
 }  // namespace sw

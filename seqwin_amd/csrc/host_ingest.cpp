@@ -10,11 +10,21 @@
 // which is all the hash ever looks at: SEED_TAB, cpp/vendor/btllib/hashing_internals.hpp:136-169).
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <chrono>
 #include <cstdlib>
 #include <memory>
 #include <thread>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "common.hpp"
 
@@ -96,27 +106,29 @@ void slurp(const std::string &path, std::vector<char> &buf)
 }
 
 // One assembly, parsed and packed by one worker.
-struct Assembly {
+struct alignas(128) Assembly {   // neighbours are filled by different workers: no shared cache lines
     std::vector<uint32_t> rec_len;
     std::vector<uint64_t> rec_base;  // local (within this assembly's packed stream)
     std::vector<uint32_t> rec_run_off;
     std::vector<uint32_t> run_pos, run_len;
-    std::vector<uint64_t> packed;  // 32 bases per word
+    std::vector<uint64_t> packed;    // 32 bases per word; private to the worker until the assembly is published
+    uint64_t n_words = 0;            // packed.size() at publication (packed itself may have gone to the sink)
     std::string ids;
     uint64_t total_bp = 0;
 };
 
 struct Packer {
     Assembly &a;
+    std::vector<uint64_t> &words;   // a local of the parsing function while packing (moved into a.packed at the end)
     uint64_t acc = 0;
     unsigned nacc = 0;     // bases in acc
     uint64_t len = 0;      // bases in the current record
     int64_t run_start = -1;
-    explicit Packer(Assembly &as) : a(as) {}
+    Packer(Assembly &as, std::vector<uint64_t> &w) : a(as), words(w) {}
 
     void open_record()
     {
-        a.rec_base.push_back((uint64_t)a.packed.size() * 32);
+        a.rec_base.push_back((uint64_t)words.size() * 32);
         a.rec_run_off.push_back((uint32_t)a.run_pos.size());
         acc = 0;
         nacc = 0;
@@ -129,12 +141,52 @@ struct Packer {
             a.run_pos.push_back((uint32_t)run_start);
             a.run_len.push_back((uint32_t)(len - (uint64_t)run_start));
         }
-        if (nacc) a.packed.push_back(acc);
+        if (nacc) words.push_back(acc);
         if (len > UINT32_MAX)  // build.cpp:143-147
             raise(SW_ERR_RUNTIME, "Sequence length exceeds uint32 range for record %s in assembly %s",
                   id.c_str(), path.c_str());
         a.rec_len.push_back((uint32_t)len);
         a.total_bp += len;
+    }
+    // nb <= 32 bases at once: codes = 2 bits per base (zero above 2 nb bits and at invalid bases), valid = 1 bit per base
+    inline void push_block(uint64_t codes, unsigned nb, uint32_t valid)
+    {
+        const uint32_t full = nb == 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+        valid &= full;
+        if (valid == full) {
+            if (run_start < 0) run_start = (int64_t)len;
+        } else {
+            unsigned pos = 0;
+            while (pos < nb) {
+                if (run_start < 0) {
+                    const uint32_t t = valid >> pos;
+                    if (!t) break;
+                    pos += (unsigned)__builtin_ctz(t);
+                    run_start = (int64_t)(len + pos);
+                } else {
+                    const uint32_t t = (~valid & full) >> pos;
+                    if (!t) break;
+                    pos += (unsigned)__builtin_ctz(t);
+                    a.run_pos.push_back((uint32_t)run_start);
+                    a.run_len.push_back((uint32_t)(len + pos - (uint64_t)run_start));
+                    run_start = -1;
+                }
+            }
+        }
+        len += nb;
+        const unsigned total = nacc + nb;
+        if (nacc == 0) {
+            acc = codes;
+        } else {
+            acc |= codes << (2 * nacc);
+        }
+        if (total >= 32) {
+            words.push_back(acc);
+            acc = nacc ? (codes >> (2 * (32 - nacc))) : 0;
+            nacc = total - 32;
+        } else {
+            nacc = total;
+        }
     }
     inline void push(unsigned code)
     {
@@ -148,22 +200,122 @@ struct Packer {
         }
         ++len;
         if (++nacc == 32) {
-            a.packed.push_back(acc);
+            words.push_back(acc);
             acc = 0;
             nacc = 0;
         }
     }
 };
 
-void parse_assembly(const std::string &path, std::vector<char> &buf, Assembly &a)
+#if defined(__x86_64__)
+#define SW_HAVE_AVX2_PACKER 1
+// 32 sequence bytes -> 2-bit codes, validity mask, and a mask of bytes <= 0x20 (whitespace / control: the caller
+// falls back to the byte loop for such a chunk).  A/C/G/T/U in either case are told apart by their low nibble.
+__attribute__((target("avx2,bmi2"))) inline void classify32(const char *q, uint64_t &codes, uint32_t &valid, uint32_t &special)
 {
-    slurp(path, buf);
-    const char *p = buf.data();
-    const char *end = p + buf.size();
-    Packer pk(a);
+    const __m256i v = _mm256_loadu_si256((const __m256i *)q);
+    const __m256i lo = _mm256_and_si256(v, _mm256_set1_epi8(0x0F));
+    // low nibble -> expected upper-case letter (0xFF: none) and 2-bit code
+    const __m256i exp_lut = _mm256_setr_epi8((char)0xFF, 'A', (char)0xFF, 'C', 'T', 'U', (char)0xFF, 'G', (char)0xFF, (char)0xFF,
+                                             (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF,
+                                             (char)0xFF, 'A', (char)0xFF, 'C', 'T', 'U', (char)0xFF, 'G', (char)0xFF, (char)0xFF,
+                                             (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF);
+    const __m256i code_lut = _mm256_setr_epi8(0, 0, 0, 1, 3, 3, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 3, 3, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i up = _mm256_and_si256(v, _mm256_set1_epi8((char)0xDF));
+    const __m256i ok = _mm256_cmpeq_epi8(up, _mm256_shuffle_epi8(exp_lut, lo));
+    const __m256i code = _mm256_and_si256(_mm256_shuffle_epi8(code_lut, lo), ok);
+    valid = (uint32_t)_mm256_movemask_epi8(ok);
+    const __m256i c20 = _mm256_set1_epi8(0x20);
+    special = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_max_epu8(v, c20), c20));
+    const uint64_t m = 0x0303030303030303ull;
+    codes = _pext_u64((uint64_t)_mm256_extract_epi64(code, 0), m) | (_pext_u64((uint64_t)_mm256_extract_epi64(code, 1), m) << 16) |
+            (_pext_u64((uint64_t)_mm256_extract_epi64(code, 2), m) << 32) | (_pext_u64((uint64_t)_mm256_extract_epi64(code, 3), m) << 48);
+}
+
+// One sequence line [ls, le).  Returns false when a chunk holds whitespace / control bytes at `*stop` (byte loop takes over).
+__attribute__((target("avx2,bmi2"))) const char *pack_line_avx2(Packer &pk, const char *ls, const char *le)
+{
+    const char *q = ls;
+    uint64_t codes;
+    uint32_t valid, special;
+    while (le - q >= 32) {
+        classify32(q, codes, valid, special);
+        if (special) return q;
+        pk.push_block(codes, 32, valid);
+        q += 32;
+    }
+    const unsigned tail = (unsigned)(le - q);
+    if (tail) {
+        alignas(32) char tmp[32];
+        memset(tmp, 'A', 32);
+        memcpy(tmp, q, tail);
+        classify32(tmp, codes, valid, special);
+        if (special) return q;
+        pk.push_block(tail == 32 ? codes : (codes & ((1ull << (2 * tail)) - 1ull)), tail, valid);
+        q = le;
+    }
+    return q;
+}
+
+bool have_avx2_packer()
+{
+    static const bool ok = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("SEQWIN_AMD_SCALAR_INGEST");
+    return ok;
+}
+#endif
+
+// Bytes of one input file: read into the worker's reusable buffer, or (single worker, plain regular file) mapped.
+struct FileBytes {
+    const char *p = nullptr;
+    size_t n = 0;
+    void *map = nullptr;
+    // use_mmap: only with a single worker -- mapping and unmapping files from many threads of one process
+    // serialises on the address-space lock and its TLB shootdowns and ends up slower than the copy it saves
+    FileBytes(const std::string &path, std::vector<char> &buf, bool use_mmap)
+    {
+        if (use_mmap && !ends_with(path, ".gz")) {
+            const int fd = open(path.c_str(), O_RDONLY);
+            if (fd < 0) raise(SW_ERR_RUNTIME, "Unable to open FASTA: %s", path.c_str());   // fasta_reader.cpp:100-102
+            struct stat st;
+            if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
+                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+                    map = m;
+                    p = (const char *)m;
+                    n = (size_t)st.st_size;
+                }
+            }
+            close(fd);
+            if (map) return;
+        }
+        slurp(path, buf);
+        p = buf.data();
+        n = buf.size();
+    }
+    ~FileBytes()
+    {
+        if (map) munmap(map, n);
+    }
+    FileBytes(const FileBytes &) = delete;
+    FileBytes &operator=(const FileBytes &) = delete;
+};
+
+void parse_assembly(const std::string &path, std::vector<char> &buf, bool use_mmap, std::vector<uint64_t> &&storage,
+                    Assembly &a)
+{
+    const FileBytes file(path, buf, use_mmap);
+    const char *p = file.p;
+    const char *end = p + file.n;
+    std::vector<uint64_t> words(std::move(storage));
+    words.clear();
+    Packer pk(a, words);
     bool have = false;
     std::string cur_id;
-    a.packed.reserve(buf.size() / 32 + 16);
+    words.reserve(file.n / 32 + 64);
+#ifdef SW_HAVE_AVX2_PACKER
+    const bool simd = have_avx2_packer();
+#endif
 
     while (p < end) {
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
@@ -189,7 +341,11 @@ void parse_assembly(const std::string &path, std::vector<char> &buf, Assembly &a
             continue;
         }
         if (!have) raise(SW_ERR_RUNTIME, "Invalid FASTA: sequence encountered before header");  // :69-71
-        for (const char *q = ls; q < le; ++q) {  // :73-88
+        const char *q = ls;
+#ifdef SW_HAVE_AVX2_PACKER
+        if (simd) q = pack_line_avx2(pk, ls, le);   // stops early at a chunk with whitespace / control bytes
+#endif
+        for (; q < le; ++q) {  // :73-88
             const unsigned code = kChar.t[(unsigned char)*q];
             if (code == 5) continue;
             if (code == 6)
@@ -200,11 +356,33 @@ void parse_assembly(const std::string &path, std::vector<char> &buf, Assembly &a
     }
     if (have) pk.close_record(path, cur_id);
     a.rec_run_off.push_back((uint32_t)a.run_pos.size());
+    a.packed = std::move(words);
+    a.n_words = a.packed.size();
 }
+
+// Recycles the packed-word buffers of assemblies that have been handed to the sink, so that a streaming ingest
+// keeps only ~n_workers buffers alive (and does not unmap / fault in fresh memory for every file).
+struct BufferPool {
+    std::mutex mu;
+    std::vector<std::vector<uint64_t>> free_list;
+    std::vector<uint64_t> get()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (free_list.empty()) return {};
+        std::vector<uint64_t> v = std::move(free_list.back());
+        free_list.pop_back();
+        return v;
+    }
+    void put(std::vector<uint64_t> &&v)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        free_list.push_back(std::move(v));
+    }
+};
 
 }  // namespace
 
-void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, HostBatch &out)
+void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, HostBatch &out, ChunkSink *sink)
 {
     if (n_paths > UINT32_MAX)  // build.cpp:337-339
         raise(SW_ERR_RUNTIME, "Number of input assemblies exceeds uint32 range");
@@ -213,43 +391,106 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
     size_t n_workers = std::max<uint64_t>(1, n_cpu);  // build.cpp:342-347
     if (n_paths > 0) n_workers = std::min(n_workers, n_paths);
 
+    const bool timing = getenv("SEQWIN_AMD_DEBUG_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    out = HostBatch();
+    const bool threaded = (n_workers > 1 && n_paths > 1) || (sink && n_paths > 0);
+    const bool use_mmap = !threaded && !getenv("SEQWIN_AMD_NO_MMAP");
+    BufferPool pool;
     std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
+    std::mutex done_mu;
+    std::condition_variable done_cv;
+    std::vector<char> done(n_paths, 0);
     auto worker = [&]() {
         std::vector<char> buf;
         for (;;) {
             size_t i = next.fetch_add(1);
             if (i >= n_paths) break;
             try {
-                parse_assembly(paths[i], buf, asms[i]);
+                parse_assembly(paths[i], buf, use_mmap, pool.get(), asms[i]);
             } catch (const Error &e) {
                 errors[i].reset(new Error(e));
             } catch (const std::exception &e) {
                 errors[i].reset(new Error(SW_ERR_RUNTIME, e.what()));
             }
+            if (errors[i]) failed.store(true);
+            if (threaded) {
+                {
+                    std::lock_guard<std::mutex> lock(done_mu);
+                    done[i] = 1;
+                }
+                done_cv.notify_all();
+            }
         }
     };
-    if (n_workers <= 1 || n_paths <= 1) {
+    out.chunks.resize(n_paths);
+    out.chunk_word0.assign(n_paths + 1, 0);
+    if (!threaded) {
         worker();
     } else {
         std::vector<std::thread> th;
         for (size_t t = 0; t < n_workers; ++t) th.emplace_back(worker);
-        for (auto &t : th) t.join();
+        if (sink) {
+            // this thread hands the finished assemblies to the sink in order while the workers go on parsing
+            uint64_t est_bytes = 0;
+            for (size_t i = 0; i < n_paths; ++i) {
+                struct stat st;
+                if (stat(paths[i], &st) == 0 && S_ISREG(st.st_mode))
+                    est_bytes += (uint64_t)st.st_size * (ends_with(paths[i], ".gz") ? 5 : 1);
+            }
+            bool sink_ok = true;
+            std::unique_ptr<Error> sink_error;
+            try {
+                sink->begin(est_bytes / 32 + est_bytes / 2048 + 1024 * n_paths);
+            } catch (const Error &e) {
+                sink_ok = false;
+                sink_error.reset(new Error(e));
+            }
+            uint64_t word_off = 0;
+            double wait_ms = 0;
+            for (size_t i = 0; i < n_paths; ++i) {
+                {
+                    const auto w0 = std::chrono::steady_clock::now();
+                    std::unique_lock<std::mutex> lock(done_mu);
+                    done_cv.wait(lock, [&] { return done[i] != 0; });
+                    wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+                }
+                if (failed.load() || !sink_ok) continue;   // keep draining the flags; the error is raised below
+                out.chunk_word0[i] = word_off;
+                try {
+                    if (!asms[i].packed.empty()) sink->chunk(asms[i].packed.data(), asms[i].packed.size(), word_off);
+                } catch (const Error &e) {
+                    sink_ok = false;
+                    sink_error.reset(new Error(e));
+                    continue;
+                }
+                word_off += asms[i].packed.size();
+                pool.put(std::move(asms[i].packed));
+                asms[i].packed = std::vector<uint64_t>();
+            }
+            out.chunk_word0[n_paths] = word_off;
+            if (timing) fprintf(stderr, "[seqwin_amd] ingest: sink thread waited %.1f ms for the parsers\n", wait_ms);
+            for (auto &t : th) t.join();
+            if (sink_error) throw *sink_error;
+        } else {
+            for (auto &t : th) t.join();
+        }
     }
     for (size_t i = 0; i < n_paths; ++i)
         if (errors[i]) throw *errors[i];
+    const auto t_parsed = std::chrono::steady_clock::now();
 
-    // concatenate in assembly order (= global record order, build.cpp:135,169,191)
-    out = HostBatch();
+    // tables in assembly order (= global record order, build.cpp:135,169,191); the packed words stay in their per-assembly chunks
     out.n_assemblies = n_paths;
     out.record_offsets.assign(n_paths + 1, 0);
-    uint64_t n_rec = 0, n_runs = 0, n_words = 0;
+    uint64_t n_rec = 0, n_runs = 0;
     for (size_t i = 0; i < n_paths; ++i) {
         n_rec += asms[i].rec_len.size();
         if (n_rec > UINT32_MAX)  // build.cpp:136-140
             raise(SW_ERR_RUNTIME, "Total number of FASTA records exceeds uint32 range");
         out.record_offsets[i + 1] = (uint32_t)n_rec;
         n_runs += asms[i].run_pos.size();
-        n_words += asms[i].packed.size();
     }
     if (n_runs > UINT32_MAX) raise(SW_ERR_RUNTIME, "Total number of valid-base runs exceeds uint32 range");
     out.rec_len.reserve(n_rec);
@@ -257,7 +498,6 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
     out.rec_run_off.reserve(n_rec + 1);
     out.run_pos.reserve(n_runs);
     out.run_len.reserve(n_runs);
-    out.packed.resize(n_words * 2 + 8, 0);  // + slack so the kernel's word reads never leave the buffer
     uint64_t word_off = 0;
     for (size_t i = 0; i < n_paths; ++i) {
         Assembly &a = asms[i];
@@ -269,12 +509,17 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
         }
         out.run_pos.insert(out.run_pos.end(), a.run_pos.begin(), a.run_pos.end());
         out.run_len.insert(out.run_len.end(), a.run_len.begin(), a.run_len.end());
-        if (!a.packed.empty()) memcpy(out.packed.data() + word_off * 2, a.packed.data(), a.packed.size() * 8);
-        word_off += a.packed.size();
+        out.chunk_word0[i] = word_off;
+        word_off += a.n_words;
+        out.chunks[i] = std::move(a.packed);   // empty when it has been streamed to the sink
         out.ids_blob.append(a.ids);
         out.total_bp += a.total_bp;
-        Assembly().packed.swap(a.packed);
     }
+    out.chunk_word0[n_paths] = word_off;
+    if (timing)
+        fprintf(stderr, "[seqwin_amd] ingest: %zu files, %zu workers: parse %.1f ms, tables %.1f ms\n", n_paths, n_workers,
+                std::chrono::duration<double, std::milli>(t_parsed - t_begin).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_parsed).count());
     out.rec_run_off.push_back((uint32_t)out.run_pos.size());
 }
 

@@ -143,3 +143,50 @@ def test_host_ingest_errors(tmp_path):
     assert _host_ingest([])[0].tolist() == [0]
     empty = tmp_path / "empty.fa"; empty.write_text("")
     assert _host_ingest([empty])[0].tolist() == [0, 0]
+
+
+def test_host_ingest_random_bytes_match_oracle_reader(tmp_path):
+    """The SIMD packer (32 bytes per step, low-nibble classification) against the oracle's reader on adversarial
+    content: every byte value except the refused control bytes, blanks inside lines, CRLF, lines of every length
+    around the 32-byte step, records shorter than a step, '>' inside sequence lines."""
+    rng = np.random.default_rng(7)
+    refused = {1, 3, 4, 5, 7}
+    any_byte = np.array([b for b in range(1, 256) if b not in refused and b not in (10, 62)], np.uint8)   # (the oracle wrapper returns NUL-terminated strings)
+    files = []
+    for f in range(12):
+        parts = []
+        for r in range(int(rng.integers(1, 6))):
+            parts.append(b">rec%d some description\n" % r)
+            n = int(rng.choice([0, 1, 31, 32, 33, 63, 64, 65, 500, 5000, 40000]))
+            style = rng.random()
+            if style < 0.5:
+                seq = rng.choice(np.frombuffer(b"ACGTacgtUuNn", np.uint8), n)
+            elif style < 0.8:
+                seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
+                k = max(1, n // 200)
+                seq[rng.integers(0, max(n, 1), k) % max(n, 1)] = rng.choice(any_byte, k) if n else []
+            else:
+                seq = rng.choice(any_byte, n)
+            width = int(rng.choice([1, 7, 31, 32, 33, 60, 64, 80, 100, 100000]))
+            eol = [b"\n", b"\r\n", b" \n", b"\t\r\n"][int(rng.integers(0, 4))]
+            raw = seq.tobytes()
+            for i in range(0, len(raw), width):
+                line = raw[i:i + width]
+                if line[:1] == b">":          # would start a new record: keep it a sequence line
+                    line = b" " + line
+                parts.append(line + eol)
+            if rng.random() < 0.3:
+                parts.append(b"\n   \n")
+        p = tmp_path / f"rnd{f}.fa"
+        p.write_bytes(b"".join(parts))
+        files.append(p)
+    for n_cpu in (1, 4):
+        offs, ids, seqs, bp = _host_ingest(files, n_cpu)
+        exp_ids, exp_seqs, exp_offs = [], [], [0]
+        for f in files:
+            recs = oracle.read_fasta(f)
+            exp_ids += [r[0] for r in recs]; exp_seqs += [_canon(r[1]) for r in recs]
+            exp_offs.append(len(exp_ids))
+        assert ids == exp_ids and offs.tolist() == exp_offs
+        assert seqs == exp_seqs
+        assert bp == sum(len(s) for s in exp_seqs)
