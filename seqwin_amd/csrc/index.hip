@@ -92,7 +92,7 @@ struct HeadFlag {
 // ---- tuple ordering -----------------------------------------------------------------------------
 __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t *__restrict__ stage_kmer,
                         const uint32_t *__restrict__ tile_count, const uint64_t *__restrict__ tile_offset,
-                        const uint64_t *__restrict__ dst_off, uint32_t n_tiles, uint64_t *__restrict__ hash,
+                        const uint64_t *__restrict__ dst_off, uint32_t n_tiles, uint64_t mult, uint64_t *__restrict__ hash,
                         uint64_t *__restrict__ kmer, uint32_t *__restrict__ key32, uint64_t *__restrict__ val)
 {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -101,7 +101,8 @@ __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t 
     const uint32_t c = tile_count[wave];
     const uint64_t src = tile_offset[wave], dst = dst_off[wave];
     for (uint32_t i = lane; i < c; i += 64) {
-        const uint64_t h = stage_hash[src + i];
+        uint64_t h = stage_hash[src + i] * mult;   // staged: canonical hash; out_hash = extend_hashes
+        h ^= h >> 27;                              // (hashing_internals.hpp:89-103)
         hash[dst + i] = h;
         kmer[dst + i] = stage_kmer[src + i];
         key32[dst + i] = (uint32_t)(h >> 32);   // first-phase sort key and payload (sort_hashes)
@@ -827,7 +828,7 @@ void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, Ord
                   (uint64_t)0, stream);
     const uint64_t threads = (uint64_t)plan.n_tiles * 64;
     hipLaunchKernelGGL(k_order, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
-                       sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, out.hash.p, out.kmer.p, out.key32.p,
+                       sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult, out.hash.p, out.kmer.p, out.key32.p,
                        out.val.p);
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));  // dst_off is released on return

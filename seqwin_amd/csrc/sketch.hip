@@ -366,9 +366,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
                 if (A.seg_idx[mid] <= g) a = mid; else b = mid;
             }
             const uint32_t pos = A.seg_pos[a] + (g - A.seg_idx[a]);
-            uint64_t oh = H[e] * A.mult;  // extend_hashes, hashing_internals.hpp:89-103
-            oh ^= oh >> 27;
-            A.stage_hash[o] = oh;
+            A.stage_hash[o] = H[e];   // canonical hash; k_order applies extend_hashes (hashing_internals.hpp:89-103)
             A.stage_kmer[o] = (uint64_t)pos | ((uint64_t)rec << 32);
             ++o;
         }
@@ -533,8 +531,34 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
                 te = tn;
             }
         }
-        idx = next_in() | (next_out() << 2);
-        uint64_t lf = LUT[2 * idx], lr = LUT[2 * idx + 1];     // entry of roll 1
+        // Rolls 1..L-1 of this lane take in-base (k + j - 1) and out-base (j - 1) of the run.  Both streams are
+        // re-aligned once to the lane's first base (funnel shifts by the wave-uniform phases), so that the base
+        // pair of every roll is a compile-time bit field: no per-step refill test, 4 VALU per LUT index.
+        uint32_t ob[L / 16], ib[L / 16];
+        {
+            const uint32_t so = 2u * ph;
+            const uint32_t pk = ph + k;
+            const uint32_t *wi = wp + (pk >> 4);
+            const uint32_t si = 2u * (pk & 15u);
+#pragma unroll
+            for (int q = 0; q < L / 16; ++q) {
+                ob[q] = __builtin_amdgcn_alignbit(wp[q + 1], wp[q], so);
+                ib[q] = __builtin_amdgcn_alignbit(wi[q + 1], wi[q], si);
+            }
+        }
+        auto lut_off = [&](int r) -> uint32_t {          // roll r (1-based): LUT row ((out << 2) | in), 16 B per row
+            const int b = r - 1, q = b >> 4, sh = 2 * (b & 15);
+            const uint32_t i4 = (sh >= 4 ? (ib[q] >> (sh - 4)) : (ib[q] << (4 - sh))) & 0x30u;
+            const uint32_t o6 = (sh >= 6 ? (ob[q] >> (sh - 6)) : (ob[q] << (6 - sh))) & 0xC0u;
+            return i4 | o6;
+        };
+        const unsigned char *LUTb = reinterpret_cast<const unsigned char *>(LUT);
+        uint64_t lf, lr;
+        {
+            const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(LUTb + lut_off(1));
+            lf = e.x;
+            lr = e.y;
+        }
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             uint32_t slo = flo + rlo;               // canonical(): 64-bit add with explicit carry
@@ -544,15 +568,14 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
             if (j + 1 < L) {
                 uint64_t nlf = 0, nlr = 0;
                 if (j + 2 < L) {                    // LUT entry of the roll after next, issued before this roll's math
-                    idx = next_in() | (next_out() << 2);
-                    nlf = LUT[2 * idx];
-                    nlr = LUT[2 * idx + 1];
+                    const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(LUTb + lut_off(j + 2));
+                    nlf = e.x;
+                    nlr = e.y;
                 }
                 apply(lf, lr);
                 lf = nlf;
                 lr = nlr;
                 // pin the rolling state here: exactly one LUT read in flight, and the arithmetic is not sunk
-                // below the (uniform) refill branches of later steps (which made the compiler spill LUT rows)
                 asm volatile("" : "+v"(flo), "+v"(fhi), "+v"(rlo), "+v"(rhi) : : "memory");
             }
         }
@@ -736,10 +759,9 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             if ((bits >> j) & 1u) {
-                asm volatile("" ::: "memory");   // keep this a real (rarely taken) branch: no speculative 64-bit multiplies
-                uint64_t oh = h[j] * A.mult;   // extend_hashes, hashing_internals.hpp:89-103
-                oh ^= oh >> 27;
-                A.stage_hash[o] = oh;
+                // the canonical hash is staged; out_hash = extend_hashes(h) (hashing_internals.hpp:89-103: one 64-bit
+                // multiply + xor-shift) is applied by k_order, which touches every tuple anyway and is HBM-bound
+                A.stage_hash[o] = h[j];
                 A.stage_kmer[o] = kmer0 + (uint32_t)j;
                 ++o;
             }
