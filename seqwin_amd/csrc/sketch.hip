@@ -467,20 +467,11 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         const uint32_t *wp = STG + tid * (L / 16);
         uint32_t icur = wp[0] >> (2u * ph), inxt = wp[1], inl = 16u - ph;
         const uint32_t *iwp = wp + 2;
-        uint32_t ocur = icur, onxt = inxt, onl = inl;
-        const uint32_t *owp = iwp;
         auto next_in = [&]() -> uint32_t {
             if (inl == 0) { icur = inxt; inxt = *iwp++; inl = 16; }
             const uint32_t c = icur & 3u;
             icur >>= 2;
             --inl;
-            return c;
-        };
-        auto next_out = [&]() -> uint32_t {
-            if (onl == 0) { ocur = onxt; onxt = *owp++; onl = 16; }
-            const uint32_t c = ocur & 3u;
-            ocur >>= 2;
-            --onl;
             return c;
         };
         uint32_t flo = 0, fhi = 0, rlo = 0, rhi = 0;
