@@ -647,36 +647,44 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         uint32_t pre_e = e0, lc_e = 0;
         uint32_t prev_arg = 0xFFFFFFFFu;
         const uint32_t xb = e0 - (w - 1);   // x of step j is xb + j (mod 2^32; only used when j >= j0)
+        const uint64_t *recA = REC + rxA * RC;          // suffix records of run rxA; run rxA + 1 follows
+        uint32_t lc_d = 0;                               // lc_e - xb: lc leaves the window of step j when lc_d < j
         auto recompute = [&](uint32_t x) {
             const bool inB = x >= bnd;
             lc_h = inB ? mB_h : mA_h;
             lc_e = inB ? mB_e : mA_e;
             const uint32_t rx = inB ? rxA + 1 : rxA;
+            const uint64_t *rp = inB ? recA + RC : recA;
             const uint32_t ox = x & LM;
             const uint32_t tb = (inB ? maskB : maskA) >> ox;     // records at offsets >= ox (never 0)
             const uint32_t slot = (uint32_t)__popc(tb) - 1u;     // records to the right of the answer
-            const uint64_t sh = REC[rx * RC + slot];             // slot < RC: overflow tiles left above
+            const uint64_t sh = rp[slot];                        // slot < RC: overflow tiles left above
             if (sh < lc_h) {                                     // further left: only if strictly smaller
                 lc_h = sh;
                 lc_e = (rx << LSH) + ox + (uint32_t)__builtin_ctz(tb);
             }
+            lc_d = lc_e - xb;
         };
         auto mark = [&](bool left, uint32_t ce) {                 // rarely taken: the minimizer changed
             const uint64_t ch = left ? lc_h : pre_h;
             if (ch != ~0ull) atomicOr(&EM[ce >> 5], 1u << (ce & 31u));   // minimizer.cpp:44-45
         };
         // wave-uniform fast variant: every lane of the wave has a full run, all its windows exist and are
-        // owned by this tile, and the left region is never empty -> no per-step edge predicates
-        const bool wave_full = __all(n == (uint32_t)L && e0 >= e_first) && w > (uint32_t)L;
+        // owned by this tile, and the left region is never empty -> no per-step edge predicates.  Every window
+        // of a lane contains the first element of its run (w > L), so with h[0] != 2^64-1 in all lanes no window
+        // minimum is the excluded value (minimizer.cpp:44-45) and that test is dropped as well.
+        const bool wave_full = __all(n == (uint32_t)L && e0 >= e_first && h[0] != ~0ull) && w > (uint32_t)L;
         if (wave_full) {
             recompute(xb);
 #pragma unroll
             for (int j = 0; j < L; ++j) {
-                if (h[j] <= pre_h) { pre_h = h[j]; pre_e = e0 + j; }      // '<=': rightmost wins
-                if (j && lc_e < xb + j) recompute(xb + j);
+                const bool keep = pre_h < h[j];                            // '<=' for the newcomer: rightmost wins
+                pre_h = keep ? pre_h : h[j];
+                pre_e = keep ? pre_e : e0 + j;
+                if (j && lc_d < (uint32_t)j) recompute(xb + j);
                 const bool left = lc_h < pre_h;
                 const uint32_t ce = left ? lc_e : pre_e;
-                if (ce != prev_arg) mark(left, ce);
+                if (ce != prev_arg) atomicOr(&EM[ce >> 5], 1u << (ce & 31u));
                 prev_arg = ce;
             }
         } else {
