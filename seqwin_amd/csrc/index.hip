@@ -616,7 +616,8 @@ __global__ void k_restore_keys(const uint64_t *__restrict__ hash, uint32_t strid
 
 // descents: q > 0 in the same phase-1 run as q-1 with a smaller full hash
 __global__ void k_find_descents(const uint32_t *__restrict__ key32, const uint64_t *__restrict__ val, uint32_t kmask,
-                                uint64_t n, uint32_t *__restrict__ bad, uint32_t cap, unsigned long long *__restrict__ n_desc)
+                                uint64_t n, uint32_t *__restrict__ bad, uint32_t cap, uint32_t *__restrict__ bad_q,
+                                uint32_t cap_q, unsigned long long *__restrict__ n_desc)
 {
     const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool desc = false;
@@ -639,7 +640,101 @@ __global__ void k_find_descents(const uint32_t *__restrict__ key32, const uint64
         if (desc) {
             const unsigned long long slot = base + __popcll(m & ((1ull << lane) - 1ull));
             if (slot < cap) bad[slot] = kq & kmask;
+            if (slot < cap_q) bad_q[slot] = (uint32_t)q;
         }
+    }
+}
+
+// ---- in-place repair (the common case: a few thousand short runs) -- no host round trip ---------------------
+// One workgroup per descent.  k_repair_plan (reads only) finds the run [a, a + len) of its descent and whether it is
+// the FIRST descent of that run (the owner); k_repair_sort lets the owner rank-sort the run in LDS by (key32, val)
+// -- val carries the original index, so the order is total and the result is the stable sort.  Anything the
+// fast path does not take (more than REPAIR_MAX_DESC descents, a run longer than REPAIR_MAX_RUN) raises `status`
+// and is left to the general side-array repair.
+constexpr uint32_t REPAIR_MAX_DESC = 8192;
+constexpr uint32_t REPAIR_MAX_RUN = 2048;
+
+__device__ __forceinline__ bool split_less(uint32_t ka, uint64_t va, uint32_t kb, uint64_t vb)
+{
+    return ka < kb || (ka == kb && va < vb);
+}
+
+__global__ __launch_bounds__(256) void k_repair_plan(const uint32_t *__restrict__ key32, const uint64_t *__restrict__ val,
+                                                     uint32_t kmask, uint64_t n, const uint32_t *__restrict__ bad_q,
+                                                     const unsigned long long *__restrict__ n_desc,
+                                                     uint32_t *__restrict__ plan, uint32_t *__restrict__ status)
+{
+    __shared__ uint32_t sh[3];
+    const unsigned long long D = *n_desc;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (D > REPAIR_MAX_DESC) {
+        if (b == 0 && tid == 0) *status = 1u;
+        return;
+    }
+    if (b >= D) return;
+    const uint32_t q = bad_q[b];
+    if (tid == 0) {
+        const uint32_t k = key32[q] & kmask;
+        uint64_t lo = 0, hi = q;          // first position of the run
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if ((key32[mid] & kmask) < k) lo = mid + 1; else hi = mid;
+        }
+        sh[0] = (uint32_t)lo;
+        lo = q;
+        hi = n;                           // first position after the run
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if ((key32[mid] & kmask) <= k) lo = mid + 1; else hi = mid;
+        }
+        sh[1] = (uint32_t)lo;
+        sh[2] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const uint32_t a = sh[0], len = sh[1] - sh[0];
+    if (len > REPAIR_MAX_RUN) {
+        if (tid == 0) {
+            *status = 1u;
+            plan[3 * b + 2] = 0u;
+        }
+        return;
+    }
+    for (uint32_t p = a + 1 + tid; p <= q; p += blockDim.x)   // first descent of the run (q itself is one)
+        if (split_less(key32[p], val[p] >> 32, key32[p - 1], val[p - 1] >> 32)) {
+            atomicMin(&sh[2], p);
+            break;
+        }
+    __syncthreads();
+    if (tid == 0) {
+        plan[3 * b] = a;
+        plan[3 * b + 1] = len;
+        plan[3 * b + 2] = (sh[2] == q) ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_repair_sort(uint32_t *__restrict__ key32, uint64_t *__restrict__ val,
+                                                     const unsigned long long *__restrict__ n_desc,
+                                                     const uint32_t *__restrict__ plan)
+{
+    __shared__ uint64_t sv[REPAIR_MAX_RUN];
+    __shared__ uint32_t sk[REPAIR_MAX_RUN];
+    const unsigned long long D = *n_desc;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (D > REPAIR_MAX_DESC || b >= D) return;
+    if (plan[3 * b + 2] == 0u) return;
+    const uint32_t a = plan[3 * b], len = plan[3 * b + 1];
+    for (uint32_t i = tid; i < len; i += blockDim.x) {
+        sk[i] = key32[a + i];
+        sv[i] = val[a + i];
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < len; i += blockDim.x) {
+        const uint32_t ki = sk[i];
+        const uint64_t vi = sv[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < len; ++j) rank += split_less(sk[j], sv[j], ki, vi) ? 1u : 0u;
+        key32[a + rank] = ki;
+        val[a + rank] = vi;
     }
 }
 
@@ -721,8 +816,15 @@ struct HashSort {
     const uint64_t *val = nullptr;     // result: low half << 32 | original index (stable)
     uint32_t *spare = nullptr;         // n free u32 for the caller (the other key buffer)
     uint64_t n_repaired = 0;
+    // repair bookkeeping (device): descents seen, list of their keys / positions, fast-path plan and status
+    DevArray<unsigned long long> n_desc;
+    DevArray<uint32_t> bad, bad_q, plan, status;
+    uint32_t cap = 0, kmask = ~0u;
+    uint64_t n = 0;
 };
 
+// Phases 1 and 2 are enqueued without any host round trip; the caller must call sort_hashes_settle() once the
+// stream is synchronised (it reads `status`) before it relies on the order.
 void sort_hashes(const uint64_t *hash, uint32_t stride, uint64_t n, bool prefilled, hipStream_t stream, HashSort &o)
 {
     unsigned bits = 32;
@@ -731,6 +833,8 @@ void sort_hashes(const uint64_t *hash, uint32_t stride, uint64_t n, bool prefill
         if (b >= 1 && b <= 32) bits = (unsigned)b;
     }
     const uint32_t kmask = ~0u << (32 - bits);
+    o.kmask = kmask;
+    o.n = n;
     if (!prefilled) {
         o.key_a.alloc(n);
         o.val_a.alloc(n);
@@ -753,18 +857,34 @@ void sort_hashes(const uint64_t *hash, uint32_t stride, uint64_t n, bool prefill
     o.key32 = keys;
     o.val = vals;
     o.spare = keys_alt;
-    const uint32_t cap = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(1u << 16, n / 16));
-    DevArray<uint32_t> bad(cap);
-    DevArray<unsigned long long> n_desc(1);
-    SW_HIP(hipMemsetAsync(n_desc.p, 0, 8, stream));
-    hipLaunchKernelGGL(k_find_descents, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, kmask, n, bad.p, cap, n_desc.p);
+    o.cap = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(1u << 16, n / 16));
+    o.bad.alloc(o.cap);
+    o.bad_q.alloc(REPAIR_MAX_DESC);
+    o.plan.alloc(3 * REPAIR_MAX_DESC);
+    o.n_desc.alloc(1);
+    o.status.alloc(1);
+    SW_HIP(hipMemsetAsync(o.n_desc.p, 0, 8, stream));
+    SW_HIP(hipMemsetAsync(o.status.p, 0, 4, stream));
+    hipLaunchKernelGGL(k_find_descents, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, kmask, n, o.bad.p, o.cap,
+                       o.bad_q.p, REPAIR_MAX_DESC, o.n_desc.p);
+    hipLaunchKernelGGL(k_repair_plan, dim3(REPAIR_MAX_DESC), dim3(256), 0, stream, keys, vals, kmask, n, o.bad_q.p, o.n_desc.p,
+                       o.plan.p, o.status.p);
+    hipLaunchKernelGGL(k_repair_sort, dim3(REPAIR_MAX_DESC), dim3(256), 0, stream, keys, vals, o.n_desc.p, o.plan.p);
     SW_HIP(hipGetLastError());
-    unsigned long long D = 0;
-    SW_HIP(hipMemcpyAsync(&D, n_desc.p, 8, hipMemcpyDeviceToHost, stream));
-    SW_HIP(hipStreamSynchronize(stream));
-    if (D == 0) return;
+}
 
-    // ---- repair ----
+// General repair, for what the in-place pass left (status != 0).  Returns true if the order changed.
+bool sort_hashes_settle(HashSort &o, unsigned long long D, uint32_t status, hipStream_t stream)
+{
+    if (D == 0 || status == 0) {
+        o.n_repaired = D;
+        return false;
+    }
+    const uint64_t n = o.n;
+    const uint32_t kmask = o.kmask, cap = o.cap;
+    uint32_t *keys = const_cast<uint32_t *>(o.key32);
+    uint64_t *vals = const_cast<uint64_t *>(o.val);
+    DevArray<uint32_t> &bad = o.bad;
     uint64_t n_sub = n;
     DevArray<uint32_t> run_start, run_len, pos;
     DevArray<uint64_t> run_off;
@@ -810,6 +930,29 @@ void sort_hashes(const uint64_t *hash, uint32_t stride, uint64_t n, bool prefill
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));   // side arrays are released on return
     o.n_repaired = n_sub;
+    return true;
+}
+
+// head counts of the sorted hashes into hs.spare; returns the number of distinct hashes (one host sync, shared with
+// the repair status)
+uint32_t sorted_head_counts(HashSort &hs, uint64_t n, hipStream_t stream)
+{
+    uint32_t *cum = hs.spare;
+    uint32_t n_nodes = 0, status = 0;
+    unsigned long long D = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
+                                                       SplitHeadFlag{hs.key32, hs.val}),
+                      cum, n, (uint32_t)0, stream);
+        SW_HIP(hipMemcpyAsync(&n_nodes, cum + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+        if (pass == 0) {
+            SW_HIP(hipMemcpyAsync(&status, hs.status.p, 4, hipMemcpyDeviceToHost, stream));
+            SW_HIP(hipMemcpyAsync(&D, hs.n_desc.p, 8, hipMemcpyDeviceToHost, stream));
+        }
+        SW_HIP(hipStreamSynchronize(stream));
+        if (pass == 1 || !sort_hashes_settle(hs, D, status, stream)) break;
+    }
+    return n_nodes;
 }
 
 }  // namespace
@@ -1043,15 +1186,10 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
         hs.key_a = std::move(occ.key32);
         hs.val_a = std::move(occ.val);
         sort_hashes(occ.hash.p, 1u, n, true, stream, hs);
+        const uint32_t n_nodes = sorted_head_counts(hs, n, stream);   // into the spare key buffer
         const uint32_t *keys = hs.key32;
         const uint64_t *vals = hs.val;
-        uint32_t *cum = hs.spare;  // reuse the spare key buffer for the inclusive head count
-        inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
-                                                       SplitHeadFlag{keys, vals}),
-                      cum, n, (uint32_t)0, stream);
-        uint32_t n_nodes = 0;
-        SW_HIP(hipMemcpyAsync(&n_nodes, cum + (n - 1), 4, hipMemcpyDeviceToHost, stream));
-        SW_HIP(hipStreamSynchronize(stream));
+        const uint32_t *cum = hs.spare;
         ix.n_nodes = n_nodes;
         ix.nodes.alloc(n_nodes);
         hipLaunchKernelGGL(k_nodes, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, cum, occ.kmer.p, 1u, n,
@@ -1174,15 +1312,10 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
     if (n) {
         HashSort hs;
         sort_hashes(d_occ_rows, 2u, n, false, stream, hs);   // stable: ties keep source-rank order
+        const uint32_t n_nodes = sorted_head_counts(hs, n, stream);
         const uint32_t *keys = hs.key32;
         const uint64_t *vals = hs.val;
-        uint32_t *cum = hs.spare;
-        inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
-                                                       SplitHeadFlag{keys, vals}),
-                      cum, n, (uint32_t)0, stream);
-        uint32_t n_nodes = 0;
-        SW_HIP(hipMemcpyAsync(&n_nodes, cum + (n - 1), 4, hipMemcpyDeviceToHost, stream));
-        SW_HIP(hipStreamSynchronize(stream));
+        const uint32_t *cum = hs.spare;
         ix.n_nodes = n_nodes;
         ix.nodes.alloc(n_nodes);
         hipLaunchKernelGGL(k_nodes, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, cum, d_occ_rows + 1, 2u, n,

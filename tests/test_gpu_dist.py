@@ -221,7 +221,8 @@ def test_routed_tuple_exchange_equals_single_batch(world):
             assert np.array_equal(got[2], ee) and np.array_equal(got[3], eo), (world, k, w, packed)
 
 
-@pytest.mark.parametrize("case", ["few_tops_random_lows", "pairs_sharing_top", "ascending_lows", "random", "one_top_long_runs"])
+@pytest.mark.parametrize("case", ["few_tops_random_lows", "pairs_sharing_top", "ascending_lows", "random", "one_top_long_runs",
+                                  "few_short_mixed_runs", "long_run_few_descents"])
 def test_two_phase_hash_sort_repairs_shared_top_halves(case):
     """The node sort orders by the top 32 bits first and repairs runs whose low halves are out of order.  The slice
     builder takes arbitrary (hash, kmer) rows, so crafted hashes reach every branch of the repair: none needed,
@@ -243,6 +244,17 @@ def test_two_phase_hash_sort_repairs_shared_top_halves(case):
         # plus a sprinkling of unrelated hashes so that most runs are clean
         h = np.concatenate([h, rng.integers(0, 2**63, n, dtype=np.uint64)])
         h = h[rng.permutation(len(h))]
+    elif case == "few_short_mixed_runs":          # ~1 000 descents in runs of <= 2048: repaired in place, no host round trip
+        tops = rng.integers(0, 2**32, 60, dtype=np.uint64)
+        lows = rng.integers(0, 2**32, (60, 3), dtype=np.uint64)
+        t = rng.integers(0, 60, 4000)
+        mixed = (tops[t] << np.uint64(32)) | lows[t, rng.integers(0, 3, 4000)]
+        h = np.concatenate([mixed, rng.integers(0, 2**63, n, dtype=np.uint64)])
+        h = h[rng.permutation(len(h))]
+    elif case == "long_run_few_descents":         # one run longer than the in-place limit with three descents
+        run = (np.uint64(9) << np.uint64(32)) | np.sort(rng.integers(0, 2**32, 6000, dtype=np.uint64))
+        run[[100, 3000, 5999]] = (np.uint64(9) << np.uint64(32)) | np.uint64(1)
+        h = np.concatenate([run, rng.integers(0, 2**63, n, dtype=np.uint64)])    # arrival order = run order
     else:
         h = rng.integers(0, 2**64, n, dtype=np.uint64)
     n = len(h)
