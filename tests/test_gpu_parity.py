@@ -420,3 +420,39 @@ def test_window_equal_to_run_length_and_overflow_tiles(tmp_path, w, monkeypatch)
         if w >= 16:   # the hand-over really happens when forced, and only rarely otherwise
             t = Batch.from_fasta([p]).build_index(21, w).timings()
             assert (t["ovf_tiles"] >= t["n_tiles"] // 2) if rc else (t["ovf_tiles"] <= max(1, t["n_tiles"] // 4))
+
+
+def test_pipelined_and_plain_upload_give_the_same_batch(tmp_path, monkeypatch):
+    """FASTA -> HBM goes through the pinned ring while later files are still being parsed (default) or in one piece
+    after parsing; with one or many workers; both must hand the kernels the same records."""
+    rng = np.random.default_rng(11)
+    paths = []
+    for f in range(9):
+        parts = []
+        for r in range(int(rng.integers(1, 4))):
+            n = int(rng.choice([0, 17, 800, 40_000, 300_000]))
+            seq = rng.choice(np.frombuffer(b"ACGTN", np.uint8), n, p=[0.245, 0.245, 0.245, 0.245, 0.02]).tobytes()
+            parts.append(b">c%d\n" % r + b"\n".join(seq[i:i + 70] for i in range(0, n, 70)) + b"\n")
+        p = tmp_path / f"s{f}.fa"
+        p.write_bytes(b"".join(parts))
+        paths.append(str(p))
+    ref = None
+    for stream_upload in (True, False):
+        for n_cpu in (1, 5):
+            if stream_upload:
+                monkeypatch.delenv("SEQWIN_AMD_NO_STREAM_UPLOAD", raising=False)
+            else:
+                monkeypatch.setenv("SEQWIN_AMD_NO_STREAM_UPLOAD", "1")
+            b = Batch.from_fasta(paths, n_cpu=n_cpu)
+            offs, ids = b.records()
+            recs = [b.record(r) for r in range(int(offs[-1]))]
+            ix = b.build_index(15, 25, np.arange(len(paths)) % 2 == 0)
+            got = (offs.tolist(), ids, recs, [a.tobytes() for a in ix.export()])
+            ix.close(); b.close()
+            if ref is None:
+                ref = got
+                ek, en, ee, eo, _ = oracle.build(paths, 15, 25)
+                oracle.get_penalty(ek, en, eo, [i % 2 == 0 for i in range(len(paths))])
+                assert got[3] == [ek.tobytes(), en.tobytes(), ee.tobytes()]
+            else:
+                assert got == ref, (stream_upload, n_cpu)
