@@ -81,11 +81,11 @@ struct U32ToU64 {
 // head-of-run flag of a sorted key array, evaluated on the fly
 struct HeadFlag {
     const uint64_t *keys;
-    uint64_t n_valid;  // keys at >= n_valid are sentinels
+    uint64_t sentinel;  // record boundaries: sort last, never a head
     __host__ __device__ uint32_t operator()(uint64_t s) const
     {
-        if (s >= n_valid) return 0u;
-        return (s == 0 || keys[s] != keys[s - 1]) ? 1u : 0u;
+        const uint64_t k = keys[s];
+        return (k != sentinel && (s == 0 || k != keys[s - 1])) ? 1u : 0u;
     }
 };
 
@@ -323,11 +323,9 @@ __global__ void k_pen_nodes(const sw_kmer *__restrict__ kmers, uint64_t n_kmers,
 // ---- edges --------------------------------------------------------------------------------------------
 __global__ void k_adj(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ rank,
                       const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, uint64_t sentinel,
-                      uint64_t *__restrict__ key, uint32_t *__restrict__ val,
-                      unsigned long long *__restrict__ n_invalid)
+                      uint64_t *__restrict__ key, uint32_t *__restrict__ val)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool invalid = false;
     if (i + 1 < n) {
         const uint32_t r0 = (uint32_t)(kmer[i] >> 32), r1 = (uint32_t)(kmer[i + 1] >> 32);
         if (r0 == r1) {  // consecutive minimizers of one record (build.cpp:177-189)
@@ -338,31 +336,29 @@ __global__ void k_adj(const uint64_t *__restrict__ kmer, const uint32_t *__restr
         } else {
             key[i] = sentinel;
             val[i] = 0xFFFFFFFFu;
-            invalid = true;
         }
     }
-    const unsigned long long m = __ballot(invalid);
-    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_invalid, (unsigned long long)__popcll(m));
 }
 
 // c[s] = 1 at the first pair of every (edge, assembly) combination
 struct AsmChangeFlag {
     const uint64_t *keys;
     const uint32_t *vals;
-    uint64_t n_valid;
+    uint64_t sentinel;
     __host__ __device__ uint32_t operator()(uint64_t s) const
     {
-        if (s >= n_valid) return 0u;
-        return (s == 0 || keys[s] != keys[s - 1] || vals[s] != vals[s - 1]) ? 1u : 0u;
+        const uint64_t k = keys[s];
+        return (k != sentinel && (s == 0 || k != keys[s - 1] || vals[s] != vals[s - 1])) ? 1u : 0u;
     }
 };
 
-__global__ void k_edge_heads(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ ecum, uint64_t n_valid,
-                             uint64_t *__restrict__ edge_start)
+__global__ void k_edge_heads(const uint64_t *__restrict__ skeys, uint64_t sentinel, const uint32_t *__restrict__ ecum,
+                             uint64_t m, uint64_t *__restrict__ edge_start)
 {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_valid) return;
-    if (s == 0 || skeys[s] != skeys[s - 1]) edge_start[ecum[s] - 1] = s;
+    if (s >= m) return;
+    const uint64_t k = skeys[s];
+    if (k != sentinel && (s == 0 || k != skeys[s - 1])) edge_start[ecum[s] - 1] = s;
 }
 
 __global__ void k_edges(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ ccum,
@@ -1013,7 +1009,7 @@ void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, Ord
                        sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult, out.hash.p, out.kmer.p, out.key32.p,
                        out.val.p);
     SW_HIP(hipGetLastError());
-    SW_HIP(hipStreamSynchronize(stream));  // dst_off is released on return
+    // (dst_off goes back to the pool here; its next user is ordered after k_order on this stream)
 }
 
 namespace {
@@ -1078,10 +1074,9 @@ namespace {
 // duplicates, so weight = number of distinct keys inside a pair's run)
 __global__ void k_adj_packed(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ rank,
                              const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, unsigned ab, uint64_t sentinel,
-                             uint64_t *__restrict__ key, unsigned long long *__restrict__ n_invalid)
+                             uint64_t *__restrict__ key)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool invalid = false;
     if (i + 1 < n) {
         const uint32_t r0 = (uint32_t)(kmer[i] >> 32), r1 = (uint32_t)(kmer[i + 1] >> 32);
         if (r0 == r1) {
@@ -1090,32 +1085,37 @@ __global__ void k_adj_packed(const uint64_t *__restrict__ kmer, const uint32_t *
             key[i] = (((((uint64_t)u << nb) | v)) << ab) | rec_asm[r0];
         } else {
             key[i] = sentinel;
-            invalid = true;
         }
     }
-    const unsigned long long m = __ballot(invalid);
-    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(n_invalid, (unsigned long long)__popcll(m));
 }
 
-struct PackedHeadFlag {   // first occurrence of a pair
+struct PackedHeadFlag {   // first occurrence of a pair (sentinels, which sort last, never count)
     const uint64_t *keys;
     unsigned ab;
+    uint64_t sentinel;
     __host__ __device__ uint32_t operator()(uint64_t s) const
     {
-        return (s == 0 || (keys[s] >> ab) != (keys[s - 1] >> ab)) ? 1u : 0u;
+        const uint64_t k = keys[s];
+        return (k != sentinel && (s == 0 || (k >> ab) != (keys[s - 1] >> ab))) ? 1u : 0u;
     }
 };
 struct PackedChangeFlag {   // first occurrence of a (pair, assembly)
     const uint64_t *keys;
-    __host__ __device__ uint32_t operator()(uint64_t s) const { return (s == 0 || keys[s] != keys[s - 1]) ? 1u : 0u; }
+    uint64_t sentinel;
+    __host__ __device__ uint32_t operator()(uint64_t s) const
+    {
+        const uint64_t k = keys[s];
+        return (k != sentinel && (s == 0 || k != keys[s - 1])) ? 1u : 0u;
+    }
 };
 
-__global__ void k_edge_heads_packed(const uint64_t *__restrict__ skeys, unsigned ab, const uint32_t *__restrict__ ecum,
-                                    uint64_t n_valid, uint64_t *__restrict__ edge_start)
+__global__ void k_edge_heads_packed(const uint64_t *__restrict__ skeys, unsigned ab, uint64_t sentinel,
+                                    const uint32_t *__restrict__ ecum, uint64_t m, uint64_t *__restrict__ edge_start)
 {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_valid) return;
-    if (s == 0 || (skeys[s] >> ab) != (skeys[s - 1] >> ab)) edge_start[ecum[s] - 1] = s;
+    if (s >= m) return;
+    const uint64_t k = skeys[s];
+    if (k != sentinel && (s == 0 || (k >> ab) != (skeys[s - 1] >> ab))) edge_start[ecum[s] - 1] = s;
 }
 
 __global__ void k_edges_packed(const uint64_t *__restrict__ skeys, unsigned ab, const uint32_t *__restrict__ ccum,
@@ -1126,7 +1126,7 @@ __global__ void k_edges_packed(const uint64_t *__restrict__ skeys, unsigned ab, 
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
     const uint64_t s = edge_start[e];
-    const uint64_t s1 = (e + 1 < n_edges) ? edge_start[e + 1] : n_valid;
+    const uint64_t s1 = (e + 1 < n_edges) ? edge_start[e + 1] : n_valid;   // (last edge: the change count is flat over the sentinels)
     const uint64_t pair = skeys[s] >> ab;
     const uint32_t u = (uint32_t)(pair >> nb), v = (uint32_t)(pair & ((1ull << nb) - 1ull));
     edges[e].first = rank_hash ? rank_hash[u] : nodes[u].hash;
@@ -1134,11 +1134,11 @@ __global__ void k_edges_packed(const uint64_t *__restrict__ skeys, unsigned ab, 
     edges[e].weight = (uint64_t)(ccum[s1 - 1] - ccum[s]) + 1ull;
 }
 
-void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t n_valid, unsigned nb, unsigned ab,
+void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t sentinel, unsigned nb, unsigned ab,
                        const uint64_t *rank_hash, hipStream_t stream, sw_index &ix)
 {
     ix.n_edges = 0;
-    if (m == 0 || n_valid == 0) return;
+    if (m == 0) return;
     {
         rocprim::double_buffer<uint64_t> dk(keys, keys_alt);
         size_t tmp_bytes = 0;
@@ -1147,21 +1147,25 @@ void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t 
         SW_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, m, 0, 2 * nb + ab, stream));
         keys = dk.current();
     }
-    DevArray<uint32_t> ecum(n_valid), ccum(n_valid);
-    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), PackedHeadFlag{keys, ab}),
-                  ecum.p, n_valid, (uint32_t)0, stream);
-    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), PackedChangeFlag{keys}),
-                  ccum.p, n_valid, (uint32_t)0, stream);
+    // record boundaries were written as `sentinel` (sorts last): they never raise a flag, so no count of them is needed
+    DevArray<uint32_t> ecum(m), ccum(m);
+    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
+                                                   PackedHeadFlag{keys, ab, sentinel}),
+                  ecum.p, m, (uint32_t)0, stream);
+    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
+                                                   PackedChangeFlag{keys, sentinel}),
+                  ccum.p, m, (uint32_t)0, stream);
     uint32_t n_edges = 0;
-    SW_HIP(hipMemcpyAsync(&n_edges, ecum.p + (n_valid - 1), 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipMemcpyAsync(&n_edges, ecum.p + (m - 1), 4, hipMemcpyDeviceToHost, stream));
     SW_HIP(hipStreamSynchronize(stream));
     ix.n_edges = n_edges;
+    if (n_edges == 0) return;
     ix.edges.alloc(n_edges);
     DevArray<uint64_t> edge_start(n_edges);
-    hipLaunchKernelGGL(k_edge_heads_packed, dim3(blocks_for(n_valid)), dim3(TPB), 0, stream, keys, ab, ecum.p, n_valid,
+    hipLaunchKernelGGL(k_edge_heads_packed, dim3(blocks_for(m)), dim3(TPB), 0, stream, keys, ab, sentinel, ecum.p, m,
                        edge_start.p);
     hipLaunchKernelGGL(k_edges_packed, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, keys, ab, ccum.p, edge_start.p,
-                       (uint64_t)n_edges, n_valid, nb, ix.nodes.p, rank_hash, ix.edges.p);
+                       (uint64_t)n_edges, m, nb, ix.nodes.p, rank_hash, ix.edges.p);
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));
 }
@@ -1171,26 +1175,27 @@ namespace {
 // keys[m] = (rank_lo << nb) | rank_hi (sentinels sort last), vals[m] = assembly; stable sort keeps equal
 // pairs in assembly order, so weight = number of assembly changes inside a run (+1).
 void edges_from_adjacency(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt, uint64_t m,
-                          uint64_t n_valid, unsigned nb, const uint64_t *rank_hash, hipStream_t stream, sw_index &ix)
+                          uint64_t sentinel, unsigned nb, const uint64_t *rank_hash, hipStream_t stream, sw_index &ix)
 {
     ix.n_edges = 0;
-    if (m == 0 || n_valid == 0) return;
+    if (m == 0) return;
     sort_pairs(keys, keys_alt, vals, vals_alt, m, 0, 2 * nb, stream);
-    DevArray<uint32_t> ecum(n_valid), ccum(n_valid);
-    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), HeadFlag{keys, n_valid}),
-                  ecum.p, n_valid, (uint32_t)0, stream);
+    DevArray<uint32_t> ecum(m), ccum(m);
+    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), HeadFlag{keys, sentinel}),
+                  ecum.p, m, (uint32_t)0, stream);
     inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
-                                                   AsmChangeFlag{keys, vals, n_valid}),
-                  ccum.p, n_valid, (uint32_t)0, stream);
+                                                   AsmChangeFlag{keys, vals, sentinel}),
+                  ccum.p, m, (uint32_t)0, stream);
     uint32_t n_edges = 0;
-    SW_HIP(hipMemcpyAsync(&n_edges, ecum.p + (n_valid - 1), 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipMemcpyAsync(&n_edges, ecum.p + (m - 1), 4, hipMemcpyDeviceToHost, stream));
     SW_HIP(hipStreamSynchronize(stream));
     ix.n_edges = n_edges;
+    if (n_edges == 0) return;
     ix.edges.alloc(n_edges);
     DevArray<uint64_t> edge_start(n_edges);
-    hipLaunchKernelGGL(k_edge_heads, dim3(blocks_for(n_valid)), dim3(TPB), 0, stream, keys, ecum.p, n_valid, edge_start.p);
+    hipLaunchKernelGGL(k_edge_heads, dim3(blocks_for(m)), dim3(TPB), 0, stream, keys, sentinel, ecum.p, m, edge_start.p);
     hipLaunchKernelGGL(k_edges, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, keys, ccum.p, edge_start.p,
-                       (uint64_t)n_edges, n_valid, nb, ix.nodes.p, rank_hash, ix.edges.p);
+                       (uint64_t)n_edges, m, nb, ix.nodes.p, rank_hash, ix.edges.p);
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));
 }
@@ -1234,7 +1239,8 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
         hipLaunchKernelGGL(k_nodes, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, cum, occ.kmer.p, 1u, n,
                            (uint64_t)0, ix.kmers.p, ix.nodes.p, rank.p);
         SW_HIP(hipGetLastError());
-        SW_HIP(hipStreamSynchronize(stream));  // sort buffers are released here
+        // (the sort buffers go back to the pool here; later users are ordered after k_nodes: this stream, or the
+        //  counts stream, which waits for ev[1])
     } else {
         ix.n_nodes = 0;
         ix.nodes.alloc(0);
@@ -1262,30 +1268,23 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
         while (((1ull << nb) - 1ull) < ix.n_nodes) ++nb;  // n_nodes <= 2^nb - 1, so (2^nb-1, 2^nb-1) is free
         unsigned ab = 1;
         while ((1ull << ab) < b.host.n_assemblies) ++ab;     // assembly index < 2^ab
-        DevArray<unsigned long long> n_invalid(1);
-        SW_HIP(hipMemsetAsync(n_invalid.p, 0, 8, stream));
-        unsigned long long inv = 0;
         if (2 * nb + ab <= 64 && !getenv("SEQWIN_AMD_NO_PACKED_EDGES")) {
             // pair and assembly in one 64-bit key: keys-only sort
             const unsigned tb = 2 * nb + ab;
             const uint64_t sentinel = (tb == 64) ? ~0ull : ((1ull << tb) - 1ull);
             DevArray<uint64_t> k0(m), k1(m);
             hipLaunchKernelGGL(k_adj_packed, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, b.d_rec_asm.p, n, nb,
-                               ab, sentinel, k0.p, n_invalid.p);
+                               ab, sentinel, k0.p);
             SW_HIP(hipGetLastError());
-            SW_HIP(hipMemcpyAsync(&inv, n_invalid.p, 8, hipMemcpyDeviceToHost, stream));
-            SW_HIP(hipStreamSynchronize(stream));
-            edges_from_packed(k0.p, k1.p, m, m - inv, nb, ab, nullptr, stream, ix);
+            edges_from_packed(k0.p, k1.p, m, sentinel, nb, ab, nullptr, stream, ix);
         } else {
             const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
             DevArray<uint64_t> k0(m), k1(m);
             DevArray<uint32_t> v0(m), v1(m);
             hipLaunchKernelGGL(k_adj, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, b.d_rec_asm.p, n, nb,
-                               sentinel, k0.p, v0.p, n_invalid.p);
+                               sentinel, k0.p, v0.p);
             SW_HIP(hipGetLastError());
-            SW_HIP(hipMemcpyAsync(&inv, n_invalid.p, 8, hipMemcpyDeviceToHost, stream));
-            SW_HIP(hipStreamSynchronize(stream));
-            edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, m - inv, nb, nullptr, stream, ix);
+            edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, sentinel, nb, nullptr, stream, ix);
         }
     }
     if (ix.n_edges == 0) ix.edges.alloc(0);
@@ -1620,13 +1619,13 @@ void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned 
     if (m && ab) {
         DevArray<uint64_t> k0(m), k1(m);
         SW_HIP(hipMemcpyAsync(k0.p, d_adj_rows, m * 8, hipMemcpyDeviceToDevice, stream));
-        edges_from_packed(k0.p, k1.p, m, m, nb, ab, d_rank_hash, stream, ix);
+        edges_from_packed(k0.p, k1.p, m, ~0ull, nb, ab, d_rank_hash, stream, ix);   // rows carry no sentinels
     } else if (m) {
         DevArray<uint64_t> k0(m), k1(m);
         DevArray<uint32_t> v0(m), v1(m);
         hipLaunchKernelGGL(k_split_rows2, dim3(blocks_for(m)), dim3(TPB), 0, stream, d_adj_rows, m, k0.p, v0.p);
         SW_HIP(hipGetLastError());
-        edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, m, nb, d_rank_hash, stream, ix);
+        edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, ~0ull, nb, d_rank_hash, stream, ix);
     }
     if (ix.n_edges == 0) ix.edges.alloc(0);
 }
