@@ -252,3 +252,20 @@ def test_hash_bounds_are_monotone_and_balanced():
     nb, eb = swdist.hash_bounds(8)
     cnt = np.histogram(first, bins=[0] + [b / 2**64 for b in eb] + [1])[0]
     assert cnt.max() / cnt.min() < 1.15     # quantile splitters balance min(u, v)
+
+
+def test_adjacency_key_width_and_bounds():
+    """Packed adjacency rows (rank_lo, rank_hi, assembly) are used exactly when they fit 64 bits; owner boundaries are
+    monotone and cover the whole range."""
+    assert swdist.adjacency_asm_bits(22, 512) == 10            # 2*22 + 10 <= 64 (bit_length(512) = 10)
+    assert swdist.adjacency_asm_bits(27, 15000) == 0           # 54 + 14 > 64: {pair, assembly} rows
+    assert swdist.adjacency_asm_bits(1, 1) == 1
+    assert swdist.adjacency_asm_bits(32, 1) == 0
+    for world in (1, 2, 3, 8, 16):
+        hb = swdist.hash_bounds(world)
+        for bounds in hb if isinstance(hb, tuple) else (hb,):
+            assert len(bounds) == world - 1 and list(bounds) == sorted(bounds)
+        rb = swdist.rank_bounds(world, 1_000_003)
+        assert len(rb) == world - 1 and list(rb) == sorted(rb) and all(0 <= x <= 1_000_003 for x in rb)
+    parts = swdist.partition_assemblies(10, 4)                  # build.cpp:350-356: the remainder goes to the first workers
+    assert parts == [(0, 3), (3, 6), (6, 8), (8, 10)]
