@@ -61,6 +61,11 @@ typedef struct sw_index sw_index; /* opaque device-resident index built from a b
 /* ---- diagnostics -------------------------------------------------------------------------- */
 const char *sw_last_error(void);
 const char *sw_version(void);
+/* Log sink (replaces log_python, cpp/src/utils/logging.cpp:9-29, which logs to Python's root logger from native code):
+ * fn(level, message) with level in {"debug", "info", "warning", "error"} is called on the thread that called into the
+ * library; NULL (the default) drops the messages.  sw_build reports one "info" line per call. */
+typedef void (*sw_log_fn)(const char *level, const char *message);
+void sw_set_log_callback(sw_log_fn fn);
 /* Number of visible HIP devices (0 when none / runtime unusable). Does not initialise a context. */
 int sw_device_count(void);
 /* Select the HIP device used by the calling thread for all later calls (default 0). */

@@ -8,6 +8,7 @@ foreign call, as the reference does with py::gil_scoped_release (:59,117,151).
 from __future__ import annotations
 
 import ctypes
+import logging
 import operator
 import os
 
@@ -55,6 +56,24 @@ def _split_ids(blob: bytes, record_offsets: np.ndarray) -> list[tuple[str, ...]]
         out.append(tuple(s.decode("utf-8") for s in names[i:i + n]))
         i += n
     return out
+
+
+# Native log lines go to Python's root logger, as log_python does in the reference (cpp/src/utils/logging.cpp:9-29).
+_LOG_FN = ctypes.CFUNCTYPE(None, ctypes.c_char_p, ctypes.c_char_p)
+
+
+def _forward_log(level, message):
+    try:
+        fn = getattr(logging.getLogger(), (level or b"info").decode("ascii", "replace"), None) or logging.getLogger().info
+        fn((message or b"").decode("utf-8", "replace"))
+    except Exception:   # never let a logging problem unwind through the C frame
+        pass
+
+
+_log_callback = _LOG_FN(_forward_log)       # kept alive for the lifetime of the module
+lib.sw_set_log_callback.argtypes = [_LOG_FN]
+lib.sw_set_log_callback.restype = None
+lib.sw_set_log_callback(_log_callback)
 
 
 def _build_native(assembly_paths, kmerlen, windowsize, n_cpu=1, low_memory=False):

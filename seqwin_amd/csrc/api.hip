@@ -1,6 +1,8 @@
 // api.hip -- C-ABI entry points of libseqwin_hip.so (see include/seqwin_hip.h for the contract and
 // the reference interfaces each one replaces), device memory pool, batch upload / synthesis.
 #include <algorithm>
+#include <atomic>
+#include <cstdarg>
 #include <chrono>
 #include <cstdlib>
 #include <memory>
@@ -355,6 +357,20 @@ extern "C" {
 
 const char *sw_last_error(void) { return g_last_error.c_str(); }
 const char *sw_version(void) { return "seqwin_amd 0.1.0 (gfx950)"; }
+
+static std::atomic<sw_log_fn> g_log_fn{nullptr};
+void sw_set_log_callback(sw_log_fn fn) { g_log_fn.store(fn); }
+static void log_message(const char *level, const char *fmt, ...)
+{
+    sw_log_fn fn = g_log_fn.load();
+    if (!fn) return;
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    fn(level, buf);
+}
 
 int sw_device_count(void)
 {
@@ -826,6 +842,10 @@ int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t km
         g->g.n_assemblies = b->host.n_assemblies;
         g->g.total_bp = b->host.total_bp;
         const auto t4 = now();
+        log_message("info", "MI355X index: %llu assemblies, %.1f Mbp -> %llu minimizers, %llu nodes, %llu edges "
+                            "(ingest + upload %.1f ms, device %.1f ms)",
+                    (unsigned long long)b->host.n_assemblies, b->host.total_bp / 1e6, (unsigned long long)g->g.ix.n_kmers,
+                    (unsigned long long)g->g.ix.n_nodes, (unsigned long long)g->g.ix.n_edges, ms(t0, t1), ms(t2, t3));
         if (dbg)
             fprintf(stderr, "[seqwin_amd] sw_build: ingest+upload %.1f ms (+%.1f), device %.1f ms, rest %.1f ms (%.1f Mbp)\n",
                     ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), b->host.total_bp / 1e6);

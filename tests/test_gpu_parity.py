@@ -456,3 +456,11 @@ def test_pipelined_and_plain_upload_give_the_same_batch(tmp_path, monkeypatch):
                 assert got[3] == [ek.tobytes(), en.tobytes(), ee.tobytes()]
             else:
                 assert got == ref, (stream_upload, n_cpu)
+
+
+def test_native_log_line_reaches_the_root_logger(smoke_paths, caplog):
+    """log_python (cpp/src/utils/logging.cpp:9-29) logs to Python's root logger from native code; so does the binding."""
+    import logging
+    with caplog.at_level(logging.INFO):
+        KmerGraph(smoke_paths, kmerlen=21, windowsize=200)
+    assert any("MI355X index" in r.getMessage() and "4 assemblies" in r.getMessage() for r in caplog.records)
