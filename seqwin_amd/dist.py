@@ -357,16 +357,20 @@ def adjacency_asm_bits(n_bits: int, n_assemblies_total: int) -> int:
 
 
 def _exchange_rows(rows, counts, dev, group):
-    """all_to_all_single of rows grouped by destination; returns (received rows, per-source counts)."""
+    """all_to_all_single of rows grouped by destination.  One all_gather makes the whole (source x destination) count
+    matrix known everywhere (instead of a count all_to_all plus further gathers of totals); returns
+    (received rows, per-source counts, matrix)."""
     import torch
     import torch.distributed as dist
-    send = torch.tensor(counts, dtype=torch.int64, device=dev)
-    recv = torch.empty_like(send)
-    dist.all_to_all_single(recv, send, group=group)
-    recv_l = [int(x) for x in recv.tolist()]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    send = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=dev)
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send, group=group)
+    matrix = torch.stack(parts).tolist()                      # matrix[src][dst]
+    recv_l = [int(matrix[src][rank]) for src in range(world)]
     out = torch.empty((sum(recv_l),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
     dist.all_to_all_single(out, rows.contiguous(), recv_l, [int(c) for c in counts], group=group)
-    return out, recv_l
+    return out, recv_l, matrix
 
 
 def _gather_ints(value: int, dev, group) -> list[int]:
@@ -375,7 +379,7 @@ def _gather_ints(value: int, dev, group) -> list[int]:
     t = torch.tensor([value], dtype=torch.int64, device=dev)
     parts = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
     dist.all_gather(parts, t, group=group)
-    return [int(p.item()) for p in parts]
+    return [int(x) for x in torch.cat(parts).tolist()]   # one device-to-host copy
 
 
 def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, group=None) -> ShardedIndex:
@@ -423,8 +427,8 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     nb, _ = hash_bounds(world)
     rows, perm, cnt = engine.partition(occ, nb, rec_base[rank])
     if multi:
-        r_rows, recv_cnt = _exchange_rows(rows, cnt, dev, group)
-        kmer_base = sum(_gather_ints(int(r_rows.shape[0]), dev, group)[:rank])
+        r_rows, recv_cnt, matrix = _exchange_rows(rows, cnt, dev, group)
+        kmer_base = sum(int(matrix[src][r]) for r in range(rank) for src in range(world))   # rows owned by lower ranks
     else:
         r_rows, recv_cnt, kmer_base = rows, cnt, 0
     t2 = time.perf_counter()
@@ -456,7 +460,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     adj, acnt = engine.adjacency(occ, perm, ranks_by_row, n_bits, asm_bits, shard.first_assembly,
                                  rank_bounds(world, total_nodes))
     if multi:
-        r_adj, _ = _exchange_rows(adj, acnt, dev, group)
+        r_adj, _, _ = _exchange_rows(adj, acnt, dev, group)
         hash_work.wait()
         rank_hash = torch.cat([p[:c] for p, c in zip(parts, node_cnt)])
     else:
