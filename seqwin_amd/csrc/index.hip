@@ -616,18 +616,37 @@ __global__ void k_restore_keys(const uint64_t *__restrict__ hash, uint32_t strid
 // in ascending position, so the key list comes out sorted.
 constexpr uint32_t DESC_BLOCK = 1024;   // positions per workgroup (256 threads x 4 consecutive positions)
 
-__device__ __forceinline__ uint32_t descents_of_thread(const uint32_t *__restrict__ key32, const uint64_t *__restrict__ val,
-                                                       uint32_t kmask, uint64_t n, uint64_t q0)
+// The two-phase sort works on a "view" of n elements ordered by (key, low): key(q) is the 32-bit phase-1 key, low(q)
+// what orders elements of equal key, load / store move a whole element.
+struct SplitView {   // hashes: key32[q] = top half, val[q] = low half << 32 | original index
+    uint32_t *key32;
+    uint64_t *val;
+    __device__ uint32_t key(uint64_t q) const { return key32[q]; }
+    __device__ uint64_t low(uint64_t q) const { return val[q] >> 32; }
+    __device__ void load(uint64_t q, uint32_t &k, uint64_t &v) const { k = key32[q]; v = val[q]; }
+    __device__ void store(uint64_t q, uint32_t k, uint64_t v) const { key32[q] = k; val[q] = v; }
+};
+struct RotView {     // packed edge keys, halves swapped: kr[q] = low half << 32 | top half (keys-only radix sort on bits 0..31)
+    uint64_t *kr;
+    __device__ uint32_t key(uint64_t q) const { return (uint32_t)kr[q]; }
+    __device__ uint64_t low(uint64_t q) const { return kr[q] >> 32; }
+    __device__ void load(uint64_t q, uint32_t &k, uint64_t &v) const { const uint64_t x = kr[q]; k = (uint32_t)x; v = x >> 32; }
+    __device__ void store(uint64_t q, uint32_t k, uint64_t v) const { kr[q] = (v << 32) | k; }
+};
+
+template <class View>
+__device__ __forceinline__ uint32_t descents_of_thread(const View &V, uint32_t kmask, uint64_t n, uint64_t q0)
 {
     uint32_t m = 0;   // bit i: position q0 + i is a descent
     if (q0 >= n) return 0;
-    uint32_t kp = q0 ? key32[q0 - 1] : 0;
-    uint32_t lp = q0 ? (uint32_t)(val[q0 - 1] >> 32) : 0;
+    uint32_t kp = q0 ? V.key(q0 - 1) : 0;
+    uint64_t lp = q0 ? V.low(q0 - 1) : 0;
 #pragma unroll
     for (uint32_t i = 0; i < 4; ++i) {
         const uint64_t q = q0 + i;
         if (q >= n) break;
-        const uint32_t kq = key32[q], lq = (uint32_t)(val[q] >> 32);
+        const uint32_t kq = V.key(q);
+        const uint64_t lq = V.low(q);
         if (q && (kq & kmask) == (kp & kmask) && (kq < kp || (kq == kp && lq < lp))) m |= 1u << i;
         kp = kq;
         lp = lq;
@@ -635,11 +654,11 @@ __device__ __forceinline__ uint32_t descents_of_thread(const uint32_t *__restric
     return m;
 }
 
-__global__ __launch_bounds__(256) void k_count_descents(const uint32_t *__restrict__ key32, const uint64_t *__restrict__ val,
-                                                        uint32_t kmask, uint64_t n, uint32_t *__restrict__ cnt)
+template <class View>
+__global__ __launch_bounds__(256) void k_count_descents(const View V, uint32_t kmask, uint64_t n, uint32_t *__restrict__ cnt)
 {
     const uint64_t q0 = (uint64_t)blockIdx.x * DESC_BLOCK + threadIdx.x * 4u;
-    const uint32_t c = (uint32_t)__popc(descents_of_thread(key32, val, kmask, n, q0));
+    const uint32_t c = (uint32_t)__popc(descents_of_thread(V, kmask, n, q0));
     __shared__ uint32_t s;
     if (threadIdx.x == 0) s = 0;
     __syncthreads();
@@ -650,18 +669,19 @@ __global__ __launch_bounds__(256) void k_count_descents(const uint32_t *__restri
     if (threadIdx.x == 0) cnt[blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(256) void k_list_descents(const uint32_t *__restrict__ key32, const uint64_t *__restrict__ val,
-                                                       uint32_t kmask, uint64_t n, const uint32_t *__restrict__ cnt,
-                                                       const uint32_t *__restrict__ off, uint32_t n_blocks,
-                                                       uint32_t *__restrict__ bad, uint32_t cap, uint32_t *__restrict__ bad_q,
-                                                       uint32_t cap_q, unsigned long long *__restrict__ n_desc)
+template <class View>
+__global__ __launch_bounds__(256) void k_list_descents(const View V, uint32_t kmask, uint64_t n,
+                                                       const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ off,
+                                                       uint32_t n_blocks, uint32_t *__restrict__ bad, uint32_t cap,
+                                                       uint32_t *__restrict__ bad_q, uint32_t cap_q,
+                                                       unsigned long long *__restrict__ n_desc)
 {
     const uint32_t b = blockIdx.x;
     const uint32_t c_blk = cnt[b];
     if (b == n_blocks - 1 && threadIdx.x == 0) *n_desc = (unsigned long long)off[b] + c_blk;
     if (c_blk == 0) return;
     const uint64_t q0 = (uint64_t)b * DESC_BLOCK + threadIdx.x * 4u;
-    const uint32_t m = descents_of_thread(key32, val, kmask, n, q0);
+    const uint32_t m = descents_of_thread(V, kmask, n, q0);
     const uint32_t c = (uint32_t)__popc(m);
     // exclusive prefix of c over the 256 threads (position order)
     __shared__ uint32_t wsum[4];
@@ -679,103 +699,152 @@ __global__ __launch_bounds__(256) void k_list_descents(const uint32_t *__restric
     while (mm) {
         const uint32_t i = (uint32_t)__builtin_ctz(mm);
         mm &= mm - 1;
-        if (base < cap) bad[base] = key32[q0 + i] & kmask;
+        if (base < cap) bad[base] = V.key(q0 + i) & kmask;
         if (base < cap_q) bad_q[base] = (uint32_t)(q0 + i);
         ++base;
     }
 }
 
-// ---- in-place repair (the common case: a few thousand short runs) -- no host round trip ---------------------
-// One workgroup per descent.  k_repair_plan (reads only) finds the run [a, a + len) of its descent and whether it is
-// the FIRST descent of that run (the owner); k_repair_sort lets the owner rank-sort the run in LDS by (key32, val)
-// -- val carries the original index, so the order is total and the result is the stable sort.  Anything the
-// fast path does not take (more than REPAIR_MAX_DESC descents, a run longer than REPAIR_MAX_RUN) raises `status`
-// and is left to the general side-array repair.
-constexpr uint32_t REPAIR_MAX_DESC = 8192;
+// ---- in-place repair (the common case: short runs) -- no host round trip -----------------------------------
+// Workgroups stride over the descents.  k_repair_plan (reads only) finds the run [a, a + len) of a descent -- galloping
+// outwards from it, runs are short -- and whether it is the FIRST descent of that run (the owner); k_repair_sort lets
+// the owner rank-sort the run in LDS by (key, low, position), a total order, so the result is the stable sort.
+// Anything the fast path does not take (more than REPAIR_MAX_DESC descents, a run longer than REPAIR_MAX_RUN)
+// raises `status` and is left to the general repair of the caller.
+constexpr uint32_t REPAIR_MAX_DESC = 1u << 18;
 constexpr uint32_t REPAIR_MAX_RUN = 2048;
+constexpr uint32_t REPAIR_GRID = 2048;
 
-__device__ __forceinline__ bool split_less(uint32_t ka, uint64_t va, uint32_t kb, uint64_t vb)
-{
-    return ka < kb || (ka == kb && va < vb);
-}
-
-__global__ __launch_bounds__(256) void k_repair_plan(const uint32_t *__restrict__ key32, const uint64_t *__restrict__ val,
-                                                     uint32_t kmask, uint64_t n, const uint32_t *__restrict__ bad_q,
+template <class View>
+__global__ __launch_bounds__(256) void k_repair_plan(const View V, uint32_t kmask, uint64_t n, const uint32_t *__restrict__ bad_q,
                                                      const unsigned long long *__restrict__ n_desc,
                                                      uint32_t *__restrict__ plan, uint32_t *__restrict__ status)
 {
     __shared__ uint32_t sh[3];
     const unsigned long long D = *n_desc;
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     if (D > REPAIR_MAX_DESC) {
-        if (b == 0 && tid == 0) *status = 1u;
+        if (blockIdx.x == 0 && tid == 0) *status = 1u;
         return;
     }
-    if (b >= D) return;
-    const uint32_t q = bad_q[b];
-    if (tid == 0) {
-        const uint32_t k = key32[q] & kmask;
-        uint64_t lo = 0, hi = q;          // first position of the run
-        while (lo < hi) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if ((key32[mid] & kmask) < k) lo = mid + 1; else hi = mid;
-        }
-        sh[0] = (uint32_t)lo;
-        lo = q;
-        hi = n;                           // first position after the run
-        while (lo < hi) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if ((key32[mid] & kmask) <= k) lo = mid + 1; else hi = mid;
-        }
-        sh[1] = (uint32_t)lo;
-        sh[2] = 0xFFFFFFFFu;
-    }
-    __syncthreads();
-    const uint32_t a = sh[0], len = sh[1] - sh[0];
-    if (len > REPAIR_MAX_RUN) {
+    for (uint32_t b = blockIdx.x; b < D; b += gridDim.x) {
+        __syncthreads();                      // sh is reused
+        const uint32_t q = bad_q[b];
         if (tid == 0) {
-            *status = 1u;
-            plan[3 * b + 2] = 0u;
+            const uint32_t k = V.key(q) & kmask;
+            // first position of the run: gallop left from q, then bisect
+            uint64_t step = 1, hi = q, lo;
+            for (;;) {
+                if (step > hi) { lo = 0; break; }
+                if ((V.key(hi - step) & kmask) != k) { lo = hi - step + 1; break; }
+                hi -= step;
+                step <<= 1;
+            }
+            // key(hi) == k and [hi, q] belongs to the run; the start lies in [lo, hi]
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if ((V.key(mid) & kmask) == k) hi = mid; else lo = mid + 1;
+            }
+            sh[0] = (uint32_t)lo;
+            // first position after the run: gallop right
+            uint64_t lo2 = q, hi2;
+            step = 1;
+            for (;;) {
+                if (lo2 + step >= n) { hi2 = n; break; }
+                if ((V.key(lo2 + step) & kmask) != k) { hi2 = lo2 + step; break; }
+                lo2 += step;
+                step <<= 1;
+            }
+            ++lo2;                            // key(lo2 - 1) == k; the end lies in [lo2, hi2]
+            while (lo2 < hi2) {
+                const uint64_t mid = (lo2 + hi2) >> 1;
+                if ((V.key(mid) & kmask) == k) lo2 = mid + 1; else hi2 = mid;
+            }
+            sh[1] = (uint32_t)lo2;
+            sh[2] = 0xFFFFFFFFu;
         }
-        return;
-    }
-    for (uint32_t p = a + 1 + tid; p <= q; p += blockDim.x)   // first descent of the run (q itself is one)
-        if (split_less(key32[p], val[p] >> 32, key32[p - 1], val[p - 1] >> 32)) {
-            atomicMin(&sh[2], p);
-            break;
+        __syncthreads();
+        const uint32_t a = sh[0], len = sh[1] - sh[0];
+        if (len > REPAIR_MAX_RUN) {
+            if (tid == 0) {
+                *status = 1u;
+                plan[3 * b + 2] = 0u;
+            }
+            continue;
         }
-    __syncthreads();
-    if (tid == 0) {
-        plan[3 * b] = a;
-        plan[3 * b + 1] = len;
-        plan[3 * b + 2] = (sh[2] == q) ? 1u : 0u;
+        for (uint32_t p = a + 1 + tid; p <= q; p += blockDim.x) {   // first descent of the run (q itself is one)
+            const uint32_t kq = V.key(p), kp = V.key(p - 1);
+            if (kq < kp || (kq == kp && V.low(p) < V.low(p - 1))) {
+                atomicMin(&sh[2], p);
+                break;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            plan[3 * b] = a;
+            plan[3 * b + 1] = len;
+            plan[3 * b + 2] = (sh[2] == q) ? 1u : 0u;
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_repair_sort(uint32_t *__restrict__ key32, uint64_t *__restrict__ val,
-                                                     const unsigned long long *__restrict__ n_desc,
+template <class View>
+__global__ __launch_bounds__(256) void k_repair_sort(const View V, const unsigned long long *__restrict__ n_desc,
                                                      const uint32_t *__restrict__ plan)
 {
     __shared__ uint64_t sv[REPAIR_MAX_RUN];
     __shared__ uint32_t sk[REPAIR_MAX_RUN];
     const unsigned long long D = *n_desc;
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    if (D > REPAIR_MAX_DESC || b >= D) return;
-    if (plan[3 * b + 2] == 0u) return;
-    const uint32_t a = plan[3 * b], len = plan[3 * b + 1];
-    for (uint32_t i = tid; i < len; i += blockDim.x) {
-        sk[i] = key32[a + i];
-        sv[i] = val[a + i];
+    const uint32_t tid = threadIdx.x;
+    if (D > REPAIR_MAX_DESC) return;
+    for (uint32_t b = blockIdx.x; b < D; b += gridDim.x) {
+        if (plan[3 * b + 2] == 0u) continue;
+        const uint32_t a = plan[3 * b], len = plan[3 * b + 1];
+        __syncthreads();                      // the previous run has been written out
+        for (uint32_t i = tid; i < len; i += blockDim.x) V.load(a + i, sk[i], sv[i]);
+        __syncthreads();
+        for (uint32_t i = tid; i < len; i += blockDim.x) {
+            const uint32_t ki = sk[i];
+            const uint64_t vi = sv[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < len; ++j) {
+                const uint32_t kj = sk[j];
+                const uint64_t vj = sv[j];
+                rank += (kj < ki || (kj == ki && (vj < vi || (vj == vi && j < i)))) ? 1u : 0u;
+            }
+            V.store(a + rank, ki, vi);
+        }
     }
-    __syncthreads();
-    for (uint32_t i = tid; i < len; i += blockDim.x) {
-        const uint32_t ki = sk[i];
-        const uint64_t vi = sv[i];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < len; ++j) rank += split_less(sk[j], sv[j], ki, vi) ? 1u : 0u;
-        key32[a + rank] = ki;
-        val[a + rank] = vi;
-    }
+}
+
+// Buffers of the in-place repair (kept by the caller until the stream has been synchronised).
+struct RepairState {
+    DevArray<unsigned long long> n_desc;
+    DevArray<uint32_t> bad_q, plan, status, blk_cnt, blk_off;
+};
+
+// enqueue: list the descents of the phase-1 order, repair short runs in place.  `bad` (may be null) also receives the
+// masked keys of the descents, ascending, for a general repair.
+template <class View>
+void enqueue_repair(const View &V, uint32_t kmask, uint64_t n, uint32_t *bad, uint32_t cap, RepairState &r, hipStream_t stream)
+{
+    const uint32_t n_blocks = (uint32_t)((n + DESC_BLOCK - 1) / DESC_BLOCK);
+    r.bad_q.alloc(REPAIR_MAX_DESC);
+    r.plan.alloc(3 * (size_t)REPAIR_MAX_DESC);
+    r.n_desc.alloc(1);
+    r.status.alloc(1);
+    r.blk_cnt.alloc(n_blocks);
+    r.blk_off.alloc(n_blocks);
+    SW_HIP(hipMemsetAsync(r.status.p, 0, 4, stream));
+    hipLaunchKernelGGL(k_count_descents<View>, dim3(n_blocks), dim3(256), 0, stream, V, kmask, n, r.blk_cnt.p);
+    SW_HIP(hipGetLastError());
+    exclusive_sum(r.blk_cnt.p, r.blk_off.p, n_blocks, (uint32_t)0, stream);
+    hipLaunchKernelGGL(k_list_descents<View>, dim3(n_blocks), dim3(256), 0, stream, V, kmask, n, r.blk_cnt.p, r.blk_off.p,
+                       n_blocks, bad, cap, r.bad_q.p, REPAIR_MAX_DESC, r.n_desc.p);
+    hipLaunchKernelGGL(k_repair_plan<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, kmask, n, r.bad_q.p, r.n_desc.p,
+                       r.plan.p, r.status.p);
+    hipLaunchKernelGGL(k_repair_sort<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, r.n_desc.p, r.plan.p);
+    SW_HIP(hipGetLastError());
 }
 
 // one thread per (sorted) bad key: the first of equal entries looks its run up in the sorted phase-1 keys
@@ -856,9 +925,9 @@ struct HashSort {
     const uint64_t *val = nullptr;     // result: low half << 32 | original index (stable)
     uint32_t *spare = nullptr;         // n free u32 for the caller (the other key buffer)
     uint64_t n_repaired = 0;
-    // repair bookkeeping (device): descents seen, list of their keys / positions, fast-path plan and status
-    DevArray<unsigned long long> n_desc;
-    DevArray<uint32_t> bad, bad_q, plan, status, blk_cnt, blk_off;
+    // repair bookkeeping (device): keys of the descents for the general repair, and the in-place repair's state
+    DevArray<uint32_t> bad;
+    RepairState rep;
     uint32_t cap = 0, kmask = ~0u;
     uint64_t n = 0;
 };
@@ -899,23 +968,7 @@ void sort_hashes(const uint64_t *hash, uint32_t stride, uint64_t n, bool prefill
     o.spare = keys_alt;
     o.cap = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(1u << 16, n / 16));
     o.bad.alloc(o.cap);
-    o.bad_q.alloc(REPAIR_MAX_DESC);
-    o.plan.alloc(3 * REPAIR_MAX_DESC);
-    o.n_desc.alloc(1);
-    o.status.alloc(1);
-    SW_HIP(hipMemsetAsync(o.status.p, 0, 4, stream));
-    const uint32_t n_blocks = (uint32_t)((n + DESC_BLOCK - 1) / DESC_BLOCK);
-    o.blk_cnt.alloc(n_blocks);
-    o.blk_off.alloc(n_blocks);
-    hipLaunchKernelGGL(k_count_descents, dim3(n_blocks), dim3(256), 0, stream, keys, vals, kmask, n, o.blk_cnt.p);
-    SW_HIP(hipGetLastError());
-    exclusive_sum(o.blk_cnt.p, o.blk_off.p, n_blocks, (uint32_t)0, stream);
-    hipLaunchKernelGGL(k_list_descents, dim3(n_blocks), dim3(256), 0, stream, keys, vals, kmask, n, o.blk_cnt.p, o.blk_off.p,
-                       n_blocks, o.bad.p, o.cap, o.bad_q.p, REPAIR_MAX_DESC, o.n_desc.p);
-    hipLaunchKernelGGL(k_repair_plan, dim3(REPAIR_MAX_DESC), dim3(256), 0, stream, keys, vals, kmask, n, o.bad_q.p, o.n_desc.p,
-                       o.plan.p, o.status.p);
-    hipLaunchKernelGGL(k_repair_sort, dim3(REPAIR_MAX_DESC), dim3(256), 0, stream, keys, vals, o.n_desc.p, o.plan.p);
-    SW_HIP(hipGetLastError());
+    enqueue_repair(SplitView{keys, vals}, kmask, n, o.bad.p, o.cap, o.rep, stream);
 }
 
 // General repair, for what the in-place pass left (status != 0).  Returns true if the order changed.
@@ -981,8 +1034,8 @@ uint32_t sorted_head_counts(HashSort &hs, uint64_t n, hipStream_t stream)
                       cum, n, (uint32_t)0, stream);
         SW_HIP(hipMemcpyAsync(&n_nodes, cum + (n - 1), 4, hipMemcpyDeviceToHost, stream));
         if (pass == 0) {
-            SW_HIP(hipMemcpyAsync(&status, hs.status.p, 4, hipMemcpyDeviceToHost, stream));
-            SW_HIP(hipMemcpyAsync(&D, hs.n_desc.p, 8, hipMemcpyDeviceToHost, stream));
+            SW_HIP(hipMemcpyAsync(&status, hs.rep.status.p, 4, hipMemcpyDeviceToHost, stream));
+            SW_HIP(hipMemcpyAsync(&D, hs.rep.n_desc.p, 8, hipMemcpyDeviceToHost, stream));
         }
         SW_HIP(hipStreamSynchronize(stream));
         if (pass == 1 || !sort_hashes_settle(hs, D, status, stream)) break;
