@@ -59,7 +59,7 @@ struct Plan {
     uint32_t L = 0;        // k-mers hashed per thread (odd, <= w)
     uint32_t NE = 0;       // elements per tile = 256 * L
     uint32_t TW = 0;       // window ends per tile = NE - w
-    uint32_t Lf = 0, TWf = 0, Lg_list = 0;  // fast class (single-segment records): run length 32 / 16 / 0 = unavailable
+    uint32_t Lf = 0, TWf = 0, Lg_list = 0, halo_f = 0;  // fast class (single-segment records): run length 32 / 16 / 0 = unavailable
     uint32_t n_tiles = 0, n_tiles_fast = 0, n_tiles_gen = 0;
     uint64_t n_windows = 0;
     uint64_t n_valid = 0;

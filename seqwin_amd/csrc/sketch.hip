@@ -71,6 +71,7 @@ struct SketchArgs {
     uint32_t tile_base;           // class tile id of blockIdx.x == 0 (launches are chunked: 2^32 work-item grid limit)
     uint64_t packed_words;
     uint64_t mult;
+    uint32_t halo;   // fast class: elements a tile holds before its first owned window end (w rounded up to whole runs)
     uint64_t *stage_hash;
     uint64_t *stage_kmer;
     unsigned long long *cursor;
@@ -438,7 +439,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
     const uint32_t nvalid = A.rec_nvalid[rec];
     const uint32_t I0 = (w - 1) + t * A.TW;
     const uint32_t I1 = (uint32_t)min((uint64_t)I0 + A.TW, (uint64_t)nvalid);   // no wrap near 2^32 k-mers
-    const uint32_t E0 = (t == 0) ? 0u : I0 - w;
+    const uint32_t E0 = (t == 0) ? 0u : I0 - A.halo;   // halo >= w, a whole number of runs when w > L
     const uint32_t ne = I1 - E0;
     const uint32_t e_first = I0 - E0;
     const uint32_t pos0 = A.seg_pos[A.rec_seg_off[rec]];   // single segment: idx g <-> pos0 + g
@@ -673,8 +674,17 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         // owned by this tile, and the left region is never empty -> no per-step edge predicates.  Every window
         // of a lane contains the first element of its run (w > L), so with h[0] != 2^64-1 in all lanes no window
         // minimum is the excluded value (minimizer.cpp:44-45) and that test is dropped as well.
-        const bool wave_full = __all(n == (uint32_t)L && e0 >= e_first && h[0] != ~0ull) && w > (uint32_t)L;
+        // Lanes of the (run-aligned) halo own no window; the last of them evaluates the window that ends just before
+        // the tile's first own one (its winner is cleared below: the previous tile emits it).
+        const bool owner = e0 >= e_first, last_halo = e0 + (uint32_t)L == e_first;
+        const bool wave_full = __all(n == (uint32_t)L && (owner || last_halo) && h[0] != ~0ull) && w > (uint32_t)L;
         if (wave_full) {
+            if (last_halo) {
+                recompute(xb + (uint32_t)(L - 1));
+                const uint64_t rm_h = RMh[tid];                         // minimum of the own run, rightmost among equals
+                MISC[0] = (lc_h < rm_h) ? lc_e : (uint32_t)RMp[tid];
+            }
+            if (owner) {
             recompute(xb);
 #pragma unroll
             for (int j = 0; j < L; ++j) {
@@ -686,6 +696,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
                 const uint32_t ce = left ? lc_e : pre_e;
                 if (ce != prev_arg) atomicOr(&EM[ce >> 5], 1u << (ce & 31u));
                 prev_arg = ce;
+            }
             }
         } else {
 #pragma unroll
@@ -702,7 +713,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
                     const bool left = lc_h < pre_h;
                     const uint32_t ce = left ? lc_e : pre_e;
                     if (e < e_first) {
-                        MISC[0] = ce;
+                        if (e + 1 == e_first) MISC[0] = ce;                  // (a run-aligned halo holds more than one such window)
                     } else if (ce != prev_arg) {
                         mark(left, ce);
                     }
@@ -804,7 +815,10 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     // are made one run-column smaller instead (256 * (Lf - 1) elements) and Lg = Lf - 1.
     p.Lg_list = p.Lf ? (w > p.Lf ? p.Lf + 1 : p.Lf - 1) : 0;
     if (p.Lf && (uint64_t)BLOCK * std::min(p.Lf, p.Lg_list) < 2ull * w) p.Lf = 0;   // (only reachable through the fast16 A/B switch)
-    p.TWf = p.Lf ? BLOCK * std::min(p.Lf, p.Lg_list) - w : 0;
+    // fast tiles start their halo on a run boundary (w rounded up to a multiple of L when w > L): the lanes of the halo
+    // then hold no owned window at all and the first wave of a tile can run the wave-uniform window pass as well
+    p.halo_f = (p.Lf && w > p.Lf) ? (w + p.Lf - 1) / p.Lf * p.Lf : w;
+    p.TWf = p.Lf ? BLOCK * std::min(p.Lf, p.Lg_list) - p.halo_f : 0;
     p.mult = 1ULL ^ ((uint64_t)k * MULTISEED);
 
     const HostBatch &h = b.host;
@@ -966,6 +980,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
             a.cls_tile_off = plan.fast_tile_off.p;
             a.L = plan.Lf;
             a.TW = plan.TWf;
+            a.halo = plan.halo_f;
             a.n_tiles = plan.n_tiles_fast;
             for (uint32_t tb = 0; tb < plan.n_tiles_fast; tb += MAX_TILES_PER_LAUNCH) {
                 const uint32_t nt = std::min(plan.n_tiles_fast - tb, MAX_TILES_PER_LAUNCH);
