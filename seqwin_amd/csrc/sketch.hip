@@ -392,7 +392,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
 //    LDS per workgroup drops from 79 KiB to ~30 KiB -> 5 workgroups (20 waves) per CU instead of 2.
 // ================================================================================================
 constexpr uint32_t KF = 256;
-constexpr uint32_t RC = 11;   // published suffix records per run (odd stride in 8-byte units)
+constexpr uint32_t RC = 12;   // published suffix records per run (12 x 8 B: the most that keeps 5 workgroups per CU)
 
 template <int L> struct FastCfg {
     static constexpr int NE = BLOCK * L;
