@@ -166,6 +166,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
 
     // ---- which record / which window range (uniform; scalar loads) ---------------------------
     // list mode: redo tiles of the fast class (same window ranges: TW = the fast class's TW <= NE - w)
+    if (A.list && A.tile_base + blockIdx.x >= *A.ovf_count) return;   // list length is only known on the device
     const uint32_t ctile = A.list ? A.list[A.tile_base + blockIdx.x] : A.tile_base + blockIdx.x;
     uint32_t lo = 0, hi = A.n_records;  // last r with cls_tile_off[r] <= ctile
     while (hi - lo > 1) {
@@ -1004,6 +1005,22 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
                 SW_HIP(hipGetLastError());
             }
         }
+        // tiles the fast kernel handed over are redone, exactly, by the generic kernel in list mode.  The list length is
+        // only known on the device: a first batch of LIST_GRID workgroups is enqueued blind (surplus workgroups exit at
+        // once), the rest -- rare -- after the count has come back.
+        constexpr uint32_t LIST_GRID = 2048;
+        SketchArgs al = a;
+        if (plan.n_tiles_fast) {
+            al.cls_tile_off = plan.fast_tile_off.p;
+            al.L = plan.Lg_list;
+            al.TW = plan.TWf;
+            al.list = ovf_list.p;
+            al.tile_base = 0;
+            al.n_tiles = LIST_GRID;
+            hipLaunchKernelGGL(sketch_generic_kernel, dim3(std::min(LIST_GRID, plan.n_tiles_fast)), dim3(BLOCK),
+                               lds_bytes_for(plan.Lg_list), stream, al);
+            SW_HIP(hipGetLastError());
+        }
         SW_HIP(hipEventRecord(ev1, stream));
         unsigned long long total = 0;
         uint32_t n_ovf = 0;
@@ -1014,17 +1031,13 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         SW_HIP(hipEventElapsedTime(&ms, ev0, ev1));
         if (sketch_ms) *sketch_ms += ms;
         ++out.launches;
-        if (n_ovf) {   // tiles the fast kernel handed over: redo them exactly with the generic kernel
-            a.cls_tile_off = plan.fast_tile_off.p;
-            a.L = plan.Lg_list;
-            a.TW = plan.TWf;
-            a.n_tiles = n_ovf;
-            a.list = ovf_list.p;
+        out.n_ovf_tiles += n_ovf;
+        if (n_ovf > LIST_GRID) {
             SW_HIP(hipEventRecord(ev0, stream));
-            for (uint32_t tb = 0; tb < n_ovf; tb += MAX_TILES_PER_LAUNCH) {
-                a.tile_base = tb;
+            for (uint32_t tb = LIST_GRID; tb < n_ovf; tb += MAX_TILES_PER_LAUNCH) {
+                al.tile_base = tb;
                 hipLaunchKernelGGL(sketch_generic_kernel, dim3(std::min(n_ovf - tb, MAX_TILES_PER_LAUNCH)), dim3(BLOCK),
-                                   lds_bytes_for(plan.Lg_list), stream, a);
+                                   lds_bytes_for(plan.Lg_list), stream, al);
                 SW_HIP(hipGetLastError());
             }
             SW_HIP(hipEventRecord(ev1, stream));
@@ -1032,7 +1045,6 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
             SW_HIP(hipStreamSynchronize(stream));
             SW_HIP(hipEventElapsedTime(&ms, ev0, ev1));
             if (sketch_ms) *sketch_ms += ms;
-            out.n_ovf_tiles += n_ovf;
         }
         if (total <= cap) {
             out.n_occ = total;
