@@ -602,6 +602,7 @@ int sw_index_timings(const sw_index *ix, sw_timings *t)
 int sw_index_export(const sw_index *ix, sw_kmer *kmers, sw_node *nodes, sw_edge *edges)
 {
     return guarded([&] {
+        index_settle(*const_cast<sw_index *>(ix));
         const HostSpan spans[3] = {{kmers, ix->n_kmers * sizeof(sw_kmer)}, {nodes, ix->n_nodes * sizeof(sw_node)},
                                    {edges, ix->n_edges * sizeof(sw_edge)}};
         prefault(spans, 3);
@@ -614,6 +615,7 @@ int sw_index_export(const sw_index *ix, sw_kmer *kmers, sw_node *nodes, sw_edge 
 int sw_index_checksums(const sw_index *ix, uint64_t *kmers_sum, uint64_t *nodes_sum, uint64_t *edges_sum)
 {
     return guarded([&] {
+        index_settle(*const_cast<sw_index *>(ix));
         uint64_t s[3];
         device_checksums(*ix, 0, s);
         *kmers_sum = s[0];
@@ -626,12 +628,14 @@ void sw_index_free(sw_index *ix) { delete ix; }
 
 int sw_index_threshold_sums(const sw_index *ix, uint64_t *sums)
 {
-    return guarded([&] { index_threshold_sums(*ix, 0, sums); });
+    return guarded([&] {
+        index_settle(*const_cast<sw_index *>(ix)); index_threshold_sums(*ix, 0, sums); });
 }
 
 int sw_index_filter_graph(const sw_index *ix, uint64_t edge_weight_th, sw_index **out)
 {
     return guarded([&] {
+        index_settle(*const_cast<sw_index *>(ix));
         std::unique_ptr<sw_index> o(new sw_index);
         index_filter_graph(*ix, edge_weight_th, 0, *o);
         *out = o.release();
@@ -642,6 +646,8 @@ int sw_index_filter_kmers(const sw_index *ix, const sw_index *nodes_from, const 
                           sw_index **out)
 {
     return guarded([&] {
+        index_settle(*const_cast<sw_index *>(ix));
+        if (nodes_from) index_settle(*const_cast<sw_index *>(nodes_from));
         std::vector<uint64_t> used(used_hashes, used_hashes + n_used);
         std::sort(used.begin(), used.end());
         DevArray<uint64_t> d_used(n_used);
@@ -716,6 +722,7 @@ int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t 
         SW_HIP(hipEventRecord(e0, (hipStream_t)stream));
         slice_edges(*ix, (const uint64_t *)adj_rows_dev, m, (unsigned)n_bits, (unsigned)asm_bits,
                     (const uint64_t *)rank_hash_dev, (hipStream_t)stream);
+        index_settle(*ix);   // the counts launched by sw_slice_build
         SW_HIP(hipEventRecord(e1, (hipStream_t)stream));
         SW_HIP(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -734,6 +741,7 @@ int sw_index_node_hashes(const sw_index *ix, void *dst_dev, void *stream)
 int sw_index_device_ptrs(const sw_index *ix, void **kmers, void **nodes, void **edges)
 {
     return guarded([&] {
+        index_settle(*const_cast<sw_index *>(ix));
         if (kmers) *kmers = ix->kmers.p;
         if (nodes) *nodes = ix->nodes.p;
         if (edges) *edges = ix->edges.p;
@@ -742,7 +750,8 @@ int sw_index_device_ptrs(const sw_index *ix, void **kmers, void **nodes, void **
 
 int sw_index_occ_rows(const sw_index *ix, uint64_t rec_offset, void *rows_dev, void *stream)
 {
-    return guarded([&] { index_occ_rows(*ix, rec_offset, (uint64_t *)rows_dev, (hipStream_t)stream); });
+    return guarded([&] {
+        index_settle(*const_cast<sw_index *>(ix)); index_occ_rows(*ix, rec_offset, (uint64_t *)rows_dev, (hipStream_t)stream); });
 }
 
 int sw_index_edge_rows(const sw_index *ix, void *rows_dev, void *stream)
@@ -758,6 +767,7 @@ int sw_index_splits(const sw_index *ix, const uint64_t *node_bounds, const uint6
                     uint64_t *occ_split, uint64_t *edge_split, void *stream)
 {
     return guarded([&] {
+        index_settle(*const_cast<sw_index *>(ix));
         index_splits(*ix, node_bounds, edge_bounds, (uint32_t)n_bounds, occ_split, edge_split, (hipStream_t)stream);
     });
 }
@@ -815,7 +825,8 @@ static void merge_like(const void *occ_rows_dev, uint64_t n_occ, const void *edg
         SW_HIP(hipEventCreate(&e1));
         SW_HIP(hipEventRecord(e0, st));
         merge_build((const uint64_t *)occ_rows_dev, n_occ, (const uint64_t *)edge_rows_dev, n_edge_rows, kmer_base,
-                    d_rec_asm.p, n_records, is_targets ? d_tar.p : nullptr, n_tar, n_neg, st, *ix, d_rank_out);
+                    d_rec_asm.p, n_records, is_targets ? d_tar.p : nullptr, n_tar, n_neg, st, *ix, d_rank_out,
+                    d_rank_out ? &d_rec_asm : nullptr, d_rank_out ? &d_tar : nullptr);   // slice build: counts stay in flight
         SW_HIP(hipEventRecord(e1, st));
         SW_HIP(hipEventSynchronize(e1));
         float ms = 0.f;

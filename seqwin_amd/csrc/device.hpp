@@ -99,6 +99,11 @@ struct sw_occ {   // ordered tuple stream of one shard (tuple-exchange form of t
     ~sw_occ();
 };
 
+namespace sw {
+struct PendingCounts;                          // index.hip: counts of a slice build still running on the side stream
+void pending_counts_delete(PendingCounts *p);
+}
+
 struct sw_index {
     int device = 0;
     uint64_t n_kmers = 0, n_nodes = 0, n_edges = 0;
@@ -106,6 +111,10 @@ struct sw_index {
     sw::DevArray<sw_node> nodes;
     sw::DevArray<sw_edge> edges;
     sw_timings timings{};
+    // sw_slice_build leaves its target / non-target counts in flight (they overlap the exchanges that follow); every
+    // reader of nodes[].start / stop / n_tar / n_neg / penalty goes through sw::index_settle first
+    sw::PendingCounts *pending = nullptr;
+    ~sw_index() { sw::pending_counts_delete(pending); }
 };
 
 namespace sw {
@@ -134,6 +143,7 @@ struct OrderedOcc {
     uint64_t n = 0;
 };
 void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out);
+void index_settle(sw_index &ix);   // finish deferred counts (no-op otherwise)
 void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target, uint64_t n_targets,
                  uint64_t n_non_targets, hipStream_t stream, sw_index &ix);
 void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
@@ -151,7 +161,8 @@ void index_splits(const sw_index &ix, const uint64_t *node_bounds, const uint64_
                   uint64_t *occ_split, uint64_t *edge_split, hipStream_t stream);
 void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_rows, uint64_t m, uint64_t kmer_base,
                  const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target, uint64_t n_targets,
-                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix, uint32_t *d_rank_out = nullptr);
+                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix, uint32_t *d_rank_out = nullptr,
+                 DevArray<uint32_t> *defer_rec_asm = nullptr, DevArray<uint8_t> *defer_is_target = nullptr);
 void occ_partition(const OrderedOcc &occ, const uint64_t *bounds, uint32_t n_bounds, uint64_t rec_offset, uint64_t *d_rows,
                    uint32_t *d_perm, uint64_t *counts_host, hipStream_t stream);
 void occ_adjacency(const OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_perm, const uint32_t *d_rank_by_row,

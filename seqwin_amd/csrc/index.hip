@@ -15,6 +15,7 @@
 // is domain-specific glue around them.
 #include <cstdlib>
 #include <cstring>  // rocprim's texture iterator needs ::memset declared first
+#include <memory>
 
 #include <rocprim/rocprim.hpp>
 
@@ -1254,6 +1255,40 @@ void edges_from_adjacency(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, ui
 }
 }  // namespace
 
+struct PendingCounts {
+    PenaltyJob job;
+    DevArray<uint32_t> rec_asm;
+    DevArray<uint8_t> is_target;
+    hipEvent_t ev = nullptr;       // recorded on the side stream after the counts
+    hipStream_t stream = nullptr;  // the build's stream
+    uint64_t kmer_base = 0;
+};
+
+void pending_counts_delete(PendingCounts *p)
+{
+    if (!p) return;
+    if (p->job.active) (void)hipStreamSynchronize(p->job.stream);   // nothing may still use the buffers
+    if (p->ev) (void)hipEventDestroy(p->ev);
+    delete p;
+}
+
+void index_settle(sw_index &ix)
+{
+    if (!ix.pending) return;
+    std::unique_ptr<PendingCounts, void (*)(PendingCounts *)> pc(ix.pending, pending_counts_delete);
+    ix.pending = nullptr;
+    const uint64_t err = penalty_finish(pc->job);
+    SW_HIP(hipStreamWaitEvent(pc->stream, pc->ev, 0));
+    if (err) raise(SW_ERR_RUNTIME, "internal error: inconsistent occurrence order in merged index (%llu)",
+                   (unsigned long long)err);
+    if (pc->kmer_base && ix.n_nodes) {
+        hipLaunchKernelGGL(k_rebase_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, pc->stream, ix.nodes.p, ix.n_nodes,
+                           pc->kmer_base);
+        SW_HIP(hipGetLastError());
+        SW_HIP(hipStreamSynchronize(pc->stream));
+    }
+}
+
 void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
                         const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,
                         uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, uint64_t *err_flags_host)
@@ -1394,7 +1429,8 @@ void index_splits(const sw_index &ix, const uint64_t *node_bounds, const uint64_
 // with globally rebased record indices), edge rows as (first, second, partial weight).
 void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_rows, uint64_t m, uint64_t kmer_base,
                  const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target, uint64_t n_targets,
-                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix, uint32_t *d_rank_out)
+                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix, uint32_t *d_rank_out,
+                 DevArray<uint32_t> *defer_rec_asm, DevArray<uint8_t> *defer_is_target)
 {
     if (n >= 0xFFFFFFFFull || m >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 rows on one device");
     ix.n_kmers = n;
@@ -1418,6 +1454,29 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
     }
     // counts on slice-local ranges, on the side stream so that they overlap the partial-edge merge below;
     // ranges are re-based after both are done
+    if (defer_rec_asm && defer_is_target && d_is_target && ix.n_nodes && m == 0) {
+        // slice build of the tuple-exchange form: the counts keep running on the side stream while the caller goes on
+        // with the rank / adjacency exchanges; index_settle() collects them (and re-bases the ranges)
+        std::unique_ptr<PendingCounts> pc(new PendingCounts);
+        pc->rec_asm = std::move(*defer_rec_asm);
+        pc->is_target = std::move(*defer_is_target);
+        pc->kmer_base = kmer_base;
+        pc->stream = stream;
+        hipStream_t side = side_stream();
+        hipEvent_t ev_nodes = nullptr;
+        SW_HIP(hipEventCreate(&ev_nodes));
+        SW_HIP(hipEventCreateWithFlags(&pc->ev, hipEventDisableTiming));
+        SW_HIP(hipEventRecord(ev_nodes, stream));
+        SW_HIP(hipStreamWaitEvent(side, ev_nodes, 0));
+        penalty_launch(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, pc->rec_asm.p, n_records, pc->is_target.p, n_targets,
+                       n_non_targets, side, pc->job);
+        SW_HIP(hipEventRecord(pc->ev, side));
+        (void)hipEventDestroy(ev_nodes);
+        ix.n_edges = 0;
+        ix.edges.alloc(0);
+        ix.pending = pc.release();
+        return;
+    }
     PenaltyJob pen;
     hipEvent_t ev_nodes = nullptr, ev_pen = nullptr;
     if (d_is_target && ix.n_nodes) {
