@@ -405,7 +405,7 @@ def test_staging_overflow_rerun(tmp_path):
 def test_window_equal_to_run_length_and_overflow_tiles(tmp_path, w, monkeypatch):
     """w == L (16 / 32) is the corner where the window never reaches past the previous run, and the tiles the
     fast kernel hands to the generic kernel (more suffix records than it publishes) must still fit that kernel's
-    geometry (run length <= w).  Found by scripts/fuzz_gpu.py; SEQWIN_AMD_RC forces the hand-over for most tiles."""
+    geometry (run length <= w).  Found by tests/tools/fuzz_gpu.py; SEQWIN_AMD_RC forces the hand-over for most tiles."""
     rng = np.random.default_rng(w)
     p = tmp_path / "long.fa"
     p.write_text(">a\n" + "".join(rng.choice(list("ACGT"), 70000)) + "\n>b\n" + "".join(rng.choice(list("ACGT"), 8193)) + "\n")

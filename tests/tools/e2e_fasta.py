@@ -3,7 +3,7 @@ reference CPU path on the same files.  Not the bench metric (which starts with i
 import os, sys, tempfile, time
 from pathlib import Path
 import numpy as np
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import oracle
 from seqwin_amd import _core

@@ -1,9 +1,9 @@
 """Long differential fuzz on the GPU box: HIP path vs oracle on random FASTA sets and (k, w).
-usage: python scripts/fuzz_gpu.py SECONDS [SEED]"""
+usage: python tests/tools/fuzz_gpu.py SECONDS [SEED]"""
 import gzip, os, random, sys, tempfile, time
 from pathlib import Path
 import numpy as np
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import oracle
 from seqwin_amd import _core

@@ -2,7 +2,7 @@
 import json, sys, time
 from pathlib import Path
 import numpy as np
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import oracle
 from seqwin_amd import _core
