@@ -111,6 +111,16 @@ void require_device()
     }
 }
 
+// Objects live on the device that was current when they were created; one process (or thread) per GPU is the model.
+void require_current_device(int device, const char *what)
+{
+    int cur = -1;
+    SW_HIP(hipGetDevice(&cur));
+    if (cur != device)
+        raise(SW_ERR_VALUE, "%s lives on device %d but the calling thread's current device is %d (sw_set_device)", what, device,
+              cur);
+}
+
 // The arrays a caller hands in for results are usually fresh (np.empty): their pages are faulted in by the
 // device-to-host copies, one page at a time on one thread.  Touching them from a few threads first takes most of
 // that time away (18 -> ~8 ms for 280 MB on the target host).
@@ -318,6 +328,7 @@ void check_targets(const uint8_t *is_targets, uint64_t n, uint64_t *n_tar, uint6
 void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targets, uint64_t n_assemblies,
                     hipStream_t stream, sw_index &ix)
 {
+    require_current_device(b.device, "the batch");
     Plan &plan = get_plan(b, k, w);
     uint64_t n_tar = 0, n_neg = 0;
     DevArray<uint8_t> d_tar;
@@ -603,6 +614,7 @@ int sw_index_export(const sw_index *ix, sw_kmer *kmers, sw_node *nodes, sw_edge 
 {
     return guarded([&] {
         index_settle(*const_cast<sw_index *>(ix));
+        require_current_device(ix->device, "the index");
         const HostSpan spans[3] = {{kmers, ix->n_kmers * sizeof(sw_kmer)}, {nodes, ix->n_nodes * sizeof(sw_node)},
                                    {edges, ix->n_edges * sizeof(sw_edge)}};
         prefault(spans, 3);
@@ -637,6 +649,7 @@ int sw_index_filter_graph(const sw_index *ix, uint64_t edge_weight_th, sw_index 
     return guarded([&] {
         index_settle(*const_cast<sw_index *>(ix));
         std::unique_ptr<sw_index> o(new sw_index);
+        o->device = ix->device;
         index_filter_graph(*ix, edge_weight_th, 0, *o);
         *out = o.release();
     });
@@ -669,6 +682,7 @@ int sw_occ_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void
 {
     return guarded([&] {
         sw_batch &bb = *const_cast<sw_batch *>(b);
+        require_current_device(bb.device, "the batch");
         Plan &plan = get_plan(bb, kmerlen, windowsize);
         std::unique_ptr<sw_occ> o(new sw_occ);
         o->batch = b;

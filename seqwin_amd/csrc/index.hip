@@ -15,6 +15,7 @@
 // is domain-specific glue around them.
 #include <cstdlib>
 #include <cstring>  // rocprim's texture iterator needs ::memset declared first
+#include <map>
 #include <memory>
 
 #include <rocprim/rocprim.hpp>
@@ -1132,9 +1133,12 @@ uint64_t penalty_finish(PenaltyJob &job)
     return e;
 }
 
-hipStream_t side_stream()
+hipStream_t side_stream()   // one per (thread, current device); never destroyed
 {
-    static thread_local hipStream_t s = nullptr;
+    static thread_local std::map<int, hipStream_t> streams;
+    int dev = 0;
+    SW_HIP(hipGetDevice(&dev));
+    hipStream_t &s = streams[dev];
     if (!s) SW_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     return s;
 }
