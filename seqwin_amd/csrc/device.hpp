@@ -69,6 +69,9 @@ struct Plan {
     DevArray<uint32_t> rec_tile_off;  // [R + 1] global tile numbering
     DevArray<uint32_t> fast_tile_off; // [R + 1] tiles of the fast class
     DevArray<uint32_t> gen_tile_off;  // [R + 1] tiles of the generic class
+    DevArray<uint32_t> fast_tile_rec; // [n_tiles_fast] record of every fast-class tile (no search in the kernel)
+    DevArray<uint32_t> gen_tile_rec;  // [n_tiles_gen]
+    uint32_t slot_cap = 0;            // stage entries reserved per tile (1.5 x the expected number of minimizers + 16)
     DevArray<uint32_t> seg_pos;       // [S]
     DevArray<uint32_t> seg_idx;       // [S]
     DevArray<uint64_t> lut;           // [40] roll tables, see sketch.hip
@@ -122,7 +125,8 @@ namespace sw {
 Plan &get_plan(sw_batch &b, uint64_t k, uint64_t w);
 
 // sketch.hip: runs the fused ntHash + window-minimum kernel over every tile of the plan.
-// Output: tuples in TILE-ALLOCATION order in (stage_hash, stage_kmer) plus per-tile (offset, count).
+// Output: tuples per tile in (stage_hash, stage_kmer) -- a tile's own slot at tile * slot_cap, or a range of the
+// overflow area behind the slots -- plus per-tile (offset, count).
 struct SketchOut {
     DevArray<uint64_t> stage_hash;
     DevArray<uint64_t> stage_kmer;   // pos | record_idx << 32

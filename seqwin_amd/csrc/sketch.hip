@@ -36,7 +36,10 @@ namespace sw {
 
 namespace {
 
-constexpr int BLOCK = 256;
+#ifndef SW_BLOCK
+#define SW_BLOCK 256
+#endif
+constexpr int BLOCK = SW_BLOCK;
 constexpr uint32_t MAX_TILES_PER_LAUNCH = 1u << 23;  // x 256 threads stays below the 2^32 work-item grid limit
 constexpr uint32_t L_MAX = 33;  // 256*33 elements * 8 B = 66 KiB of hashes -> two workgroups per CU
 
@@ -74,8 +77,11 @@ struct SketchArgs {
     uint32_t halo;   // fast class: elements a tile holds before its first owned window end (w rounded up to whole runs)
     uint64_t *stage_hash;
     uint64_t *stage_kmer;
-    unsigned long long *cursor;
-    uint64_t cap;
+    unsigned long long *cursor;   // entries taken from the shared overflow area (tiles with more than slot_cap winners)
+    uint64_t cap;                 // total entries of the stage arrays (slots + overflow area)
+    uint64_t ovf_base;            // first entry of the overflow area = n_tiles * slot_cap
+    uint32_t slot_cap;            // entries of a tile's own slot at tile * slot_cap
+    const uint32_t *cls_tile_rec; // [class tiles] record of every tile of the class this launch covers
     uint32_t *tile_count;
     uint64_t *tile_offset;
     uint32_t *ovf_count;          // fast kernel: number of tiles handed over to the generic kernel
@@ -168,12 +174,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
     // list mode: redo tiles of the fast class (same window ranges: TW = the fast class's TW <= NE - w)
     if (A.list && A.tile_base + blockIdx.x >= *A.ovf_count) return;   // list length is only known on the device
     const uint32_t ctile = A.list ? A.list[A.tile_base + blockIdx.x] : A.tile_base + blockIdx.x;
-    uint32_t lo = 0, hi = A.n_records;  // last r with cls_tile_off[r] <= ctile
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (A.cls_tile_off[mid] <= ctile) lo = mid; else hi = mid;
-    }
-    const uint32_t rec = lo;
+    const uint32_t rec = A.cls_tile_rec[ctile];   // (one load instead of a 15-step search: the chain is pure latency)
     const uint32_t t = ctile - A.cls_tile_off[rec];
     const uint32_t tile = A.rec_tile_off[rec] + t;  // global tile id (order pass)
     const uint32_t nvalid = A.rec_nvalid[rec];
@@ -346,15 +347,23 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
         if (i < wave) wave_off += v;
         total += v;
     }
+    // Output range: the tile's own slot (no atomic, no round trip); only a tile with more winners than the slot holds
+    // takes a range of the shared overflow area.  (One atomic per tile on one address caps the whole launch at
+    // ~80 M tiles/s on MI355X, measured: that was the sketch kernel's real bound.)
+    uint64_t base = (uint64_t)tile * A.slot_cap;
+    if (__builtin_amdgcn_readfirstlane(total) > A.slot_cap) {   // workgroup-uniform
+        if (tid == 0) {
+            const unsigned long long got = atomicAdd(A.cursor, (unsigned long long)total);
+            MISC[8] = (uint32_t)got;
+            MISC[9] = (uint32_t)(got >> 32);
+        }
+        __syncthreads();
+        base = A.ovf_base + make64(MISC[8], MISC[9]);
+    }
     if (tid == 0) {
-        const unsigned long long base = atomicAdd(A.cursor, (unsigned long long)total);
         A.tile_count[tile] = total;
         A.tile_offset[tile] = base;
-        MISC[8] = (uint32_t)base;
-        MISC[9] = (uint32_t)(base >> 32);
     }
-    __syncthreads();
-    const uint64_t base = make64(MISC[8], MISC[9]);
     if (cnt && base + total <= A.cap) {
         uint64_t o = base + wave_off + (incl - cnt);
         while (bits) {
@@ -429,12 +438,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
     const uint32_t tid = threadIdx.x, w = A.w, k = A.k;
 
     const uint32_t ctile = A.tile_base + blockIdx.x;
-    uint32_t lo = 0, hi = A.n_records;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (A.cls_tile_off[mid] <= ctile) lo = mid; else hi = mid;
-    }
-    const uint32_t rec = lo;
+    const uint32_t rec = A.cls_tile_rec[ctile];
     const uint32_t t = ctile - A.cls_tile_off[rec];
     const uint32_t tile = A.rec_tile_off[rec] + t;
     const uint32_t nvalid = A.rec_nvalid[rec];
@@ -527,7 +531,9 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         // Rolls 1..L-1 of this lane take in-base (k + j - 1) and out-base (j - 1) of the run.  Both streams are
         // re-aligned once to the lane's first base (funnel shifts by the wave-uniform phases), so that the base
         // pair of every roll is a compile-time bit field: no per-step refill test, 4 VALU per LUT index.
-        uint32_t ob[L / 16], ib[L / 16];
+        // The two 2-bit fields are interleaved once per word into 4-bit LUT rows ((out << 2) | in): rows of the even
+        // bases in `ev`, of the odd bases in `od` -> one shift + one mask per roll.
+        uint32_t ev[L / 16], od[L / 16];
         {
             const uint32_t so = 2u * ph;
             const uint32_t pk = ph + k;
@@ -535,15 +541,16 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
             const uint32_t si = 2u * (pk & 15u);
 #pragma unroll
             for (int q = 0; q < L / 16; ++q) {
-                ob[q] = __builtin_amdgcn_alignbit(wp[q + 1], wp[q], so);
-                ib[q] = __builtin_amdgcn_alignbit(wi[q + 1], wi[q], si);
+                const uint32_t ob = __builtin_amdgcn_alignbit(wp[q + 1], wp[q], so);
+                const uint32_t ib = __builtin_amdgcn_alignbit(wi[q + 1], wi[q], si);
+                ev[q] = (ib & 0x33333333u) | ((ob & 0x33333333u) << 2);
+                od[q] = ((ib >> 2) & 0x33333333u) | (ob & 0xCCCCCCCCu);
             }
         }
-        auto lut_off = [&](int r) -> uint32_t {          // roll r (1-based): LUT row ((out << 2) | in), 16 B per row
-            const int b = r - 1, q = b >> 4, sh = 2 * (b & 15);
-            const uint32_t i4 = (sh >= 4 ? (ib[q] >> (sh - 4)) : (ib[q] << (4 - sh))) & 0x30u;
-            const uint32_t o6 = (sh >= 6 ? (ob[q] >> (sh - 6)) : (ob[q] << (6 - sh))) & 0xC0u;
-            return i4 | o6;
+        auto lut_off = [&](int r) -> uint32_t {          // roll r (1-based): byte offset of LUT row, 16 B per row
+            const int b = r - 1, q = b >> 4, sh = 4 * ((b & 15) >> 1);
+            const uint32_t m = (b & 1) ? od[q] : ev[q];
+            return (sh >= 4 ? (m >> (sh - 4)) : (m << 4)) & 0xF0u;
         };
         const unsigned char *LUTb = reinterpret_cast<const unsigned char *>(LUT);
         uint64_t lf, lr;
@@ -686,18 +693,27 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
                 MISC[0] = (lc_h < rm_h) ? lc_e : (uint32_t)RMp[tid];
             }
             if (owner) {
-            recompute(xb);
+                // Winners inside the own run are collected in a register (bit j = element e0 + j, the lane's own
+                // bits of the emit bitmap) and published once; a left winner is marked when it is (re)computed:
+                // the own prefix minimum only falls while it stays current, so it wins some window iff it wins
+                // the first one.  No per-step LDS atomic, no "did the winner change" test (marks are idempotent).
+                uint32_t own = 0, pre_bit = 0;
 #pragma unroll
-            for (int j = 0; j < L; ++j) {
-                const bool keep = pre_h < h[j];                            // '<=' for the newcomer: rightmost wins
-                pre_h = keep ? pre_h : h[j];
-                pre_e = keep ? pre_e : e0 + j;
-                if (j && lc_d < (uint32_t)j) recompute(xb + j);
-                const bool left = lc_h < pre_h;
-                const uint32_t ce = left ? lc_e : pre_e;
-                if (ce != prev_arg) atomicOr(&EM[ce >> 5], 1u << (ce & 31u));
-                prev_arg = ce;
-            }
+                for (int j = 0; j < L; ++j) {
+                    const bool keep = pre_h < h[j];                        // '<=' for the newcomer: rightmost wins
+                    pre_h = keep ? pre_h : h[j];
+                    pre_bit = keep ? pre_bit : (1u << j);
+                    if (j == 0 || lc_d < (uint32_t)j) {
+                        recompute(xb + j);
+                        if (lc_h < pre_h) atomicOr(&EM[lc_e >> 5], 1u << (lc_e & 31u));
+                    }
+                    // pin the loop state: without it the compiler threads the two compares below and above through
+                    // each other and keeps 30+ more values live (128 VGPRs + spills instead of 95)
+                    asm volatile("" : "+v"(lc_h), "+v"(pre_h), "+v"(own), "+v"(pre_bit));
+                    own |= (lc_h < pre_h) ? 0u : pre_bit;
+                }
+                if (L == 32) atomicOr(&EM[tid], own);
+                else atomicOr(&EM[tid >> 1], own << ((tid & 1u) * 16u));
             }
         } else {
 #pragma unroll
@@ -755,15 +771,23 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         if (i < wave) wave_off += v;
         total += v;
     }
+    // Output range: the tile's own slot (no atomic, no round trip); only a tile with more winners than the slot holds
+    // takes a range of the shared overflow area.  (One atomic per tile on one address caps the whole launch at
+    // ~80 M tiles/s on MI355X, measured: that was the sketch kernel's real bound.)
+    uint64_t base = (uint64_t)tile * A.slot_cap;
+    if (__builtin_amdgcn_readfirstlane(total) > A.slot_cap) {   // workgroup-uniform
+        if (tid == 0) {
+            const unsigned long long got = atomicAdd(A.cursor, (unsigned long long)total);
+            MISC[8] = (uint32_t)got;
+            MISC[9] = (uint32_t)(got >> 32);
+        }
+        __syncthreads();
+        base = A.ovf_base + make64(MISC[8], MISC[9]);
+    }
     if (tid == 0) {
-        const unsigned long long base = atomicAdd(A.cursor, (unsigned long long)total);
         A.tile_count[tile] = total;
         A.tile_offset[tile] = base;
-        MISC[8] = (uint32_t)base;
-        MISC[9] = (uint32_t)(base >> 32);
     }
-    __syncthreads();
-    const uint64_t base = make64(MISC[8], MISC[9]);
     if (cnt && base + total <= A.cap) {
         uint64_t o = base + wave_off + (incl - cnt);
         const uint64_t kmer0 = (uint64_t)(pos0 + E0 + e0) | ((uint64_t)rec << 32);
@@ -778,6 +802,16 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
             }
         }
     }
+}
+
+// n_occ = sum of the per-tile counts (the tiles take no shared cursor any more): one atomic per workgroup of 4096 tiles.
+__global__ void k_sum_counts(const uint32_t *__restrict__ tile_count, uint32_t n_tiles, unsigned long long *__restrict__ total)
+{
+    unsigned long long v = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_tiles; i += (uint64_t)gridDim.x * blockDim.x)
+        v += tile_count[i];
+    for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(total, v);
 }
 
 size_t lds_bytes_for(uint32_t L)
@@ -825,7 +859,7 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     const HostBatch &h = b.host;
     const size_t R = h.rec_len.size();
     std::vector<uint32_t> rec_seg_off(R + 1, 0), rec_nvalid(R, 0), rec_tile_off(R + 1, 0), fast_off(R + 1, 0),
-        gen_off(R + 1, 0), seg_pos, seg_idx;
+        gen_off(R + 1, 0), seg_pos, seg_idx, fast_rec, gen_rec;
     uint64_t tiles = 0, tiles_f = 0, tiles_g = 0;
     for (size_t r = 0; r < R; ++r) {
         rec_seg_off[r] = (uint32_t)seg_pos.size();
@@ -849,10 +883,12 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
             p.n_windows += windows;
             if (p.Lf && nseg == 1) {
                 const uint64_t nt = (windows + p.TWf - 1) / p.TWf;
+                fast_rec.insert(fast_rec.end(), nt, (uint32_t)r);
                 tiles_f += nt;
                 tiles += nt;
             } else {
                 const uint64_t nt = (windows + p.TW - 1) / p.TW;
+                gen_rec.insert(gen_rec.end(), nt, (uint32_t)r);
                 tiles_g += nt;
                 tiles += nt;
             }
@@ -866,6 +902,11 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     p.n_tiles = (uint32_t)tiles;
     p.n_tiles_fast = (uint32_t)tiles_f;
     p.n_tiles_gen = (uint32_t)tiles_g;
+    {   // a tile's own stage slot: 1.5 x the expected 2 / (w + 1) minimizers per window end, + 16
+        const uint64_t tw = std::max<uint64_t>(p.TW, p.TWf);
+        p.slot_cap = (uint32_t)std::min<uint64_t>(tw + w, (3 * tw / (w + 1) + 16 + 7) / 8 * 8);
+        if (const char *e = getenv("SEQWIN_AMD_SLOT_CAP")) p.slot_cap = (uint32_t)std::max(1, atoi(e));   // test hook
+    }
 
     uint64_t lut[40];
     const uint64_t S[4] = {SEED_A, SEED_C, SEED_G, SEED_T};
@@ -887,6 +928,8 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     up32(p.rec_tile_off, rec_tile_off);
     up32(p.fast_tile_off, fast_off);
     up32(p.gen_tile_off, gen_off);
+    up32(p.fast_tile_rec, fast_rec);
+    up32(p.gen_tile_rec, gen_rec);
     up32(p.seg_pos, seg_pos);
     up32(p.seg_idx, seg_idx);
     p.lut.alloc(40);
@@ -935,18 +978,20 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
     out.tile_offset.alloc(plan.n_tiles);
     if (plan.n_tiles == 0) return;
 
-    DevArray<unsigned long long> cursor(1);
+    DevArray<unsigned long long> cursor(2);   // [0] entries taken from the overflow area, [1] sum of the tile counts
     DevArray<uint32_t> ovf_count(1), ovf_list(plan.n_tiles_fast);
-    // expected density 2/(w+1) per window; grow and re-run in the (rare) overflow case
-    uint64_t cap = std::min<uint64_t>(plan.n_windows,
-                                      plan.n_windows / (plan.w + 1) * 3 + (uint64_t)plan.n_tiles * 4 + 4096);
+    // every tile owns a slot of slot_cap entries (1.5 x the expected density 2/(w+1) per window end); tiles with more
+    // winners share an overflow area behind the slots, which is grown to the exact size and the pass re-run if it is too small
+    const uint64_t slots = (uint64_t)plan.n_tiles * plan.slot_cap;
+    uint64_t ovf_cap = std::max<uint64_t>(4096, slots / 64);
     hipEvent_t ev0, ev1;
     SW_HIP(hipEventCreate(&ev0));
     SW_HIP(hipEventCreate(&ev1));
     for (;;) {
+        const uint64_t cap = slots + ovf_cap;
         out.stage_hash.alloc(cap);
         out.stage_kmer.alloc(cap);
-        SW_HIP(hipMemsetAsync(cursor.p, 0, sizeof(unsigned long long), stream));
+        SW_HIP(hipMemsetAsync(cursor.p, 0, 2 * sizeof(unsigned long long), stream));
         SketchArgs a;
         a.packed = b.d_packed.p;
         a.rec_base = b.d_rec_base.p;
@@ -966,6 +1011,8 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         a.stage_kmer = out.stage_kmer.p;
         a.cursor = cursor.p;
         a.cap = cap;
+        a.ovf_base = slots;
+        a.slot_cap = plan.slot_cap;
         a.tile_count = out.tile_count.p;
         a.tile_offset = out.tile_offset.p;
         a.ovf_count = ovf_count.p;
@@ -979,6 +1026,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         SW_HIP(hipEventRecord(ev0, stream));
         if (plan.n_tiles_fast) {
             a.cls_tile_off = plan.fast_tile_off.p;
+            a.cls_tile_rec = plan.fast_tile_rec.p;
             a.L = plan.Lf;
             a.TW = plan.TWf;
             a.halo = plan.halo_f;
@@ -995,6 +1043,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         }
         if (plan.n_tiles_gen) {
             a.cls_tile_off = plan.gen_tile_off.p;
+            a.cls_tile_rec = plan.gen_tile_rec.p;
             a.L = plan.L;
             a.TW = plan.TW;
             a.n_tiles = plan.n_tiles_gen;
@@ -1012,6 +1061,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         SketchArgs al = a;
         if (plan.n_tiles_fast) {
             al.cls_tile_off = plan.fast_tile_off.p;
+            al.cls_tile_rec = plan.fast_tile_rec.p;
             al.L = plan.Lg_list;
             al.TW = plan.TWf;
             al.list = ovf_list.p;
@@ -1021,10 +1071,16 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
                                lds_bytes_for(plan.Lg_list), stream, al);
             SW_HIP(hipGetLastError());
         }
+        auto sum_counts = [&]() {
+            const uint32_t blocks = (uint32_t)std::min<uint64_t>(1024, ((uint64_t)plan.n_tiles + 4095) / 4096);
+            hipLaunchKernelGGL(k_sum_counts, dim3(blocks), dim3(256), 0, stream, out.tile_count.p, plan.n_tiles, cursor.p + 1);
+            SW_HIP(hipGetLastError());
+        };
+        sum_counts();
         SW_HIP(hipEventRecord(ev1, stream));
-        unsigned long long total = 0;
+        unsigned long long total[2] = {0, 0};   // overflow entries taken, n_occ
         uint32_t n_ovf = 0;
-        SW_HIP(hipMemcpyAsync(&total, cursor.p, sizeof total, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipMemcpyAsync(total, cursor.p, sizeof total, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipMemcpyAsync(&n_ovf, ovf_count.p, 4, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipStreamSynchronize(stream));
         float ms = 0.f;
@@ -1040,17 +1096,19 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
                                    lds_bytes_for(plan.Lg_list), stream, al);
                 SW_HIP(hipGetLastError());
             }
+            SW_HIP(hipMemsetAsync(cursor.p + 1, 0, sizeof(unsigned long long), stream));
+            sum_counts();
             SW_HIP(hipEventRecord(ev1, stream));
-            SW_HIP(hipMemcpyAsync(&total, cursor.p, sizeof total, hipMemcpyDeviceToHost, stream));
+            SW_HIP(hipMemcpyAsync(total, cursor.p, sizeof total, hipMemcpyDeviceToHost, stream));
             SW_HIP(hipStreamSynchronize(stream));
             SW_HIP(hipEventElapsedTime(&ms, ev0, ev1));
             if (sketch_ms) *sketch_ms += ms;
         }
-        if (total <= cap) {
-            out.n_occ = total;
+        if (total[0] <= ovf_cap) {
+            out.n_occ = total[1];
             break;
         }
-        cap = total;  // exact size is now known
+        ovf_cap = total[0];  // exact size is now known
     }
     SW_HIP(hipEventDestroy(ev0));
     SW_HIP(hipEventDestroy(ev1));

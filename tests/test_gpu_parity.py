@@ -401,6 +401,28 @@ def test_staging_overflow_rerun(tmp_path):
         assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
 
 
+@pytest.mark.parametrize("slot_cap", ["1", "40", "90"])
+def test_tile_slots_and_shared_overflow_area(tmp_path, slot_cap, monkeypatch):
+    """Every tile writes its tuples into its own stage slot; a tile with more winners than the slot holds takes a range
+    of the shared overflow area (one atomic), and the pass is re-run with the exact size when that area is too small.
+    SEQWIN_AMD_SLOT_CAP shrinks the slot so that all (1), most (40) or some (90 of ~80 expected) tiles overflow."""
+    rng = np.random.default_rng(int(slot_cap))
+    paths = []
+    for i in range(3):
+        p = tmp_path / f"g{i}.fa"
+        seq = "".join(rng.choice(list("ACGT"), 150000 + 977 * i))
+        p.write_text(f">a{i}\n{seq[:90001]}\n>b{i}\n{seq[90001:110000]}NNN{seq[110000:]}\n")
+        paths.append(p)
+    exp = oracle.build(paths, 21, 200)
+    monkeypatch.setenv("SEQWIN_AMD_SLOT_CAP", slot_cap)
+    got = _build(paths, 21, 200)
+    assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
+    t = Batch.from_fasta(paths).build_index(21, 200).timings()
+    assert t["sketch_launches"] in (1, 2)   # 2: the first overflow area (4096 entries here) was outgrown and the pass re-run
+    monkeypatch.delenv("SEQWIN_AMD_SLOT_CAP")
+    assert Batch.from_fasta(paths).build_index(21, 200).timings()["sketch_launches"] == 1
+
+
 @pytest.mark.parametrize("w", [16, 17, 31, 32, 33])
 def test_window_equal_to_run_length_and_overflow_tiles(tmp_path, w, monkeypatch):
     """w == L (16 / 32) is the corner where the window never reaches past the previous run, and the tiles the
