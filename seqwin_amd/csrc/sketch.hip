@@ -425,7 +425,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
     constexpr uint32_t LM = L - 1;
     constexpr uint32_t LSH = (L == 32) ? 5 : 4;
     static_assert(L == 32 || L == 16, "run length must be 16 or 32");
-    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ __align__(16) unsigned char smem[C::bytes];   // static: LDS addresses are compile-time constants
     uint64_t *REC = reinterpret_cast<uint64_t *>(smem + C::off_REC);
     uint64_t *RMh = reinterpret_cast<uint64_t *>(smem + C::off_RMh);
     uint64_t *LUT = reinterpret_cast<uint64_t *>(smem + C::off_LUT);
@@ -789,16 +789,20 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         A.tile_offset[tile] = base;
     }
     if (cnt && base + total <= A.cap) {
-        uint64_t o = base + wave_off + (incl - cnt);
-        const uint64_t kmer0 = (uint64_t)(pos0 + E0 + e0) | ((uint64_t)rec << 32);
+        // uniform 64-bit bases in SGPRs + a 32-bit lane offset: one shift per store instead of 64-bit address arithmetic
+        const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base), bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        uint64_t *const sh = A.stage_hash + make64(blo, bhi);
+        uint64_t *const sk = A.stage_kmer + make64(blo, bhi);
+        uint32_t ob = (wave_off + (incl - cnt)) * 8u;   // byte offset inside the tile's range (< 2^32: a range holds <= NE entries)
+        const uint32_t kpos = pos0 + E0 + e0;
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             if ((bits >> j) & 1u) {
                 // the canonical hash is staged; out_hash = extend_hashes(h) (hashing_internals.hpp:89-103: one 64-bit
                 // multiply + xor-shift) is applied by k_order, which touches every tuple anyway and is HBM-bound
-                A.stage_hash[o] = h[j];
-                A.stage_kmer[o] = kmer0 + (uint32_t)j;
-                ++o;
+                *reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(sh) + ob) = h[j];
+                *reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(sk) + ob) = make64(kpos + (uint32_t)j, rec);
+                ob += 8u;
             }
         }
     }
@@ -964,10 +968,6 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         if (!done[dev]) {
             SW_HIP(hipFuncSetAttribute((const void *)sketch_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes_for(L_MAX)));
-            SW_HIP(hipFuncSetAttribute((const void *)sketch_fast_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)FastCfg<32>::bytes));
-            SW_HIP(hipFuncSetAttribute((const void *)sketch_fast_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)FastCfg<16>::bytes));
             done[dev] = true;
         }
     }
@@ -1035,9 +1035,9 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
                 const uint32_t nt = std::min(plan.n_tiles_fast - tb, MAX_TILES_PER_LAUNCH);
                 a.tile_base = tb;
                 if (plan.Lf == 32)
-                    hipLaunchKernelGGL(sketch_fast_kernel<32>, dim3(nt), dim3(BLOCK), FastCfg<32>::bytes, stream, a);
+                    hipLaunchKernelGGL(sketch_fast_kernel<32>, dim3(nt), dim3(BLOCK), 0, stream, a);
                 else
-                    hipLaunchKernelGGL(sketch_fast_kernel<16>, dim3(nt), dim3(BLOCK), FastCfg<16>::bytes, stream, a);
+                    hipLaunchKernelGGL(sketch_fast_kernel<16>, dim3(nt), dim3(BLOCK), 0, stream, a);
                 SW_HIP(hipGetLastError());
             }
         }
