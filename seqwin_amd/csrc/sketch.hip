@@ -116,22 +116,30 @@ struct BaseStream {
 };
 
 // Split-rotate the 64-bit value (hi:lo) left by one: bits [0,32] and [33,63] rotate separately
-// (hashing_internals.hpp:29-35), in 32-bit halves: 5 VALU ops.
+// (hashing_internals.hpp:29-35), in 32-bit halves.  The instruction choice is pinned with inline assembly: on gfx950 the
+// three-register VOP3 forms the compiler fuses these into (v_bitop3 / v_or3 / v_and_or with three VGPRs, v_lshlrev) issue
+// at ~4.2 cycles per wave, v_bitop3 with an inline constant, v_add and v_lshrrev at ~2.4-2.9 (scripts/micro/valu_kinds.hip).
+// bitop3:0xe2 with src1 = constant M is the bit-field insert (src0 & M) | (src2 & ~M).
 __device__ __forceinline__ void srol1(uint32_t &lo, uint32_t &hi)
 {
-    const uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 31);  // (hi << 1) | (lo >> 31)
-    const uint32_t nlo = (lo << 1) | (hi & 1u);                 // old bit 32 -> bit 0
-    hi = (t & ~2u) | ((hi >> 30) & 2u);                         // old bit 63 -> bit 33
+    uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 31);   // (hi << 1) | (lo >> 31)
+    uint32_t u = hi >> 30, l2, nhi, nlo;                   // bit 1 of u = old bit 63
+    asm("v_bitop3_b32 %0, %1, 2, %2 bitop3:0xe2" : "=v"(nhi) : "v"(u), "v"(t));      // old bit 63 -> bit 33
+    asm("v_add_u32_e32 %0, %1, %1" : "=v"(l2) : "v"(lo));                            // lo << 1
+    asm("v_bitop3_b32 %0, %1, 1, %2 bitop3:0xe2" : "=v"(nlo) : "v"(hi), "v"(l2));    // old bit 32 -> bit 0
     lo = nlo;
+    hi = nhi;
 }
 // Inverse (hashing_internals.hpp:69-74).
 __device__ __forceinline__ void sror1(uint32_t &lo, uint32_t &hi)
 {
-    const uint32_t nlo = __builtin_amdgcn_alignbit(hi, lo, 1);  // (lo >> 1) | (hi << 31)
-    uint32_t t = hi >> 1;
-    t = (t & ~1u) | (lo & 1u);                                  // old bit 0 -> bit 32
-    hi = (t & 0x7FFFFFFFu) | ((hi << 30) & 0x80000000u);        // old bit 33 -> bit 63
+    const uint32_t nlo = __builtin_amdgcn_alignbit(hi, lo, 1);   // (lo >> 1) | (hi << 31): old bit 32 -> bit 31
+    const uint32_t t1 = hi >> 1;
+    const uint32_t t2 = __builtin_amdgcn_alignbit(t1, hi, 1);    // (hi >> 1) | (old bit 33 << 31): old bit 33 -> bit 63
+    uint32_t nhi;
+    asm("v_bitop3_b32 %0, %1, 1, %2 bitop3:0xe2" : "=v"(nhi) : "v"(lo), "v"(t2));    // old bit 0 -> bit 32
     lo = nlo;
+    hi = nhi;
 }
 
 // srol / sror applied N times (1 <= N <= 30) in one go: rotate the low 33 and the high 31 bits by N.
