@@ -666,8 +666,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         const uint32_t xb = e0 - (w - 1);   // x of step j is xb + j (mod 2^32; only used when j >= j0)
         const uint64_t *recA = REC + rxA * RC;          // suffix records of run rxA; run rxA + 1 follows
         uint32_t lc_d = 0;                               // lc_e - xb: lc leaves the window of step j when lc_d < j
-        auto recompute = [&](uint32_t x) {
-            const bool inB = x >= bnd;
+        auto recompute = [&](uint32_t x, bool inB) {   // inB: x lies in run rxA + 1 (x >= bnd)
             lc_h = inB ? mB_h : mA_h;
             lc_e = inB ? mB_e : mA_e;
             const uint32_t rx = inB ? rxA + 1 : rxA;
@@ -696,7 +695,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         const bool wave_full = __all(n == (uint32_t)L && (owner || last_halo) && h[0] != ~0ull) && w > (uint32_t)L;
         if (wave_full) {
             if (last_halo) {
-                recompute(xb + (uint32_t)(L - 1));
+                recompute(xb + (uint32_t)(L - 1), xb + (uint32_t)(L - 1) >= bnd);
                 const uint64_t rm_h = RMh[tid];                         // minimum of the own run, rightmost among equals
                 MISC[0] = (lc_h < rm_h) ? lc_e : (uint32_t)RMp[tid];
             }
@@ -706,13 +705,17 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
                 // the own prefix minimum only falls while it stays current, so it wins some window iff it wins
                 // the first one.  No per-step LDS atomic, no "did the winner change" test (marks are idempotent).
                 uint32_t own = 0, pre_bit = 0;
+                const uint32_t jb = ((w - 1u) & LM) ? ((w - 1u) & LM) : (uint32_t)L;   // wave-uniform (kernel argument)
 #pragma unroll
                 for (int j = 0; j < L; ++j) {
                     const bool keep = pre_h < h[j];                        // '<=' for the newcomer: rightmost wins
                     pre_h = keep ? pre_h : h[j];
                     pre_bit = keep ? pre_bit : (1u << j);
                     if (j == 0 || lc_d < (uint32_t)j) {
-                        recompute(xb + j);
+                        // e0 is a multiple of L, so every lane's x = e0 + j - (w - 1) enters run rxA + 1 at the same step
+                        // jb: which run the lookup goes to is a scalar branch, not five per-lane selects
+                        if ((uint32_t)j >= jb) recompute(xb + j, true);
+                        else recompute(xb + j, false);
                         if (lc_h < pre_h) atomicOr(&EM[lc_e >> 5], 1u << (lc_e & 31u));
                     }
                     // pin the loop state: without it the compiler threads the two compares below and above through
@@ -733,7 +736,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
                     if (x >= e0) {
                         lc_h = ~0ull;                                    // no left region (w == L): never wins
                     } else if ((uint32_t)j == j0 || lc_e < x) {
-                        recompute(x);
+                        recompute(x, x >= bnd);
                     }
                     const bool left = lc_h < pre_h;
                     const uint32_t ce = left ? lc_e : pre_e;
