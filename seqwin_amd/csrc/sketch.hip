@@ -708,9 +708,18 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
                 const uint32_t jb = ((w - 1u) & LM) ? ((w - 1u) & LM) : (uint32_t)L;   // wave-uniform (kernel argument)
 #pragma unroll
                 for (int j = 0; j < L; ++j) {
-                    const bool keep = pre_h < h[j];                        // '<=' for the newcomer: rightmost wins
-                    pre_h = keep ? pre_h : h[j];
-                    pre_bit = keep ? pre_bit : (1u << j);
+                    // prefix minimum, '<=' for the newcomer (rightmost wins): lanes with pre_h >= h[j] take h[j] and bit j.
+                    // Written with EXEC masking (restored inside the statement): v_cndmask issues at ~4.2 cycles per
+                    // wave on gfx950, a masked v_mov / v_or at ~2.5 (scripts/micro/valu_kinds.hip).
+                    unsigned long long sv;
+                    asm volatile("v_cmp_ge_u64_e32 vcc, %[pre], %[hj]\n\t"
+                                 "s_and_saveexec_b64 %[sv], vcc\n\t"
+                                 "v_mov_b64_e32 %[pre], %[hj]\n\t"
+                                 "v_mov_b32_e32 %[pb], %[bit]\n\t"
+                                 "s_mov_b64 exec, %[sv]"
+                                 : [pre] "+v"(pre_h), [pb] "+v"(pre_bit), [sv] "=&s"(sv)
+                                 : [hj] "v"(h[j]), [bit] "n"(1u << j)
+                                 : "vcc", "scc");   // s_and_saveexec writes SCC
                     if (j == 0 || lc_d < (uint32_t)j) {
                         // e0 is a multiple of L, so every lane's x = e0 + j - (w - 1) enters run rxA + 1 at the same step
                         // jb: which run the lookup goes to is a scalar branch, not five per-lane selects
@@ -718,10 +727,14 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
                         else recompute(xb + j, false);
                         if (lc_h < pre_h) atomicOr(&EM[lc_e >> 5], 1u << (lc_e & 31u));
                     }
-                    // pin the loop state: without it the compiler threads the two compares below and above through
-                    // each other and keeps 30+ more values live (128 VGPRs + spills instead of 95)
-                    asm volatile("" : "+v"(lc_h), "+v"(pre_h), "+v"(own), "+v"(pre_bit));
-                    own |= (lc_h < pre_h) ? 0u : pre_bit;
+                    // the own prefix minimum wins this window unless the left region holds a strictly smaller hash
+                    asm volatile("v_cmp_ge_u64_e32 vcc, %[lc], %[pre]\n\t"
+                                 "s_and_saveexec_b64 %[sv], vcc\n\t"
+                                 "v_or_b32_e32 %[own], %[own], %[pb]\n\t"
+                                 "s_mov_b64 exec, %[sv]"
+                                 : [own] "+v"(own), [sv] "=&s"(sv)
+                                 : [lc] "v"(lc_h), [pre] "v"(pre_h), [pb] "v"(pre_bit)
+                                 : "vcc", "scc");   // s_and_saveexec writes SCC
                 }
                 if (L == 32) atomicOr(&EM[tid], own);
                 else atomicOr(&EM[tid >> 1], own << ((tid & 1u) * 16u));
