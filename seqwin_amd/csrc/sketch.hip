@@ -162,6 +162,31 @@ template <int N> __device__ __forceinline__ void srorN(uint32_t &lo, uint32_t &h
     hi = (nh << 1) | nb32;
 }
 
+// srol^4 / sror^4 for the 4-base warm-up steps, in funnel shifts (same instruction-cost reasoning as srol1 / sror1).
+// Bits: lo = [31:0], hi bit 0 = bit 32 (top of the 33-bit word), hi[31:1] = the 31-bit word.
+__device__ __forceinline__ void srol4(uint32_t &lo, uint32_t &hi)
+{
+    const uint32_t x = __builtin_amdgcn_alignbit(hi, lo, 1);     // [bit 32, lo[31:1]]
+    const uint32_t nlo = __builtin_amdgcn_alignbit(lo, x, 28);   // (lo << 4) | [bit 32, lo[31:29]]
+    const uint32_t r4 = __builtin_amdgcn_alignbit(hi, hi, 28);   // rotl32(hi, 4): bits [31:5] = hi[27:1] are in place
+    const uint32_t low5 = __builtin_amdgcn_alignbit(hi >> 28, lo << 3, 31);   // (hi[31:28] << 1) | lo[28]
+    uint32_t nhi;
+    asm("v_bitop3_b32 %0, %1, 31, %2 bitop3:0xe2" : "=v"(nhi) : "v"(low5), "v"(r4));   // (low5 & 31) | (r4 & ~31)
+    lo = nlo;
+    hi = nhi;
+}
+__device__ __forceinline__ void sror4(uint32_t &lo, uint32_t &hi)
+{
+    uint32_t l2, y, n;
+    asm("v_add_u32_e32 %0, %1, %1" : "=v"(l2) : "v"(lo));                          // lo << 1
+    asm("v_bitop3_b32 %0, %1, 1, %2 bitop3:0xe2" : "=v"(y) : "v"(hi), "v"(l2));    // [lo[30:0], bit 32]
+    const uint32_t nlo = __builtin_amdgcn_alignbit(y, lo, 4);                      // (lo >> 4) | [lo[2:0], bit 32] << 28
+    asm("v_bitop3_b32 %0, %1, 16, %2 bitop3:0xe2" : "=v"(n) : "v"(l2), "v"(hi));   // hi with bit 4 := lo[3]
+    const uint32_t nhi = __builtin_amdgcn_alignbit(hi >> 1, n, 4);                 // [hi[4:1], hi[31:5], lo[3]]
+    lo = nlo;
+    hi = nhi;
+}
+
 __device__ __forceinline__ uint64_t make64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchArgs A)
@@ -433,6 +458,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
     constexpr uint32_t LM = L - 1;
     constexpr uint32_t LSH = (L == 32) ? 5 : 4;
     static_assert(L == 32 || L == 16, "run length must be 16 or 32");
+    static_assert((size_t)BLOCK * RC * 8 >= 4096, "the warm-up table shares the suffix-record area");
     __shared__ __align__(16) unsigned char smem[C::bytes];   // static: LDS addresses are compile-time constants
     uint64_t *REC = reinterpret_cast<uint64_t *>(smem + C::off_REC);
     uint64_t *RMh = reinterpret_cast<uint64_t *>(smem + C::off_RMh);
@@ -469,6 +495,10 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         for (uint32_t i = tid; i < (uint32_t)C::NEM; i += BLOCK) EM[i] = 0;
         if (tid < 40) LUT[tid] = A.lut[tid];
         if (tid == 0) MISC[1] = 0;
+        // the 4 KiB warm-up table lives in LDS while the runs are hashed, in the space the suffix records take afterwards
+        // (five dependent gathers per lane from global memory were ~4 % of the kernel's time, all of it latency)
+        for (uint32_t i = tid; i < 256u; i += BLOCK)
+            reinterpret_cast<ulonglong2 *>(REC)[i] = reinterpret_cast<const ulonglong2 *>(A.t4)[i];
     }
     __syncthreads();
 
@@ -499,7 +529,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         };
         // warm-up (first k-mer of the run): k = r + 4q bases; r single-base steps through the roll LUT,
         // then q steps of 4 bases through the 256-entry table t4 (F' = srol^4(F) ^ F4[b], R' = sror^4(R) ^ R4[b]),
-        // gathered from global memory (4 KiB, L1/L2 resident) one step ahead of use
+        // read from LDS one step ahead of use
         uint32_t idx;
         for (uint32_t s4 = 0; s4 < (k & 3u); ++s4) {
             idx = 16u | next_in();
@@ -521,16 +551,16 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
                 return b;
             };
             const uint32_t q = k >> 2;
-            const ulonglong2 *T4 = reinterpret_cast<const ulonglong2 *>(A.t4);
+            const ulonglong2 *T4 = reinterpret_cast<const ulonglong2 *>(REC);
             ulonglong2 te = make_ulonglong2(0, 0);
             if (q) te = T4[next4()];
             for (uint32_t s4 = 0; s4 < q; ++s4) {
                 ulonglong2 tn = te;
                 if (s4 + 1 < q) tn = T4[next4()];
-                srolN<4>(flo, fhi);
+                srol4(flo, fhi);
                 flo ^= (uint32_t)te.x;
                 fhi ^= (uint32_t)(te.x >> 32);
-                srorN<4>(rlo, rhi);
+                sror4(rlo, rhi);
                 rlo ^= (uint32_t)te.y;
                 rhi ^= (uint32_t)(te.y >> 32);
                 te = tn;
@@ -587,6 +617,9 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
                 asm volatile("" : "+v"(flo), "+v"(fhi), "+v"(rlo), "+v"(rhi) : : "memory");
             }
         }
+    }
+    __syncthreads();   // every wave is done with the warm-up table: its space now takes the suffix records
+    if (n) {
         // ---- suffix records of the run, right to left (registers only) ---------------------------
         uint64_t cur = 0;
         uint32_t mask = 0, cnt = 0;

@@ -190,3 +190,13 @@ def test_host_ingest_random_bytes_match_oracle_reader(tmp_path):
         assert ids == exp_ids and offs.tolist() == exp_offs
         assert seqs == exp_seqs
         assert bp == sum(len(s) for s in exp_seqs)
+
+
+def test_half_word_rotate_formulas(tmp_path):
+    """The sketch kernel writes srol / sror (hashing_internals.hpp:29-35, 69-74) and their 4-fold forms as funnel shifts
+    and bit-field inserts on 32-bit halves (sketch.hip: srol1, sror1, srol4, sror4); tests/tools/rot_check.cpp restates
+    exactly those formulas on the host and compares them with the reference definitions on 2 M values + all single bits."""
+    import subprocess
+    exe = tmp_path / "rot_check"
+    subprocess.check_call(["g++", "-O2", str(ROOT / "tests" / "tools" / "rot_check.cpp"), "-o", str(exe)])
+    assert subprocess.run([str(exe)], capture_output=True, text=True).stdout.strip() == "bad = 0"
