@@ -530,10 +530,20 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
         // warm-up (first k-mer of the run): k = r + 4q bases; r single-base steps through the roll LUT,
         // then q steps of 4 bases through the 256-entry table t4 (F' = srol^4(F) ^ F4[b], R' = sror^4(R) ^ R4[b]),
         // read from LDS one step ahead of use
-        uint32_t idx;
-        for (uint32_t s4 = 0; s4 < (k & 3u); ++s4) {
-            idx = 16u | next_in();
-            apply(LUT[2 * idx], LUT[2 * idx + 1]);
+        // All table rows of a batch are requested first (their addresses depend only on the bases) and the dependent
+        // rotate / xor chain runs afterwards: one exposed LDS round trip per batch instead of one per step.
+        {
+            const uint32_t r = k & 3u;                      // uniform
+            ulonglong2 ts[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if ((uint32_t)i < r) {
+                    const uint32_t idx = 16u | next_in();
+                    ts[i] = *reinterpret_cast<const ulonglong2 *>(LUT + 2 * idx);
+                }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if ((uint32_t)i < r) apply(ts[i].x, ts[i].y);
         }
         {
             auto next4 = [&]() -> uint32_t {             // next 4 bases as one byte (uniform control flow)
@@ -552,18 +562,23 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
             };
             const uint32_t q = k >> 2;
             const ulonglong2 *T4 = reinterpret_cast<const ulonglong2 *>(REC);
-            ulonglong2 te = make_ulonglong2(0, 0);
-            if (q) te = T4[next4()];
-            for (uint32_t s4 = 0; s4 < q; ++s4) {
-                ulonglong2 tn = te;
-                if (s4 + 1 < q) tn = T4[next4()];
-                srol4(flo, fhi);
-                flo ^= (uint32_t)te.x;
-                fhi ^= (uint32_t)(te.x >> 32);
-                sror4(rlo, rhi);
-                rlo ^= (uint32_t)te.y;
-                rhi ^= (uint32_t)(te.y >> 32);
-                te = tn;
+            constexpr int WB = 8;                           // rows in flight (32 VGPRs, free at this point of the kernel)
+            for (uint32_t s4 = 0; s4 < q; s4 += WB) {
+                const uint32_t nb = min((uint32_t)WB, q - s4);   // uniform
+                ulonglong2 te[WB];
+#pragma unroll
+                for (int i = 0; i < WB; ++i)
+                    if ((uint32_t)i < nb) te[i] = T4[next4()];
+#pragma unroll
+                for (int i = 0; i < WB; ++i)
+                    if ((uint32_t)i < nb) {
+                        srol4(flo, fhi);
+                        flo ^= (uint32_t)te[i].x;
+                        fhi ^= (uint32_t)(te[i].x >> 32);
+                        sror4(rlo, rhi);
+                        rlo ^= (uint32_t)te[i].y;
+                        rhi ^= (uint32_t)(te[i].y >> 32);
+                    }
             }
         }
         // Rolls 1..L-1 of this lane take in-base (k + j - 1) and out-base (j - 1) of the run.  Both streams are
