@@ -1150,7 +1150,7 @@ namespace {
 // duplicates, so weight = number of distinct keys inside a pair's run)
 __global__ void k_adj_packed(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ rank,
                              const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, unsigned ab, uint64_t sentinel,
-                             uint64_t *__restrict__ key)
+                             bool asm_high, uint64_t *__restrict__ key)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i + 1 < n) {
@@ -1158,7 +1158,8 @@ __global__ void k_adj_packed(const uint64_t *__restrict__ kmer, const uint32_t *
         if (r0 == r1) {
             uint32_t u = rank[i], v = rank[i + 1];
             if (v < u) { const uint32_t t = u; u = v; v = t; }
-            key[i] = (((((uint64_t)u << nb) | v)) << ab) | rec_asm[r0];
+            const uint64_t pair = ((uint64_t)u << nb) | v;
+            key[i] = asm_high ? (((uint64_t)rec_asm[r0] << (2 * nb)) | pair) : ((pair << ab) | rec_asm[r0]);
         } else {
             key[i] = sentinel;
         }
@@ -1167,12 +1168,13 @@ __global__ void k_adj_packed(const uint64_t *__restrict__ kmer, const uint32_t *
 
 struct PackedHeadFlag {   // first occurrence of a pair (sentinels, which sort last, never count)
     const uint64_t *keys;
-    unsigned ab;
+    unsigned pshift;      // pair = (key >> pshift) & pmask: (ab, ~0) for pair-above-assembly keys, (0, 2^(2 nb) - 1) for
+    uint64_t pmask;       // assembly-above-pair keys
     uint64_t sentinel;
     __host__ __device__ uint32_t operator()(uint64_t s) const
     {
         const uint64_t k = keys[s];
-        return (k != sentinel && (s == 0 || (k >> ab) != (keys[s - 1] >> ab))) ? 1u : 0u;
+        return (k != sentinel && (s == 0 || ((k >> pshift) & pmask) != ((keys[s - 1] >> pshift) & pmask))) ? 1u : 0u;
     }
 };
 struct PackedChangeFlag {   // first occurrence of a (pair, assembly)
@@ -1185,16 +1187,16 @@ struct PackedChangeFlag {   // first occurrence of a (pair, assembly)
     }
 };
 
-__global__ void k_edge_heads_packed(const uint64_t *__restrict__ skeys, unsigned ab, uint64_t sentinel,
+__global__ void k_edge_heads_packed(const uint64_t *__restrict__ skeys, unsigned pshift, uint64_t pmask, uint64_t sentinel,
                                     const uint32_t *__restrict__ ecum, uint64_t m, uint64_t *__restrict__ edge_start)
 {
     const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= m) return;
     const uint64_t k = skeys[s];
-    if (k != sentinel && (s == 0 || (k >> ab) != (skeys[s - 1] >> ab))) edge_start[ecum[s] - 1] = s;
+    if (k != sentinel && (s == 0 || ((k >> pshift) & pmask) != ((skeys[s - 1] >> pshift) & pmask))) edge_start[ecum[s] - 1] = s;
 }
 
-__global__ void k_edges_packed(const uint64_t *__restrict__ skeys, unsigned ab, const uint32_t *__restrict__ ccum,
+__global__ void k_edges_packed(const uint64_t *__restrict__ skeys, unsigned pshift, uint64_t pmask, const uint32_t *__restrict__ ccum,
                                const uint64_t *__restrict__ edge_start, uint64_t n_edges, uint64_t n_valid, unsigned nb,
                                const sw_node *__restrict__ nodes, const uint64_t *__restrict__ rank_hash,
                                sw_edge *__restrict__ edges)
@@ -1203,30 +1205,36 @@ __global__ void k_edges_packed(const uint64_t *__restrict__ skeys, unsigned ab, 
     if (e >= n_edges) return;
     const uint64_t s = edge_start[e];
     const uint64_t s1 = (e + 1 < n_edges) ? edge_start[e + 1] : n_valid;   // (last edge: the change count is flat over the sentinels)
-    const uint64_t pair = skeys[s] >> ab;
+    const uint64_t pair = (skeys[s] >> pshift) & pmask;
     const uint32_t u = (uint32_t)(pair >> nb), v = (uint32_t)(pair & ((1ull << nb) - 1ull));
     edges[e].first = rank_hash ? rank_hash[u] : nodes[u].hash;
     edges[e].second = rank_hash ? rank_hash[v] : nodes[v].hash;
     edges[e].weight = (uint64_t)(ccum[s1 - 1] - ccum[s]) + 1ull;
 }
 
+// asm_high: keys are (assembly << 2 nb) | pair and arrive in assembly order (the single-GPU build emits them in
+// (record, pos) order, records are assembly-major): a STABLE sort on the 2 nb pair bits alone leaves every pair's run in
+// assembly order, so the assembly bits are never sorted (one radix pass fewer at the default workload: 44 instead of 53 bits).
 void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t sentinel, unsigned nb, unsigned ab,
-                       const uint64_t *rank_hash, hipStream_t stream, sw_index &ix)
+                       const uint64_t *rank_hash, hipStream_t stream, sw_index &ix, bool asm_high = false)
 {
     ix.n_edges = 0;
     if (m == 0) return;
+    const unsigned pshift = asm_high ? 0u : ab;
+    const uint64_t pmask = asm_high ? ((2 * nb >= 64) ? ~0ull : ((1ull << (2 * nb)) - 1ull)) : ~0ull;
     {
+        const unsigned sort_bits = asm_high ? 2 * nb : 2 * nb + ab;
         rocprim::double_buffer<uint64_t> dk(keys, keys_alt);
         size_t tmp_bytes = 0;
-        SW_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, dk, m, 0, 2 * nb + ab, stream));
+        SW_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, dk, m, 0, sort_bits, stream));
         DevArray<unsigned char> tmp(tmp_bytes);
-        SW_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, m, 0, 2 * nb + ab, stream));
+        SW_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, m, 0, sort_bits, stream));
         keys = dk.current();
     }
     // record boundaries were written as `sentinel` (sorts last): they never raise a flag, so no count of them is needed
     DevArray<uint32_t> ecum(m), ccum(m);
     inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
-                                                   PackedHeadFlag{keys, ab, sentinel}),
+                                                   PackedHeadFlag{keys, pshift, pmask, sentinel}),
                   ecum.p, m, (uint32_t)0, stream);
     inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
                                                    PackedChangeFlag{keys, sentinel}),
@@ -1238,9 +1246,9 @@ void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t 
     if (n_edges == 0) return;
     ix.edges.alloc(n_edges);
     DevArray<uint64_t> edge_start(n_edges);
-    hipLaunchKernelGGL(k_edge_heads_packed, dim3(blocks_for(m)), dim3(TPB), 0, stream, keys, ab, sentinel, ecum.p, m,
+    hipLaunchKernelGGL(k_edge_heads_packed, dim3(blocks_for(m)), dim3(TPB), 0, stream, keys, pshift, pmask, sentinel, ecum.p, m,
                        edge_start.p);
-    hipLaunchKernelGGL(k_edges_packed, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, keys, ab, ccum.p, edge_start.p,
+    hipLaunchKernelGGL(k_edges_packed, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, keys, pshift, pmask, ccum.p, edge_start.p,
                        (uint64_t)n_edges, m, nb, ix.nodes.p, rank_hash, ix.edges.p);
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));
@@ -1384,9 +1392,9 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
             const uint64_t sentinel = (tb == 64) ? ~0ull : ((1ull << tb) - 1ull);
             DevArray<uint64_t> k0(m), k1(m);
             hipLaunchKernelGGL(k_adj_packed, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, b.d_rec_asm.p, n, nb,
-                               ab, sentinel, k0.p);
+                               ab, sentinel, true, k0.p);
             SW_HIP(hipGetLastError());
-            edges_from_packed(k0.p, k1.p, m, sentinel, nb, ab, nullptr, stream, ix);
+            edges_from_packed(k0.p, k1.p, m, sentinel, nb, ab, nullptr, stream, ix, true);
         } else {
             const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
             DevArray<uint64_t> k0(m), k1(m);
