@@ -39,13 +39,19 @@
 #define S_LSHR(x) asm volatile("v_lshrrev_b32_e32 %0, 30, %0" : "+v"(x));
 #define S_ADD3(x) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
 #define S_BCNT(x) asm volatile("v_bcnt_u32_b32 %0, %0, 0" : "+v"(x));
+#define S_ADD64(x) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q) : "v"(r));
+#define S_ADDU32(x) asm volatile("v_add_u32_e32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define S_MOV32(x) asm volatile("v_mov_b32_e32 %0, %1" : "=v"(x) : "v"(b));
+#define S_MINU32(x) asm volatile("v_min_u32_e32 %0, %0, %1" : "+v"(x) : "v"(b));
+#define S_XOR3(x) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(x) : "v"(b), "v"(c));
+#define S_PERM(x) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(b), "v"(c));
 #define S_CMPCND(x) asm volatile("v_cmp_lt_u64_e32 vcc, %1, %2\n s_nop 1\n v_cndmask_b32_e32 %0, %0, %3, vcc" : "+v"(x) : "v"(q), "v"(r), "v"(b) : "vcc");
 
 KERNEL(k_xor, S_XOR) KERNEL(k_align, S_ALIGN) KERNEL(k_andor, S_ANDOR) KERNEL(k_bitop3, S_BITOP3) KERNEL(k_bitop3c, S_BITOP3C)
 KERNEL(k_or3, S_OR3) KERNEL(k_lshlor, S_LSHLOR) KERNEL(k_cnd32, S_CND32) KERNEL(k_cnd64, S_CND64) KERNEL(k_cmp64, S_CMP64)
 KERNEL(k_cmp32, S_CMP32) KERNEL(k_cmp64s, S_CMP64S) KERNEL(k_shl, S_SHL) KERNEL(k_andlit, S_ANDLIT) KERNEL(k_andinl, S_ANDINL)
 KERNEL(k_addco, S_ADDCO) KERNEL(k_mov64, S_MOV64) KERNEL(k_bfe, S_BFE) KERNEL(k_lshr, S_LSHR) KERNEL(k_add3, S_ADD3)
-KERNEL(k_bcnt, S_BCNT) KERNEL(k_cmpcnd, S_CMPCND)
+KERNEL(k_bcnt, S_BCNT) KERNEL(k_cmpcnd, S_CMPCND) KERNEL(k_add64, S_ADD64) KERNEL(k_addu32, S_ADDU32) KERNEL(k_mov32, S_MOV32) KERNEL(k_minu32, S_MINU32) KERNEL(k_xor3, S_XOR3) KERNEL(k_perm, S_PERM)
 
 typedef void (*kern_t)(uint32_t *, int, uint32_t);
 int main()
@@ -67,7 +73,9 @@ int main()
         {"v_lshlrev_b32_e32 const", k_shl, 1}, {"v_and_b32 literal", k_andlit, 1}, {"v_and_b32 inline const", k_andinl, 1},
         {"v_add_co + v_addc pair", k_addco, 2}, {"v_mov_b64", k_mov64, 1}, {"v_bfe_u32 v,v,4,4", k_bfe, 1},
         {"v_lshrrev_b32_e32 const", k_lshr, 1}, {"v_add3_u32 (3 VGPR)", k_add3, 1}, {"v_bcnt_u32_b32", k_bcnt, 1},
-        {"cmp_u64 + s_nop 1 + cndmask (triple)", k_cmpcnd, 1}};
+        {"cmp_u64 + s_nop 1 + cndmask (triple)", k_cmpcnd, 1},
+        {"v_lshl_add_u64 (64-bit add)", k_add64, 1}, {"v_add_u32_e32", k_addu32, 1}, {"v_mov_b32_e32", k_mov32, 1},
+        {"v_min_u32_e32", k_minu32, 1}, {"v_bitop3_b32 xor3 (3 VGPR)", k_xor3, 1}, {"v_perm_b32 (3 VGPR)", k_perm, 1}};
     const int iters = 20000, wg_per_cu = 5;
     printf("%s CUs=%d clock=%.2f GHz, %d waves per SIMD, cycles per wave-instruction per SIMD:\n", p.gcnArchName, cus, ghz, wg_per_cu);
     for (auto &k : ks) {
