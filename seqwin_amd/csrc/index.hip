@@ -1166,50 +1166,31 @@ __global__ void k_adj_packed(const uint64_t *__restrict__ kmer, const uint32_t *
     }
 }
 
-struct PackedHeadFlag {   // first occurrence of a pair (sentinels, which sort last, never count)
+struct PackedChangeAny {   // 1 where the whole key differs from its predecessor (first element: 1)
     const uint64_t *keys;
-    unsigned pshift;      // pair = (key >> pshift) & pmask: (ab, ~0) for pair-above-assembly keys, (0, 2^(2 nb) - 1) for
-    uint64_t pmask;       // assembly-above-pair keys
-    uint64_t sentinel;
-    __host__ __device__ uint32_t operator()(uint64_t s) const
-    {
-        const uint64_t k = keys[s];
-        return (k != sentinel && (s == 0 || ((k >> pshift) & pmask) != ((keys[s - 1] >> pshift) & pmask))) ? 1u : 0u;
-    }
+    __host__ __device__ uint32_t operator()(uint64_t s) const { return (s == 0 || keys[s] != keys[s - 1]) ? 1u : 0u; }
 };
-struct PackedChangeFlag {   // first occurrence of a (pair, assembly)
-    const uint64_t *keys;
-    uint64_t sentinel;
-    __host__ __device__ uint32_t operator()(uint64_t s) const
-    {
-        const uint64_t k = keys[s];
-        return (k != sentinel && (s == 0 || k != keys[s - 1])) ? 1u : 0u;
-    }
+struct PackedPairEq {      // same (rank_lo, rank_hi) pair
+    unsigned pshift;
+    uint64_t pmask;
+    __host__ __device__ bool operator()(uint64_t a, uint64_t b) const { return ((a >> pshift) & pmask) == ((b >> pshift) & pmask); }
 };
-
-__global__ void k_edge_heads_packed(const uint64_t *__restrict__ skeys, unsigned pshift, uint64_t pmask, uint64_t sentinel,
-                                    const uint32_t *__restrict__ ecum, uint64_t m, uint64_t *__restrict__ edge_start)
+__global__ void k_drop_sentinel_run(const uint64_t *__restrict__ ukeys, uint64_t sentinel, uint32_t *__restrict__ count)
 {
-    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= m) return;
-    const uint64_t k = skeys[s];
-    if (k != sentinel && (s == 0 || ((k >> pshift) & pmask) != ((skeys[s - 1] >> pshift) & pmask))) edge_start[ecum[s] - 1] = s;
+    const uint32_t n = *count;
+    if (n && ukeys[n - 1] == sentinel) *count = n - 1;   // the run of record boundaries (all keys == sentinel) is no edge
 }
-
-__global__ void k_edges_packed(const uint64_t *__restrict__ skeys, unsigned pshift, uint64_t pmask, const uint32_t *__restrict__ ccum,
-                               const uint64_t *__restrict__ edge_start, uint64_t n_edges, uint64_t n_valid, unsigned nb,
-                               const sw_node *__restrict__ nodes, const uint64_t *__restrict__ rank_hash,
-                               sw_edge *__restrict__ edges)
+__global__ void k_edges_runs(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ usum, unsigned pshift, uint64_t pmask,
+                             uint64_t n_edges, unsigned nb, const sw_node *__restrict__ nodes,
+                             const uint64_t *__restrict__ rank_hash, sw_edge *__restrict__ edges)
 {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
-    const uint64_t s = edge_start[e];
-    const uint64_t s1 = (e + 1 < n_edges) ? edge_start[e + 1] : n_valid;   // (last edge: the change count is flat over the sentinels)
-    const uint64_t pair = (skeys[s] >> pshift) & pmask;
+    const uint64_t pair = (ukeys[e] >> pshift) & pmask;
     const uint32_t u = (uint32_t)(pair >> nb), v = (uint32_t)(pair & ((1ull << nb) - 1ull));
     edges[e].first = rank_hash ? rank_hash[u] : nodes[u].hash;
     edges[e].second = rank_hash ? rank_hash[v] : nodes[v].hash;
-    edges[e].weight = (uint64_t)(ccum[s1 - 1] - ccum[s]) + 1ull;
+    edges[e].weight = usum[e];
 }
 
 // asm_high: keys are (assembly << 2 nb) | pair and arrive in assembly order (the single-GPU build emits them in
@@ -1231,25 +1212,33 @@ void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t 
         SW_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, m, 0, sort_bits, stream));
         keys = dk.current();
     }
-    // record boundaries were written as `sentinel` (sorts last): they never raise a flag, so no count of them is needed
-    DevArray<uint32_t> ecum(m), ccum(m);
-    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
-                                                   PackedHeadFlag{keys, pshift, pmask, sentinel}),
-                  ecum.p, m, (uint32_t)0, stream);
-    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
-                                                   PackedChangeFlag{keys, sentinel}),
-                  ccum.p, m, (uint32_t)0, stream);
-    uint32_t n_edges = 0;
-    SW_HIP(hipMemcpyAsync(&n_edges, ecum.p + (m - 1), 4, hipMemcpyDeviceToHost, stream));
-    SW_HIP(hipStreamSynchronize(stream));
-    ix.n_edges = n_edges;
-    if (n_edges == 0) return;
-    ix.edges.alloc(n_edges);
-    DevArray<uint64_t> edge_start(n_edges);
-    hipLaunchKernelGGL(k_edge_heads_packed, dim3(blocks_for(m)), dim3(TPB), 0, stream, keys, pshift, pmask, sentinel, ecum.p, m,
-                       edge_start.p);
-    hipLaunchKernelGGL(k_edges_packed, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, keys, pshift, pmask, ccum.p, edge_start.p,
-                       (uint64_t)n_edges, m, nb, ix.nodes.p, rank_hash, ix.edges.p);
+    // One run-length pass over the sorted keys (rocprim::reduce_by_key, decoupled look-back): runs = equal pairs, value of
+    // an element = 1 where the whole key (pair, assembly) differs from its predecessor, so a run's sum is the number of
+    // distinct assemblies of the pair = the edge weight (build.cpp:170-196).  Replaces two prefix sums over all keys, a
+    // head scatter and their re-reads.  Record boundaries were written as `sentinel`; they sort last and form the final run.
+    DevArray<uint64_t> ukeys(m);
+    DevArray<uint32_t> usum(m);
+    DevArray<uint32_t> ucount(1);
+    {
+        auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), PackedChangeAny{keys});
+        const PackedPairEq eq{pshift, pmask};
+        size_t tmp_bytes = 0;
+        SW_HIP(rocprim::reduce_by_key(nullptr, tmp_bytes, keys, flags, m, ukeys.p, usum.p, ucount.p, rocprim::plus<uint32_t>(), eq,
+                                      stream));
+        DevArray<unsigned char> tmp(tmp_bytes);
+        SW_HIP(rocprim::reduce_by_key(tmp.p, tmp_bytes, keys, flags, m, ukeys.p, usum.p, ucount.p, rocprim::plus<uint32_t>(), eq,
+                                      stream));
+        hipLaunchKernelGGL(k_drop_sentinel_run, dim3(1), dim3(1), 0, stream, ukeys.p, sentinel, ucount.p);
+        SW_HIP(hipGetLastError());
+        uint32_t n_edges = 0;
+        SW_HIP(hipMemcpyAsync(&n_edges, ucount.p, 4, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));   // (tmp is released here, after the pass has finished)
+        ix.n_edges = n_edges;
+    }
+    if (ix.n_edges == 0) return;
+    ix.edges.alloc(ix.n_edges);
+    hipLaunchKernelGGL(k_edges_runs, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, usum.p, pshift, pmask,
+                       (uint64_t)ix.n_edges, nb, ix.nodes.p, rank_hash, ix.edges.p);
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));
 }
