@@ -348,41 +348,34 @@ __global__ void k_adj(const uint64_t *__restrict__ kmer, const uint32_t *__restr
     }
 }
 
-// c[s] = 1 at the first pair of every (edge, assembly) combination
-struct AsmChangeFlag {
+// 1 at the first row of every (pair, assembly) combination of the sorted adjacency rows (first row: 1)
+struct AsmChangeAny {
     const uint64_t *keys;
     const uint32_t *vals;
-    uint64_t sentinel;
     __host__ __device__ uint32_t operator()(uint64_t s) const
     {
-        const uint64_t k = keys[s];
-        return (k != sentinel && (s == 0 || k != keys[s - 1] || vals[s] != vals[s - 1])) ? 1u : 0u;
+        return (s == 0 || keys[s] != keys[s - 1] || vals[s] != vals[s - 1]) ? 1u : 0u;
     }
 };
 
-__global__ void k_edge_heads(const uint64_t *__restrict__ skeys, uint64_t sentinel, const uint32_t *__restrict__ ecum,
-                             uint64_t m, uint64_t *__restrict__ edge_start)
+__global__ void k_drop_sentinel_run(const uint64_t *__restrict__ ukeys, uint64_t sentinel, uint32_t *__restrict__ count)
 {
-    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= m) return;
-    const uint64_t k = skeys[s];
-    if (k != sentinel && (s == 0 || k != skeys[s - 1])) edge_start[ecum[s] - 1] = s;
+    const uint32_t n = *count;
+    if (n && ukeys[n - 1] == sentinel) *count = n - 1;   // the run of record boundaries (all keys == sentinel) is no edge
 }
 
-__global__ void k_edges(const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ ccum,
-                        const uint64_t *__restrict__ edge_start, uint64_t n_edges, uint64_t n_valid, unsigned nb,
-                        const sw_node *__restrict__ nodes, const uint64_t *__restrict__ rank_hash,
-                        sw_edge *__restrict__ edges)
+// one thread per run of equal pairs: pair = (ukeys >> pshift) & pmask, weight = distinct assemblies in the run
+__global__ void k_edges_runs(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ usum, unsigned pshift, uint64_t pmask,
+                             uint64_t n_edges, unsigned nb, const sw_node *__restrict__ nodes,
+                             const uint64_t *__restrict__ rank_hash, sw_edge *__restrict__ edges)
 {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_edges) return;
-    const uint64_t s = edge_start[e];
-    const uint64_t s1 = (e + 1 < n_edges) ? edge_start[e + 1] : n_valid;
-    const uint64_t key = skeys[s];
-    const uint32_t u = (uint32_t)(key >> nb), v = (uint32_t)(key & ((1ull << nb) - 1ull));
+    const uint64_t pair = (ukeys[e] >> pshift) & pmask;
+    const uint32_t u = (uint32_t)(pair >> nb), v = (uint32_t)(pair & ((1ull << nb) - 1ull));
     edges[e].first = rank_hash ? rank_hash[u] : nodes[u].hash;
     edges[e].second = rank_hash ? rank_hash[v] : nodes[v].hash;
-    edges[e].weight = (uint64_t)(ccum[s1 - 1] - ccum[s]) + 1ull;
+    edges[e].weight = usum[e];
 }
 
 // ---- tuple-exchange form of the multi-GPU build (dist.py) ---------------------------------------------
@@ -1175,24 +1168,6 @@ struct PackedPairEq {      // same (rank_lo, rank_hi) pair
     uint64_t pmask;
     __host__ __device__ bool operator()(uint64_t a, uint64_t b) const { return ((a >> pshift) & pmask) == ((b >> pshift) & pmask); }
 };
-__global__ void k_drop_sentinel_run(const uint64_t *__restrict__ ukeys, uint64_t sentinel, uint32_t *__restrict__ count)
-{
-    const uint32_t n = *count;
-    if (n && ukeys[n - 1] == sentinel) *count = n - 1;   // the run of record boundaries (all keys == sentinel) is no edge
-}
-__global__ void k_edges_runs(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ usum, unsigned pshift, uint64_t pmask,
-                             uint64_t n_edges, unsigned nb, const sw_node *__restrict__ nodes,
-                             const uint64_t *__restrict__ rank_hash, sw_edge *__restrict__ edges)
-{
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_edges) return;
-    const uint64_t pair = (ukeys[e] >> pshift) & pmask;
-    const uint32_t u = (uint32_t)(pair >> nb), v = (uint32_t)(pair & ((1ull << nb) - 1ull));
-    edges[e].first = rank_hash ? rank_hash[u] : nodes[u].hash;
-    edges[e].second = rank_hash ? rank_hash[v] : nodes[v].hash;
-    edges[e].weight = usum[e];
-}
-
 // asm_high: keys are (assembly << 2 nb) | pair and arrive in assembly order (the single-GPU build emits them in
 // (record, pos) order, records are assembly-major): a STABLE sort on the 2 nb pair bits alone leaves every pair's run in
 // assembly order, so the assembly bits are never sorted (one radix pass fewer at the default workload: 44 instead of 53 bits).
@@ -1253,22 +1228,29 @@ void edges_from_adjacency(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, ui
     ix.n_edges = 0;
     if (m == 0) return;
     sort_pairs(keys, keys_alt, vals, vals_alt, m, 0, 2 * nb, stream);
-    DevArray<uint32_t> ecum(m), ccum(m);
-    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), HeadFlag{keys, sentinel}),
-                  ecum.p, m, (uint32_t)0, stream);
-    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
-                                                   AsmChangeFlag{keys, vals, sentinel}),
-                  ccum.p, m, (uint32_t)0, stream);
-    uint32_t n_edges = 0;
-    SW_HIP(hipMemcpyAsync(&n_edges, ecum.p + (m - 1), 4, hipMemcpyDeviceToHost, stream));
-    SW_HIP(hipStreamSynchronize(stream));
-    ix.n_edges = n_edges;
-    if (n_edges == 0) return;
-    ix.edges.alloc(n_edges);
-    DevArray<uint64_t> edge_start(n_edges);
-    hipLaunchKernelGGL(k_edge_heads, dim3(blocks_for(m)), dim3(TPB), 0, stream, keys, sentinel, ecum.p, m, edge_start.p);
-    hipLaunchKernelGGL(k_edges, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, keys, ccum.p, edge_start.p,
-                       (uint64_t)n_edges, m, nb, ix.nodes.p, rank_hash, ix.edges.p);
+    // one run-length pass (see edges_from_packed): runs = equal pairs, a run's sum of (pair, assembly) changes = its weight
+    DevArray<uint64_t> ukeys(m);
+    DevArray<uint32_t> usum(m);
+    DevArray<uint32_t> ucount(1);
+    {
+        auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), AsmChangeAny{keys, vals});
+        size_t tmp_bytes = 0;
+        SW_HIP(rocprim::reduce_by_key(nullptr, tmp_bytes, keys, flags, m, ukeys.p, usum.p, ucount.p, rocprim::plus<uint32_t>(),
+                                      rocprim::equal_to<uint64_t>(), stream));
+        DevArray<unsigned char> tmp(tmp_bytes);
+        SW_HIP(rocprim::reduce_by_key(tmp.p, tmp_bytes, keys, flags, m, ukeys.p, usum.p, ucount.p, rocprim::plus<uint32_t>(),
+                                      rocprim::equal_to<uint64_t>(), stream));
+        hipLaunchKernelGGL(k_drop_sentinel_run, dim3(1), dim3(1), 0, stream, ukeys.p, sentinel, ucount.p);
+        SW_HIP(hipGetLastError());
+        uint32_t n_edges = 0;
+        SW_HIP(hipMemcpyAsync(&n_edges, ucount.p, 4, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));   // (tmp is released here, after the pass has finished)
+        ix.n_edges = n_edges;
+    }
+    if (ix.n_edges == 0) return;
+    ix.edges.alloc(ix.n_edges);
+    hipLaunchKernelGGL(k_edges_runs, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, usum.p, 0u, ~0ull,
+                       (uint64_t)ix.n_edges, nb, ix.nodes.p, rank_hash, ix.edges.p);
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));
 }
