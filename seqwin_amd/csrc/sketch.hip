@@ -645,16 +645,20 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
             cur = h[L - 1];
             mask = 1u << (L - 1);
             rec[0] = cur;
-            cnt = 1;
+            // the record slot is tracked as an LDS byte address (one add per record, no shift-add); slots past RC - 1
+            // are not written and the count is recovered from the address
+            const uint32_t ra0 = (uint32_t)(C::off_REC + (size_t)tid * RC * 8), ra_end = ra0 + RC * 8;
+            uint32_t ra = ra0 + 8;
 #pragma unroll
             for (int j = L - 2; j >= 0; --j) {
                 if (h[j] < cur) {                   // strictly smaller than everything to its right
                     cur = h[j];
                     mask |= 1u << j;
-                    if (cnt < RC) rec[cnt] = cur;
-                    ++cnt;
+                    if (ra < ra_end) *reinterpret_cast<uint64_t *>(smem + ra) = cur;
+                    ra += 8;
                 }
             }
+            cnt = (ra - ra0) >> 3;
         } else {
 #pragma unroll
             for (int j = L - 1; j >= 0; --j) {
