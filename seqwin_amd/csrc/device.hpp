@@ -71,6 +71,10 @@ struct Plan {
     DevArray<uint32_t> gen_tile_off;  // [R + 1] tiles of the generic class
     DevArray<uint32_t> fast_tile_rec; // [n_tiles_fast] record of every fast-class tile (no search in the kernel)
     DevArray<uint32_t> gen_tile_rec;  // [n_tiles_gen]
+    DevArray<uint32_t> fast_tile_pos0; // [n_tiles_fast] position of idx 0 of the tile's segment (pos = pos0 + idx), or
+                                       // 0xFFFFFFFF: the tile's reach crosses an invalid-base gap -> generic kernel (gap_list)
+    DevArray<uint32_t> gap_list;       // fast-class ids of those tiles
+    uint32_t n_gap_tiles = 0;
     uint32_t slot_cap = 0;            // stage entries reserved per tile (1.5 x the expected number of minimizers + 16)
     DevArray<uint32_t> seg_pos;       // [S]
     DevArray<uint32_t> seg_idx;       // [S]

@@ -82,6 +82,7 @@ struct SketchArgs {
     uint64_t ovf_base;            // first entry of the overflow area = n_tiles * slot_cap
     uint32_t slot_cap;            // entries of a tile's own slot at tile * slot_cap
     const uint32_t *cls_tile_rec; // [class tiles] record of every tile of the class this launch covers
+    const uint32_t *cls_tile_pos0; // fast class: [class tiles] pos of idx 0 of the tile's segment, 0xFFFFFFFF = gap tile (skipped)
     uint32_t *tile_count;
     uint64_t *tile_offset;
     uint32_t *ovf_count;          // fast kernel: number of tiles handed over to the generic kernel
@@ -481,7 +482,8 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
     const uint32_t E0 = (t == 0) ? 0u : I0 - A.halo;   // halo >= w, a whole number of runs when w > L
     const uint32_t ne = I1 - E0;
     const uint32_t e_first = I0 - E0;
-    const uint32_t pos0 = A.seg_pos[A.rec_seg_off[rec]];   // single segment: idx g <-> pos0 + g
+    const uint32_t pos0 = A.cls_tile_pos0[ctile];   // the tile lies in ONE valid segment: idx g <-> pos0 + g
+    if (pos0 == 0xFFFFFFFFu) return;                // its reach crosses invalid bases: the generic kernel does it (gap list)
     const uint64_t b_first = A.rec_base[rec] + pos0 + E0;
     const uint32_t ph = (uint32_t)b_first & 15u;
     const uint64_t word0 = b_first >> 4;
@@ -941,7 +943,7 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     const HostBatch &h = b.host;
     const size_t R = h.rec_len.size();
     std::vector<uint32_t> rec_seg_off(R + 1, 0), rec_nvalid(R, 0), rec_tile_off(R + 1, 0), fast_off(R + 1, 0),
-        gen_off(R + 1, 0), seg_pos, seg_idx, fast_rec, gen_rec;
+        gen_off(R + 1, 0), seg_pos, seg_idx, fast_rec, gen_rec, fast_pos0, gap_list;
     uint64_t tiles = 0, tiles_f = 0, tiles_g = 0;
     for (size_t r = 0; r < R; ++r) {
         rec_seg_off[r] = (uint32_t)seg_pos.size();
@@ -963,9 +965,42 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
         if (nv >= w) {
             const uint64_t windows = nv - w + 1;
             p.n_windows += windows;
-            if (p.Lf && nseg == 1) {
-                const uint64_t nt = (windows + p.TWf - 1) / p.TWf;
+            // Fast class: tiles that lie in ONE valid segment (idx <-> pos is affine there).  A record with invalid bases is
+            // cut into the same tiles; those whose reach [E0, I1) crosses a gap are pre-listed for the generic kernel's
+            // list mode (the fast kernel skips them) -- unless most of its tiles would be, then the whole record goes to
+            // the generic class as before.
+            bool fast = p.Lf && nseg == 1;
+            const uint64_t ntf = p.Lf ? (windows + p.TWf - 1) / p.TWf : 0;
+            std::vector<uint32_t> tp0;
+            if (p.Lf && nseg > 1) {
+                const uint32_t s0 = rec_seg_off[r], s1 = (uint32_t)seg_pos.size();
+                uint32_t sgm = s0;
+                uint64_t gap_free = 0;
+                tp0.resize(ntf);
+                for (uint64_t t = 0; t < ntf; ++t) {
+                    const uint64_t I0 = (w - 1) + t * p.TWf, I1 = std::min<uint64_t>(I0 + p.TWf, nv);
+                    const uint64_t E0 = t ? I0 - p.halo_f : 0;
+                    while (sgm + 1 < s1 && seg_idx[sgm + 1] <= E0) ++sgm;          // segment holding idx E0
+                    const uint64_t seg_end = (sgm + 1 < s1) ? seg_idx[sgm + 1] : nv;
+                    if (I1 <= seg_end) {
+                        tp0[t] = seg_pos[sgm] - seg_idx[sgm];
+                        ++gap_free;
+                    } else {
+                        tp0[t] = 0xFFFFFFFFu;
+                    }
+                }
+                fast = gap_free * 2 >= ntf;
+            }
+            if (fast) {
+                const uint64_t nt = ntf;
                 fast_rec.insert(fast_rec.end(), nt, (uint32_t)r);
+                if (nseg == 1) {
+                    fast_pos0.insert(fast_pos0.end(), nt, seg_pos[rec_seg_off[r]]);
+                } else {
+                    for (uint64_t t = 0; t < nt; ++t)
+                        if (tp0[t] == 0xFFFFFFFFu) gap_list.push_back((uint32_t)(tiles_f + t));
+                    fast_pos0.insert(fast_pos0.end(), tp0.begin(), tp0.end());
+                }
                 tiles_f += nt;
                 tiles += nt;
             } else {
@@ -1011,6 +1046,9 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     up32(p.fast_tile_off, fast_off);
     up32(p.gen_tile_off, gen_off);
     up32(p.fast_tile_rec, fast_rec);
+    up32(p.fast_tile_pos0, fast_pos0);
+    up32(p.gap_list, gap_list);
+    p.n_gap_tiles = (uint32_t)gap_list.size();
     up32(p.gen_tile_rec, gen_rec);
     up32(p.seg_pos, seg_pos);
     up32(p.seg_idx, seg_idx);
@@ -1096,15 +1134,21 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         a.ovf_count = ovf_count.p;
         a.ovf_list = ovf_list.p;
         a.list = nullptr;
+        a.cls_tile_pos0 = nullptr;
+        a.cls_tile_rec = nullptr;
         {
             const char *rc = getenv("SEQWIN_AMD_RC");   // test hook: force the overflow (list-mode) path
             a.rc_limit = rc ? std::min<uint32_t>(RC, (uint32_t)atoi(rc)) : RC;
         }
-        SW_HIP(hipMemsetAsync(ovf_count.p, 0, 4, stream));
+        // the list of tiles for the generic kernel's list mode starts with the plan's gap tiles; the fast kernel appends
+        SW_HIP(hipMemsetD32Async((hipDeviceptr_t)ovf_count.p, (int)plan.n_gap_tiles, 1, stream));
+        if (plan.n_gap_tiles)
+            SW_HIP(hipMemcpyAsync(ovf_list.p, plan.gap_list.p, (size_t)plan.n_gap_tiles * 4, hipMemcpyDeviceToDevice, stream));
         SW_HIP(hipEventRecord(ev0, stream));
         if (plan.n_tiles_fast) {
             a.cls_tile_off = plan.fast_tile_off.p;
             a.cls_tile_rec = plan.fast_tile_rec.p;
+            a.cls_tile_pos0 = plan.fast_tile_pos0.p;
             a.L = plan.Lf;
             a.TW = plan.TWf;
             a.halo = plan.halo_f;

@@ -401,6 +401,30 @@ def test_staging_overflow_rerun(tmp_path):
         assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
 
 
+def test_records_with_gaps_use_the_fast_kernel_tile_by_tile(tmp_path):
+    """A record with invalid bases is cut into fast-class tiles; only tiles whose reach crosses a gap are pre-listed for the
+    generic kernel (get_plan: gap_list).  Gaps are put inside tiles, right at tile seams (7968 window ends per tile at
+    w = 200), at the record's ends and closer together than k; a record that is mostly gaps stays in the generic class."""
+    rng = np.random.default_rng(99)
+    def seq(n):
+        return rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
+    a = seq(70000)
+    for start, ln in [(0, 3), (5000, 1), (7968 + 199 - 5, 40), (2 * 7968 + 230, 700), (30000, 20), (30015, 2), (45000, 1500), (69990, 10)]:
+        a[start:start + ln] = ord("N")
+    b = seq(40000)
+    b[::150] = ord("N")                       # a gap in every tile reach: generic class
+    c = seq(33000)
+    c[16000:16005] = ord("n")
+    p = tmp_path / "gaps.fa"
+    p.write_bytes(b">a\n" + a.tobytes() + b"\n>b\n" + b.tobytes() + b"\n>c\n" + c.tobytes() + b"\n>d\n" + seq(25000).tobytes() + b"\n")
+    for k, w in [(21, 200), (31, 64), (15, 20)]:
+        exp = oracle.build([p], k, w)
+        got = _build([p], k, w)
+        assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
+    t = Batch.from_fasta([p]).build_index(21, 200).timings()
+    assert 2 <= t["ovf_tiles"] < t["n_tiles"] // 2     # some tiles of a and c went through the list pass, most did not
+
+
 @pytest.mark.parametrize("slot_cap", ["1", "40", "90"])
 def test_tile_slots_and_shared_overflow_area(tmp_path, slot_cap, monkeypatch):
     """Every tile writes its tuples into its own stage slot; a tile with more winners than the slot holds takes a range
