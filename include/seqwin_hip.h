@@ -171,7 +171,7 @@ typedef struct sw_timings {
     uint64_t n_tiles;
     uint64_t total_bp;
     uint64_t n_windows;
-    uint64_t ovf_tiles;  /* fast-class tiles redone exactly by the generic kernel (more suffix records than published) */
+    uint64_t ovf_tiles;  /* fast-class tiles done by the generic kernel's list pass: tiles crossing invalid bases + tiles with more suffix records than published */
 } sw_timings;
 
 /*

@@ -138,7 +138,7 @@ struct SketchOut {
     DevArray<uint64_t> tile_offset;
     uint64_t n_occ = 0;
     uint64_t launches = 0;
-    uint64_t n_ovf_tiles = 0;   // fast-class tiles redone by the generic kernel (more than RC suffix records in a run)
+    uint64_t n_ovf_tiles = 0;   // fast-class tiles done by the generic kernel's list pass (gap tiles + more than RC suffix records in a run)
 };
 void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchOut &out, float *sketch_ms);
 
