@@ -13,9 +13,10 @@
 // reference's ring buffer does).  The reference emits the rightmost minimum of every window whenever its
 // position advances; because that position is monotone in the window index this equals "the set of
 // elements that are the rightmost minimum of at least one window", in position order.  A workgroup
-// owns one TILE = TW consecutive window ends of one record plus a halo of w earlier elements:
+// owns one TILE = TW consecutive window ends of one record plus a halo of w earlier elements (the generic kernel
+// below is the plain form of the scheme; the fast kernel further down keeps hashes in registers):
 //   phase 1  each of the 256 threads rolls ntHash over its own run of L consecutive k-mers
-//            (k-1 warm-up steps, then one LDS LUT lookup + ~35 integer VALU ops per base) and stores
+//            (k-1 warm-up steps, then one LDS LUT lookup + ~20 integer VALU ops per base) and stores
 //            the 64-bit canonical hash of every element in LDS; it also keeps its run minimum and,
 //            walking back, the offset of the suffix minimum of its run from every element (1 byte).
 //   phase 2  every window [x, e] is (suffix of an earlier run from x) + (whole runs) + (prefix of the
@@ -23,9 +24,10 @@
 //            the whole-run part from <= w/L run minima and the suffix part from two LDS reads, and
 //            sets a bit for the winner (ds_or, idempotent -> duplicates vanish).
 //   phase 3  the bit of the minimizer of the window just before the tile is cleared (the previous
-//            tile owns it), bits are counted (workgroup scan), one 64-bit atomicAdd reserves the
-//            tile's output range and the tuples are written in position order.
-// Tiles land in allocation order; index.hip's order pass restores (record_idx, pos) order.
+//            tile owns it), bits are counted (workgroup scan) and the tuples are written in position order
+//            into the tile's own slot of the stage arrays (tile * slot_cap; a tile with more winners than
+//            its slot takes a range of a shared overflow area with one atomicAdd).
+// Tiles land slot by slot; index.hip's order pass packs them into (record_idx, pos) order.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
