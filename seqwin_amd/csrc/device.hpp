@@ -59,22 +59,29 @@ struct Plan {
     uint32_t L = 0;        // k-mers hashed per thread (odd, <= w)
     uint32_t NE = 0;       // elements per tile = 256 * L
     uint32_t TW = 0;       // window ends per tile = NE - w
-    uint32_t Lf = 0, TWf = 0, Lg_list = 0, halo_f = 0;  // fast class (single-segment records): run length 32 / 16 / 0 = unavailable
-    uint32_t n_tiles = 0, n_tiles_fast = 0, n_tiles_gen = 0;
+    uint32_t Lf = 0, Lg_list = 0, halo_f = 0;  // fast classes: run length 32 / 16 / 0 = unavailable; list-mode run length; halo
+    uint32_t n_tiles = 0, n_tiles_gen = 0;
+    // Fast tile classes: [0] 256-thread workgroups (256 * L elements per tile), [1] 64-thread workgroups (64 * L) for
+    // records that are short: a tile occupies its workgroup's LDS whatever its fill, so a 1 kbp contig in a 256-thread
+    // tile keeps 3 of 4 waves idle and the CU at a quarter of its occupancy.
+    struct FastClass {
+        uint32_t B = 0;                // threads per workgroup
+        uint32_t TW = 0;               // window ends per tile (0 = class unavailable)
+        uint32_t n_tiles = 0, n_gap = 0;
+        DevArray<uint32_t> tile_off;   // [R + 1] class tile numbering (record-major)
+        DevArray<uint32_t> tile_rec;   // [n_tiles] record of every tile (no search in the kernel)
+        DevArray<uint32_t> tile_pos0;  // [n_tiles] position of idx 0 of the tile's segment (pos = pos0 + idx), or
+                                       // 0xFFFFFFFF: the tile's reach crosses an invalid-base gap -> generic kernel (gap_list)
+        DevArray<uint32_t> gap_list;   // [n_gap] class ids of those tiles
+    } fc[2];
     uint64_t n_windows = 0;
     uint64_t n_valid = 0;
     size_t lds_bytes = 0;
     DevArray<uint32_t> rec_seg_off;   // [R + 1]
     DevArray<uint32_t> rec_nvalid;    // [R]
     DevArray<uint32_t> rec_tile_off;  // [R + 1] global tile numbering
-    DevArray<uint32_t> fast_tile_off; // [R + 1] tiles of the fast class
     DevArray<uint32_t> gen_tile_off;  // [R + 1] tiles of the generic class
-    DevArray<uint32_t> fast_tile_rec; // [n_tiles_fast] record of every fast-class tile (no search in the kernel)
     DevArray<uint32_t> gen_tile_rec;  // [n_tiles_gen]
-    DevArray<uint32_t> fast_tile_pos0; // [n_tiles_fast] position of idx 0 of the tile's segment (pos = pos0 + idx), or
-                                       // 0xFFFFFFFF: the tile's reach crosses an invalid-base gap -> generic kernel (gap_list)
-    DevArray<uint32_t> gap_list;       // fast-class ids of those tiles
-    uint32_t n_gap_tiles = 0;
     uint32_t slot_cap = 0;            // stage entries reserved per tile (1.5 x the expected number of minimizers + 16)
     DevArray<uint32_t> seg_pos;       // [S]
     DevArray<uint32_t> seg_idx;       // [S]

@@ -440,28 +440,28 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
 constexpr uint32_t KF = 256;
 constexpr uint32_t RC = 12;   // published suffix records per run (12 x 8 B: the most that keeps 5 workgroups per CU)
 
-template <int L> struct FastCfg {
-    static constexpr int NE = BLOCK * L;
+template <int L, int B> struct FastCfg {
+    static constexpr int NE = B * L;
     static constexpr int NSTG = NE / 16 + KF / 16 + 4;
     static constexpr int NEM = NE / 32 + 2;
     static constexpr size_t off_REC = 0;
-    static constexpr size_t off_RMh = off_REC + (size_t)BLOCK * RC * 8;
-    static constexpr size_t off_LUT = off_RMh + BLOCK * 8;
+    static constexpr size_t off_RMh = off_REC + (size_t)B * RC * 8;
+    static constexpr size_t off_LUT = off_RMh + B * 8;
     static constexpr size_t off_STG = off_LUT + 40 * 8;
     static constexpr size_t off_EM = off_STG + (size_t)NSTG * 4;
     static constexpr size_t off_MASK = off_EM + (size_t)NEM * 4;
-    static constexpr size_t off_MISC = off_MASK + BLOCK * 4;
+    static constexpr size_t off_MISC = off_MASK + B * 4;
     static constexpr size_t off_RMp = off_MISC + 16 * 4;
-    static constexpr size_t bytes = off_RMp + BLOCK * 2;
+    static constexpr size_t bytes = off_RMp + B * 2;
 };
 
-template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(const SketchArgs A)
+template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kernel(const SketchArgs A)
 {
-    using C = FastCfg<L>;
+    using C = FastCfg<L, B>;
     constexpr uint32_t LM = L - 1;
     constexpr uint32_t LSH = (L == 32) ? 5 : 4;
     static_assert(L == 32 || L == 16, "run length must be 16 or 32");
-    static_assert((size_t)BLOCK * RC * 8 >= 4096, "the warm-up table shares the suffix-record area");
+    static_assert((size_t)B * RC * 8 >= 4096, "the warm-up table shares the suffix-record area");
     __shared__ __align__(16) unsigned char smem[C::bytes];   // static: LDS addresses are compile-time constants
     uint64_t *REC = reinterpret_cast<uint64_t *>(smem + C::off_REC);
     uint64_t *RMh = reinterpret_cast<uint64_t *>(smem + C::off_RMh);
@@ -492,16 +492,16 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
 
     {   // stage the tile's packed words (coalesced), clear the emit bitmap, load the LUT
         const uint32_t nw = (ph + ne + k + 14) / 16 + 2;
-        for (uint32_t i = tid; i < nw; i += BLOCK) {
+        for (uint32_t i = tid; i < nw; i += B) {
             const uint64_t gw = word0 + i;
             STG[i] = (gw < A.packed_words) ? A.packed[gw] : 0u;
         }
-        for (uint32_t i = tid; i < (uint32_t)C::NEM; i += BLOCK) EM[i] = 0;
+        for (uint32_t i = tid; i < (uint32_t)C::NEM; i += B) EM[i] = 0;
         if (tid < 40) LUT[tid] = A.lut[tid];
         if (tid == 0) MISC[1] = 0;
         // the 4 KiB warm-up table lives in LDS while the runs are hashed, in the space the suffix records take afterwards
         // (five dependent gathers per lane from global memory were ~4 % of the kernel's time, all of it latency)
-        for (uint32_t i = tid; i < 256u; i += BLOCK)
+        for (uint32_t i = tid; i < 256u; i += B)
             reinterpret_cast<ulonglong2 *>(REC)[i] = reinterpret_cast<const ulonglong2 *>(A.t4)[i];
     }
     __syncthreads();
@@ -848,7 +848,7 @@ template <int L> __global__ __launch_bounds__(BLOCK, 4) void sketch_fast_kernel(
     if (lane == 63) MISC[4 + wave] = incl;
     __syncthreads();
     uint32_t wave_off = 0, total = 0;
-    for (uint32_t i = 0; i < BLOCK / 64; ++i) {
+    for (uint32_t i = 0; i < B / 64; ++i) {
         const uint32_t v = MISC[4 + i];
         if (i < wave) wave_off += v;
         total += v;
@@ -939,18 +939,26 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     // fast tiles start their halo on a run boundary (w rounded up to a multiple of L when w > L): the lanes of the halo
     // then hold no owned window at all and the first wave of a tile can run the wave-uniform window pass as well
     p.halo_f = (p.Lf && w > p.Lf) ? (w + p.Lf - 1) / p.Lf * p.Lf : w;
-    p.TWf = p.Lf ? BLOCK * std::min(p.Lf, p.Lg_list) - p.halo_f : 0;
+    p.fc[0].B = BLOCK;
+    p.fc[0].TW = p.Lf ? BLOCK * std::min(p.Lf, p.Lg_list) - p.halo_f : 0;
+    // 64-thread tiles for short records: only while the halo stays below a quarter of such a tile (w <= 512 at L = 32)
+    p.fc[1].B = 64;
+    p.fc[1].TW = (p.Lf && 4u * p.halo_f <= 64u * std::min(p.Lf, p.Lg_list) && !(force && !strcmp(force, "big")))
+                     ? 64u * std::min(p.Lf, p.Lg_list) - p.halo_f : 0;
     p.mult = 1ULL ^ ((uint64_t)k * MULTISEED);
 
     const HostBatch &h = b.host;
     const size_t R = h.rec_len.size();
-    std::vector<uint32_t> rec_seg_off(R + 1, 0), rec_nvalid(R, 0), rec_tile_off(R + 1, 0), fast_off(R + 1, 0),
-        gen_off(R + 1, 0), seg_pos, seg_idx, fast_rec, gen_rec, fast_pos0, gap_list;
-    uint64_t tiles = 0, tiles_f = 0, tiles_g = 0;
+    std::vector<uint32_t> rec_seg_off(R + 1, 0), rec_nvalid(R, 0), rec_tile_off(R + 1, 0), gen_off(R + 1, 0), seg_pos, seg_idx,
+        gen_rec;
+    struct HostClass { std::vector<uint32_t> off, rec, pos0, gaps; uint64_t tiles = 0; } hc[2];
+    for (auto &c : hc) c.off.assign(R + 1, 0);
+    uint64_t tiles = 0, tiles_g = 0;
+    std::vector<uint32_t> tp0;
     for (size_t r = 0; r < R; ++r) {
         rec_seg_off[r] = (uint32_t)seg_pos.size();
         rec_tile_off[r] = (uint32_t)tiles;
-        fast_off[r] = (uint32_t)tiles_f;
+        for (auto &c : hc) c.off[r] = (uint32_t)c.tiles;
         gen_off[r] = (uint32_t)tiles_g;
         uint64_t nv = 0;
         uint32_t nseg = 0;
@@ -967,44 +975,58 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
         if (nv >= w) {
             const uint64_t windows = nv - w + 1;
             p.n_windows += windows;
-            // Fast class: tiles that lie in ONE valid segment (idx <-> pos is affine there).  A record with invalid bases is
+            // Fast classes: tiles that lie in ONE valid segment (idx <-> pos is affine there).  A record with invalid bases is
             // cut into the same tiles; those whose reach [E0, I1) crosses a gap are pre-listed for the generic kernel's
             // list mode (the fast kernel skips them) -- unless most of its tiles would be, then the whole record goes to
-            // the generic class as before.
-            bool fast = p.Lf && nseg == 1;
-            const uint64_t ntf = p.Lf ? (windows + p.TWf - 1) / p.TWf : 0;
-            std::vector<uint32_t> tp0;
-            if (p.Lf && nseg > 1) {
-                const uint32_t s0 = rec_seg_off[r], s1 = (uint32_t)seg_pos.size();
-                uint32_t sgm = s0;
-                uint64_t gap_free = 0;
-                tp0.resize(ntf);
-                for (uint64_t t = 0; t < ntf; ++t) {
-                    const uint64_t I0 = (w - 1) + t * p.TWf, I1 = std::min<uint64_t>(I0 + p.TWf, nv);
-                    const uint64_t E0 = t ? I0 - p.halo_f : 0;
-                    while (sgm + 1 < s1 && seg_idx[sgm + 1] <= E0) ++sgm;          // segment holding idx E0
-                    const uint64_t seg_end = (sgm + 1 < s1) ? seg_idx[sgm + 1] : nv;
-                    if (I1 <= seg_end) {
-                        tp0[t] = seg_pos[sgm] - seg_idx[sgm];
-                        ++gap_free;
-                    } else {
-                        tp0[t] = 0xFFFFFFFFu;
-                    }
+            // the generic class.  Which class: a tile costs its workgroup's time whatever its fill, and a 64-thread tile
+            // costs about a third of a 256-thread one (measured, tests/tools/fragment_timing.py: 3.6-4.1 ns against
+            // 11.0-12.5 ns per tile), so the class with the smaller tile count x cost takes the record (the 96 kbp contigs of
+            // the default workload: 13 x 1 against 53 x 0.32 -> 256-thread tiles; records below ~5 kbp: 64-thread tiles).
+            int cls = -1;
+            if (p.Lf) {
+                const uint64_t nt0 = (windows + p.fc[0].TW - 1) / p.fc[0].TW;
+                cls = 0;
+                if (p.fc[1].TW) {
+                    const uint64_t nt1 = (windows + p.fc[1].TW - 1) / p.fc[1].TW;
+                    if (nt1 * 32 < nt0 * 100) cls = 1;
                 }
-                fast = gap_free * 2 >= ntf;
             }
-            if (fast) {
-                const uint64_t nt = ntf;
-                fast_rec.insert(fast_rec.end(), nt, (uint32_t)r);
-                if (nseg == 1) {
-                    fast_pos0.insert(fast_pos0.end(), nt, seg_pos[rec_seg_off[r]]);
-                } else {
-                    for (uint64_t t = 0; t < nt; ++t)
-                        if (tp0[t] == 0xFFFFFFFFu) gap_list.push_back((uint32_t)(tiles_f + t));
-                    fast_pos0.insert(fast_pos0.end(), tp0.begin(), tp0.end());
+            uint64_t ntf = 0;
+            if (cls >= 0) {
+                const uint32_t TWc = p.fc[cls].TW;
+                ntf = (windows + TWc - 1) / TWc;
+                if (nseg > 1) {
+                    const uint32_t s0 = rec_seg_off[r], s1 = (uint32_t)seg_pos.size();
+                    uint32_t sgm = s0;
+                    uint64_t gap_free = 0;
+                    tp0.assign(ntf, 0);
+                    for (uint64_t t = 0; t < ntf; ++t) {
+                        const uint64_t I0 = (w - 1) + t * TWc, I1 = std::min<uint64_t>(I0 + TWc, nv);
+                        const uint64_t E0 = t ? I0 - p.halo_f : 0;
+                        while (sgm + 1 < s1 && seg_idx[sgm + 1] <= E0) ++sgm;          // segment holding idx E0
+                        const uint64_t seg_end = (sgm + 1 < s1) ? seg_idx[sgm + 1] : nv;
+                        if (I1 <= seg_end) {
+                            tp0[t] = seg_pos[sgm] - seg_idx[sgm];
+                            ++gap_free;
+                        } else {
+                            tp0[t] = 0xFFFFFFFFu;
+                        }
+                    }
+                    if (gap_free * 2 < ntf) cls = -1;
                 }
-                tiles_f += nt;
-                tiles += nt;
+            }
+            if (cls >= 0) {
+                HostClass &c = hc[cls];
+                c.rec.insert(c.rec.end(), ntf, (uint32_t)r);
+                if (nseg == 1) {
+                    c.pos0.insert(c.pos0.end(), ntf, seg_pos[rec_seg_off[r]]);
+                } else {
+                    for (uint64_t t = 0; t < ntf; ++t)
+                        if (tp0[t] == 0xFFFFFFFFu) c.gaps.push_back((uint32_t)(c.tiles + t));
+                    c.pos0.insert(c.pos0.end(), tp0.begin(), tp0.end());
+                }
+                c.tiles += ntf;
+                tiles += ntf;
             } else {
                 const uint64_t nt = (windows + p.TW - 1) / p.TW;
                 gen_rec.insert(gen_rec.end(), nt, (uint32_t)r);
@@ -1016,13 +1038,12 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     }
     rec_seg_off[R] = (uint32_t)seg_pos.size();
     rec_tile_off[R] = (uint32_t)tiles;
-    fast_off[R] = (uint32_t)tiles_f;
+    for (auto &c : hc) c.off[R] = (uint32_t)c.tiles;
     gen_off[R] = (uint32_t)tiles_g;
     p.n_tiles = (uint32_t)tiles;
-    p.n_tiles_fast = (uint32_t)tiles_f;
     p.n_tiles_gen = (uint32_t)tiles_g;
     {   // a tile's own stage slot: 1.5 x the expected 2 / (w + 1) minimizers per window end, + 16
-        const uint64_t tw = std::max<uint64_t>(p.TW, p.TWf);
+        const uint64_t tw = std::max<uint64_t>(p.TW, p.fc[0].TW);
         p.slot_cap = (uint32_t)std::min<uint64_t>(tw + w, (3 * tw / (w + 1) + 16 + 7) / 8 * 8);
         if (const char *e = getenv("SEQWIN_AMD_SLOT_CAP")) p.slot_cap = (uint32_t)std::max(1, atoi(e));   // test hook
     }
@@ -1045,12 +1066,15 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     up32(p.rec_seg_off, rec_seg_off);
     up32(p.rec_nvalid, rec_nvalid);
     up32(p.rec_tile_off, rec_tile_off);
-    up32(p.fast_tile_off, fast_off);
+    for (int c = 0; c < 2; ++c) {
+        p.fc[c].n_tiles = (uint32_t)hc[c].tiles;
+        p.fc[c].n_gap = (uint32_t)hc[c].gaps.size();
+        up32(p.fc[c].tile_off, hc[c].off);
+        up32(p.fc[c].tile_rec, hc[c].rec);
+        up32(p.fc[c].tile_pos0, hc[c].pos0);
+        up32(p.fc[c].gap_list, hc[c].gaps);
+    }
     up32(p.gen_tile_off, gen_off);
-    up32(p.fast_tile_rec, fast_rec);
-    up32(p.fast_tile_pos0, fast_pos0);
-    up32(p.gap_list, gap_list);
-    p.n_gap_tiles = (uint32_t)gap_list.size();
     up32(p.gen_tile_rec, gen_rec);
     up32(p.seg_pos, seg_pos);
     up32(p.seg_idx, seg_idx);
@@ -1097,7 +1121,10 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
     if (plan.n_tiles == 0) return;
 
     DevArray<unsigned long long> cursor(2);   // [0] entries taken from the overflow area, [1] sum of the tile counts
-    DevArray<uint32_t> ovf_count(1), ovf_list(plan.n_tiles_fast);
+    // per fast class: the list of tiles for the generic kernel's list mode (gap tiles of the plan, then the tiles the fast
+    // kernel hands over) and its length
+    DevArray<uint32_t> ovf_count(2), ovf_list0(plan.fc[0].n_tiles), ovf_list1(plan.fc[1].n_tiles);
+    uint32_t *const ovf_list[2] = {ovf_list0.p, ovf_list1.p};
     // every tile owns a slot of slot_cap entries (1.5 x the expected density 2/(w+1) per window end); tiles with more
     // winners share an overflow area behind the slots, which is grown to the exact size and the pass re-run if it is too small
     const uint64_t slots = (uint64_t)plan.n_tiles * plan.slot_cap;
@@ -1133,35 +1160,42 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         a.slot_cap = plan.slot_cap;
         a.tile_count = out.tile_count.p;
         a.tile_offset = out.tile_offset.p;
-        a.ovf_count = ovf_count.p;
-        a.ovf_list = ovf_list.p;
         a.list = nullptr;
         a.cls_tile_pos0 = nullptr;
         a.cls_tile_rec = nullptr;
+        a.ovf_count = nullptr;
+        a.ovf_list = nullptr;
+        a.halo = plan.halo_f;
         {
             const char *rc = getenv("SEQWIN_AMD_RC");   // test hook: force the overflow (list-mode) path
             a.rc_limit = rc ? std::min<uint32_t>(RC, (uint32_t)atoi(rc)) : RC;
         }
-        // the list of tiles for the generic kernel's list mode starts with the plan's gap tiles; the fast kernel appends
-        SW_HIP(hipMemsetD32Async((hipDeviceptr_t)ovf_count.p, (int)plan.n_gap_tiles, 1, stream));
-        if (plan.n_gap_tiles)
-            SW_HIP(hipMemcpyAsync(ovf_list.p, plan.gap_list.p, (size_t)plan.n_gap_tiles * 4, hipMemcpyDeviceToDevice, stream));
+        // the lists start with the plan's gap tiles; the fast kernels append
+        for (int c = 0; c < 2; ++c) {
+            SW_HIP(hipMemsetD32Async((hipDeviceptr_t)(ovf_count.p + c), (int)plan.fc[c].n_gap, 1, stream));
+            if (plan.fc[c].n_gap)
+                SW_HIP(hipMemcpyAsync(ovf_list[c], plan.fc[c].gap_list.p, (size_t)plan.fc[c].n_gap * 4, hipMemcpyDeviceToDevice,
+                                      stream));
+        }
         SW_HIP(hipEventRecord(ev0, stream));
-        if (plan.n_tiles_fast) {
-            a.cls_tile_off = plan.fast_tile_off.p;
-            a.cls_tile_rec = plan.fast_tile_rec.p;
-            a.cls_tile_pos0 = plan.fast_tile_pos0.p;
+        for (int c = 0; c < 2; ++c) {
+            const Plan::FastClass &fc = plan.fc[c];
+            if (!fc.n_tiles) continue;
+            a.cls_tile_off = fc.tile_off.p;
+            a.cls_tile_rec = fc.tile_rec.p;
+            a.cls_tile_pos0 = fc.tile_pos0.p;
+            a.ovf_count = ovf_count.p + c;
+            a.ovf_list = ovf_list[c];
             a.L = plan.Lf;
-            a.TW = plan.TWf;
-            a.halo = plan.halo_f;
-            a.n_tiles = plan.n_tiles_fast;
-            for (uint32_t tb = 0; tb < plan.n_tiles_fast; tb += MAX_TILES_PER_LAUNCH) {
-                const uint32_t nt = std::min(plan.n_tiles_fast - tb, MAX_TILES_PER_LAUNCH);
+            a.TW = fc.TW;
+            a.n_tiles = fc.n_tiles;
+            for (uint32_t tb = 0; tb < fc.n_tiles; tb += MAX_TILES_PER_LAUNCH) {
+                const uint32_t nt = std::min(fc.n_tiles - tb, MAX_TILES_PER_LAUNCH);
                 a.tile_base = tb;
-                if (plan.Lf == 32)
-                    hipLaunchKernelGGL(sketch_fast_kernel<32>, dim3(nt), dim3(BLOCK), 0, stream, a);
-                else
-                    hipLaunchKernelGGL(sketch_fast_kernel<16>, dim3(nt), dim3(BLOCK), 0, stream, a);
+                if (plan.Lf == 32 && c == 0) hipLaunchKernelGGL((sketch_fast_kernel<32, BLOCK>), dim3(nt), dim3(BLOCK), 0, stream, a);
+                else if (plan.Lf == 32) hipLaunchKernelGGL((sketch_fast_kernel<32, 64>), dim3(nt), dim3(64), 0, stream, a);
+                else if (c == 0) hipLaunchKernelGGL((sketch_fast_kernel<16, BLOCK>), dim3(nt), dim3(BLOCK), 0, stream, a);
+                else hipLaunchKernelGGL((sketch_fast_kernel<16, 64>), dim3(nt), dim3(64), 0, stream, a);
                 SW_HIP(hipGetLastError());
             }
         }
@@ -1178,21 +1212,24 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
                 SW_HIP(hipGetLastError());
             }
         }
-        // tiles the fast kernel handed over are redone, exactly, by the generic kernel in list mode.  The list length is
-        // only known on the device: a first batch of LIST_GRID workgroups is enqueued blind (surplus workgroups exit at
-        // once), the rest -- rare -- after the count has come back.
+        // the listed tiles are done, exactly, by the generic kernel in list mode (same window ranges as the fast tiles of
+        // their class).  The list length is only known on the device: a first batch of LIST_GRID workgroups per class is
+        // enqueued blind (surplus workgroups exit at once), the rest -- rare -- after the counts have come back.
         constexpr uint32_t LIST_GRID = 2048;
-        SketchArgs al = a;
-        if (plan.n_tiles_fast) {
-            al.cls_tile_off = plan.fast_tile_off.p;
-            al.cls_tile_rec = plan.fast_tile_rec.p;
-            al.L = plan.Lg_list;
-            al.TW = plan.TWf;
-            al.list = ovf_list.p;
-            al.tile_base = 0;
-            al.n_tiles = LIST_GRID;
-            hipLaunchKernelGGL(sketch_generic_kernel, dim3(std::min(LIST_GRID, plan.n_tiles_fast)), dim3(BLOCK),
-                               lds_bytes_for(plan.Lg_list), stream, al);
+        SketchArgs al[2] = {a, a};
+        for (int c = 0; c < 2; ++c) {
+            const Plan::FastClass &fc = plan.fc[c];
+            if (!fc.n_tiles) continue;
+            al[c].cls_tile_off = fc.tile_off.p;
+            al[c].cls_tile_rec = fc.tile_rec.p;
+            al[c].ovf_count = ovf_count.p + c;
+            al[c].L = plan.Lg_list;
+            al[c].TW = fc.TW;
+            al[c].list = ovf_list[c];
+            al[c].tile_base = 0;
+            al[c].n_tiles = LIST_GRID;
+            hipLaunchKernelGGL(sketch_generic_kernel, dim3(std::min(LIST_GRID, fc.n_tiles)), dim3(BLOCK),
+                               lds_bytes_for(plan.Lg_list), stream, al[c]);
             SW_HIP(hipGetLastError());
         }
         auto sum_counts = [&]() {
@@ -1203,23 +1240,24 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         sum_counts();
         SW_HIP(hipEventRecord(ev1, stream));
         unsigned long long total[2] = {0, 0};   // overflow entries taken, n_occ
-        uint32_t n_ovf = 0;
+        uint32_t n_ovf[2] = {0, 0};
         SW_HIP(hipMemcpyAsync(total, cursor.p, sizeof total, hipMemcpyDeviceToHost, stream));
-        SW_HIP(hipMemcpyAsync(&n_ovf, ovf_count.p, 4, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipMemcpyAsync(n_ovf, ovf_count.p, sizeof n_ovf, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipStreamSynchronize(stream));
         float ms = 0.f;
         SW_HIP(hipEventElapsedTime(&ms, ev0, ev1));
         if (sketch_ms) *sketch_ms += ms;
         ++out.launches;
-        out.n_ovf_tiles += n_ovf;
-        if (n_ovf > LIST_GRID) {
+        out.n_ovf_tiles += (uint64_t)n_ovf[0] + n_ovf[1];
+        if (n_ovf[0] > LIST_GRID || n_ovf[1] > LIST_GRID) {
             SW_HIP(hipEventRecord(ev0, stream));
-            for (uint32_t tb = LIST_GRID; tb < n_ovf; tb += MAX_TILES_PER_LAUNCH) {
-                al.tile_base = tb;
-                hipLaunchKernelGGL(sketch_generic_kernel, dim3(std::min(n_ovf - tb, MAX_TILES_PER_LAUNCH)), dim3(BLOCK),
-                                   lds_bytes_for(plan.Lg_list), stream, al);
-                SW_HIP(hipGetLastError());
-            }
+            for (int c = 0; c < 2; ++c)
+                for (uint32_t tb = LIST_GRID; tb < n_ovf[c]; tb += MAX_TILES_PER_LAUNCH) {
+                    al[c].tile_base = tb;
+                    hipLaunchKernelGGL(sketch_generic_kernel, dim3(std::min(n_ovf[c] - tb, MAX_TILES_PER_LAUNCH)), dim3(BLOCK),
+                                       lds_bytes_for(plan.Lg_list), stream, al[c]);
+                    SW_HIP(hipGetLastError());
+                }
             SW_HIP(hipMemsetAsync(cursor.p + 1, 0, sizeof(unsigned long long), stream));
             sum_counts();
             SW_HIP(hipEventRecord(ev1, stream));

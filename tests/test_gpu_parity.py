@@ -408,12 +408,12 @@ def test_records_with_gaps_use_the_fast_kernel_tile_by_tile(tmp_path):
     rng = np.random.default_rng(99)
     def seq(n):
         return rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
-    a = seq(70000)
-    for start, ln in [(0, 3), (5000, 1), (7968 + 199 - 5, 40), (2 * 7968 + 230, 700), (30000, 20), (30015, 2), (45000, 1500), (69990, 10)]:
+    a = seq(200000)
+    for start, ln in [(0, 3), (5000, 1), (7968 + 199 - 5, 40), (2 * 7968 + 230, 700), (30000, 20), (30015, 2), (45000, 1500), (199990, 10)]:
         a[start:start + ln] = ord("N")
     b = seq(40000)
     b[::150] = ord("N")                       # a gap in every tile reach: generic class
-    c = seq(33000)
+    c = seq(33000)                            # short enough for the 64-thread tile class (18 tiles, one of them crosses the gap)
     c[16000:16005] = ord("n")
     p = tmp_path / "gaps.fa"
     p.write_bytes(b">a\n" + a.tobytes() + b"\n>b\n" + b.tobytes() + b"\n>c\n" + c.tobytes() + b"\n>d\n" + seq(25000).tobytes() + b"\n")
