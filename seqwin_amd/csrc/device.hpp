@@ -62,14 +62,16 @@ struct Plan {
     uint32_t Lf = 0, Lg_list = 0, halo_f = 0;  // fast classes: run length 32 / 16 / 0 = unavailable; list-mode run length; halo
     uint32_t n_tiles = 0, n_tiles_gen = 0;
     // Fast tile classes: [0] 256-thread workgroups (256 * L elements per tile), [1] 64-thread workgroups (64 * L) for
-    // records that are short: a tile occupies its workgroup's LDS whatever its fill, so a 1 kbp contig in a 256-thread
-    // tile keeps 3 of 4 waves idle and the CU at a quarter of its occupancy.
+    // short records: a tile occupies its workgroup's LDS whatever its fill, so a 1 kbp contig in a 256-thread tile keeps
+    // 3 of 4 waves idle and the CU at a quarter of its occupancy.  Every tile carries its own (record, first window end,
+    // global id), so the classes can mix inside a record (get_plan: only behind SEQWIN_AMD_SKETCH=tails, measured slower).
     struct FastClass {
         uint32_t B = 0;                // threads per workgroup
         uint32_t TW = 0;               // window ends per tile (0 = class unavailable)
         uint32_t n_tiles = 0, n_gap = 0;
-        DevArray<uint32_t> tile_off;   // [R + 1] class tile numbering (record-major)
         DevArray<uint32_t> tile_rec;   // [n_tiles] record of every tile (no search in the kernel)
+        DevArray<uint32_t> tile_i0;    // [n_tiles] idx of the tile's first window end (w - 1 for the first tile of a record)
+        DevArray<uint32_t> tile_gid;   // [n_tiles] global tile id (record-major, window order: the order pass follows it)
         DevArray<uint32_t> tile_pos0;  // [n_tiles] position of idx 0 of the tile's segment (pos = pos0 + idx), or
                                        // 0xFFFFFFFF: the tile's reach crosses an invalid-base gap -> generic kernel (gap_list)
         DevArray<uint32_t> gap_list;   // [n_gap] class ids of those tiles

@@ -84,6 +84,8 @@ struct SketchArgs {
     uint64_t ovf_base;            // first entry of the overflow area = n_tiles * slot_cap
     uint32_t slot_cap;            // entries of a tile's own slot at tile * slot_cap
     const uint32_t *cls_tile_rec; // [class tiles] record of every tile of the class this launch covers
+    const uint32_t *cls_tile_i0;  // fast classes (and their list mode): idx of the tile's first window end; nullptr: (w - 1) + t * TW
+    const uint32_t *cls_tile_gid; // fast classes (and their list mode): global tile id; nullptr: rec_tile_off[rec] + t
     const uint32_t *cls_tile_pos0; // fast class: [class tiles] pos of idx 0 of the tile's segment, 0xFFFFFFFF = gap tile (skipped)
     uint32_t *tile_count;
     uint64_t *tile_offset;
@@ -211,12 +213,14 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
     if (A.list && A.tile_base + blockIdx.x >= *A.ovf_count) return;   // list length is only known on the device
     const uint32_t ctile = A.list ? A.list[A.tile_base + blockIdx.x] : A.tile_base + blockIdx.x;
     const uint32_t rec = A.cls_tile_rec[ctile];   // (one load instead of a 15-step search: the chain is pure latency)
-    const uint32_t t = ctile - A.cls_tile_off[rec];
-    const uint32_t tile = A.rec_tile_off[rec] + t;  // global tile id (order pass)
+    // own class: tiles of a record are numbered t = 0, 1, ...; tiles of the fast classes carry their own descriptors
+    const uint32_t t = A.cls_tile_i0 ? 0u : ctile - A.cls_tile_off[rec];
+    const uint32_t tile = A.cls_tile_gid ? A.cls_tile_gid[ctile] : A.rec_tile_off[rec] + t;  // global tile id (order pass)
     const uint32_t nvalid = A.rec_nvalid[rec];
-    const uint32_t I0 = (w - 1) + t * A.TW;                   // first window end (idx space)
+    const uint32_t I0 = A.cls_tile_i0 ? A.cls_tile_i0[ctile] : (w - 1) + t * A.TW;   // first window end (idx space)
+    const bool first = I0 == w - 1;                           // first tile of its record
     const uint32_t I1 = (uint32_t)min((uint64_t)I0 + A.TW, (uint64_t)nvalid);   // no wrap near 2^32 k-mers               // one past the last window end
-    const uint32_t E0 = (t == 0) ? 0u : I0 - w;               // first element held by this tile
+    const uint32_t E0 = first ? 0u : I0 - w;                  // first element held by this tile
     const uint32_t ne = I1 - E0;                              // elements held (<= NE)
     const uint32_t e_first = I0 - E0;                         // tile-local index of the first owned window end
     const uint32_t slo = A.rec_seg_off[rec], shi = A.rec_seg_off[rec + 1];
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
         }
     }
     __syncthreads();
-    if (tid == 0 && t != 0) {
+    if (tid == 0 && !first) {
         const uint32_t sarg = MISC[0];
         EM[sarg >> 5] &= ~(1u << (sarg & 31u));
     }
@@ -476,12 +480,12 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
 
     const uint32_t ctile = A.tile_base + blockIdx.x;
     const uint32_t rec = A.cls_tile_rec[ctile];
-    const uint32_t t = ctile - A.cls_tile_off[rec];
-    const uint32_t tile = A.rec_tile_off[rec] + t;
+    const uint32_t tile = A.cls_tile_gid[ctile];
     const uint32_t nvalid = A.rec_nvalid[rec];
-    const uint32_t I0 = (w - 1) + t * A.TW;
+    const uint32_t I0 = A.cls_tile_i0[ctile];
+    const bool first = I0 == w - 1;                    // first tile of its record
     const uint32_t I1 = (uint32_t)min((uint64_t)I0 + A.TW, (uint64_t)nvalid);   // no wrap near 2^32 k-mers
-    const uint32_t E0 = (t == 0) ? 0u : I0 - A.halo;   // halo >= w, a whole number of runs when w > L
+    const uint32_t E0 = first ? 0u : I0 - A.halo;      // halo >= w, a whole number of runs when w > L
     const uint32_t ne = I1 - E0;
     const uint32_t e_first = I0 - E0;
     const uint32_t pos0 = A.cls_tile_pos0[ctile];   // the tile lies in ONE valid segment: idx g <-> pos0 + g
@@ -822,7 +826,7 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
         }
     }
     __syncthreads();
-    if (tid == 0 && t != 0) {
+    if (tid == 0 && !first) {
         const uint32_t sarg = MISC[0];
         EM[sarg >> 5] &= ~(1u << (sarg & 31u));
     }
@@ -951,23 +955,20 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     const size_t R = h.rec_len.size();
     std::vector<uint32_t> rec_seg_off(R + 1, 0), rec_nvalid(R, 0), rec_tile_off(R + 1, 0), gen_off(R + 1, 0), seg_pos, seg_idx,
         gen_rec;
-    struct HostClass { std::vector<uint32_t> off, rec, pos0, gaps; uint64_t tiles = 0; } hc[2];
-    for (auto &c : hc) c.off.assign(R + 1, 0);
+    struct HostClass { std::vector<uint32_t> rec, pos0, i0, gid, gaps; uint64_t tiles = 0; } hc[2];
     uint64_t tiles = 0, tiles_g = 0;
-    std::vector<uint32_t> tp0;
+    struct TileDesc { uint32_t cls, i0, pos0; };
+    std::vector<TileDesc> td;
     for (size_t r = 0; r < R; ++r) {
         rec_seg_off[r] = (uint32_t)seg_pos.size();
         rec_tile_off[r] = (uint32_t)tiles;
-        for (auto &c : hc) c.off[r] = (uint32_t)c.tiles;
         gen_off[r] = (uint32_t)tiles_g;
         uint64_t nv = 0;
-        uint32_t nseg = 0;
         for (uint32_t q = h.rec_run_off[r]; q < h.rec_run_off[r + 1]; ++q) {
             if (h.run_len[q] < k) continue;
             seg_pos.push_back(h.run_pos[q]);
             seg_idx.push_back((uint32_t)nv);
             nv += h.run_len[q] - k + 1;
-            ++nseg;
         }
         rec_nvalid[r] = (uint32_t)nv;
         p.n_valid += nv;
@@ -975,58 +976,59 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
         if (nv >= w) {
             const uint64_t windows = nv - w + 1;
             p.n_windows += windows;
-            // Fast classes: tiles that lie in ONE valid segment (idx <-> pos is affine there).  A record with invalid bases is
-            // cut into the same tiles; those whose reach [E0, I1) crosses a gap are pre-listed for the generic kernel's
-            // list mode (the fast kernel skips them) -- unless most of its tiles would be, then the whole record goes to
-            // the generic class.  Which class: a tile costs its workgroup's time whatever its fill, and a 64-thread tile
-            // costs about a third of a 256-thread one (measured, tests/tools/fragment_timing.py: 3.6-4.1 ns against
-            // 11.0-12.5 ns per tile), so the class with the smaller tile count x cost takes the record (the 96 kbp contigs of
-            // the default workload: 13 x 1 against 53 x 0.32 -> 256-thread tiles; records below ~5 kbp: 64-thread tiles).
-            int cls = -1;
+            // Fast classes: tiles that lie in ONE valid segment (idx <-> pos is affine there).  A tile costs its workgroup's
+            // time whatever its fill, and a 64-thread tile costs about a third of a 256-thread one (measured,
+            // tests/tools/fragment_timing.py: 3.6-4.1 ns against 11.0-12.5 ns per tile).  A record is cut, whichever is
+            // cheaper in tile count x cost, into (a) 256-thread tiles or (c) 64-thread tiles only.  (b) -- full 256-thread
+            // tiles + 64-thread tiles for the tail -- is implemented (every tile carries its own descriptor) but measured
+            // SLOWER on the default workload (96 kbp contigs, 12 + 1 tiles instead of 13: 3.85 against 3.72 ms): a nearly empty
+            // 256-thread tile leaves the VALU to its neighbours and costs well under a full one, so the model above does not
+            // hold for tails; it stays behind SEQWIN_AMD_SKETCH=tails for experiments.
+            bool fast = false;
+            td.clear();
             if (p.Lf) {
-                const uint64_t nt0 = (windows + p.fc[0].TW - 1) / p.fc[0].TW;
-                cls = 0;
-                if (p.fc[1].TW) {
-                    const uint64_t nt1 = (windows + p.fc[1].TW - 1) / p.fc[1].TW;
-                    if (nt1 * 32 < nt0 * 100) cls = 1;
-                }
-            }
-            uint64_t ntf = 0;
-            if (cls >= 0) {
-                const uint32_t TWc = p.fc[cls].TW;
-                ntf = (windows + TWc - 1) / TWc;
-                if (nseg > 1) {
-                    const uint32_t s0 = rec_seg_off[r], s1 = (uint32_t)seg_pos.size();
-                    uint32_t sgm = s0;
-                    uint64_t gap_free = 0;
-                    tp0.assign(ntf, 0);
-                    for (uint64_t t = 0; t < ntf; ++t) {
-                        const uint64_t I0 = (w - 1) + t * TWc, I1 = std::min<uint64_t>(I0 + TWc, nv);
-                        const uint64_t E0 = t ? I0 - p.halo_f : 0;
-                        while (sgm + 1 < s1 && seg_idx[sgm + 1] <= E0) ++sgm;          // segment holding idx E0
-                        const uint64_t seg_end = (sgm + 1 < s1) ? seg_idx[sgm + 1] : nv;
-                        if (I1 <= seg_end) {
-                            tp0[t] = seg_pos[sgm] - seg_idx[sgm];
-                            ++gap_free;
-                        } else {
-                            tp0[t] = 0xFFFFFFFFu;
-                        }
+                const uint64_t TW0 = p.fc[0].TW, TW1 = p.fc[1].TW;
+                const uint64_t nb = windows / TW0, rem = windows % TW0;
+                const uint64_t cost_a = (nb + (rem ? 1 : 0)) * 100;
+                const bool tails = force && !strcmp(force, "tails");
+                const uint64_t cost_b = (TW1 && tails) ? nb * 100 + (rem + TW1 - 1) / TW1 * 32 : ~0ull;
+                const uint64_t cost_c = TW1 ? (windows + TW1 - 1) / TW1 * 32 : ~0ull;
+                uint64_t n_big = nb + (rem ? 1 : 0), n_small = 0;                       // (a)
+                if (cost_b < cost_a && cost_b <= cost_c) { n_big = nb; n_small = (rem + TW1 - 1) / TW1; }   // (b)
+                else if (cost_c < cost_a) { n_big = 0; n_small = (windows + TW1 - 1) / TW1; }               // (c)
+                for (uint64_t t = 0; t < n_big; ++t) td.push_back({0u, (uint32_t)((w - 1) + t * TW0), 0u});
+                for (uint64_t t = 0; t < n_small; ++t) td.push_back({1u, (uint32_t)((w - 1) + n_big * TW0 + t * TW1), 0u});
+                // a record with invalid bases is cut into the same tiles; those whose reach [E0, I1) crosses a gap are
+                // pre-listed for the generic kernel's list mode (the fast kernels skip them) -- unless most of its tiles
+                // would be, then the whole record goes to the generic class
+                const uint32_t s0 = rec_seg_off[r], s1 = (uint32_t)seg_pos.size();
+                uint32_t sgm = s0;
+                uint64_t gap_free = 0;
+                for (TileDesc &d : td) {
+                    const uint64_t I0 = d.i0, I1 = std::min<uint64_t>(I0 + p.fc[d.cls].TW, nv);
+                    const uint64_t E0 = (I0 == w - 1) ? 0 : I0 - p.halo_f;
+                    while (sgm + 1 < s1 && seg_idx[sgm + 1] <= E0) ++sgm;          // segment holding idx E0
+                    const uint64_t seg_end = (sgm + 1 < s1) ? seg_idx[sgm + 1] : nv;
+                    if (I1 <= seg_end) {
+                        d.pos0 = seg_pos[sgm] - seg_idx[sgm];
+                        ++gap_free;
+                    } else {
+                        d.pos0 = 0xFFFFFFFFu;
                     }
-                    if (gap_free * 2 < ntf) cls = -1;
                 }
+                fast = gap_free * 2 >= td.size();
             }
-            if (cls >= 0) {
-                HostClass &c = hc[cls];
-                c.rec.insert(c.rec.end(), ntf, (uint32_t)r);
-                if (nseg == 1) {
-                    c.pos0.insert(c.pos0.end(), ntf, seg_pos[rec_seg_off[r]]);
-                } else {
-                    for (uint64_t t = 0; t < ntf; ++t)
-                        if (tp0[t] == 0xFFFFFFFFu) c.gaps.push_back((uint32_t)(c.tiles + t));
-                    c.pos0.insert(c.pos0.end(), tp0.begin(), tp0.end());
+            if (fast) {
+                for (const TileDesc &d : td) {
+                    HostClass &c = hc[d.cls];
+                    if (d.pos0 == 0xFFFFFFFFu) c.gaps.push_back((uint32_t)c.tiles);
+                    c.rec.push_back((uint32_t)r);
+                    c.pos0.push_back(d.pos0);
+                    c.i0.push_back(d.i0);
+                    c.gid.push_back((uint32_t)tiles);
+                    ++c.tiles;
+                    ++tiles;
                 }
-                c.tiles += ntf;
-                tiles += ntf;
             } else {
                 const uint64_t nt = (windows + p.TW - 1) / p.TW;
                 gen_rec.insert(gen_rec.end(), nt, (uint32_t)r);
@@ -1038,7 +1040,6 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     }
     rec_seg_off[R] = (uint32_t)seg_pos.size();
     rec_tile_off[R] = (uint32_t)tiles;
-    for (auto &c : hc) c.off[R] = (uint32_t)c.tiles;
     gen_off[R] = (uint32_t)tiles_g;
     p.n_tiles = (uint32_t)tiles;
     p.n_tiles_gen = (uint32_t)tiles_g;
@@ -1069,8 +1070,9 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
     for (int c = 0; c < 2; ++c) {
         p.fc[c].n_tiles = (uint32_t)hc[c].tiles;
         p.fc[c].n_gap = (uint32_t)hc[c].gaps.size();
-        up32(p.fc[c].tile_off, hc[c].off);
         up32(p.fc[c].tile_rec, hc[c].rec);
+        up32(p.fc[c].tile_i0, hc[c].i0);
+        up32(p.fc[c].tile_gid, hc[c].gid);
         up32(p.fc[c].tile_pos0, hc[c].pos0);
         up32(p.fc[c].gap_list, hc[c].gaps);
     }
@@ -1113,6 +1115,19 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
             done[dev] = true;
         }
     }
+    // the 64-thread tile class runs beside the 256-thread one on a stream of its own (forked from / joined into `stream`):
+    // back to back in one stream the second kernel would start only when the first has drained
+    hipStream_t side = nullptr;
+    if (plan.fc[0].n_tiles && plan.fc[1].n_tiles) {
+        static std::mutex &mu2 = *new std::mutex;                 // leaked on purpose (see api.hip: pool())
+        static std::map<std::pair<int, hipStream_t>, hipStream_t> &sides = *new std::map<std::pair<int, hipStream_t>, hipStream_t>;
+        int dev = 0;
+        SW_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(mu2);
+        hipStream_t &sref = sides[std::make_pair(dev, stream)];    // one per (device, caller's stream): callers do not share it
+        if (!sref) SW_HIP(hipStreamCreateWithFlags(&sref, hipStreamNonBlocking));
+        side = sref;
+    }
     out.n_occ = 0;
     out.launches = 0;
     if (sketch_ms) *sketch_ms = 0.f;
@@ -1129,9 +1144,10 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
     // winners share an overflow area behind the slots, which is grown to the exact size and the pass re-run if it is too small
     const uint64_t slots = (uint64_t)plan.n_tiles * plan.slot_cap;
     uint64_t ovf_cap = std::max<uint64_t>(4096, slots / 64);
-    hipEvent_t ev0, ev1;
+    hipEvent_t ev0, ev1, evj;
     SW_HIP(hipEventCreate(&ev0));
     SW_HIP(hipEventCreate(&ev1));
+    SW_HIP(hipEventCreateWithFlags(&evj, hipEventDisableTiming));
     for (;;) {
         const uint64_t cap = slots + ovf_cap;
         out.stage_hash.alloc(cap);
@@ -1163,6 +1179,9 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         a.list = nullptr;
         a.cls_tile_pos0 = nullptr;
         a.cls_tile_rec = nullptr;
+        a.cls_tile_i0 = nullptr;
+        a.cls_tile_gid = nullptr;
+        a.cls_tile_off = nullptr;
         a.ovf_count = nullptr;
         a.ovf_list = nullptr;
         a.halo = plan.halo_f;
@@ -1178,12 +1197,15 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
                                       stream));
         }
         SW_HIP(hipEventRecord(ev0, stream));
-        for (int c = 0; c < 2; ++c) {
+        if (side) SW_HIP(hipStreamWaitEvent(side, ev0, 0));
+        for (int c = 1; c >= 0; --c) {
             const Plan::FastClass &fc = plan.fc[c];
             if (!fc.n_tiles) continue;
-            a.cls_tile_off = fc.tile_off.p;
+            hipStream_t cs = (c == 1 && side) ? side : stream;
             a.cls_tile_rec = fc.tile_rec.p;
             a.cls_tile_pos0 = fc.tile_pos0.p;
+            a.cls_tile_i0 = fc.tile_i0.p;
+            a.cls_tile_gid = fc.tile_gid.p;
             a.ovf_count = ovf_count.p + c;
             a.ovf_list = ovf_list[c];
             a.L = plan.Lf;
@@ -1192,16 +1214,20 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
             for (uint32_t tb = 0; tb < fc.n_tiles; tb += MAX_TILES_PER_LAUNCH) {
                 const uint32_t nt = std::min(fc.n_tiles - tb, MAX_TILES_PER_LAUNCH);
                 a.tile_base = tb;
-                if (plan.Lf == 32 && c == 0) hipLaunchKernelGGL((sketch_fast_kernel<32, BLOCK>), dim3(nt), dim3(BLOCK), 0, stream, a);
-                else if (plan.Lf == 32) hipLaunchKernelGGL((sketch_fast_kernel<32, 64>), dim3(nt), dim3(64), 0, stream, a);
-                else if (c == 0) hipLaunchKernelGGL((sketch_fast_kernel<16, BLOCK>), dim3(nt), dim3(BLOCK), 0, stream, a);
-                else hipLaunchKernelGGL((sketch_fast_kernel<16, 64>), dim3(nt), dim3(64), 0, stream, a);
+                if (plan.Lf == 32 && c == 0) hipLaunchKernelGGL((sketch_fast_kernel<32, BLOCK>), dim3(nt), dim3(BLOCK), 0, cs, a);
+                else if (plan.Lf == 32) hipLaunchKernelGGL((sketch_fast_kernel<32, 64>), dim3(nt), dim3(64), 0, cs, a);
+                else if (c == 0) hipLaunchKernelGGL((sketch_fast_kernel<16, BLOCK>), dim3(nt), dim3(BLOCK), 0, cs, a);
+                else hipLaunchKernelGGL((sketch_fast_kernel<16, 64>), dim3(nt), dim3(64), 0, cs, a);
                 SW_HIP(hipGetLastError());
             }
+            if (c == 1 && side) SW_HIP(hipEventRecord(evj, side));
         }
+        if (side) SW_HIP(hipStreamWaitEvent(stream, evj, 0));   // join: everything below is ordered after both classes
         if (plan.n_tiles_gen) {
             a.cls_tile_off = plan.gen_tile_off.p;
             a.cls_tile_rec = plan.gen_tile_rec.p;
+            a.cls_tile_i0 = nullptr;      // own class: tile t of its record, (w - 1) + t * TW
+            a.cls_tile_gid = nullptr;
             a.L = plan.L;
             a.TW = plan.TW;
             a.n_tiles = plan.n_tiles_gen;
@@ -1220,8 +1246,9 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         for (int c = 0; c < 2; ++c) {
             const Plan::FastClass &fc = plan.fc[c];
             if (!fc.n_tiles) continue;
-            al[c].cls_tile_off = fc.tile_off.p;
             al[c].cls_tile_rec = fc.tile_rec.p;
+            al[c].cls_tile_i0 = fc.tile_i0.p;
+            al[c].cls_tile_gid = fc.tile_gid.p;
             al[c].ovf_count = ovf_count.p + c;
             al[c].L = plan.Lg_list;
             al[c].TW = fc.TW;
@@ -1274,6 +1301,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
     }
     SW_HIP(hipEventDestroy(ev0));
     SW_HIP(hipEventDestroy(ev1));
+    SW_HIP(hipEventDestroy(evj));
 }
 
 }  // namespace sw
