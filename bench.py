@@ -212,7 +212,7 @@ def main() -> None:
                                    f"({anc} ancestors, {snp / 1e4:g}% substitutions), on-device generator",
                        "genomes": G * world, "mean_bp": rpg * rl, "k": k, "w": w,
                        "parallelism": f"assembly-sharded x{world}" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "sketch_fast_kernel<32>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "sketch_fast_kernel<32, 256>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(sk_bytes), "avg_launch_ms": round(sk_ms, 4),

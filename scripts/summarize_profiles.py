@@ -3,7 +3,7 @@ import collections, csv, glob, json, re, sys
 tag = sys.argv[1]          # e.g. r1f
 out_prefix = sys.argv[2]   # e.g. profiles/r01f_v4
 def short(n):
-    m = re.search(r'(k_\w+|sketch_\w+(<\d+>)?)', n)
+    m = re.search(r'(k_\w+|sketch_\w+(<\d+(, ?\d+)?>)?)', n)
     if m: return m.group(1)
     if 'radix_sort' in n: return 'rocprim::radix_sort_onesweep'
     if 'scan' in n: return 'rocprim::scan'
