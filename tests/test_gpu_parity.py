@@ -510,3 +510,30 @@ def test_native_log_line_reaches_the_root_logger(smoke_paths, caplog):
     with caplog.at_level(logging.INFO):
         KmerGraph(smoke_paths, kmerlen=21, windowsize=200)
     assert any("MI355X index" in r.getMessage() and "4 assemblies" in r.getMessage() for r in caplog.records)
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the fields the driver reads (metric, value, unit, n_gpus, steps, warmup,
+    ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config.workload) plus roofline and -- at N = 1 --
+    cpu_baseline.  Run on the small workload, with a 4-genome CPU sample."""
+    import json
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "bench.py"), "--workload", "tiny", "--steps", "2", "--warmup", "1",
+                          "--cpu-sample-genomes", "4"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Gbp/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["unit"] == "Gbp/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
