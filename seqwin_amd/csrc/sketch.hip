@@ -38,10 +38,7 @@ namespace sw {
 
 namespace {
 
-#ifndef SW_BLOCK
-#define SW_BLOCK 256
-#endif
-constexpr int BLOCK = SW_BLOCK;
+constexpr int BLOCK = 256;   // threads of the generic kernel and of the large fast tile class
 constexpr uint32_t MAX_TILES_PER_LAUNCH = 1u << 23;  // x 256 threads stays below the 2^32 work-item grid limit
 constexpr uint32_t L_MAX = 33;  // 256*33 elements * 8 B = 66 KiB of hashes -> two workgroups per CU
 
