@@ -7,10 +7,15 @@
 One "step" = one full pass of the hot path over the synthetic genome set, with the 2-bit packed
 contigs and record tables already resident in HBM: fused ntHash + window-minimizer sketch -> tuple
 ordering -> nodes / kmers (radix sort + run-length) -> per-node target / non-target assembly counts
-and penalty -> adjacency edges; for N > 1 additionally the merge of the per-GPU partial graphs over
-RCCL (seqwin_amd/dist.py).  Default workload = BASELINE.json configs[1]'s stand-in:
-512 genomes x 4.8 Mbp (50 contigs each) from 5 ancestors with 1 % substitutions, k=21, w=200, per GPU
-(weak scaling).  Rank 0 prints ONE JSON line.
+and penalty -> adjacency edges; for N > 1 additionally the exchange of tuples / node ranks / adjacency rows
+between the per-GPU shards over RCCL (seqwin_amd/dist.py).
+
+Default workload = BASELINE.json configs[2] / configs[3]: 15 000 genomes x 5 Mbp
+(50 contigs each) from 30 ancestors with 1 % substitutions, k = 21, w = 200 -- 75 Gbp.  With --gpus N the SAME
+15 000 genomes are sharded over the N GPUs with the reference's worker partition (build.cpp:350-356): strong
+scaling; the checksums of the N slices must add up to the single-GPU checksums (shard-count invariance,
+tests/smoke/test_graph.py:67-127 at full size).  `--scaling weak` gives every GPU its own genome set instead.
+Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -26,24 +31,21 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 WORKLOADS = {
-    # name: (genomes per GPU, records per genome, record length, ancestors, snp ppm)
-    "salmonella500": (512, 50, 96_000, 5, 10_000),       # configs[1] stand-in, 2.46 Gbp per GPU
-    "bacteria15k": (15_000, 50, 100_000, 30, 10_000),    # configs[2], 75 Gbp on one GPU
-    "random": (2_000, 1, 5_000_000, 2_000, 0),           # configs[4] slice: iid-uniform genomes, 10 Gbp
-    "tiny": (16, 4, 50_000, 2, 10_000),
+    # name: (genomes, records per genome, record length, ancestors, snp ppm, default scaling)
+    "bacteria15k": (15_000, 50, 100_000, 30, 10_000, "strong"),   # configs[2] (1 GPU) / configs[3] (sharded), 75 Gbp
+    "salmonella500": (512, 50, 96_000, 5, 10_000, "weak"),         # configs[1] stand-in, 2.46 Gbp per GPU
+    "random": (2_000, 1, 5_000_000, 2_000, 0, "weak"),             # configs[4] slice: iid-uniform genomes, 10 Gbp per GPU
+    "random100k": (12_500, 1, 5_000_000, 12_500, 0, "weak"),       # configs[4]: 100 000 x 5 Mbp over 8 GPUs (12 500 per GPU)
+    "tiny": (16, 4, 50_000, 2, 10_000, "strong"),
 }
+SEED = 20260821
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+GOLDEN = ROOT / "tests" / "golden" / "bench_checksums.json"
 
 
-def cpu_baseline(batch, k, w, n_genomes_sample, is_targets):
-    """Time the reference CPU path (oracle/_ref, kind 'reference'; else the C restatement, kind 'port') on a
-    bounded sample of the same workload, FASTA files on local disk -> final arrays incl. get_penalty."""
-    import numpy as np
-
-    import oracle
+def write_fasta_sample(batch, n, tmp):
+    """First n assemblies of a device batch as plain FASTA files (decoded from HBM) -> (paths, bases)."""
     offs, ids = batch.records()
-    n = min(n_genomes_sample, len(offs) - 1)
-    tmp = tempfile.mkdtemp(prefix="seqwin_cpu_")
     paths, bp = [], 0
     for a in range(n):
         p = os.path.join(tmp, f"g{a}.fa")
@@ -53,6 +55,20 @@ def cpu_baseline(batch, k, w, n_genomes_sample, is_targets):
                 bp += len(seq)
                 f.write(b">" + ids[a][r - int(offs[a])].encode() + b"\n" + seq + b"\n")
         paths.append(p)
+    return paths, bp
+
+
+def cpu_baseline_and_parity(batch, k, w, n_genomes_sample, is_targets):
+    """Time the reference CPU path (oracle/_ref, kind 'reference'; else the C restatement, kind 'port') on a bounded
+    sample of the same workload -- FASTA files on local disk -> final arrays incl. get_penalty -- and compare its
+    arrays, element for element, with the HIP path's on the same files (checker only: nothing here is timed as `value`)."""
+    import numpy as np
+
+    import oracle
+    from seqwin_amd.device import Batch
+    n = min(n_genomes_sample, batch.info()["n_assemblies"])
+    tmp = tempfile.mkdtemp(prefix="seqwin_cpu_")
+    paths, bp = write_fasta_sample(batch, n, tmp)
     tar = np.asarray(is_targets[:n], np.bool_).copy()
     if tar.all() or not tar.any():
         tar[: n // 2] = True
@@ -76,26 +92,48 @@ def cpu_baseline(batch, k, w, n_genomes_sample, is_targets):
         oracle.get_penalty(kmers, nodes, ro, tar)
         runs.append((time.perf_counter() - t0, 1))
     dt, used = min(runs)
+    # the HIP path on the same files, through the same ingest as sw_build
+    sb = Batch.from_fasta(paths, n_cpu=min(16, cores))
+    six = sb.build_index(k, w, tar)
+    gk, gn, ge = six.export()
+    equal = bool(np.array_equal(gk, kmers) and np.array_equal(gn, nodes) and np.array_equal(ge, edges)
+                 and np.array_equal(sb.record_offsets(), ro))
+    six.close()
+    sb.close()
     for p in paths:
         os.unlink(p)
     os.rmdir(tmp)
-    return {"value": round(bp / dt / 1e9, 4), "unit": "Gbp/s", "cores": used, "kind": kind,
+    base = {"value": round(bp / dt / 1e9, 4), "unit": "Gbp/s", "cores": used, "kind": kind,
             "sample": f"first {n} genomes of the workload ({bp / 1e6:.0f} Mbp) as plain FASTA on local disk -> "
                       f"kmers/nodes/edges + get_penalty; wall " + ", ".join(f"{t:.2f} s at n_cpu={c}" for t, c in runs)
                       + f" (host has {cores} hardware threads)",
             "n_kmers": int(len(kmers)), "n_nodes": int(len(nodes)), "n_edges": int(len(edges))}
+    parity = {"vs": kind, "sample_genomes": n, "equal": equal,
+              "compared": "kmers, nodes (hash, start, stop, n_tar, n_neg, penalty bit-for-bit), edges, record_offsets"}
+    return base, parity
+
+
+def golden_checksums(workload, k, w):
+    try:
+        return json.loads(GOLDEN.read_text()).get(f"{workload}/k{k}/w{w}")
+    except Exception:
+        return None
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="salmonella500", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="bacteria15k", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="strong: the workload's genomes are sharded over the GPUs; weak: every GPU gets its own set")
+    ap.add_argument("--genomes", type=int, default=None, help="override the workload's genome count")
     ap.add_argument("-k", "--kmerlen", type=int, default=21)
     ap.add_argument("-w", "--windowsize", type=int, default=200)
     ap.add_argument("--cpu-sample-genomes", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--write-golden", action="store_true", help="record this run's N=1 checksums in tests/golden/")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,21 +158,33 @@ def main() -> None:
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    from seqwin_amd import dist as swdist
     from seqwin_amd.device import Batch, set_device
     set_device(local_rank)
 
-    G, rpg, rl, anc, snp = WORKLOADS[args.workload]
+    G, rpg, rl, anc, snp, default_scaling = WORKLOADS[args.workload]
+    if args.genomes:
+        G = args.genomes
+    scaling = args.scaling or default_scaling
     k, w = args.kmerlen, args.windowsize
-    # weak scaling: every rank holds its own G genomes (assemblies [rank*G, (rank+1)*G) of the job)
-    batch = Batch.synthetic(G, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=20260821 + rank)
-    is_targets_global = np.arange(G * world) % 2 == 0
-    my_targets = is_targets_global[rank * G:(rank + 1) * G]
-    bp_rank = G * rpg * rl
+    if scaling == "strong":
+        # ONE job of G genomes; rank r holds the contiguous assembly range of "thread r" (build.cpp:350-356)
+        G_total = G
+        first, end = swdist.partition_assemblies(G_total, world)[rank]
+        batch = Batch.synthetic(end - first, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED, first_genome=first)
+    else:
+        # every rank holds its own G genomes (assemblies [rank*G, (rank+1)*G) of the job)
+        G_total = G * world
+        first, end = rank * G, (rank + 1) * G
+        batch = Batch.synthetic(G, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED + rank)
+    is_targets_global = np.arange(G_total) % 2 == 0
+    my_targets = is_targets_global[first:end]
+    bp_rank = (end - first) * rpg * rl
+    total_bp = G_total * rpg * rl
 
     use_dist = world > 1 or os.environ.get("SEQWIN_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: cost of the sharded path at N=1
     if use_dist:
-        from seqwin_amd import dist as swdist
-        shard = swdist.Shard(batch, first_assembly=rank * G, n_assemblies_total=G * world)
+        shard = swdist.Shard(batch, first_assembly=first, n_assemblies_total=G_total)
         engine = swdist.HipEngine("device" if world == 1 or dist.get_backend() == "nccl" else "host")
 
         def step():
@@ -165,29 +215,31 @@ def main() -> None:
         release(ix)
         ix = step()
         for key, v in ix.timings().items():
-            if key.endswith("_ms"):
+            if key.endswith("_ms") and key != "plan_ms":
                 stage[key] = stage.get(key, 0.0) + v
     fence()
     dt = time.perf_counter() - t0
+    red_dev = engine.device if use_dist and world > 1 else torch.device("cuda", local_rank)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=engine.device)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     nk, nn, ne = ix.sizes()
     tm = ix.timings()
-    counts = torch.tensor([nk, nn, ne], dtype=torch.int64, device=engine.device if world > 1 else "cuda")
+    counts = torch.tensor([nk, nn, ne], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(counts)
     n_occ_local = tm.get("n_occ_local", nk)
+    # checksums of the whole (concatenated) result: at N > 1 the slices' shares add up modulo 2^64
+    sums = ix.global_checksums() if use_dist else ix.checksums()
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        total_bp = bp_rank * world
         value = total_bp / (dt / args.steps) / 1e9
         stage = {key: v / args.steps for key, v in stage.items()}
-        # dominant kernel = sketch_kernel (one launch per step per GPU).  Algorithmic bytes per launch
-        # (DESIGN.md section 5): read the 2-bit input once + write one 16 B tuple per minimizer.
+        # dominant kernel = sketch_fast_kernel (one launch per step per GPU).  Algorithmic bytes per launch
+        # (DESIGN.md section 3.3): read the 2-bit input once + write one 16 B tuple per minimizer.
         sk_bytes = 0.25 * bp_rank + 16.0 * n_occ_local
         sk_ms = stage["sketch_ms"]
         achieved = sk_bytes / (sk_ms * 1e-3) / 1e9
@@ -207,20 +259,24 @@ def main() -> None:
         out = {
             "metric": "Gbp/s minimizer-indexed", "value": round(value, 3), "unit": "Gbp/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {G} genomes/GPU x {rpg} contigs x {rl} bp "
-                                   f"({anc} ancestors, {snp / 1e4:g}% substitutions), on-device generator",
-                       "genomes": G * world, "mean_bp": rpg * rl, "k": k, "w": w,
-                       "parallelism": f"assembly-sharded x{world}" if world > 1 else "single GPU"},
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {G_total} genomes x {rpg} contigs x {rl} bp ({anc} ancestors, "
+                                   f"{snp / 1e4:g}% substitutions), on-device generator, seed {SEED}",
+                       "genomes": G_total, "genomes_per_gpu": end - first, "mean_bp": rpg * rl, "k": k, "w": w,
+                       "parallelism": f"assembly-sharded x{world} ({scaling} scaling)" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "sketch_fast_kernel<32, 256>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(sk_bytes), "avg_launch_ms": round(sk_ms, 4),
                          "note": "integer-VALU issue bound at w=200 (DESIGN.md section 3.1); measured HBM traffic is in profiles/",
+                         "path_algorithmic_bytes": int(path_bytes),
                          "path_achieved_GBs": round(path_bytes / world / (dt / args.steps) / 1e9, 2),
+                         "path_frac": round(path_bytes / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
                          "sketch_Gbp_per_s_per_gpu": round(bp_rank / (sk_ms * 1e-3) / 1e9, 2)},
             "stages_ms": {key: round(v, 4) for key, v in stage.items()},
+            "plan_ms": round(tm.get("plan_ms", 0.0), 3),
             "counts": {"kmers": tot[0], "nodes": tot[1], "edges": tot[2]},
+            "checksums": [f"{s:016x}" for s in sums],
         }
         if valu_insts:
             # explanatory (not the mandated roofline): integer VALU issue, 256 CU x 4 SIMD x 32 lanes x 2.4 GHz peak
@@ -232,8 +288,20 @@ def main() -> None:
                                        "note": "peak = 32 lanes/clk/SIMD (2 cycles per wave64 VOP2); three-operand VOP3, v_cndmask, "
                                                "v_cmp and 64-bit moves measure 4.2-4.9 cycles (scripts/micro/valu_kinds.hip), "
                                                "so this instruction mix cannot reach that peak"}
+        parity = {}
+        gold = golden_checksums(args.workload, k, w) if scaling == "strong" and not args.genomes else None
+        if args.write_golden and world == 1 and not use_dist:
+            allg = json.loads(GOLDEN.read_text()) if GOLDEN.exists() else {}
+            allg[f"{args.workload}/k{k}/w{w}"] = {"checksums": out["checksums"], "counts": out["counts"]}
+            GOLDEN.write_text(json.dumps(allg, indent=1, sort_keys=True) + "\n")
+        elif gold is not None:
+            # shard-count invariance at full size: same checksums whatever the number of GPUs (and as in earlier rounds)
+            parity["n1_checksums_equal"] = gold["checksums"] == out["checksums"] and gold["counts"] == out["counts"]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(batch, k, w, args.cpu_sample_genomes, my_targets)
+            out["cpu_baseline"], ref_par = cpu_baseline_and_parity(batch, k, w, args.cpu_sample_genomes, my_targets)
+            parity.update(ref_par)
+        if parity:
+            out["parity"] = parity
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -147,6 +147,11 @@ int sw_batch_from_fasta(const char *const *assembly_paths, size_t n_assemblies, 
  * substitution probability snp_ppm / 1e6 (counter-based RNG, `seed`).  No host ingest. */
 int sw_batch_synthetic(uint64_t n_genomes, uint64_t records_per_genome, uint64_t record_len,
                        uint64_t n_ancestors, uint64_t snp_ppm, uint64_t seed, sw_batch **out);
+/* Genomes [first_genome, first_genome + n_genomes) of the same job: bases and record ids are those the unsharded
+ * batch holds for these genomes (one rank's contiguous assembly range, cpp/src/seqwin/build.cpp:350-356). */
+int sw_batch_synthetic_shard(uint64_t n_genomes, uint64_t records_per_genome, uint64_t record_len,
+                             uint64_t n_ancestors, uint64_t snp_ppm, uint64_t seed, uint64_t first_genome,
+                             sw_batch **out);
 
 /* Copy the ASCII sequence of record `record_idx` (A/C/G/T, 'N' for invalid bases) back to the host;
  * used by tests to hand the same input to the oracle. *len_out receives the record length. */
@@ -172,6 +177,9 @@ typedef struct sw_timings {
     uint64_t total_bp;
     uint64_t n_windows;
     uint64_t ovf_tiles;  /* fast-class tiles done by the generic kernel's list pass: tiles crossing invalid bases + tiles with more suffix records than published */
+    double plan_ms;      /* host + upload time the (batch, k, w) launch plan took when it was built (tile tables, roll LUTs);
+                            cached in the batch afterwards, so it is outside total_ms except for the first build */
+    uint64_t plan_cached; /* 1: this build found the plan in the batch's cache */
 } sw_timings;
 
 /*
@@ -191,6 +199,10 @@ int sw_index_export(const sw_index *ix, sw_kmer *kmers, sw_node *nodes, sw_edge 
 /* 64-bit checksums of the three arrays (sum over elements of a mix of the element and its index, so order matters),
  * computed on device; seqwin_amd.device.host_checksums is the numpy restatement. */
 int sw_index_checksums(const sw_index *ix, uint64_t *kmers_sum, uint64_t *nodes_sum, uint64_t *edges_sum);
+/* The same for one rank's slice of a sharded index: element i of the slice counts as element base + i of the
+ * concatenated arrays, so the sums of all slices add up (mod 2^64) to the checksums of the unsharded index --
+ * shard-count invariance (reference tests/smoke/test_graph.py:67-127) checked without gathering.  sums[3]. */
+int sw_index_checksums_at(const sw_index *ix, uint64_t kmer_base, uint64_t node_base, uint64_t edge_base, uint64_t *sums);
 /* The sketch stage alone: (out_hash, pos, record_idx) of every minimizer in (record_idx, pos) order.
  * Two-phase like sw_filter_kmers: pass NULL buffers to get *n_out. */
 int sw_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *stream, uint64_t *out_hash,

@@ -1,56 +1,152 @@
-"""Turn rocprofv3 CSV output under gpurun_out/ into the small text summaries committed under profiles/."""
-import collections, csv, glob, json, re, sys
-tag = sys.argv[1]          # e.g. r1f
-out_prefix = sys.argv[2]   # e.g. profiles/r01f_v4
-def short(n):
-    m = re.search(r'(k_\w+|sketch_\w+(<\d+(, ?\d+)?>)?)', n)
-    if m: return m.group(1)
-    if 'radix_sort' in n: return 'rocprim::radix_sort_onesweep'
-    if 'scan' in n: return 'rocprim::scan'
-    return n[:40]
-ks = glob.glob(f'gpurun_out/prof_{tag}/*/*kernel_stats.csv')[0]
-rows = list(csv.DictReader(open(ks)))
-with open(out_prefix + '_kernel_stats.txt', 'w') as f:
-    f.write("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1   (salmonella500; 6 passes incl. warm-up)\n")
-    f.write(f"{'kernel':34s} {'calls':>6s} {'avg_us':>10s} {'total_ms':>9s} {'pct':>6s}\n")
-    for r in rows[:24]:
-        f.write(f"{short(r['Name']):34s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:10.1f} {float(r['TotalDurationNs'])/1e6:9.2f} {float(r['Percentage']):6.2f}\n")
+"""Turn rocprofv3 output under gpurun_out/ into the small text summaries committed under profiles/.
+
+    python scripts/summarize_profiles.py <run_dir> <out_prefix> --workload bacteria15k --bp 75e9 --steps N [--title "..."]
+
+<run_dir> holds up to four sub-directories written by four separate rocprofv3 runs of the same bench command
+(the PMC passes are never combined with tracing, and FETCH / WRITE are collected separately, as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes):
+    stats/   rocprofv3 --kernel-trace --stats --output-format csv   -> <out_prefix>_kernel_stats.txt
+    pmc/     rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES ...             -> <out_prefix>_pmc_sketch.txt
+    fetch/   rocprofv3 --pmc FETCH_SIZE                              -> <out_prefix>_hbm_traffic.txt (+ profiles/traffic.json)
+    write/   rocprofv3 --pmc WRITE_SIZE
+Kernel names: hand-written kernels are named by their own symbol (anchored on the sw:: namespace, so that `k_\\w+` can
+no longer match inside rocPRIM's `block_id_wrapper` / `lookback_scan_determinism`); rocPRIM kernels are labelled rocprim::.
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import re
+
+
+def short(name: str) -> str:
+    n = name
+    if "rocprim" in n:
+        types = ""
+        m = re.search(r"wrapped_\w+_config<[^,]+, ((?:unsigned |long |int|char|short|[\w:<>, ])+?)>, \(", n)
+        if m:
+            t = m.group(1)
+            for a, b in (("unsigned long", "u64"), ("unsigned int", "u32"), ("unsigned short", "u16"), ("unsigned char", "u8")):
+                t = t.replace(a, b)
+            t = re.sub(r"rocprim::ROCPRIM_\d+_NS::", "", t)
+            types = "<" + t.replace(" ", "") + ">"
+        for key, label in (("radix_sort_onesweep_iteration", "radix_sort_onesweep pass"),
+                           ("radix_sort_onesweep_global_offsets", "radix_sort_onesweep histogram"),
+                           ("radix_sort_onesweep_histogram", "radix_sort_onesweep histogram"),
+                           ("reduce_by_key_init", "reduce_by_key init"), ("reduce_by_key", "reduce_by_key"),
+                           ("init_lookback_scan_state", "scan init"), ("scan_impl", "scan (decoupled look-back)"),
+                           ("radix_sort", "radix_sort"), ("scan", "scan"), ("reduce", "reduce"), ("partition", "partition")):
+            if key in n:
+                return f"rocprim::{label}{types}"
+        return "rocprim::" + n[:40]
+    m = re.search(r"sw::(?:\(anonymous namespace\)::)?((?:k_|sketch_)\w+(?:<[^>(]*>)?)", n)
+    if m:
+        return m.group(1).replace("sw::(anonymous namespace)::", "")
+    if n.startswith("__amd_rocclr_"):
+        return n.replace(".kd", "")
+    return n[:48]
+
+
+def one(pattern):
+    g = glob.glob(pattern, recursive=True)
+    return g[0] if g else None
+
+
 def agg(path, names):
     a = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        if r['Counter_Name'] in names: a[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+        if r["Counter_Name"] in names:
+            a[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return a
-pm = glob.glob(f'gpurun_out/pmc_{tag}/*/*counter_collection.csv')[0]
-names = ['SQ_WAVES','SQ_BUSY_CYCLES','SQ_WAVE_CYCLES','SQ_INSTS_VALU','SQ_INSTS_SALU','SQ_INSTS_LDS','SQ_WAIT_ANY','SQ_WAIT_INST_ANY']
-a = agg(pm, names)
-bp = 2.4576e9
-with open(out_prefix + '_pmc_sketch.txt', 'w') as f:
-    f.write("rocprofv3 --pmc SQ_* -- python3 bench.py --steps 2 --warmup 1 (salmonella500, 2.4576 Gbp per launch); per-dispatch averages\n")
-    for k, v in a.items():
-        if 'sketch' not in k: continue
-        f.write(f"{k}\n")
-        for c in names:
-            if c in v: f.write(f"   {c:18s} {sum(v[c])/len(v[c]):16.0f}\n")
-        if 'fast' in k:
-            iv = sum(v['SQ_INSTS_VALU'])/len(v['SQ_INSTS_VALU'])
-            f.write(f"   => {iv/bp:.3f} VALU wave-instructions per bp = {iv/bp*64:.1f} lane-operations per bp; "
-                    f"WAIT_ANY/WAVE_CYCLES = {sum(v['SQ_WAIT_ANY'])/sum(v['SQ_WAVE_CYCLES']):.2f}\n")
-fe = agg(glob.glob(f'gpurun_out/pmc_{tag}_fetch/*/*counter_collection.csv')[0], ['FETCH_SIZE'])
-wr = agg(glob.glob(f'gpurun_out/pmc_{tag}_write/*/*counter_collection.csv')[0], ['WRITE_SIZE'])
-traffic = {}
-with open(out_prefix + '_hbm_traffic.txt', 'w') as f:
-    f.write("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 (salmonella500)\n")
-    f.write("FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of wide\ncoalesced reads, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact.  Per-dispatch averages:\n")
-    for k in fe:
-        fk = sum(fe[k]['FETCH_SIZE'])/len(fe[k]['FETCH_SIZE']); wk = sum(wr.get(k,{}).get('WRITE_SIZE',[0]))/max(1,len(wr.get(k,{}).get('WRITE_SIZE',[0])))
-        f.write(f"  {k:34s} n={len(fe[k]['FETCH_SIZE']):3d} FETCH={fk:11.0f} KiB WRITE={wk:11.0f} KiB -> read {2*fk*1024/1e6:8.1f} MB (corrected) write {wk*1024/1e6:8.1f} MB\n")
-        if 'sketch_fast' in k:
-            traffic = dict(kernel=k, workload='salmonella500', k=21, w=200, fetch_kib=fk, write_kib=wk,
-                           read_bytes_corrected=2*fk*1024, write_bytes=wk*1024, hbm_bytes_per_launch=2*fk*1024+wk*1024,
-                           note='FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes; FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md',
-                           source=out_prefix + '_hbm_traffic.txt')
-fast = [v for k, v in a.items() if 'sketch_fast' in k]
-if fast and traffic:
-    traffic['valu_wave_insts_per_launch'] = sum(fast[0]['SQ_INSTS_VALU']) / len(fast[0]['SQ_INSTS_VALU'])
-json.dump(traffic, open('profiles/traffic.json', 'w'), indent=1)
-print(open(out_prefix + '_kernel_stats.txt').read()); print(open(out_prefix + '_pmc_sketch.txt').read()); print(traffic)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("run_dir")
+    ap.add_argument("out_prefix")
+    ap.add_argument("--workload", default="bacteria15k")
+    ap.add_argument("--bp", type=float, default=75e9, help="bases per step on this GPU")
+    ap.add_argument("--steps", type=int, required=True, help="passes of the hot path in the profiled command (warm-up + timed)")
+    ap.add_argument("-k", type=int, default=21)
+    ap.add_argument("-w", type=int, default=200)
+    ap.add_argument("--title", default="")
+    a = ap.parse_args()
+
+    ks = one(f"{a.run_dir}/stats/**/*kernel_stats.csv")
+    if ks:
+        rows = list(csv.DictReader(open(ks)))
+        merged = collections.OrderedDict()
+        for r in rows:
+            s = short(r["Name"])
+            m = merged.setdefault(s, [0, 0.0])
+            m[0] += int(r["Calls"])
+            m[1] += float(r["TotalDurationNs"])
+        total = sum(v[1] for v in merged.values())
+        with open(a.out_prefix + "_kernel_stats.txt", "w") as f:
+            f.write(f"rocprofv3 --kernel-trace --stats -- {a.title}   ({a.workload}; {a.steps} passes incl. warm-up)\n")
+            f.write(f"{'kernel':56s} {'calls/pass':>10s} {'avg_us':>10s} {'ms/pass':>9s} {'pct':>6s}\n")
+            for s, (calls, ns) in sorted(merged.items(), key=lambda kv: -kv[1][1]):
+                if ns / 1e6 / a.steps < 0.004:
+                    continue
+                f.write(f"{s:56s} {calls / a.steps:10.1f} {ns / calls / 1e3:10.1f} {ns / 1e6 / a.steps:9.3f} {100 * ns / total:6.2f}\n")
+            f.write(f"{'all kernels':56s} {'':10s} {'':10s} {total / 1e6 / a.steps:9.3f}\n")
+        print(open(a.out_prefix + "_kernel_stats.txt").read())
+
+    names = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAIT_ANY",
+             "SQ_WAIT_INST_ANY"]
+    pm = one(f"{a.run_dir}/pmc/**/*counter_collection.csv")
+    pmc = agg(pm, names) if pm else {}
+    if pm:
+        with open(a.out_prefix + "_pmc_sketch.txt", "w") as f:
+            f.write(f"rocprofv3 --pmc SQ_* -- {a.title} ({a.workload}, {a.bp / 1e9:.4g} Gbp per pass); per-dispatch averages\n")
+            for k, v in pmc.items():
+                if "sketch" not in k:
+                    continue
+                f.write(f"{k}   ({len(v[names[0]])} dispatches)\n")
+                for c in names:
+                    if c in v:
+                        f.write(f"   {c:18s} {sum(v[c]) / len(v[c]):16.0f}\n")
+                if "fast" in k and v.get("SQ_INSTS_VALU"):
+                    per_pass = sum(v["SQ_INSTS_VALU"]) / a.steps
+                    f.write(f"   => {per_pass / a.bp:.3f} VALU wave-instructions per bp = {per_pass / a.bp * 64:.1f} lane-operations per bp; "
+                            f"WAIT_ANY/WAVE_CYCLES = {sum(v['SQ_WAIT_ANY']) / sum(v['SQ_WAVE_CYCLES']):.2f}\n")
+        print(open(a.out_prefix + "_pmc_sketch.txt").read())
+
+    fe_p, wr_p = one(f"{a.run_dir}/fetch/**/*counter_collection.csv"), one(f"{a.run_dir}/write/**/*counter_collection.csv")
+    traffic = {}
+    if fe_p and wr_p:
+        fe, wr = agg(fe_p, ["FETCH_SIZE"]), agg(wr_p, ["WRITE_SIZE"])
+        with open(a.out_prefix + "_hbm_traffic.txt", "w") as f:
+            f.write(f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- {a.title} ({a.workload})\n")
+            f.write("FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of the bytes of wide\n"
+                    "coalesced reads, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact.  Sums per pass of the hot path:\n")
+            tot_r = tot_w = 0.0
+            for k in sorted(fe, key=lambda k: -sum(fe[k]["FETCH_SIZE"])):
+                fk = sum(fe[k]["FETCH_SIZE"]) / a.steps
+                wk = sum(wr.get(k, {}).get("WRITE_SIZE", [0])) / a.steps
+                if k.startswith("k_synth"):
+                    continue
+                tot_r += 2 * fk * 1024
+                tot_w += wk * 1024
+                f.write(f"  {k:56s} launches/pass={len(fe[k]['FETCH_SIZE']) / a.steps:5.1f} FETCH={fk:12.0f} KiB WRITE={wk:12.0f} KiB -> "
+                        f"read {2 * fk * 1024 / 1e6:9.1f} MB (corrected) write {wk * 1024 / 1e6:9.1f} MB\n")
+                if k.startswith("sketch_fast") and "256" in k:
+                    nl = len(fe[k]["FETCH_SIZE"]) / a.steps
+                    traffic = dict(kernel=k, workload=a.workload, k=a.k, w=a.w, launches_per_pass=nl,
+                                   read_bytes_corrected=2 * fk * 1024 / nl, write_bytes=wk * 1024 / nl,
+                                   hbm_bytes_per_launch=(2 * fk * 1024 + wk * 1024) / nl,
+                                   note="FETCH_SIZE and WRITE_SIZE from separate rocprofv3 --pmc passes; FETCH_SIZE doubled per the gfx950 "
+                                        "correction in MI355X_MICROARCH.md", source=a.out_prefix + "_hbm_traffic.txt")
+            f.write(f"  whole pass: read {tot_r / 1e9:.2f} GB (corrected) + write {tot_w / 1e9:.2f} GB = {(tot_r + tot_w) / 1e9:.2f} GB\n")
+        fast = [v for k, v in pmc.items() if k.startswith("sketch_fast") and "256" in k]
+        if fast and traffic and fast[0].get("SQ_INSTS_VALU"):
+            traffic["valu_wave_insts_per_launch"] = sum(fast[0]["SQ_INSTS_VALU"]) / len(fast[0]["SQ_INSTS_VALU"])
+        if traffic:
+            json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
+        print(open(a.out_prefix + "_hbm_traffic.txt").read())
+        print(traffic)
+
+
+if __name__ == "__main__":
+    main()

@@ -23,7 +23,7 @@ class Timings(ctypes.Structure):
     _fields_ = [("total_ms", ctypes.c_double), ("sketch_ms", ctypes.c_double), ("order_ms", ctypes.c_double),
                 ("nodes_ms", ctypes.c_double), ("counts_ms", ctypes.c_double), ("edges_ms", ctypes.c_double),
                 ("sketch_launches", c_u64), ("n_tiles", c_u64), ("total_bp", c_u64), ("n_windows", c_u64),
-                ("ovf_tiles", c_u64)]
+                ("ovf_tiles", c_u64), ("plan_ms", ctypes.c_double), ("plan_cached", c_u64)]
 
 
 def _load() -> ctypes.CDLL:

@@ -289,11 +289,14 @@ __host__ __device__ inline uint64_t mix64(uint64_t x)
 
 // One thread = one packed word (16 bases) of one record.
 __global__ void k_synth(uint32_t *packed, uint64_t words_per_record, uint64_t n_words, uint64_t records_per_genome,
-                        uint64_t record_len, uint64_t n_ancestors, uint64_t snp_ppm, uint64_t seed, uint64_t word_base)
+                        uint64_t record_len, uint64_t n_ancestors, uint64_t snp_ppm, uint64_t seed, uint64_t word_base,
+                        uint64_t first_record)
 {
     const uint64_t wi = word_base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (wi >= n_words) return;
-    const uint64_t rec = wi / words_per_record, wr = wi % words_per_record;
+    // `rec` is the record's number in the whole job (a shard starts at first_record): a shard of a job holds the same
+    // bases as the same genomes of the unsharded batch
+    const uint64_t rec = first_record + wi / words_per_record, wr = wi % words_per_record;
     const uint64_t g = rec / records_per_genome, c = rec % records_per_genome;
     const uint64_t anc = g % n_ancestors;
     uint32_t word = 0;
@@ -329,7 +332,8 @@ void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targe
                     hipStream_t stream, sw_index &ix)
 {
     require_current_device(b.device, "the batch");
-    Plan &plan = get_plan(b, k, w);
+    bool plan_cached = false;
+    Plan &plan = get_plan(b, k, w, &plan_cached);
     uint64_t n_tar = 0, n_neg = 0;
     DevArray<uint8_t> d_tar;
     if (is_targets) {
@@ -370,6 +374,8 @@ void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targe
     ix.timings.total_bp = b.host.total_bp;
     ix.timings.n_windows = plan.n_windows;
     ix.timings.ovf_tiles = ovf_tiles;
+    ix.timings.plan_ms = plan.build_ms;
+    ix.timings.plan_cached = plan_cached ? 1 : 0;
     SW_HIP(hipEventDestroy(e0));
     SW_HIP(hipEventDestroy(e1));
     SW_HIP(hipEventDestroy(e2));
@@ -442,6 +448,12 @@ int sw_batch_from_fasta(const char *const *assembly_paths, size_t n_assemblies, 
 int sw_batch_synthetic(uint64_t n_genomes, uint64_t records_per_genome, uint64_t record_len, uint64_t n_ancestors,
                        uint64_t snp_ppm, uint64_t seed, sw_batch **out)
 {
+    return sw_batch_synthetic_shard(n_genomes, records_per_genome, record_len, n_ancestors, snp_ppm, seed, 0, out);
+}
+
+int sw_batch_synthetic_shard(uint64_t n_genomes, uint64_t records_per_genome, uint64_t record_len, uint64_t n_ancestors,
+                             uint64_t snp_ppm, uint64_t seed, uint64_t first_genome, sw_batch **out)
+{
     return guarded([&] {
         require_device();
         if (n_ancestors == 0 || records_per_genome == 0) raise(SW_ERR_VALUE, "n_ancestors and records_per_genome must be >= 1");
@@ -466,7 +478,7 @@ int sw_batch_synthetic(uint64_t n_genomes, uint64_t records_per_genome, uint64_t
         for (uint64_t r = 0; r < R; ++r) {
             h.rec_base[r] = r * padded;
             h.rec_run_off[r] = record_len ? (uint32_t)r : 0;
-            int len = snprintf(name, sizeof name, "g%llu_c%llu", (unsigned long long)(r / records_per_genome),
+            int len = snprintf(name, sizeof name, "g%llu_c%llu", (unsigned long long)(first_genome + r / records_per_genome),
                                (unsigned long long)(r % records_per_genome));
             h.ids_blob.append(name, (size_t)len + 1);
         }
@@ -480,7 +492,7 @@ int sw_batch_synthetic(uint64_t n_genomes, uint64_t records_per_genome, uint64_t
         for (uint64_t base = 0; base < n_words; base += (1ull << 30)) {
             const uint64_t cnt = std::min<uint64_t>(n_words - base, 1ull << 30);
             hipLaunchKernelGGL(k_synth, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, b->d_packed.p, wpr, base + cnt,
-                               records_per_genome, record_len, n_ancestors, snp_ppm, seed, base);
+                               records_per_genome, record_len, n_ancestors, snp_ppm, seed, base, first_genome * records_per_genome);
             SW_HIP(hipGetLastError());
         }
         SW_HIP(hipDeviceSynchronize());
@@ -633,6 +645,14 @@ int sw_index_checksums(const sw_index *ix, uint64_t *kmers_sum, uint64_t *nodes_
         *kmers_sum = s[0];
         *nodes_sum = s[1];
         *edges_sum = s[2];
+    });
+}
+
+int sw_index_checksums_at(const sw_index *ix, uint64_t kmer_base, uint64_t node_base, uint64_t edge_base, uint64_t *sums)
+{
+    return guarded([&] {
+        index_settle(*const_cast<sw_index *>(ix));
+        device_checksums(*ix, 0, sums, kmer_base, node_base, edge_base);
     });
 }
 

@@ -90,6 +90,7 @@ struct Plan {
     DevArray<uint64_t> lut;           // [40] roll tables, see sketch.hip
     DevArray<uint64_t> t4;            // [256][2] 4-base warm-up table
     uint64_t mult = 0;                // 1 ^ (k * MULTISEED)
+    double build_ms = 0;              // wall time get_plan took to build this plan (host loops + table uploads)
 };
 
 }  // namespace sw
@@ -135,7 +136,7 @@ struct sw_index {
 
 namespace sw {
 
-Plan &get_plan(sw_batch &b, uint64_t k, uint64_t w);
+Plan &get_plan(sw_batch &b, uint64_t k, uint64_t w, bool *cached = nullptr);
 
 // sketch.hip: runs the fused ntHash + window-minimum kernel over every tile of the plan.
 // Output: tuples per tile in (stage_hash, stage_kmer) -- a tile's own slot at tile * slot_cap, or a range of the
@@ -170,7 +171,8 @@ void device_filter_kmers(const sw_kmer *d_kmers, uint64_t n_kmers, const sw_node
                          const uint64_t *d_used_sorted, uint64_t n_used, hipStream_t stream,
                          DevArray<sw_kmer> &kmers_out, DevArray<sw_node> &nodes_out, uint64_t *n_kmers_out,
                          uint64_t *n_nodes_out);
-void device_checksums(const sw_index &ix, hipStream_t stream, uint64_t *sums3);
+void device_checksums(const sw_index &ix, hipStream_t stream, uint64_t *sums3, uint64_t kbase = 0, uint64_t nbase = 0,
+                      uint64_t ebase = 0);
 void index_threshold_sums(const sw_index &ix, hipStream_t stream, uint64_t *sums3);
 void index_filter_graph(const sw_index &ix, uint64_t weight_th, hipStream_t stream, sw_index &out);
 void index_occ_rows(const sw_index &ix, uint64_t rec_offset, uint64_t *d_rows, hipStream_t stream);

@@ -556,17 +556,19 @@ __host__ __device__ inline uint64_t mix64(uint64_t x)
     return x;
 }
 
+// element i of a slice is element base + i of the whole (concatenated) array: the sums of the slices of a sharded
+// index add up (mod 2^64) to the checksums of the unsharded one
 __global__ void k_checksum(const sw_kmer *kmers, uint64_t nk, const sw_node *nodes, uint64_t nn, const sw_edge *edges,
-                           uint64_t ne, unsigned long long *sums)
+                           uint64_t ne, uint64_t kbase, uint64_t nbase, uint64_t ebase, unsigned long long *sums)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t G = 0x9E3779B97F4A7C15ULL;
     uint64_t a = 0, b = 0, c = 0;
-    if (i < nk) a = mix64(i * G + ((uint64_t)kmers[i].pos | ((uint64_t)kmers[i].record_idx << 32)));
+    if (i < nk) a = mix64((kbase + i) * G + ((uint64_t)kmers[i].pos | ((uint64_t)kmers[i].record_idx << 32)));
     if (i < nn)
-        b = mix64(i * G + nodes[i].hash) + mix64(nodes[i].start * 3 + 1) + mix64(nodes[i].stop * 5 + 2) +
+        b = mix64((nbase + i) * G + nodes[i].hash) + mix64(nodes[i].start * 3 + 1) + mix64(nodes[i].stop * 5 + 2) +
             mix64(((uint64_t)nodes[i].n_tar << 32 | nodes[i].n_neg) + 7);
-    if (i < ne) c = mix64(i * G + edges[i].first) + mix64(edges[i].second * 3 + 1) + mix64(edges[i].weight * 5 + 2);
+    if (i < ne) c = mix64((ebase + i) * G + edges[i].first) + mix64(edges[i].second * 3 + 1) + mix64(edges[i].weight * 5 + 2);
     for (int d = 32; d; d >>= 1) {
         a += __shfl_down(a, d, 64);
         b += __shfl_down(b, d, 64);
@@ -1842,14 +1844,14 @@ void device_filter_kmers(const sw_kmer *d_kmers, uint64_t n_kmers, const sw_node
     SW_HIP(hipStreamSynchronize(stream));
 }
 
-void device_checksums(const sw_index &ix, hipStream_t stream, uint64_t *sums3)
+void device_checksums(const sw_index &ix, hipStream_t stream, uint64_t *sums3, uint64_t kbase, uint64_t nbase, uint64_t ebase)
 {
     DevArray<unsigned long long> sums(3);
     SW_HIP(hipMemsetAsync(sums.p, 0, 24, stream));
     const uint64_t n = std::max(ix.n_kmers, std::max(ix.n_nodes, ix.n_edges));
     if (n) {
         hipLaunchKernelGGL(k_checksum, dim3(blocks_for(n)), dim3(TPB), 0, stream, ix.kmers.p, ix.n_kmers, ix.nodes.p,
-                           ix.n_nodes, ix.edges.p, ix.n_edges, sums.p);
+                           ix.n_nodes, ix.edges.p, ix.n_edges, kbase, nbase, ebase, sums.p);
         SW_HIP(hipGetLastError());
     }
     unsigned long long h[3];

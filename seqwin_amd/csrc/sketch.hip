@@ -29,6 +29,7 @@
 //            its slot takes a range of a shared overflow area with one atomicAdd).
 // Tiles land slot by slot; index.hip's order pass packs them into (record_idx, pos) order.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -39,7 +40,7 @@ namespace sw {
 namespace {
 
 constexpr int BLOCK = 256;   // threads of the generic kernel and of the large fast tile class
-constexpr uint32_t MAX_TILES_PER_LAUNCH = 1u << 23;  // x 256 threads stays below the 2^32 work-item grid limit
+constexpr uint32_t MAX_TILES_PER_LAUNCH = 0xFFFFFFu;  // x 256 threads stays below the 2^32 work-item grid limit (15k genomes: 10.2 M tiles, one launch)
 constexpr uint32_t L_MAX = 33;  // 256*33 elements * 8 B = 66 KiB of hashes -> two workgroups per CU
 
 // hashing_internals.hpp:128-131
@@ -909,14 +910,16 @@ size_t lds_bytes_for(uint32_t L)
 
 }  // namespace
 
-Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
+Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
 {
     check_kw(k64, w64);
     const uint32_t k = (uint32_t)k64, w = (uint32_t)w64;
     std::lock_guard<std::mutex> lock(b.plan_mu);
     auto key = std::make_pair(k, w);
     auto it = b.plans.find(key);
+    if (cached) *cached = it != b.plans.end();
     if (it != b.plans.end()) return it->second;
+    const auto t_begin = std::chrono::steady_clock::now();
 
     Plan p;
     p.k = k;
@@ -1095,6 +1098,7 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64)
         p.t4.alloc(512);
         SW_HIP(hipMemcpy(p.t4.p, t4.data(), 512 * 8, hipMemcpyHostToDevice));
     }
+    p.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return b.plans.emplace(key, std::move(p)).first->second;
 }
 

@@ -39,10 +39,13 @@ class Batch:
 
     @classmethod
     def synthetic(cls, n_genomes: int, records_per_genome: int, record_len: int, n_ancestors: int = 1,
-                  snp_ppm: int = 10000, seed: int = 1) -> "Batch":
+                  snp_ppm: int = 10000, seed: int = 1, first_genome: int = 0) -> "Batch":
+        """Genomes [first_genome, first_genome + n_genomes) of the synthetic job ``seed``: a shard holds exactly the
+        bases and record ids the unsharded batch holds for these genomes."""
         h = c_vp()
-        check(lib.sw_batch_synthetic(c_u64(n_genomes), c_u64(records_per_genome), c_u64(record_len),
-                                     c_u64(n_ancestors), c_u64(snp_ppm), c_u64(seed), ctypes.byref(h)))
+        check(lib.sw_batch_synthetic_shard(c_u64(n_genomes), c_u64(records_per_genome), c_u64(record_len),
+                                           c_u64(n_ancestors), c_u64(snp_ppm), c_u64(seed), c_u64(first_genome),
+                                           ctypes.byref(h)))
         return cls(h)
 
     def info(self) -> dict:
@@ -156,10 +159,12 @@ class Index:
         np.savez(path, allow_pickle=False, kmers=kmers, nodes=nodes, edges=edges,
                  record_offsets=np.asarray(record_offsets, np.uint32))
 
-    def checksums(self):
-        v = [c_u64() for _ in range(3)]
-        check(lib.sw_index_checksums(self._h, *[ctypes.byref(x) for x in v]))
-        return tuple(x.value for x in v)
+    def checksums(self, kmer_base: int = 0, node_base: int = 0, edge_base: int = 0):
+        """(kmers, nodes, edges) checksums; with bases: this slice's share of the checksums of the concatenated arrays
+        (the shares of all slices add up modulo 2^64)."""
+        v = (c_u64 * 3)()
+        check(lib.sw_index_checksums_at(self._h, c_u64(kmer_base), c_u64(node_base), c_u64(edge_base), v))
+        return tuple(int(x) for x in v)
 
     def close(self) -> None:
         if self._h:
@@ -184,16 +189,16 @@ def _mix64(x: np.ndarray) -> np.ndarray:
     return x
 
 
-def host_checksums(kmers, nodes, edges):
-    """numpy restatement of sw_index_checksums (index.hip:k_checksum) for host arrays."""
+def host_checksums(kmers, nodes, edges, kmer_base: int = 0, node_base: int = 0, edge_base: int = 0):
+    """numpy restatement of sw_index_checksums / sw_index_checksums_at (index.hip:k_checksum) for host arrays."""
     with np.errstate(over="ignore"):
-        i = np.arange(len(kmers), dtype=np.uint64)
+        i = np.arange(len(kmers), dtype=np.uint64) + np.uint64(kmer_base)
         a = _mix64(i * _G + (kmers["pos"].astype(np.uint64) | (kmers["record_idx"].astype(np.uint64) << np.uint64(32)))).sum(dtype=np.uint64)
-        i = np.arange(len(nodes), dtype=np.uint64)
+        i = np.arange(len(nodes), dtype=np.uint64) + np.uint64(node_base)
         b = (_mix64(i * _G + nodes["hash"]) + _mix64(nodes["start"].astype(np.uint64) * np.uint64(3) + np.uint64(1)) +
              _mix64(nodes["stop"].astype(np.uint64) * np.uint64(5) + np.uint64(2)) +
              _mix64(((nodes["n_tar"].astype(np.uint64) << np.uint64(32)) | nodes["n_neg"].astype(np.uint64)) + np.uint64(7))).sum(dtype=np.uint64)
-        i = np.arange(len(edges), dtype=np.uint64)
+        i = np.arange(len(edges), dtype=np.uint64) + np.uint64(edge_base)
         c = (_mix64(i * _G + edges["first"]) + _mix64(edges["second"] * np.uint64(3) + np.uint64(1)) +
              _mix64(edges["weight"].astype(np.uint64) * np.uint64(5) + np.uint64(2))).sum(dtype=np.uint64)
     return int(a), int(b), int(c)

@@ -158,7 +158,7 @@ class HipEngine:
         check(lib.sw_occ_sketch(shard.batch._h, c_u64(k), c_u64(w), c_vp(self._stream()), ctypes.byref(h)))
         n, ms = c_u64(), ctypes.c_double()
         check(lib.sw_occ_size(h, ctypes.byref(n), ctypes.byref(ms)))
-        return _Occ(h, n.value, ms.value)
+        return _Occ(h, n.value, ms.value, shard.batch)
 
     def partition(self, occ, bounds, rec_offset: int):
         from ._lib import c_u64, c_vp, check, lib
@@ -229,12 +229,16 @@ class HipEngine:
     def export(self, ix):
         return ix.export()
 
+    def checksums(self, ix, kmer_base: int = 0, node_base: int = 0, edge_base: int = 0):
+        return ix.checksums(kmer_base, node_base, edge_base)
+
 
 class _Occ:
     """Handle of a device-resident ordered tuple stream (sw_occ)."""
 
-    def __init__(self, h, n, sketch_ms):
+    def __init__(self, h, n, sketch_ms, batch=None):
         self._h, self.n, self.sketch_ms = h, n, sketch_ms
+        self._batch = batch   # sw_occ refers to its batch's record table (sw_occ_adjacency): keep the batch alive
 
     def close(self):
         from ._lib import lib
@@ -252,8 +256,8 @@ class _Occ:
 class ShardedIndex:
     """This rank's slice (a hash range) of the merged graph, plus the job-wide metadata."""
 
-    def __init__(self, engine, merged, record_offsets, timings, kmer_base):
-        self.engine, self.merged = engine, merged
+    def __init__(self, engine, merged, record_offsets, timings, kmer_base, group=None):
+        self.engine, self.merged, self.group = engine, merged, group
         self.record_offsets, self._timings, self.kmer_base = record_offsets, timings, kmer_base
 
     def sizes(self):
@@ -265,15 +269,61 @@ class ShardedIndex:
     def export(self):
         return self.engine.export(self.merged)
 
-    def gather(self, dst: int = 0, group=None):
-        """Concatenate all slices on rank ``dst`` -> (kmers, nodes, edges, record_offsets) or None elsewhere."""
+    def _all_sizes(self):
+        """sizes of every rank's slice: [(n_kmers, n_nodes, n_edges)] * world (one small all_gather)."""
+        import torch
         import torch.distributed as dist
-        parts = [None] * dist.get_world_size(group)
-        dist.all_gather_object(parts, self.export(), group=group)
-        if dist.get_rank(group) != dst:
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return [self.sizes()], 0
+        world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+        mine = torch.tensor(self.sizes(), dtype=torch.int64, device=self.engine.device)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=self.group)
+        return [tuple(int(v) for v in row) for row in torch.stack(parts).tolist()], rank
+
+    def global_checksums(self):
+        """Checksums of the concatenated arrays of all slices, identical on every rank: each rank checksums its slice
+        at its offsets in the whole (sw_index_checksums_at), the shares add up modulo 2^64 (one all_reduce of 3 words)."""
+        import torch
+        import torch.distributed as dist
+        sizes, rank = self._all_sizes()
+        bases = [sum(s[j] for s in sizes[:rank]) for j in range(3)]
+        mine = np.array(self.engine.checksums(self.merged, *bases), np.uint64)
+        if len(sizes) == 1:
+            return tuple(int(v) for v in mine)
+        t = torch.from_numpy(mine.view(np.int64).copy()).to(self.engine.device)   # int64 addition wraps = sum modulo 2^64
+        dist.all_reduce(t, group=self.group)
+        return tuple(int(v) for v in t.cpu().numpy().view(np.uint64))
+
+    def gather(self, dst: int = 0, group=None):
+        """Concatenate all slices on rank ``dst`` -> (kmers, nodes, edges, record_offsets) or None elsewhere.
+
+        The slices travel as raw bytes: sizes first (one all_gather), then each array as one ``dist.gather`` of uint8
+        tensors padded to the largest slice -- no pickling, nothing is sent to ranks other than ``dst``."""
+        import torch
+        import torch.distributed as dist
+
+        from ._core import EDGE_DTYPE, KMER_DTYPE, NODE_DTYPE
+        group = group if group is not None else self.group
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return (*self.export(), self.record_offsets)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        sizes, _ = self._all_sizes()
+        arrays = self.export()
+        out = []
+        for j, (arr, dt) in enumerate(zip(arrays, (KMER_DTYPE, NODE_DTYPE, EDGE_DTYPE))):
+            pad = max(s[j] for s in sizes) * dt.itemsize
+            buf = torch.zeros((max(pad, 1),), dtype=torch.uint8)
+            raw = np.frombuffer(arr.tobytes(), np.uint8) if len(arr) else np.zeros(0, np.uint8)
+            buf[:len(raw)] = torch.from_numpy(raw.copy())
+            buf = buf.to(self.engine.device)
+            parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+            dist.gather(buf, parts, dst=dst, group=group)
+            if rank == dst:
+                out.append(np.concatenate([p.cpu().numpy()[:sizes[r][j] * dt.itemsize].view(dt) for r, p in enumerate(parts)]))
+        if rank != dst:
             return None
-        return (np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
-                np.concatenate([p[2] for p in parts]), self.record_offsets)
+        return (out[0], out[1], out[2], self.record_offsets)
 
 
 def build_sharded_index_merge(shard: Shard, k: int, w: int, is_targets, engine=None, group=None) -> ShardedIndex:
@@ -338,7 +388,7 @@ def build_sharded_index_merge(shard: Shard, k: int, w: int, is_targets, engine=N
     t3 = time.perf_counter()
     tm.update(n_occ_local=n_occ_local, local_build_wall_ms=(t1 - t0) * 1e3, exchange_wall_ms=(t2 - t1) * 1e3,
               merge_wall_ms=(t3 - t2) * 1e3)
-    return ShardedIndex(engine, merged, record_offsets, tm, kmer_base)
+    return ShardedIndex(engine, merged, record_offsets, tm, kmer_base, group)
 
 
 def rank_bounds(n_parts: int, total_nodes: int) -> list[int]:
@@ -443,7 +493,8 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
         node_base, total_nodes = sum(node_cnt[:rank]), sum(node_cnt)
         if total_nodes >= 0xFFFFFFFF:
             raise RuntimeError("more than 2^32-2 nodes")
-        r_ranks = (r_ranks.to(torch.int64) + node_base).to(torch.int32)   # uint32 bit pattern (wraps above 2^31)
+        # slice-local ranks are uint32 bit patterns held in int32: widen UNSIGNED before adding the base
+        r_ranks = ((r_ranks.to(torch.int64) & 0xFFFFFFFF) + node_base).to(torch.int32)
         ranks_by_row = torch.empty((occ.n,), dtype=torch.int32, device=dev)
         dist.all_to_all_single(ranks_by_row, r_ranks.contiguous(), [int(c) for c in cnt], recv_cnt, group=group)
         hashes = engine.node_hashes(ix)
@@ -472,7 +523,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     tm.update(sketch_ms=occ.sketch_ms, n_occ_local=occ.n, sketch_wall_ms=(t1 - t0) * 1e3, tuple_exchange_wall_ms=(t2 - t1) * 1e3,
               slice_build_wall_ms=(t3 - t2) * 1e3, rank_adj_exchange_wall_ms=(t4 - t3) * 1e3, slice_edges_wall_ms=(t5 - t4) * 1e3)
     engine.free_occ(occ)
-    return ShardedIndex(engine, ix, record_offsets, tm, kmer_base)
+    return ShardedIndex(engine, ix, record_offsets, tm, kmer_base, group)
 
 
 def build_graph_distributed(assembly_paths, k: int, w: int, is_targets=None, n_cpu: int = 1, group=None):
@@ -486,4 +537,4 @@ def build_graph_distributed(assembly_paths, k: int, w: int, is_targets=None, n_c
     start, end = partition_assemblies(len(paths), world)[rank]
     shard = Shard(Batch.from_fasta(paths[start:end], n_cpu=n_cpu), start, len(paths))
     sharded = build_sharded_index(shard, k, w, is_targets, group=group)
-    return sharded.gather(0, group=group) if world > 1 else (*sharded.export(), sharded.record_offsets)
+    return sharded.gather(0, group=group)

@@ -88,6 +88,10 @@ class NumpyEngine:
     def export(self, ix):
         return ix["kmers"], ix["nodes"], ix["edges"]
 
+    def checksums(self, ix, kmer_base=0, node_base=0, edge_base=0):
+        from seqwin_amd.device import host_checksums
+        return host_checksums(ix["kmers"], ix["nodes"], ix["edges"], kmer_base, node_base, edge_base)
+
     # ---- tuple-exchange form (same interface as seqwin_amd.dist.HipEngine) -------------------------------
     def sketch(self, shard, k, w):
         from types import SimpleNamespace
@@ -176,9 +180,14 @@ def _worker(rank, world, port, paths, k, w, tar, out_path, mode):
         eng._offs = oracle.build(mine, k, w)[3]
         build = swdist.build_sharded_index if mode == "tuples" else swdist.build_sharded_index_merge
         sharded = build(swdist.Shard(mine, start, len(paths)), k, w, tar, engine=eng)
+        sums = sharded.global_checksums()   # every rank: shares of the slices add up to the checksums of the whole
         full = sharded.gather(0)
+        assert (full is None) == (rank != 0)
         if rank == 0:
-            np.savez(out_path, kmers=full[0], nodes=full[1], edges=full[2], record_offsets=full[3])
+            np.savez(out_path, kmers=full[0], nodes=full[1], edges=full[2], record_offsets=full[3],
+                     sums=np.array(sums, np.uint64))
+        else:
+            np.save(out_path + f".sums{rank}.npy", np.array(sums, np.uint64))
     finally:
         dist.destroy_process_group()
 
@@ -207,6 +216,12 @@ def test_sharded_build_equals_single(tmp_path, world, case, mode):
     oracle.get_penalty(ek, en, eo, tar)
     assert np.array_equal(got["kmers"], ek) and np.array_equal(got["nodes"], en)
     assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
+    # shard-count invariance without gathering: the all-reduced checksums are those of the single-process result
+    from seqwin_amd.device import host_checksums
+    exp_sums = np.array(host_checksums(ek, en, ee), np.uint64)
+    assert np.array_equal(got["sums"], exp_sums)
+    for r in range(1, world):
+        assert np.array_equal(np.load(str(out) + f".sums{r}.npy"), exp_sums)
 
 
 def test_partition_formula():
