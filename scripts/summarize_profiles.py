@@ -67,7 +67,8 @@ def main():
     ap.add_argument("out_prefix")
     ap.add_argument("--workload", default="bacteria15k")
     ap.add_argument("--bp", type=float, default=75e9, help="bases per step on this GPU")
-    ap.add_argument("--steps", type=int, required=True, help="passes of the hot path in the profiled command (warm-up + timed)")
+    ap.add_argument("--steps", type=int, required=True, help="passes of the hot path in the --stats command (warm-up + timed)")
+    ap.add_argument("--pmc-steps", type=int, default=2, help="passes of the hot path in each --pmc command (warm-up + timed)")
     ap.add_argument("-k", type=int, default=21)
     ap.add_argument("-w", type=int, default=200)
     ap.add_argument("--title", default="")
@@ -86,11 +87,16 @@ def main():
         with open(a.out_prefix + "_kernel_stats.txt", "w") as f:
             f.write(f"rocprofv3 --kernel-trace --stats -- {a.title}   ({a.workload}; {a.steps} passes incl. warm-up)\n")
             f.write(f"{'kernel':56s} {'calls/pass':>10s} {'avg_us':>10s} {'ms/pass':>9s} {'pct':>6s}\n")
+            outside = ("k_synth", "k_checksum")   # input generation / result checksums: not in a pass of the hot path
+            total = sum(v[1] for s, v in merged.items() if s not in outside)
             for s, (calls, ns) in sorted(merged.items(), key=lambda kv: -kv[1][1]):
-                if ns / 1e6 / a.steps < 0.004:
+                if ns / 1e6 / a.steps < 0.004 or s in outside:
                     continue
                 f.write(f"{s:56s} {calls / a.steps:10.1f} {ns / calls / 1e3:10.1f} {ns / 1e6 / a.steps:9.3f} {100 * ns / total:6.2f}\n")
-            f.write(f"{'all kernels':56s} {'':10s} {'':10s} {total / 1e6 / a.steps:9.3f}\n")
+            f.write(f"{'all kernels of a pass':56s} {'':10s} {'':10s} {total / 1e6 / a.steps:9.3f}\n")
+            for s in outside:
+                if s in merged:
+                    f.write(f"(outside the timed passes: {s} {merged[s][0]} calls, {merged[s][1] / 1e6:.1f} ms in the whole run)\n")
         print(open(a.out_prefix + "_kernel_stats.txt").read())
 
     names = ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAIT_ANY",
@@ -108,7 +114,7 @@ def main():
                     if c in v:
                         f.write(f"   {c:18s} {sum(v[c]) / len(v[c]):16.0f}\n")
                 if "fast" in k and v.get("SQ_INSTS_VALU"):
-                    per_pass = sum(v["SQ_INSTS_VALU"]) / a.steps
+                    per_pass = sum(v["SQ_INSTS_VALU"]) / a.pmc_steps
                     f.write(f"   => {per_pass / a.bp:.3f} VALU wave-instructions per bp = {per_pass / a.bp * 64:.1f} lane-operations per bp; "
                             f"WAIT_ANY/WAVE_CYCLES = {sum(v['SQ_WAIT_ANY']) / sum(v['SQ_WAVE_CYCLES']):.2f}\n")
         print(open(a.out_prefix + "_pmc_sketch.txt").read())
@@ -123,16 +129,16 @@ def main():
                     "coalesced reads, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact.  Sums per pass of the hot path:\n")
             tot_r = tot_w = 0.0
             for k in sorted(fe, key=lambda k: -sum(fe[k]["FETCH_SIZE"])):
-                fk = sum(fe[k]["FETCH_SIZE"]) / a.steps
-                wk = sum(wr.get(k, {}).get("WRITE_SIZE", [0])) / a.steps
-                if k.startswith("k_synth"):
+                fk = sum(fe[k]["FETCH_SIZE"]) / a.pmc_steps
+                wk = sum(wr.get(k, {}).get("WRITE_SIZE", [0])) / a.pmc_steps
+                if k.startswith("k_synth") or k.startswith("k_checksum"):
                     continue
                 tot_r += 2 * fk * 1024
                 tot_w += wk * 1024
-                f.write(f"  {k:56s} launches/pass={len(fe[k]['FETCH_SIZE']) / a.steps:5.1f} FETCH={fk:12.0f} KiB WRITE={wk:12.0f} KiB -> "
+                f.write(f"  {k:56s} launches/pass={len(fe[k]['FETCH_SIZE']) / a.pmc_steps:5.1f} FETCH={fk:12.0f} KiB WRITE={wk:12.0f} KiB -> "
                         f"read {2 * fk * 1024 / 1e6:9.1f} MB (corrected) write {wk * 1024 / 1e6:9.1f} MB\n")
                 if k.startswith("sketch_fast") and "256" in k:
-                    nl = len(fe[k]["FETCH_SIZE"]) / a.steps
+                    nl = len(fe[k]["FETCH_SIZE"]) / a.pmc_steps
                     traffic = dict(kernel=k, workload=a.workload, k=a.k, w=a.w, launches_per_pass=nl,
                                    read_bytes_corrected=2 * fk * 1024 / nl, write_bytes=wk * 1024 / nl,
                                    hbm_bytes_per_launch=(2 * fk * 1024 + wk * 1024) / nl,
