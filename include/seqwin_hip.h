@@ -203,6 +203,14 @@ int sw_index_checksums(const sw_index *ix, uint64_t *kmers_sum, uint64_t *nodes_
  * concatenated arrays, so the sums of all slices add up (mod 2^64) to the checksums of the unsharded index --
  * shard-count invariance (reference tests/smoke/test_graph.py:67-127) checked without gathering.  sums[3]. */
 int sw_index_checksums_at(const sw_index *ix, uint64_t kmer_base, uint64_t node_base, uint64_t edge_base, uint64_t *sums);
+/* Self-check of a resident index on the device -- the size-independent properties of the reference's output, for sets
+ * too large to compare on the host.  out[10]: numbers of violations [0] nodes strictly ascending by hash
+ * (build_internals.cpp:220), [1] node ranges partition the occurrences (:203-218), [2] (record_idx, pos) strictly ascending
+ * inside a node (build.cpp:232-240), [3] edges strictly ascending by (first, second) (build_internals.cpp:261),
+ * [4] first <= second, [5] 1 <= weight <= n_assemblies (build.cpp:177-189), [6] edge endpoints are node hashes,
+ * [7] (scored != 0) 1 <= n_tar + n_neg <= min(node size, n_assemblies) (filter.cpp:62-136); then [8] the sum of the
+ * edge weights and [9] reserved.  All of [0..7] are 0 for a correct index. */
+int sw_index_verify(const sw_index *ix, uint64_t n_assemblies, int scored, uint64_t *out);
 /* The sketch stage alone: (out_hash, pos, record_idx) of every minimizer in (record_idx, pos) order.
  * Two-phase like sw_filter_kmers: pass NULL buffers to get *n_out. */
 int sw_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *stream, uint64_t *out_hash,

@@ -656,6 +656,15 @@ int sw_index_checksums_at(const sw_index *ix, uint64_t kmer_base, uint64_t node_
     });
 }
 
+int sw_index_verify(const sw_index *ix, uint64_t n_assemblies, int scored, uint64_t *out)
+{
+    return guarded([&] {
+        index_settle(*const_cast<sw_index *>(ix));
+        require_current_device(ix->device, "the index");
+        index_verify(*ix, n_assemblies, scored != 0, 0, out);
+    });
+}
+
 void sw_index_free(sw_index *ix) { delete ix; }
 
 int sw_index_threshold_sums(const sw_index *ix, uint64_t *sums)

@@ -174,6 +174,7 @@ void device_filter_kmers(const sw_kmer *d_kmers, uint64_t n_kmers, const sw_node
 void device_checksums(const sw_index &ix, hipStream_t stream, uint64_t *sums3, uint64_t kbase = 0, uint64_t nbase = 0,
                       uint64_t ebase = 0);
 void index_threshold_sums(const sw_index &ix, hipStream_t stream, uint64_t *sums3);
+void index_verify(const sw_index &ix, uint64_t n_assemblies, bool scored, hipStream_t stream, uint64_t *out10);
 void index_filter_graph(const sw_index &ix, uint64_t weight_th, hipStream_t stream, sw_index &out);
 void index_occ_rows(const sw_index &ix, uint64_t rec_offset, uint64_t *d_rows, hipStream_t stream);
 void index_splits(const sw_index &ix, const uint64_t *node_bounds, const uint64_t *edge_bounds, uint32_t n_bounds,

@@ -581,6 +581,85 @@ __global__ void k_checksum(const sw_kmer *kmers, uint64_t nk, const sw_node *nod
     }
 }
 
+// ---- self-check of a resident index (size-independent properties, for sets too large to compare on the host) ----
+// out[0] nodes not strictly ascending by hash     out[1] node ranges not a partition of [0, n_kmers) (empty nodes count too)
+// out[2] (record_idx, pos) not strictly ascending inside a node   out[3] edges not strictly ascending by (first, second)
+// out[4] edges with first > second                out[5] edge weight outside [1, n_assemblies]
+// out[6] edge endpoints that are no node hash     out[7] nodes with n_tar + n_neg outside [1, min(size, n_assemblies)] (scored only)
+// out[8] sum of edge weights                      out[9] number of records that hold at least one occurrence
+__global__ void k_verify_nodes(const sw_node *__restrict__ nodes, uint64_t n_nodes, uint64_t n_kmers, uint64_t base,
+                               uint64_t n_assemblies, int scored, uint32_t *__restrict__ start_bits,
+                               unsigned long long *__restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const sw_node nd = nodes[i];
+    if (i && !(nodes[i - 1].hash < nd.hash)) atomicAdd(&out[0], 1ull);
+    const uint64_t prev_stop = i ? nodes[i - 1].stop : base;
+    bool bad = nd.start != prev_stop || nd.stop <= nd.start || nd.stop - base > n_kmers;
+    if (i == n_nodes - 1 && nd.stop - base != n_kmers) bad = true;
+    if (bad) atomicAdd(&out[1], 1ull);
+    else atomicOr(&start_bits[(nd.start - base) >> 5], 1u << ((nd.start - base) & 31u));
+    if (scored) {
+        const uint64_t c = (uint64_t)nd.n_tar + nd.n_neg, size = nd.stop - nd.start;
+        if (c < 1 || c > size || c > n_assemblies) atomicAdd(&out[7], 1ull);
+    }
+}
+
+__global__ void k_verify_kmers(const sw_kmer *__restrict__ kmers, uint64_t n, const uint32_t *__restrict__ start_bits,
+                               unsigned long long *__restrict__ out)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bad = 0, first_of_record = 0;
+    if (s < n) {
+        const uint64_t cur = ((uint64_t)kmers[s].record_idx << 32) | kmers[s].pos;
+        const bool head = (start_bits[s >> 5] >> (s & 31u)) & 1u;
+        if (s && !head) {
+            const uint64_t prev = ((uint64_t)kmers[s - 1].record_idx << 32) | kmers[s - 1].pos;
+            if (!(prev < cur)) bad = 1;
+        }
+    }
+    (void)first_of_record;
+    for (int d = 32; d; d >>= 1) bad += __shfl_down(bad, d, 64);
+    if ((threadIdx.x & 63u) == 0 && bad) atomicAdd(&out[2], bad);
+}
+
+__global__ void k_verify_edges(const sw_edge *__restrict__ edges, uint64_t n_edges, const sw_node *__restrict__ nodes,
+                               uint64_t n_nodes, const uint64_t *__restrict__ rank_hash, uint64_t n_rank_hash,
+                               uint64_t n_assemblies, unsigned long long *__restrict__ out)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long wsum = 0;
+    if (e < n_edges) {
+        const sw_edge ed = edges[e];
+        if (e) {
+            const sw_edge pe = edges[e - 1];
+            if (!(pe.first < ed.first || (pe.first == ed.first && pe.second < ed.second))) atomicAdd(&out[3], 1ull);
+        }
+        if (ed.first > ed.second) atomicAdd(&out[4], 1ull);
+        if (ed.weight < 1 || ed.weight > n_assemblies) atomicAdd(&out[5], 1ull);
+        wsum = ed.weight;
+        for (int side = 0; side < 2; ++side) {
+            const uint64_t h = side ? ed.second : ed.first;
+            bool found;
+            if (rank_hash) {   // slice of a sharded index: endpoints may be nodes of another slice
+                uint64_t lo = 0, hi = n_rank_hash;
+                while (lo < hi) {
+                    const uint64_t mid = (lo + hi) >> 1;
+                    if (rank_hash[mid] < h) lo = mid + 1; else hi = mid;
+                }
+                found = lo < n_rank_hash && rank_hash[lo] == h;
+            } else {
+                const uint64_t lo = node_index_of(nodes, n_nodes, h);
+                found = lo < n_nodes && nodes[lo].hash == h;
+            }
+            if (!found) atomicAdd(&out[6], 1ull);
+        }
+    }
+    for (int d = 32; d; d >>= 1) wsum += __shfl_down(wsum, d, 64);
+    if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(&out[8], wsum);
+}
+
 // ---- stable sort of 64-bit hashes in two phases -------------------------------------------------------
 // Phase 1: 4 radix passes over the TOP 32 bits only, carrying (low 32 bits << 32 | original index) as a 64-bit
 // payload: 24 B per element and pass for 4 passes instead of 8.  The result stays in this split form
@@ -1842,6 +1921,31 @@ void device_filter_kmers(const sw_kmer *d_kmers, uint64_t n_kmers, const sw_node
                            dst_start.p, (uint64_t)n_kept, n_out, kmers_out.p);
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));
+}
+
+void index_verify(const sw_index &ix, uint64_t n_assemblies, bool scored, hipStream_t stream, uint64_t *out10)
+{
+    DevArray<unsigned long long> out(10);
+    SW_HIP(hipMemsetAsync(out.p, 0, 80, stream));
+    DevArray<uint32_t> bits(ix.n_kmers / 32 + 2);
+    SW_HIP(hipMemsetAsync(bits.p, 0, bits.bytes(), stream));
+    uint64_t base = 0;   // a slice's node ranges are offset by the occurrences of lower ranks
+    if (ix.n_nodes) SW_HIP(hipMemcpyAsync(&base, &ix.nodes.p[0].start, 8, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    if (ix.n_nodes)
+        hipLaunchKernelGGL(k_verify_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, ix.n_kmers, base,
+                           n_assemblies, scored ? 1 : 0, bits.p, out.p);
+    if (ix.n_kmers)
+        hipLaunchKernelGGL(k_verify_kmers, dim3(blocks_for(ix.n_kmers)), dim3(TPB), 0, stream, ix.kmers.p, ix.n_kmers, bits.p, out.p);
+    if (ix.n_edges)
+        hipLaunchKernelGGL(k_verify_edges, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ix.edges.p, ix.n_edges, ix.nodes.p,
+                           ix.n_nodes, (const uint64_t *)nullptr, (uint64_t)0, n_assemblies, out.p);
+    SW_HIP(hipGetLastError());
+    unsigned long long h[10];
+    SW_HIP(hipMemcpyAsync(h, out.p, 80, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    if (ix.n_nodes == 0 && ix.n_kmers) h[1] += 1;
+    for (int i = 0; i < 10; ++i) out10[i] = h[i];
 }
 
 void device_checksums(const sw_index &ix, hipStream_t stream, uint64_t *sums3, uint64_t kbase, uint64_t nbase, uint64_t ebase)

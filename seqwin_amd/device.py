@@ -166,6 +166,14 @@ class Index:
         check(lib.sw_index_checksums_at(self._h, c_u64(kmer_base), c_u64(node_base), c_u64(edge_base), v))
         return tuple(int(x) for x in v)
 
+    def verify(self, n_assemblies: int, scored: bool = True) -> dict:
+        """Device-side self-check (sw_index_verify): violation counts of the output's structural properties."""
+        v = (c_u64 * 10)()
+        check(lib.sw_index_verify(self._h, c_u64(n_assemblies), ctypes.c_int(1 if scored else 0), v))
+        names = ("node_order", "node_ranges", "kmer_order", "edge_order", "edge_first_gt_second", "edge_weight_range",
+                 "edge_endpoint_missing", "count_range", "weight_sum", "reserved")
+        return dict(zip(names, (int(x) for x in v)))
+
     def close(self) -> None:
         if self._h:
             lib.sw_index_free(self._h)

@@ -1,0 +1,146 @@
+"""GPU (-m gpu): the code paths and sizes of BASELINE.json's large configs.
+
+* configs[1] at full size (512 genomes, 2.46 Gbp) against the COMPILED REFERENCE (oracle/_ref travels to the GPU box as a
+  checker), array for array -- at 3.8 M nodes the two-phase hash sort repairs ~1 700 shared-top-half runs per build, a
+  path no small case reaches naturally.
+* the branches the 15 000-genome set takes (pair-sorted edges because 2 x 27 + 14 > 64 bits, the general sort repair,
+  the occurrence-order validation) forced on small inputs through their switches, against the oracle.
+* configs[2] at full size (75 Gbp): device-side structural self-check + the committed N = 1 checksums, and the first
+  256 genomes of the same generator against the compiled reference.
+"""
+import json
+import os
+import random
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, ROOT, assert_graph_equal
+from seqwin_amd import KmerGraph, _get_penalty
+from seqwin_amd.device import Batch, host_checksums
+
+sys.path.insert(0, str(ROOT))
+from bench import SEED, WORKLOADS, write_fasta_sample  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_arrays(paths, k, w, tar):
+    """kmers / scored nodes / edges / offsets from the compiled reference (or, where it is absent, the C oracle)."""
+    ref = oracle.load_ref()
+    if ref is not None:
+        n_cpu = min(16, os.cpu_count() or 1)
+        kmers, nodes, edges, ro, _ = ref._build_native([str(p) for p in paths], k, w, n_cpu, False)
+        ref._get_penalty_native(kmers, nodes, ro, np.asarray(tar, np.bool_), n_cpu)
+        return kmers, nodes, edges, ro, "reference"
+    kmers, nodes, edges, ro, _ = oracle.build(paths, k, w)
+    oracle.get_penalty(kmers, nodes, ro, tar)
+    return kmers, nodes, edges, ro, "oracle"
+
+
+def test_config1_full_size_equals_reference(tmp_path):
+    G, rpg, rl, anc, snp, _ = WORKLOADS["salmonella500"]
+    k, w = 21, 200
+    b = Batch.synthetic(G, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED)
+    tar = np.arange(G) < G // 2                     # the first 256 genomes are the targets
+    ix = b.build_index(k, w, tar)
+    K, N, E = ix.export()
+    assert ix.timings()["total_bp"] == G * rpg * rl
+    paths, bp = write_fasta_sample(b, G, str(tmp_path))
+    assert bp == G * rpg * rl
+    ek, en, ee, eo, kind = _reference_arrays(paths, k, w, tar)
+    assert np.array_equal(b.record_offsets(), eo)
+    assert np.array_equal(K, ek), kind
+    assert np.array_equal(N, en), kind               # incl. n_tar / n_neg and the f64 penalty, bit for bit
+    assert np.array_equal(E, ee), kind
+    assert ix.checksums() == host_checksums(ek, en, ee)
+    v = ix.verify(G)
+    assert all(v[key] == 0 for key in list(v)[:8]), v
+    assert v["weight_sum"] == int(ee["weight"].sum())
+
+
+KNOBS = [
+    {"SEQWIN_AMD_NO_PACKED_EDGES": "1"},                                   # 15k: 2 x 27 + 14 > 64 -> k_adj + pair sort
+    {"SEQWIN_AMD_SORT_KEYBITS": "10"},                                     # many shared phase-1 keys: general repair
+    {"SEQWIN_AMD_SORT_KEYBITS": "20", "SEQWIN_AMD_CHECK_ORDER": "1"},      # in-place repair + order validation flags
+    {"SEQWIN_AMD_NO_PACKED_EDGES": "1", "SEQWIN_AMD_SORT_KEYBITS": "10", "SEQWIN_AMD_CHECK_ORDER": "1"},
+]
+
+
+@pytest.mark.parametrize("knobs", KNOBS, ids=lambda d: "+".join(f"{k[11:]}={v}" for k, v in d.items()))
+def test_large_config_branches_match_oracle(tmp_path, monkeypatch, knobs):
+    for key, val in knobs.items():
+        monkeypatch.setenv(key, val)
+    ng, rpg, rl, k, w = 12, 5, 60000, 21, 200
+    b = Batch.synthetic(ng, rpg, rl, n_ancestors=3, snp_ppm=10000, seed=SEED)
+    tar = [i < ng // 2 for i in range(ng)]
+    paths, _ = write_fasta_sample(b, ng, str(tmp_path))
+    ek, en, ee, eo, _ = oracle.build(paths, k, w)
+    oracle.get_penalty(ek, en, eo, tar)
+    ix = b.build_index(k, w, tar)
+    K, N, E = ix.export()
+    assert np.array_equal(K, ek) and np.array_equal(N, en) and np.array_equal(E, ee)
+    # and through the drop-in boundary on ragged FASTA (IUPAC, lowercase, N runs, empty records), small windows too
+    rng = random.Random(7)
+    for it in range(12):
+        ps = []
+        for a in range(rng.randrange(2, 5)):
+            txt = ""
+            for r in range(rng.randrange(0, 4)):
+                n = rng.choice([0, 30, 400, 9000, 30000])
+                s = "".join(rng.choice("ACGT" if rng.random() > 0.02 else "NnRacgtU") for _ in range(n))
+                txt += f">r{r}\n{s}\n"
+            p = tmp_path / f"f{it}_{a}.fa"
+            p.write_text(txt)
+            ps.append(p)
+        kk, ww = rng.choice([(7, 10), (15, 16), (21, 33), (31, 200), (17, 3)])
+        g = KmerGraph(ps, kmerlen=kk, windowsize=ww, n_cpu=2)
+        exp = oracle.build(ps, kk, ww)
+        assert_graph_equal((g.kmers, g.nodes, g.edges, g.record_offsets, g.record_ids),
+                           dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
+        if len(g.nodes) and len(ps) >= 2:
+            tar2 = [i % 2 == 0 for i in range(len(ps))]
+            oracle.get_penalty(exp[0], exp[1], exp[3], tar2)
+            _get_penalty(g.kmers, g.nodes, g.record_offsets, tar2)
+            assert np.array_equal(g.nodes, exp[1])
+
+
+def test_config2_full_size_properties(tmp_path):
+    """15 000 genomes x 5 Mbp on one GPU: nothing leaves HBM except counts and checksums."""
+    G, rpg, rl, anc, snp, _ = WORKLOADS["bacteria15k"]
+    k, w = 21, 200
+    b = Batch.synthetic(G, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED)
+    tar = np.arange(G) % 2 == 0                      # as bench.py
+    ix = b.build_index(k, w, tar)
+    nk, nn, ne = ix.sizes()
+    t = ix.timings()
+    assert t["total_bp"] == G * rpg * rl == 75_000_000_000 and t["sketch_launches"] == 1
+    assert 0.0097 < nk / t["total_bp"] < 0.0102       # minimizer density ~ 2 / (w + 1)
+    v = ix.verify(G)
+    assert all(v[key] == 0 for key in list(v)[:8]), v  # strict hash order, range partition, occurrence order, edge order, weights, endpoints, counts
+    assert nn <= nk and ne <= nk - G * rpg and ne <= v["weight_sum"] <= nk - G * rpg   # sum of weights <= adjacent pairs
+    gold = json.loads((GOLDEN / "bench_checksums.json").read_text())["bacteria15k/k21/w200"]
+    assert gold["counts"] == {"kmers": nk, "nodes": nn, "edges": ne}
+    assert [f"{s:016x}" for s in ix.checksums()] == gold["checksums"]
+    # idempotence at full size
+    ix.close()
+    ix2 = b.build_index(k, w, tar)
+    assert [f"{s:016x}" for s in ix2.checksums()] == gold["checksums"]
+    ix2.close()
+    # the first 256 genomes of the same 30-ancestor generator, against the compiled reference
+    n = 256
+    sub = Batch.synthetic(n, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED)
+    assert sub.record(0) == b.record(0) and sub.record(n * rpg - 1) == b.record(n * rpg - 1)
+    b.close()
+    paths, _ = write_fasta_sample(sub, n, str(tmp_path))
+    ek, en, ee, eo, kind = _reference_arrays(paths, k, w, tar[:n])
+    six = sub.build_index(k, w, tar[:n])
+    K, N, E = six.export()
+    assert np.array_equal(K, ek) and np.array_equal(N, en) and np.array_equal(E, ee), kind
+    # a shard of the job holds the same genomes as the unsharded batch (bench.py --gpus N, strong scaling)
+    sh = Batch.synthetic(3, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED, first_genome=100)
+    offs, ids = sh.records()
+    assert ids[0][0] == "g100_c0" and sh.record(0) == sub.record(100 * rpg) and sh.record(3 * rpg - 1) == sub.record(103 * rpg - 1)
