@@ -15,12 +15,29 @@ namespace sw {
 static thread_local std::string g_last_error;
 void set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
 
-// ---- caching allocator ---------------------------------------------------------------------------
+// ---- caching allocator, stream-aware -----------------------------------------------------------------
+// Blocks go back to the pool while work that uses them may still be queued, so every cached block remembers the stream
+// context it was released under (the calling thread's StreamScope): the scope's main stream, and one event per forked
+// side stream that was active at that moment (recorded at the release, so it covers exactly the work queued before it).
+// A later dev_alloc under main stream T
+//   * takes a block released under the same main stream as is (stream order covers the hand-over),
+//   * for a block released under a different main stream S records an event on S now (S is in order, so the event
+//     covers the block's last use) and lets T wait for it,
+//   * lets T wait for the block's side-stream events.
+// All waits are hipStreamWaitEvent: device-side ordering, the host never blocks.  Two host threads (or two torch
+// streams) driving the same device with different streams therefore never see each other's blocks early, and blocks
+// released while an exception unwinds past forked side-stream launches are fenced by those streams' events.
 namespace {
+struct FreeBlock {
+    void *ptr = nullptr;
+    hipStream_t main = nullptr;
+    std::vector<std::pair<hipStream_t, hipEvent_t>> side;
+};
 struct Pool {
     std::mutex mu;
-    std::multimap<std::pair<int, size_t>, void *> free_blocks;  // (device, size) -> ptr
-    std::map<void *, std::pair<int, size_t>> live;              // ptr -> (device, size)
+    std::multimap<std::pair<int, size_t>, FreeBlock> free_blocks;  // (device, size) -> block
+    std::map<void *, std::pair<int, size_t>> live;                 // ptr -> (device, size)
+    std::vector<hipEvent_t> spare_events;
     uint64_t total = 0;
 };
 Pool &pool()
@@ -35,7 +52,49 @@ size_t round_size(size_t b)
     if (b < (1u << 20)) return (b + 511) & ~(size_t)511;
     return (b + ((1u << 20) - 1)) & ~(size_t)((1u << 20) - 1);
 }
+struct AllocCtx {
+    hipStream_t main = nullptr;
+    std::vector<hipStream_t> side;
+};
+thread_local AllocCtx g_alloc_ctx;
+
+hipEvent_t take_event(Pool &p)   // p.mu held
+{
+    if (!p.spare_events.empty()) {
+        hipEvent_t e = p.spare_events.back();
+        p.spare_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return e;
+}
 }  // namespace
+
+StreamScope::StreamScope(hipStream_t s) : prev_main(g_alloc_ctx.main), prev_side(std::move(g_alloc_ctx.side))
+{
+    g_alloc_ctx.main = s;
+    g_alloc_ctx.side.clear();
+}
+StreamScope::~StreamScope()
+{
+    g_alloc_ctx.main = prev_main;
+    g_alloc_ctx.side = std::move(prev_side);
+}
+void alloc_fork(hipStream_t side)
+{
+    for (hipStream_t s : g_alloc_ctx.side)
+        if (s == side) return;
+    g_alloc_ctx.side.push_back(side);
+}
+void alloc_join(hipStream_t side)
+{
+    auto &v = g_alloc_ctx.side;
+    v.erase(std::remove(v.begin(), v.end(), side), v.end());
+}
 
 void *dev_alloc(size_t bytes)
 {
@@ -43,14 +102,30 @@ void *dev_alloc(size_t bytes)
     const size_t sz = round_size(bytes);
     int dev = 0;
     (void)hipGetDevice(&dev);
+    const hipStream_t T = g_alloc_ctx.main;
     {
-        std::lock_guard<std::mutex> lock(p.mu);
+        std::unique_lock<std::mutex> lock(p.mu);
         auto it = p.free_blocks.lower_bound(std::make_pair(dev, sz));
         if (it != p.free_blocks.end() && it->first.first == dev && it->first.second <= sz + sz / 4 + (1u << 20)) {
-            void *ptr = it->second;
-            p.live[ptr] = it->first;
+            FreeBlock blk = std::move(it->second);
+            p.live[blk.ptr] = it->first;
             p.free_blocks.erase(it);
-            return ptr;
+            bool ok = true;
+            if (blk.main != T) {   // released under another stream: fence on that stream's work up to now
+                hipEvent_t e = take_event(p);
+                ok = e && hipEventRecord(e, blk.main) == hipSuccess && hipStreamWaitEvent(T, e, 0) == hipSuccess;
+                if (e) p.spare_events.push_back(e);
+            }
+            for (auto &se : blk.side) {
+                if (se.first != T && ok) ok = hipStreamWaitEvent(T, se.second, 0) == hipSuccess;
+                p.spare_events.push_back(se.second);
+            }
+            if (!ok) {   // could not order the hand-over on the device: order it on the host
+                (void)hipGetLastError();
+                lock.unlock();
+                (void)hipDeviceSynchronize();
+            }
+            return blk.ptr;
         }
     }
     if (getenv("SEQWIN_AMD_DEBUG_ALLOC") && sz >= (1ull << 28)) fprintf(stderr, "[seqwin_amd] hipMalloc %.3f GiB\n", sz / 1073741824.0);
@@ -75,24 +150,49 @@ void dev_free(void *ptr)
 {
     if (!ptr) return;
     Pool &p = pool();
-    std::lock_guard<std::mutex> lock(p.mu);
+    std::unique_lock<std::mutex> lock(p.mu);
     auto it = p.live.find(ptr);
     if (it == p.live.end()) return;
-    p.free_blocks.emplace(it->second, ptr);
+    const std::pair<int, size_t> key = it->second;
     p.live.erase(it);
+    FreeBlock blk;
+    blk.ptr = ptr;
+    blk.main = g_alloc_ctx.main;
+    bool ok = true;
+    for (hipStream_t s : g_alloc_ctx.side) {   // forked streams that may still use the block: fence them precisely, here
+        hipEvent_t e = take_event(p);
+        if (!e || hipEventRecord(e, s) != hipSuccess) {
+            (void)hipGetLastError();
+            if (e) p.spare_events.push_back(e);
+            ok = false;
+            break;
+        }
+        blk.side.emplace_back(s, e);
+    }
+    if (!ok) {   // no fence possible (runtime error state): do not cache the block; hipFree waits for the device
+        for (auto &se : blk.side) p.spare_events.push_back(se.second);
+        p.total -= key.second;
+        lock.unlock();
+        (void)hipFree(ptr);
+        return;
+    }
+    p.free_blocks.emplace(key, std::move(blk));
 }
 
 void dev_pool_trim()
 {
     Pool &p = pool();
-    std::vector<std::pair<std::pair<int, size_t>, void *>> blocks;
+    std::vector<std::pair<std::pair<int, size_t>, FreeBlock>> blocks;
     {
         std::lock_guard<std::mutex> lock(p.mu);
-        blocks.assign(p.free_blocks.begin(), p.free_blocks.end());
+        for (auto &kv : p.free_blocks) blocks.emplace_back(kv.first, std::move(kv.second));
         p.free_blocks.clear();
-        for (auto &b : blocks) p.total -= b.first.second;
+        for (auto &b : blocks) {
+            p.total -= b.first.second;
+            for (auto &se : b.second.side) p.spare_events.push_back(se.second);
+        }
     }
-    for (auto &b : blocks) (void)hipFree(b.second);
+    for (auto &b : blocks) (void)hipFree(b.second.ptr);   // hipFree waits for outstanding work on the block's device
 }
 
 uint64_t dev_pool_bytes() { return pool().total; }
@@ -332,6 +432,7 @@ void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targe
                     hipStream_t stream, sw_index &ix)
 {
     require_current_device(b.device, "the batch");
+    StreamScope scope(stream);
     bool plan_cached = false;
     Plan &plan = get_plan(b, k, w, &plan_cached);
     uint64_t n_tar = 0, n_neg = 0;
@@ -343,10 +444,7 @@ void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targe
         d_tar.alloc(n_assemblies);
         SW_HIP(hipMemcpyAsync(d_tar.p, is_targets, n_assemblies, hipMemcpyHostToDevice, stream));
     }
-    hipEvent_t e0, e1, e2;
-    SW_HIP(hipEventCreate(&e0));
-    SW_HIP(hipEventCreate(&e1));
-    SW_HIP(hipEventCreate(&e2));
+    Event e0, e1, e2, e3;
     SW_HIP(hipEventRecord(e0, stream));
     SketchOut sk;
     float sketch_ms = 0.f;
@@ -359,8 +457,6 @@ void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targe
     SW_HIP(hipEventRecord(e2, stream));
     ix.device = b.device;
     build_index(b, occ, is_targets ? d_tar.p : nullptr, n_tar, n_neg, stream, ix);
-    hipEvent_t e3;
-    SW_HIP(hipEventCreate(&e3));
     SW_HIP(hipEventRecord(e3, stream));
     SW_HIP(hipEventSynchronize(e3));
     float ms = 0.f;
@@ -376,10 +472,6 @@ void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targe
     ix.timings.ovf_tiles = ovf_tiles;
     ix.timings.plan_ms = plan.build_ms;
     ix.timings.plan_cached = plan_cached ? 1 : 0;
-    SW_HIP(hipEventDestroy(e0));
-    SW_HIP(hipEventDestroy(e1));
-    SW_HIP(hipEventDestroy(e2));
-    SW_HIP(hipEventDestroy(e3));
 }
 
 }  // namespace
@@ -688,8 +780,11 @@ int sw_index_filter_kmers(const sw_index *ix, const sw_index *nodes_from, const 
                           sw_index **out)
 {
     return guarded([&] {
+        const sw_index *nf = nodes_from ? nodes_from : ix;   // NULL: the index's own nodes
+        require_current_device(ix->device, "the index");
+        if (nf->device != ix->device) raise(SW_ERR_VALUE, "the two indexes live on different devices (%d, %d)", ix->device, nf->device);
         index_settle(*const_cast<sw_index *>(ix));
-        if (nodes_from) index_settle(*const_cast<sw_index *>(nodes_from));
+        index_settle(*const_cast<sw_index *>(nf));
         std::vector<uint64_t> used(used_hashes, used_hashes + n_used);
         std::sort(used.begin(), used.end());
         DevArray<uint64_t> d_used(n_used);
@@ -697,7 +792,7 @@ int sw_index_filter_kmers(const sw_index *ix, const sw_index *nodes_from, const 
         std::unique_ptr<sw_index> o(new sw_index);
         o->device = ix->device;
         uint64_t nk = 0, nn = 0;
-        device_filter_kmers(ix->kmers.p, ix->n_kmers, nodes_from->nodes.p, nodes_from->n_nodes, d_used.p, n_used, 0, o->kmers,
+        device_filter_kmers(ix->kmers.p, ix->n_kmers, nf->nodes.p, nf->n_nodes, d_used.p, n_used, 0, o->kmers,
                             o->nodes, &nk, &nn);
         o->n_kmers = nk;
         o->n_nodes = nn;
@@ -712,6 +807,7 @@ int sw_occ_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void
     return guarded([&] {
         sw_batch &bb = *const_cast<sw_batch *>(b);
         require_current_device(bb.device, "the batch");
+        StreamScope scope((hipStream_t)stream);
         Plan &plan = get_plan(bb, kmerlen, windowsize);
         std::unique_ptr<sw_occ> o(new sw_occ);
         o->batch = b;
@@ -737,6 +833,7 @@ int sw_occ_partition(const sw_occ *o, const uint64_t *bounds, uint64_t n_bounds,
                      void *perm_dev, uint64_t *counts, void *stream)
 {
     return guarded([&] {
+        StreamScope scope((hipStream_t)stream);
         occ_partition(*o->occ, bounds, (uint32_t)n_bounds, rec_offset, (uint64_t *)rows_dev, (uint32_t *)perm_dev, counts,
                       (hipStream_t)stream);
     });
@@ -749,6 +846,7 @@ int sw_occ_adjacency(const sw_occ *o, const void *perm_dev, const void *rank_by_
     return guarded([&] {
         if (n_bits < 1 || n_bits > 32) raise(SW_ERR_VALUE, "n_bits must be in [1, 32]");
         if (asm_bits && 2 * n_bits + asm_bits > 64) raise(SW_ERR_VALUE, "packed adjacency keys need 2 n_bits + asm_bits <= 64");
+        StreamScope scope((hipStream_t)stream);
         occ_adjacency(*o->occ, o->batch->d_rec_asm.p, (const uint32_t *)perm_dev, (const uint32_t *)rank_by_row_dev,
                       (unsigned)n_bits, (unsigned)asm_bits, asm_base, rank_bounds, (uint32_t)n_bounds, (uint64_t *)rows_dev,
                       counts, (hipStream_t)stream);
@@ -759,9 +857,8 @@ int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t 
                    const void *rank_hash_dev, void *stream)
 {
     return guarded([&] {
-        hipEvent_t e0, e1;
-        SW_HIP(hipEventCreate(&e0));
-        SW_HIP(hipEventCreate(&e1));
+        StreamScope scope((hipStream_t)stream);
+        Event e0, e1;
         SW_HIP(hipEventRecord(e0, (hipStream_t)stream));
         slice_edges(*ix, (const uint64_t *)adj_rows_dev, m, (unsigned)n_bits, (unsigned)asm_bits,
                     (const uint64_t *)rank_hash_dev, (hipStream_t)stream);
@@ -771,14 +868,15 @@ int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t 
         float ms = 0.f;
         SW_HIP(hipEventElapsedTime(&ms, e0, e1));
         ix->timings.edges_ms = ms;
-        SW_HIP(hipEventDestroy(e0));
-        SW_HIP(hipEventDestroy(e1));
     });
 }
 
 int sw_index_node_hashes(const sw_index *ix, void *dst_dev, void *stream)
 {
-    return guarded([&] { index_node_hashes(*ix, (uint64_t *)dst_dev, (hipStream_t)stream); });
+    return guarded([&] {
+        StreamScope scope((hipStream_t)stream);
+        index_node_hashes(*ix, (uint64_t *)dst_dev, (hipStream_t)stream);
+    });
 }
 
 int sw_index_device_ptrs(const sw_index *ix, void **kmers, void **nodes, void **edges)
@@ -794,7 +892,10 @@ int sw_index_device_ptrs(const sw_index *ix, void **kmers, void **nodes, void **
 int sw_index_occ_rows(const sw_index *ix, uint64_t rec_offset, void *rows_dev, void *stream)
 {
     return guarded([&] {
-        index_settle(*const_cast<sw_index *>(ix)); index_occ_rows(*ix, rec_offset, (uint64_t *)rows_dev, (hipStream_t)stream); });
+        StreamScope scope((hipStream_t)stream);
+        index_settle(*const_cast<sw_index *>(ix));
+        index_occ_rows(*ix, rec_offset, (uint64_t *)rows_dev, (hipStream_t)stream);
+    });
 }
 
 int sw_index_edge_rows(const sw_index *ix, void *rows_dev, void *stream)
@@ -810,6 +911,7 @@ int sw_index_splits(const sw_index *ix, const uint64_t *node_bounds, const uint6
                     uint64_t *occ_split, uint64_t *edge_split, void *stream)
 {
     return guarded([&] {
+        StreamScope scope((hipStream_t)stream);
         index_settle(*const_cast<sw_index *>(ix));
         index_splits(*ix, node_bounds, edge_bounds, (uint32_t)n_bounds, occ_split, edge_split, (hipStream_t)stream);
     });
@@ -845,6 +947,7 @@ static void merge_like(const void *occ_rows_dev, uint64_t n_occ, const void *edg
     {
         require_device();
         hipStream_t st = (hipStream_t)stream;
+        StreamScope scope(st);
         std::unique_ptr<sw_index> ix(new sw_index);
         SW_HIP(hipGetDevice(&ix->device));
         uint64_t n_tar = 0, n_neg = 0;
@@ -863,9 +966,7 @@ static void merge_like(const void *occ_rows_dev, uint64_t n_occ, const void *edg
             SW_HIP(hipMemcpyAsync(d_tar.p, is_targets, n_assemblies, hipMemcpyHostToDevice, st));
             SW_HIP(hipStreamSynchronize(st));
         }
-        hipEvent_t e0, e1;
-        SW_HIP(hipEventCreate(&e0));
-        SW_HIP(hipEventCreate(&e1));
+        Event e0, e1;
         SW_HIP(hipEventRecord(e0, st));
         merge_build((const uint64_t *)occ_rows_dev, n_occ, (const uint64_t *)edge_rows_dev, n_edge_rows, kmer_base,
                     d_rec_asm.p, n_records, is_targets ? d_tar.p : nullptr, n_tar, n_neg, st, *ix, d_rank_out,
@@ -875,8 +976,6 @@ static void merge_like(const void *occ_rows_dev, uint64_t n_occ, const void *edg
         float ms = 0.f;
         SW_HIP(hipEventElapsedTime(&ms, e0, e1));
         ix->timings.total_ms = ms;
-        SW_HIP(hipEventDestroy(e0));
-        SW_HIP(hipEventDestroy(e1));
         *out = ix.release();
     }
 }
@@ -886,6 +985,7 @@ int sw_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *st
 {
     return guarded([&] {
         sw_batch &bb = *const_cast<sw_batch *>(b);
+        StreamScope scope((hipStream_t)stream);
         Plan &plan = get_plan(bb, kmerlen, windowsize);
         SketchOut sk;
         run_sketch(bb, plan, (hipStream_t)stream, sk, nullptr);

@@ -15,11 +15,38 @@ namespace sw {
                         __FILE__, __LINE__, #expr);                                                    \
     } while (0)
 
-// ---- caching device allocator (steady-state index builds do no hipMalloc) --------------------
+// ---- caching device allocator (steady-state index builds do no hipMalloc), stream-aware: api.hip ----------
 void *dev_alloc(size_t bytes);
 void dev_free(void *p);
 void dev_pool_trim();
 uint64_t dev_pool_bytes();
+// The stream a C-ABI call works on, for the calling thread: blocks released inside the scope are tagged with it and
+// blocks taken inside it are fenced against the stream context they were released under.
+struct StreamScope {
+    explicit StreamScope(hipStream_t s);
+    ~StreamScope();
+    StreamScope(const StreamScope &) = delete;
+    StreamScope &operator=(const StreamScope &) = delete;
+private:
+    hipStream_t prev_main;
+    std::vector<hipStream_t> prev_side;
+};
+// Between fork and join of a side stream, blocks released by this thread also carry an event of that stream.
+void alloc_fork(hipStream_t side);
+void alloc_join(hipStream_t side);
+
+// hipEvent_t with a destructor (no leak when an exception unwinds through a build)
+struct Event {
+    hipEvent_t e = nullptr;
+    explicit Event(bool timing = true)
+    {
+        SW_HIP(timing ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    ~Event() { if (e) (void)hipEventDestroy(e); }
+    Event(const Event &) = delete;
+    Event &operator=(const Event &) = delete;
+    operator hipEvent_t() const { return e; }
+};
 
 template <class T> struct DevArray {
     T *p = nullptr;

@@ -1386,8 +1386,7 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
 {
     const uint64_t n = occ.n;
     if (n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
-    hipEvent_t ev[6];
-    for (auto &e : ev) SW_HIP(hipEventCreate(&e));
+    Event ev[6];
     SW_HIP(hipEventRecord(ev[0], stream));
 
     ix.n_kmers = n;
@@ -1422,6 +1421,7 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
     PenaltyJob pen;
     hipStream_t side = side_stream();
     if (d_is_target && ix.n_nodes) {
+        alloc_fork(side);   // blocks released from here on are fenced against the counts stream as well
         SW_HIP(hipStreamWaitEvent(side, ev[1], 0));
         SW_HIP(hipEventRecord(ev[4], side));
         penalty_launch(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, b.d_rec_asm.p, b.n_records, d_is_target, n_targets,
@@ -1462,6 +1462,7 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
     if (had_pen) {
         const uint64_t err = penalty_finish(pen);
         SW_HIP(hipStreamWaitEvent(stream, ev[5], 0));   // the build is complete on `stream` only after the counts
+        alloc_join(side);
         if (err) raise(SW_ERR_RUNTIME, "internal error: inconsistent occurrence order in device index (%llu)",
                        (unsigned long long)err);
     }
@@ -1477,7 +1478,6 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
     }
     SW_HIP(hipEventElapsedTime(&ms, ev[2], ev[3]));
     ix.timings.edges_ms = ms;
-    for (auto &e : ev) SW_HIP(hipEventDestroy(e));
 }
 
 void index_occ_rows(const sw_index &ix, uint64_t rec_offset, uint64_t *d_rows, hipStream_t stream)
@@ -1545,26 +1545,26 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
         pc->kmer_base = kmer_base;
         pc->stream = stream;
         hipStream_t side = side_stream();
-        hipEvent_t ev_nodes = nullptr;
-        SW_HIP(hipEventCreate(&ev_nodes));
+        Event ev_nodes(false);
         SW_HIP(hipEventCreateWithFlags(&pc->ev, hipEventDisableTiming));
         SW_HIP(hipEventRecord(ev_nodes, stream));
         SW_HIP(hipStreamWaitEvent(side, ev_nodes, 0));
+        // (the job keeps every buffer it uses -- held by PendingCounts until index_settle -- and only reads the index's own
+        //  kmers / nodes, so nothing released later needs a fence against this stream)
         penalty_launch(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, pc->rec_asm.p, n_records, pc->is_target.p, n_targets,
                        n_non_targets, side, pc->job);
         SW_HIP(hipEventRecord(pc->ev, side));
-        (void)hipEventDestroy(ev_nodes);
         ix.n_edges = 0;
         ix.edges.alloc(0);
         ix.pending = pc.release();
         return;
     }
     PenaltyJob pen;
-    hipEvent_t ev_nodes = nullptr, ev_pen = nullptr;
+    Event ev_nodes(false), ev_pen(false);
+    hipStream_t side = nullptr;
     if (d_is_target && ix.n_nodes) {
-        hipStream_t side = side_stream();
-        SW_HIP(hipEventCreate(&ev_nodes));
-        SW_HIP(hipEventCreate(&ev_pen));
+        side = side_stream();
+        alloc_fork(side);
         SW_HIP(hipEventRecord(ev_nodes, stream));
         SW_HIP(hipStreamWaitEvent(side, ev_nodes, 0));
         penalty_launch(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, d_rec_asm, n_records, d_is_target, n_targets, n_non_targets,
@@ -1607,11 +1607,10 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
     if (pen.active) {
         const uint64_t err = penalty_finish(pen);
         SW_HIP(hipStreamWaitEvent(stream, ev_pen, 0));
+        alloc_join(side);
         if (err) raise(SW_ERR_RUNTIME, "internal error: inconsistent occurrence order in merged index (%llu)",
                        (unsigned long long)err);
     }
-    if (ev_nodes) (void)hipEventDestroy(ev_nodes);
-    if (ev_pen) (void)hipEventDestroy(ev_pen);
     if (kmer_base && ix.n_nodes) {
         hipLaunchKernelGGL(k_rebase_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes,
                            kmer_base);

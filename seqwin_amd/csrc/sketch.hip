@@ -1145,10 +1145,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
     // winners share an overflow area behind the slots, which is grown to the exact size and the pass re-run if it is too small
     const uint64_t slots = (uint64_t)plan.n_tiles * plan.slot_cap;
     uint64_t ovf_cap = std::max<uint64_t>(4096, slots / 64);
-    hipEvent_t ev0, ev1, evj;
-    SW_HIP(hipEventCreate(&ev0));
-    SW_HIP(hipEventCreate(&ev1));
-    SW_HIP(hipEventCreateWithFlags(&evj, hipEventDisableTiming));
+    Event ev0, ev1, evj(false);
     for (;;) {
         const uint64_t cap = slots + ovf_cap;
         out.stage_hash.alloc(cap);
@@ -1198,7 +1195,10 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
                                       stream));
         }
         SW_HIP(hipEventRecord(ev0, stream));
-        if (side) SW_HIP(hipStreamWaitEvent(side, ev0, 0));
+        if (side) {
+            alloc_fork(side);
+            SW_HIP(hipStreamWaitEvent(side, ev0, 0));
+        }
         for (int c = 1; c >= 0; --c) {
             const Plan::FastClass &fc = plan.fc[c];
             if (!fc.n_tiles) continue;
@@ -1223,7 +1223,10 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
             }
             if (c == 1 && side) SW_HIP(hipEventRecord(evj, side));
         }
-        if (side) SW_HIP(hipStreamWaitEvent(stream, evj, 0));   // join: everything below is ordered after both classes
+        if (side) {
+            SW_HIP(hipStreamWaitEvent(stream, evj, 0));   // join: everything below is ordered after both classes
+            alloc_join(side);
+        }
         if (plan.n_tiles_gen) {
             a.cls_tile_off = plan.gen_tile_off.p;
             a.cls_tile_rec = plan.gen_tile_rec.p;
@@ -1300,9 +1303,6 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         }
         ovf_cap = total[0];  // exact size is now known
     }
-    SW_HIP(hipEventDestroy(ev0));
-    SW_HIP(hipEventDestroy(ev1));
-    SW_HIP(hipEventDestroy(evj));
 }
 
 }  // namespace sw

@@ -269,3 +269,36 @@ def test_two_phase_hash_sort_repairs_shared_top_halves(case):
     assert np.array_equal(N["hash"], uh) and np.array_equal(N["start"], start.astype(np.uint64))
     assert np.array_equal(N["stop"], (start + cnt).astype(np.uint64))
     assert np.array_equal(ranks.cpu().numpy().view(np.uint32), np.searchsorted(uh, h).astype(np.uint32))
+
+
+@pytest.mark.parametrize("workload,extra", [("tiny", []), ("salmonella500", ["--scaling", "strong", "--genomes", "48"])])
+def test_bench_strong_scaling_reproduces_n1_checksums(workload, extra):
+    """bench.py --gpus 2 (strong scaling: the SAME genomes sharded by build.cpp:350-356's partition, every collective of
+    seqwin_amd/dist.py issued for real -- over gloo with host staging, two ranks sharing this box's one GPU) must print
+    the checksums and counts of the single-GPU run: shard-count invariance as the driver's SCALE runs see it."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    base = [str(root / "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra
+
+    def run(cmd, env=None):
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    one = run([sys.executable] + base)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import os
+    env = dict(os.environ, SEQWIN_BENCH_BACKEND="gloo")
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + base + ["--gpus", "2"], env)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["genomes"] == one["config"]["genomes"] and two["config"]["genomes_per_gpu"] * 2 == one["config"]["genomes"]
+    assert two["counts"] == one["counts"] and two["checksums"] == one["checksums"]

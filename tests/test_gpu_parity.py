@@ -538,3 +538,37 @@ def test_bench_line_contract():
     assert "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["unit"] == "Gbp/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_two_host_threads_two_streams_share_the_block_pool():
+    """The caching allocator hands blocks from one stream's build to another's (two host threads, each with its own HIP
+    stream, on one device): every hand-over is fenced on the device (StreamScope / events, api.hip), so every build must
+    give the single-threaded result."""
+    import threading
+
+    import torch
+    b1 = Batch.synthetic(24, 4, 40000, n_ancestors=3, snp_ppm=10000, seed=5)
+    b2 = Batch.synthetic(16, 3, 70000, n_ancestors=2, snp_ppm=20000, seed=6)
+    t1, t2 = np.arange(24) % 2 == 0, np.arange(16) % 3 == 0
+    ref1, ref2 = b1.build_index(21, 200, t1).checksums(), b2.build_index(15, 50, t2).checksums()
+    errors = []
+
+    def work(batch, k, w, tar, ref, n):
+        try:
+            s = torch.cuda.Stream()
+            for _ in range(n):
+                ix = batch.build_index(k, w, tar, stream=int(s.cuda_stream))
+                if ix.checksums() != ref:
+                    errors.append((k, w))
+                ix.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(b1, 21, 200, t1, ref1, 25)),
+          threading.Thread(target=work, args=(b2, 15, 50, t2, ref2, 25)),
+          threading.Thread(target=work, args=(b1, 21, 200, t1, ref1, 25))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
