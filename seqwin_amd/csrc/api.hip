@@ -451,12 +451,12 @@ void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targe
     run_sketch(b, plan, stream, sk, &sketch_ms);
     SW_HIP(hipEventRecord(e1, stream));
     OrderedOcc occ;
-    order_tuples(sk, plan, stream, occ);
+    order_tuples(sk, plan, stream, occ, true);
     const uint64_t launches = sk.launches, ovf_tiles = sk.n_ovf_tiles;
     sk = SketchOut();
     SW_HIP(hipEventRecord(e2, stream));
     ix.device = b.device;
-    build_index(b, occ, is_targets ? d_tar.p : nullptr, n_tar, n_neg, stream, ix);
+    build_index(b.d_rec_asm.p, b.n_records, b.host.n_assemblies, occ, is_targets ? d_tar.p : nullptr, n_tar, n_neg, stream, ix);
     SW_HIP(hipEventRecord(e3, stream));
     SW_HIP(hipEventSynchronize(e3));
     float ms = 0.f;

@@ -180,17 +180,27 @@ struct SketchOut {
 void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchOut &out, float *sketch_ms);
 
 // index.hip
+// What the node sort moves with every occurrence (16 B): the low half of its hash (the high half is the sort key), its
+// (pos, record_idx) -- so that `kmers` comes out of the sort in order, without a gather -- and its place in the
+// (record_idx, pos) stream, which brings its node's rank back to that stream for the adjacency (index.hip: unsort).
+struct alignas(16) OccPay {
+    uint32_t low, pos, rec, idx;
+};
 struct OrderedOcc {
+    // exchange form (multi-GPU tuple exchange, sw_sketch): the tuples themselves
     DevArray<uint64_t> hash;   // out_hash in (record_idx, pos) order
     DevArray<uint64_t> kmer;   // pos | record_idx << 32
-    DevArray<uint32_t> key32;  // out_hash >> 32: first-phase key of the node sort (consumed by it)
-    DevArray<uint64_t> val;    // out_hash << 32 | position in this stream: its payload (consumed by it)
+    // index form (single-GPU build): the node sort's input, consumed by it, and the records for the adjacency
+    DevArray<uint32_t> key32;  // out_hash >> 32: first-phase sort key
+    DevArray<OccPay> pay;
+    DevArray<uint32_t> rec;    // record_idx in (record_idx, pos) order
     uint64_t n = 0;
 };
-void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out);
+void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out, bool index_form = false);
 void index_settle(sw_index &ix);   // finish deferred counts (no-op otherwise)
-void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target, uint64_t n_targets,
-                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix);
+// occ: index form (key32 / pay / rec); d_rec_asm[n_records] = assembly of every record of the stream
+void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assemblies, OrderedOcc &occ,
+                 const uint8_t *d_is_target, uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, sw_index &ix);
 void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
                         const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,
                         uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, uint64_t *err_flags_host);

@@ -92,10 +92,15 @@ struct HeadFlag {
 };
 
 // ---- tuple ordering -----------------------------------------------------------------------------
+// One wave per tile: the tile's tuples move from its stage slot to their place in (record_idx, pos) order; the staged
+// canonical hash becomes out_hash = extend_hashes (hashing_internals.hpp:89-103).  INDEX form writes the node sort's
+// input (key32, OccPay) and the record of every occurrence; exchange form writes the tuples (hash, pos | record << 32).
+template <bool INDEX>
 __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t *__restrict__ stage_kmer,
                         const uint32_t *__restrict__ tile_count, const uint64_t *__restrict__ tile_offset,
                         const uint64_t *__restrict__ dst_off, uint32_t n_tiles, uint64_t mult, uint64_t *__restrict__ hash,
-                        uint64_t *__restrict__ kmer, uint32_t *__restrict__ key32, uint64_t *__restrict__ val)
+                        uint64_t *__restrict__ kmer, uint32_t *__restrict__ key32, OccPay *__restrict__ pay,
+                        uint32_t *__restrict__ rec)
 {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
@@ -103,13 +108,38 @@ __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t 
     const uint32_t c = tile_count[wave];
     const uint64_t src = tile_offset[wave], dst = dst_off[wave];
     for (uint32_t i = lane; i < c; i += 64) {
-        uint64_t h = stage_hash[src + i] * mult;   // staged: canonical hash; out_hash = extend_hashes
-        h ^= h >> 27;                              // (hashing_internals.hpp:89-103)
-        hash[dst + i] = h;
-        kmer[dst + i] = stage_kmer[src + i];
-        key32[dst + i] = (uint32_t)(h >> 32);   // first-phase sort key and payload (sort_hashes)
-        val[dst + i] = (h << 32) | (dst + i);
+        uint64_t h = stage_hash[src + i] * mult;
+        h ^= h >> 27;
+        const uint64_t km = stage_kmer[src + i];
+        if (INDEX) {
+            key32[dst + i] = (uint32_t)(h >> 32);
+            OccPay p;
+            p.low = (uint32_t)h;
+            p.pos = (uint32_t)km;
+            p.rec = (uint32_t)(km >> 32);
+            p.idx = (uint32_t)(dst + i);
+            pay[dst + i] = p;
+            rec[dst + i] = p.rec;
+        } else {
+            hash[dst + i] = h;
+            kmer[dst + i] = km;
+        }
     }
+}
+
+// rows[n][2] = {hash, pos | record << 32} (exchanged tuples) -> the node sort's input
+__global__ void k_rows_to_pay(const uint64_t *__restrict__ rows, uint64_t n, uint32_t *__restrict__ key32, OccPay *__restrict__ pay)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t h = rows[2 * i], km = rows[2 * i + 1];
+    key32[i] = (uint32_t)(h >> 32);
+    OccPay p;
+    p.low = (uint32_t)h;
+    p.pos = (uint32_t)km;
+    p.rec = (uint32_t)(km >> 32);
+    p.idx = (uint32_t)i;
+    pay[i] = p;
 }
 
 __global__ void k_iota(uint32_t *v, uint64_t n)
@@ -119,32 +149,148 @@ __global__ void k_iota(uint32_t *v, uint64_t n)
 }
 
 // ---- nodes / kmers / ranks ------------------------------------------------------------------------
-// sorted hashes arrive in the split form of sort_hashes: key32[s] = top half, val[s] = low half << 32 | original index
-__global__ void k_nodes(const uint32_t *__restrict__ key32, const uint64_t *__restrict__ val,
-                        const uint32_t *__restrict__ cum, const uint64_t *__restrict__ kmer_in, uint32_t kmer_stride,
-                        uint64_t n, uint64_t base, sw_kmer *__restrict__ kmers, sw_node *__restrict__ nodes,
-                        uint32_t *__restrict__ rank)
+// The sorted occurrences (key32[s] = top half of the hash, pay[s] = low half, pos, record, original index) stream through
+// once: kmers[s] = (pos, record); a head of a run of equal hashes starts node cum[s] - 1; (original index, node) goes to
+// the unsort, which brings every occurrence's node rank back to (record_idx, pos) order; and -- when the counts are wanted --
+// one bit per occurrence says "first occurrence of a target (T) / non-target (N) assembly in its node" (the occurrences of
+// a node are in record order, records are assembly-major, filter.cpp:62-136), so a node's counts are two popcounts.
+// A workgroup takes NODES_ITEMS x 256 consecutive occurrences, 256 at a time (lane s of a wave = occurrence s of a
+// 64-aligned group: the bits of a group are one ballot).
+constexpr int NODES_ITEMS = 8;
+constexpr uint32_t UNSORT_BITS = 14;                 // the unsort's last step handles 2^14 consecutive indices in LDS
+constexpr uint32_t UNSORT_RANGE = 1u << UNSORT_BITS;
+constexpr uint64_t UNSORT_DIRECT_MAX = 1ull << 20;   // up to here the rank array stays in L2: scatter directly
+
+template <bool BITS>
+__global__ __launch_bounds__(256) void k_nodes(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay,
+                                               const uint32_t *__restrict__ cum, uint64_t n, uint64_t base,
+                                               const uint32_t *__restrict__ rec_flag, sw_kmer *__restrict__ kmers,
+                                               sw_node *__restrict__ nodes, uint32_t *__restrict__ rank_direct,
+                                               uint32_t *__restrict__ ukey, uint64_t *__restrict__ uval,
+                                               unsigned long long *__restrict__ tbits, unsigned long long *__restrict__ nbits)
 {
-    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n) return;
-    const uint32_t nid = cum[s] - 1;
-    const uint64_t v = val[s];
-    const uint32_t src = (uint32_t)v;
-    const uint64_t km = kmer_in[(uint64_t)src * kmer_stride];
-    kmers[s].pos = (uint32_t)km;
-    kmers[s].record_idx = (uint32_t)(km >> 32);
-    if (rank) rank[src] = nid;
-    const uint64_t key = ((uint64_t)key32[s] << 32) | (v >> 32);
-    const bool head = (s == 0) || key != (((uint64_t)key32[s - 1] << 32) | (val[s - 1] >> 32));
-    if (head) {
-        nodes[nid].hash = key;
-        nodes[nid].start = base + s;
-        nodes[nid].n_tar = 0;
-        nodes[nid].n_neg = 0;
-        nodes[nid].penalty = 0.0;
-        if (s) nodes[nid - 1].stop = base + s;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t s0 = (uint64_t)blockIdx.x * (256 * NODES_ITEMS);
+#pragma unroll 2
+    for (int j = 0; j < NODES_ITEMS; ++j) {
+        const uint64_t s = s0 + (uint64_t)j * 256 + threadIdx.x;
+        const bool live = s < n;
+        uint32_t k = 0, nid = 0;
+        OccPay p = {0, 0, 0, 0};
+        if (live) {
+            k = key32[s];
+            p = pay[s];
+            nid = cum[s] - 1;
+        }
+        // the previous occurrence: the lane below, or (lane 0) a load
+        uint32_t pk = __shfl_up(k, 1, 64), plow = __shfl_up(p.low, 1, 64), prec = __shfl_up(p.rec, 1, 64);
+        if (lane == 0 && live && s) {
+            pk = key32[s - 1];
+            const OccPay q = pay[s - 1];
+            plow = q.low;
+            prec = q.rec;
+        }
+        const bool head = live && (s == 0 || k != pk || p.low != plow);
+        if (live) {
+            sw_kmer km;
+            km.pos = p.pos;
+            km.record_idx = p.rec;
+            kmers[s] = km;
+            if (rank_direct) {
+                rank_direct[p.idx] = nid;
+            } else if (ukey) {
+                ukey[s] = p.idx >> UNSORT_BITS;
+                uval[s] = ((uint64_t)nid << 32) | p.idx;
+            }
+            if (head) {
+                // (stop is written by the next head / the last occurrence: two stores to one node never race on a field)
+                nodes[nid].hash = ((uint64_t)k << 32) | p.low;
+                nodes[nid].start = base + s;
+                nodes[nid].n_tar = 0;
+                nodes[nid].n_neg = 0;
+                nodes[nid].penalty = 0.0;
+                if (s) nodes[nid - 1].stop = base + s;
+            }
+            if (s == n - 1) nodes[nid].stop = base + n;
+        }
+        if (BITS) {
+            // rec_flag[r] = assembly << 1 | is_target
+            const uint32_t f = live ? rec_flag[p.rec] : 0u;
+            uint32_t pf = __shfl_up(f, 1, 64);
+            if (lane == 0 && live && s) pf = rec_flag[prec];
+            const bool first_of_asm = live && (head || (f >> 1) != (pf >> 1));
+            const unsigned long long tb = __ballot(first_of_asm && (f & 1u));
+            const unsigned long long nb = __ballot(first_of_asm && !(f & 1u));
+            if (lane == 0 && live) {   // (lane 0 holds the group's first occurrence: dead there = the whole group is past the end)
+                tbits[s >> 6] = tb;
+                nbits[s >> 6] = nb;
+            }
+        }
     }
-    if (s == n - 1) nodes[nid].stop = base + n;
+}
+
+// bits [a, b) of a bitmap of 64-bit words
+__device__ __forceinline__ uint32_t popc_range(const unsigned long long *__restrict__ w, uint64_t a, uint64_t b)
+{
+    if (a >= b) return 0;
+    const uint64_t wa = a >> 6, wb = (b - 1) >> 6;
+    const unsigned long long ma = ~0ull << (a & 63u), mb = ~0ull >> (63u - ((b - 1) & 63u));
+    if (wa == wb) return (uint32_t)__popcll(w[wa] & ma & mb);
+    uint32_t c = (uint32_t)__popcll(w[wa] & ma) + (uint32_t)__popcll(w[wb] & mb);
+    for (uint64_t i = wa + 1; i < wb; ++i) c += (uint32_t)__popcll(w[i]);
+    return c;
+}
+
+// per-node distinct target / non-target assemblies from the two bitmaps + penalty (filter.cpp:89-90, 125-134)
+__global__ void k_pen_bits(sw_node *__restrict__ nodes, uint64_t n_nodes, uint64_t base, const unsigned long long *__restrict__ tbits,
+                           const unsigned long long *__restrict__ nbits, double inv_tar, double inv_neg)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint64_t a = nodes[i].start - base, b = nodes[i].stop - base;
+    const uint32_t n_tar = popc_range(tbits, a, b), n_neg = popc_range(nbits, a, b);
+    nodes[i].n_tar = n_tar;
+    nodes[i].n_neg = n_neg;
+    {
+// filter.cpp:132-134 evaluated with separate IEEE multiply / add / sqrt (no FMA contraction)
+#pragma clang fp contract(off)
+        const double ft = (double)n_tar * inv_tar;
+        const double fn = (double)n_neg * inv_neg;
+        const double omf = 1.0 - ft;
+        const double aa = omf * omf;
+        const double bb = fn * fn;
+        const double sum = aa + bb;
+        nodes[i].penalty = __dsqrt_rn(sum);
+    }
+}
+
+__global__ void k_rec_flag(const uint32_t *__restrict__ rec_asm, const uint8_t *__restrict__ is_target, uint64_t n_records,
+                           uint32_t *__restrict__ rec_flag)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_records) {
+        const uint32_t a = rec_asm[r];
+        rec_flag[r] = (a << 1) | (is_target[a] ? 1u : 0u);
+    }
+}
+
+// ---- unsort: node rank of every occurrence, back in (record_idx, pos) order --------------------------------------
+// (index, rank) pairs arrive in hash order, i.e. with random indices: scattering 4 B to rank[index] costs a 128-B HBM
+// line each (26 ms for 745 M on MI355X).  Instead the pairs are first brought into buckets of 2^14 consecutive indices
+// (a stable radix sort on the index's high bits only -- the indices are a permutation of [0, n), so bucket b is
+// exactly positions [b * 2^14, (b + 1) * 2^14)), and one workgroup per bucket scatters its pairs inside LDS and writes
+// the 64 KiB of ranks out in order.
+__global__ __launch_bounds__(1024) void k_unsort_bucket(const uint64_t *__restrict__ uval, uint64_t n, uint32_t *__restrict__ rank)
+{
+    __shared__ uint32_t sr[UNSORT_RANGE];
+    const uint64_t b0 = (uint64_t)blockIdx.x * UNSORT_RANGE;
+    const uint32_t cnt = (uint32_t)min((uint64_t)UNSORT_RANGE, n - b0);
+    for (uint32_t t = threadIdx.x; t < cnt; t += 1024) {
+        const uint64_t v = uval[b0 + t];
+        sr[(uint32_t)v & (UNSORT_RANGE - 1u)] = (uint32_t)(v >> 32);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < cnt; t += 1024) rank[b0 + t] = sr[t];
 }
 
 // ---- multi-GPU merge helpers ---------------------------------------------------------------------
@@ -329,22 +475,52 @@ __global__ void k_pen_nodes(const sw_kmer *__restrict__ kmers, uint64_t n_kmers,
 }
 
 // ---- edges --------------------------------------------------------------------------------------------
-__global__ void k_adj(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ rank,
-                      const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, uint64_t sentinel,
-                      uint64_t *__restrict__ key, uint32_t *__restrict__ val)
+// Adjacency keys of consecutive minimizers of a record (build.cpp:177-189) from the node rank and the record of every
+// occurrence, both in (record_idx, pos) order: key = (rank_lo << nb) | rank_hi, record boundaries -> sentinel (sorts last).
+// PACKED: the assembly sits above the pair in the same 64-bit key (keys-only sort), else it is a 32-bit value next to it.
+// Four consecutive occurrences per thread: 16-B loads of ranks and records, 2 x 16-B stores of keys.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_adj_keys(const uint32_t *__restrict__ rec, const uint32_t *__restrict__ rank,
+                                                  const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, uint64_t sentinel,
+                                                  uint64_t *__restrict__ key, uint32_t *__restrict__ val)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i + 1 < n) {
-        const uint32_t r0 = (uint32_t)(kmer[i] >> 32), r1 = (uint32_t)(kmer[i + 1] >> 32);
-        if (r0 == r1) {  // consecutive minimizers of one record (build.cpp:177-189)
-            uint32_t u = rank[i], v = rank[i + 1];
-            if (v < u) { const uint32_t t = u; u = v; v = t; }
-            key[i] = ((uint64_t)u << nb) | v;
-            val[i] = rec_asm[r0];
-        } else {
-            key[i] = sentinel;
-            val[i] = 0xFFFFFFFFu;
+    const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 + 1 >= n) return;
+    uint32_t r[5], k[5];
+    if (i0 + 4 < n) {
+        const uint4 rv = *reinterpret_cast<const uint4 *>(rec + i0), kv = *reinterpret_cast<const uint4 *>(rank + i0);
+        r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w; r[4] = rec[i0 + 4];
+        k[0] = kv.x; k[1] = kv.y; k[2] = kv.z; k[3] = kv.w; k[4] = rank[i0 + 4];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            r[j] = (i0 + j < n) ? rec[i0 + j] : 0xFFFFFFFFu;
+            k[j] = (i0 + j < n) ? rank[i0 + j] : 0u;
         }
+    }
+    uint64_t out[4];
+    uint32_t asmv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool pair = i0 + j + 1 < n && r[j] == r[j + 1];
+        uint32_t u = k[j], v = k[j + 1];
+        if (v < u) { const uint32_t t = u; u = v; v = t; }
+        const uint32_t a = pair ? rec_asm[r[j]] : 0xFFFFFFFFu;
+        const uint64_t pk = ((uint64_t)u << nb) | v;
+        out[j] = pair ? (PACKED ? (((uint64_t)a << (2 * nb)) | pk) : pk) : sentinel;
+        asmv[j] = a;
+    }
+    if (i0 + 4 < n) {   // all four keys exist (m = n - 1 keys): vector stores
+        *reinterpret_cast<ulonglong2 *>(key + i0) = make_ulonglong2(out[0], out[1]);
+        *reinterpret_cast<ulonglong2 *>(key + i0 + 2) = make_ulonglong2(out[2], out[3]);
+        if (!PACKED) *reinterpret_cast<uint4 *>(val + i0) = make_uint4(asmv[0], asmv[1], asmv[2], asmv[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j + 1 < n) {
+                key[i0 + j] = out[j];
+                if (!PACKED) val[i0 + j] = asmv[j];
+            }
     }
 }
 
@@ -660,36 +836,22 @@ __global__ void k_verify_edges(const sw_edge *__restrict__ edges, uint64_t n_edg
     if ((threadIdx.x & 63u) == 0 && wsum) atomicAdd(&out[8], wsum);
 }
 
-// ---- stable sort of 64-bit hashes in two phases -------------------------------------------------------
-// Phase 1: 4 radix passes over the TOP 32 bits only, carrying (low 32 bits << 32 | original index) as a 64-bit
-// payload: 24 B per element and pass for 4 passes instead of 8.  The result stays in this split form
-// (key32[q], val[q]); consumers rebuild hash = key32 << 32 | val >> 32 and index = (u32)val on the fly.
+// ---- stable sort of the occurrences by their 64-bit hash, in two phases ----------------------------------
+// Phase 1: 4 radix passes over the TOP 32 bits only (key32), carrying OccPay (low half, pos, record, original index):
+// 20 B per element and pass for 4 passes instead of 24 B for 8.  The result stays in this split form; consumers
+// rebuild hash = key32 << 32 | pay.low on the fly.
 // Phase 2: a run of equal top halves whose low halves are out of order (two different hashes sharing 32 bits:
-// ~n_nodes^2 / 2^33 runs) is repaired: the runs are located by binary search in the sorted keys, their elements
-// are pulled into a side array, sorted by the full hash (stable) and put back into the same positions --
-// positions ascend with the top half, so the outcome is exactly the stable 64-bit sort.
+// ~n_nodes^2 / 2^33 runs) is repaired in place; what the in-place pass does not take is pulled into a side array,
+// sorted by the full hash (stable) and put back into the same positions -- positions ascend with the top half, so
+// the outcome is exactly the stable 64-bit sort.
 // SEQWIN_AMD_SORT_KEYBITS=b (tests) makes phase 1 look at the top b bits only.
-__global__ void k_key32(const uint64_t *__restrict__ hash, uint32_t stride, uint64_t n, uint32_t *__restrict__ key32,
-                        uint64_t *__restrict__ val)
+__global__ void k_rot_keys(uint32_t *__restrict__ key32, uint64_t n, unsigned left)   // rotate left by `left` (1..31)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t h = hash[i * stride];
-    key32[i] = (uint32_t)(h >> 32);
-    val[i] = (h << 32) | i;
-}
-
-__global__ void k_mask_keys(uint32_t *__restrict__ key32, uint64_t n, uint32_t mask)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) key32[i] &= mask;
-}
-
-__global__ void k_restore_keys(const uint64_t *__restrict__ hash, uint32_t stride, const uint64_t *__restrict__ val,
-                               uint64_t n, uint32_t *__restrict__ key32)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) key32[i] = (uint32_t)(hash[(uint64_t)(uint32_t)val[i] * stride] >> 32);
+    if (i < n) {
+        const uint32_t k = key32[i];
+        key32[i] = (k << left) | (k >> (32u - left));
+    }
 }
 
 // descents: q > 0 in the same phase-1 run as q-1 with a smaller full hash.  Two passes without global atomics (a
@@ -700,20 +862,15 @@ constexpr uint32_t DESC_BLOCK = 1024;   // positions per workgroup (256 threads 
 
 // The two-phase sort works on a "view" of n elements ordered by (key, low): key(q) is the 32-bit phase-1 key, low(q)
 // what orders elements of equal key, load / store move a whole element.
-struct SplitView {   // hashes: key32[q] = top half, val[q] = low half << 32 | original index
+struct PayView {   // key32[q] = top half of the hash, pay[q].low = its low half
+    using Elem = OccPay;
     uint32_t *key32;
-    uint64_t *val;
+    OccPay *pay;
     __device__ uint32_t key(uint64_t q) const { return key32[q]; }
-    __device__ uint64_t low(uint64_t q) const { return val[q] >> 32; }
-    __device__ void load(uint64_t q, uint32_t &k, uint64_t &v) const { k = key32[q]; v = val[q]; }
-    __device__ void store(uint64_t q, uint32_t k, uint64_t v) const { key32[q] = k; val[q] = v; }
-};
-struct RotView {     // packed edge keys, halves swapped: kr[q] = low half << 32 | top half (keys-only radix sort on bits 0..31)
-    uint64_t *kr;
-    __device__ uint32_t key(uint64_t q) const { return (uint32_t)kr[q]; }
-    __device__ uint64_t low(uint64_t q) const { return kr[q] >> 32; }
-    __device__ void load(uint64_t q, uint32_t &k, uint64_t &v) const { const uint64_t x = kr[q]; k = (uint32_t)x; v = x >> 32; }
-    __device__ void store(uint64_t q, uint32_t k, uint64_t v) const { kr[q] = (v << 32) | k; }
+    __device__ uint64_t low(uint64_t q) const { return pay[q].low; }
+    __device__ static uint64_t low_of(const OccPay &v) { return v.low; }
+    __device__ void load(uint64_t q, uint32_t &k, OccPay &v) const { k = key32[q]; v = pay[q]; }
+    __device__ void store(uint64_t q, uint32_t k, const OccPay &v) const { key32[q] = k; pay[q] = v; }
 };
 
 template <class View>
@@ -793,7 +950,7 @@ __global__ __launch_bounds__(256) void k_list_descents(const View V, uint32_t km
 // the owner rank-sort the run in LDS by (key, low, position), a total order, so the result is the stable sort.
 // Anything the fast path does not take (more than REPAIR_MAX_DESC descents, a run longer than REPAIR_MAX_RUN)
 // raises `status` and is left to the general repair of the caller.
-constexpr uint32_t REPAIR_MAX_DESC = 1u << 18;
+constexpr uint32_t REPAIR_MAX_DESC = 1u << 22;   // 15k genomes: 7.3e5 descents (79 M nodes); 2^22 covers ~190 M nodes
 constexpr uint32_t REPAIR_MAX_RUN = 2048;
 constexpr uint32_t REPAIR_GRID = 2048;
 
@@ -874,7 +1031,7 @@ template <class View>
 __global__ __launch_bounds__(256) void k_repair_sort(const View V, const unsigned long long *__restrict__ n_desc,
                                                      const uint32_t *__restrict__ plan)
 {
-    __shared__ uint64_t sv[REPAIR_MAX_RUN];
+    __shared__ typename View::Elem sv[REPAIR_MAX_RUN];
     __shared__ uint32_t sk[REPAIR_MAX_RUN];
     const unsigned long long D = *n_desc;
     const uint32_t tid = threadIdx.x;
@@ -887,12 +1044,13 @@ __global__ __launch_bounds__(256) void k_repair_sort(const View V, const unsigne
         __syncthreads();
         for (uint32_t i = tid; i < len; i += blockDim.x) {
             const uint32_t ki = sk[i];
-            const uint64_t vi = sv[i];
+            const typename View::Elem vi = sv[i];
+            const uint64_t li = View::low_of(vi);
             uint32_t rank = 0;
             for (uint32_t j = 0; j < len; ++j) {
                 const uint32_t kj = sk[j];
-                const uint64_t vj = sv[j];
-                rank += (kj < ki || (kj == ki && (vj < vi || (vj == vi && j < i)))) ? 1u : 0u;
+                const uint64_t lj = View::low_of(sv[j]);
+                rank += (kj < ki || (kj == ki && (lj < li || (lj == li && j < i)))) ? 1u : 0u;
             }
             V.store(a + rank, ki, vi);
         }
@@ -911,8 +1069,9 @@ template <class View>
 void enqueue_repair(const View &V, uint32_t kmask, uint64_t n, uint32_t *bad, uint32_t cap, RepairState &r, hipStream_t stream)
 {
     const uint32_t n_blocks = (uint32_t)((n + DESC_BLOCK - 1) / DESC_BLOCK);
-    r.bad_q.alloc(REPAIR_MAX_DESC);
-    r.plan.alloc(3 * (size_t)REPAIR_MAX_DESC);
+    const uint32_t max_desc = (uint32_t)std::min<uint64_t>(REPAIR_MAX_DESC, std::max<uint64_t>(n, 1));
+    r.bad_q.alloc(max_desc);
+    r.plan.alloc(3 * (size_t)max_desc);
     r.n_desc.alloc(1);
     r.status.alloc(1);
     r.blk_cnt.alloc(n_blocks);
@@ -922,7 +1081,7 @@ void enqueue_repair(const View &V, uint32_t kmask, uint64_t n, uint32_t *bad, ui
     SW_HIP(hipGetLastError());
     exclusive_sum(r.blk_cnt.p, r.blk_off.p, n_blocks, (uint32_t)0, stream);
     hipLaunchKernelGGL(k_list_descents<View>, dim3(n_blocks), dim3(256), 0, stream, V, kmask, n, r.blk_cnt.p, r.blk_off.p,
-                       n_blocks, bad, cap, r.bad_q.p, REPAIR_MAX_DESC, r.n_desc.p);
+                       n_blocks, bad, cap, r.bad_q.p, max_desc, r.n_desc.p);
     hipLaunchKernelGGL(k_repair_plan<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, kmask, n, r.bad_q.p, r.n_desc.p,
                        r.plan.p, r.status.p);
     hipLaunchKernelGGL(k_repair_sort<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, r.n_desc.p, r.plan.p);
@@ -957,9 +1116,9 @@ __global__ void k_bad_runs(const uint32_t *__restrict__ bad, uint32_t n_bad, con
 }
 
 // sub[t] = element t of the concatenated bad runs (run_off = exclusive sum of run_len; null: identity, everything)
-__global__ void k_gather_sub(const uint32_t *__restrict__ key32, const uint64_t *__restrict__ val,
+__global__ void k_gather_sub(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay,
                              const uint32_t *__restrict__ run_start, const uint64_t *__restrict__ run_off, uint32_t n_bad,
-                             uint64_t n_sub, uint64_t *__restrict__ sub_h, uint32_t *__restrict__ sub_p,
+                             uint64_t n_sub, uint64_t *__restrict__ sub_h, OccPay *__restrict__ sub_v,
                              uint32_t *__restrict__ pos)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -974,37 +1133,36 @@ __global__ void k_gather_sub(const uint32_t *__restrict__ key32, const uint64_t 
         q = (uint64_t)run_start[lo] + (t - run_off[lo]);
         pos[t] = (uint32_t)q;
     }
-    const uint64_t v = val[q];
-    sub_h[t] = ((uint64_t)key32[q] << 32) | (v >> 32);
-    sub_p[t] = (uint32_t)v;
+    const OccPay v = pay[q];
+    sub_h[t] = ((uint64_t)key32[q] << 32) | v.low;
+    sub_v[t] = v;
 }
 
-__global__ void k_scatter_sub(const uint64_t *__restrict__ sub_h, const uint32_t *__restrict__ sub_p,
+__global__ void k_scatter_sub(const uint64_t *__restrict__ sub_h, const OccPay *__restrict__ sub_v,
                               const uint32_t *__restrict__ pos, uint64_t n_sub, uint32_t *__restrict__ key32,
-                              uint64_t *__restrict__ val)
+                              OccPay *__restrict__ pay)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_sub) return;
     const uint64_t q = pos ? pos[t] : t;
-    const uint64_t h = sub_h[t];
-    key32[q] = (uint32_t)(h >> 32);
-    val[q] = (h << 32) | sub_p[t];
+    key32[q] = (uint32_t)(sub_h[t] >> 32);
+    pay[q] = sub_v[t];   // (its low half is the hash's: it travelled with the element)
 }
 
-struct SplitHeadFlag {   // head-of-run flag over the split (key32, val) form of the sorted hashes
+struct PayHeadFlag {   // head-of-run flag over the split (key32, pay.low) form of the sorted hashes
     const uint32_t *key32;
-    const uint64_t *val;
+    const OccPay *pay;
     __host__ __device__ uint32_t operator()(uint64_t s) const
     {
-        return (s == 0 || key32[s] != key32[s - 1] || (val[s] >> 32) != (val[s - 1] >> 32)) ? 1u : 0u;
+        return (s == 0 || key32[s] != key32[s - 1] || pay[s].low != pay[s - 1].low) ? 1u : 0u;
     }
 };
 
-struct HashSort {
-    DevArray<uint32_t> key_a, key_b;   // phase-1 double buffers (key_a / val_a may be handed in prefilled)
-    DevArray<uint64_t> val_a, val_b;
-    const uint32_t *key32 = nullptr;   // result: top halves, ascending
-    const uint64_t *val = nullptr;     // result: low half << 32 | original index (stable)
+struct PaySort {
+    DevArray<uint32_t> key_a, key_b;   // phase-1 double buffers; key_a / pay_a are handed in filled
+    DevArray<OccPay> pay_a, pay_b;
+    uint32_t *key32 = nullptr;         // result: top halves, ascending
+    OccPay *pay = nullptr;             // result: low half, pos, record, original index (stable)
     uint32_t *spare = nullptr;         // n free u32 for the caller (the other key buffer)
     uint64_t n_repaired = 0;
     // repair bookkeeping (device): keys of the descents for the general repair, and the in-place repair's state
@@ -1014,47 +1172,40 @@ struct HashSort {
     uint64_t n = 0;
 };
 
-// Phases 1 and 2 are enqueued without any host round trip; the caller must call sort_hashes_settle() once the
+// Phases 1 and 2 are enqueued without any host round trip; the caller must call sort_pay_settle() once the
 // stream is synchronised (it reads `status`) before it relies on the order.
-void sort_hashes(const uint64_t *hash, uint32_t stride, uint64_t n, bool prefilled, hipStream_t stream, HashSort &o)
+void sort_pay(uint64_t n, hipStream_t stream, PaySort &o)
 {
     unsigned bits = 32;
     if (const char *e = getenv("SEQWIN_AMD_SORT_KEYBITS")) {
         const int b = atoi(e);
         if (b >= 1 && b <= 32) bits = (unsigned)b;
     }
-    const uint32_t kmask = ~0u << (32 - bits);
-    o.kmask = kmask;
+    o.kmask = ~0u << (32 - bits);
     o.n = n;
-    if (!prefilled) {
-        o.key_a.alloc(n);
-        o.val_a.alloc(n);
-        hipLaunchKernelGGL(k_key32, dim3(blocks_for(n)), dim3(TPB), 0, stream, hash, stride, n, o.key_a.p, o.val_a.p);
-        SW_HIP(hipGetLastError());
-    }
-    if (~kmask) {   // test knob: sort on cleared low key bits (always over 32 bits), then restore the true keys
-        hipLaunchKernelGGL(k_mask_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, o.key_a.p, n, kmask);
-        SW_HIP(hipGetLastError());
-    }
     o.key_b.alloc(n);
-    o.val_b.alloc(n);
+    o.pay_b.alloc(n);
     uint32_t *keys = o.key_a.p, *keys_alt = o.key_b.p;
-    uint64_t *vals = o.val_a.p, *vals_alt = o.val_b.p;
-    sort_pairs(keys, keys_alt, vals, vals_alt, n, 0, 32, stream);
-    if (~kmask) {
-        hipLaunchKernelGGL(k_restore_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, hash, stride, vals, n, keys);
+    OccPay *vals = o.pay_a.p, *vals_alt = o.pay_b.p;
+    if (bits < 32) {   // test knob: the top `bits` bits rotated down to bit 0, sorted there, rotated back (no bit is lost)
+        hipLaunchKernelGGL(k_rot_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, n, bits);
+        SW_HIP(hipGetLastError());
+    }
+    sort_pairs(keys, keys_alt, vals, vals_alt, n, 0, bits, stream);
+    if (bits < 32) {
+        hipLaunchKernelGGL(k_rot_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, n, 32 - bits);
         SW_HIP(hipGetLastError());
     }
     o.key32 = keys;
-    o.val = vals;
+    o.pay = vals;
     o.spare = keys_alt;
     o.cap = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(1u << 16, n / 16));
     o.bad.alloc(o.cap);
-    enqueue_repair(SplitView{keys, vals}, kmask, n, o.bad.p, o.cap, o.rep, stream);
+    enqueue_repair(PayView{keys, vals}, o.kmask, n, o.bad.p, o.cap, o.rep, stream);
 }
 
 // General repair, for what the in-place pass left (status != 0).  Returns true if the order changed.
-bool sort_hashes_settle(HashSort &o, unsigned long long D, uint32_t status, hipStream_t stream)
+bool sort_pay_settle(PaySort &o, unsigned long long D, uint32_t status, hipStream_t stream)
 {
     if (D == 0 || status == 0) {
         o.n_repaired = D;
@@ -1062,8 +1213,8 @@ bool sort_hashes_settle(HashSort &o, unsigned long long D, uint32_t status, hipS
     }
     const uint64_t n = o.n;
     const uint32_t kmask = o.kmask, cap = o.cap;
-    uint32_t *keys = const_cast<uint32_t *>(o.key32);
-    uint64_t *vals = const_cast<uint64_t *>(o.val);
+    uint32_t *keys = o.key32;
+    OccPay *vals = o.pay;
     DevArray<uint32_t> &bad = o.bad;
     uint64_t n_sub = n;
     DevArray<uint32_t> run_start, run_len, pos;
@@ -1088,12 +1239,12 @@ bool sort_hashes_settle(HashSort &o, unsigned long long D, uint32_t status, hipS
         pos.alloc(n_sub);
     }
     DevArray<uint64_t> sh0(n_sub), sh1(n_sub);
-    DevArray<uint32_t> sp0(n_sub), sp1(n_sub);
+    DevArray<OccPay> sp0(n_sub), sp1(n_sub);
     hipLaunchKernelGGL(k_gather_sub, dim3(blocks_for(n_sub)), dim3(TPB), 0, stream, keys, vals, run_start.p,
                        listed ? run_off.p : (const uint64_t *)nullptr, (uint32_t)(listed ? D : 0), n_sub, sh0.p, sp0.p, pos.p);
     SW_HIP(hipGetLastError());
     uint64_t *sk = sh0.p, *sk_alt = sh1.p;
-    uint32_t *sv = sp0.p, *sv_alt = sp1.p;
+    OccPay *sv = sp0.p, *sv_alt = sp1.p;
     sort_pairs(sk, sk_alt, sv, sv_alt, n_sub, 0, 64, stream);
     hipLaunchKernelGGL(k_scatter_sub, dim3(blocks_for(n_sub)), dim3(TPB), 0, stream, sk, sv,
                        listed ? pos.p : (const uint32_t *)nullptr, n_sub, keys, vals);
@@ -1103,46 +1254,101 @@ bool sort_hashes_settle(HashSort &o, unsigned long long D, uint32_t status, hipS
     return true;
 }
 
-// head counts of the sorted hashes into hs.spare; returns the number of distinct hashes (one host sync, shared with
+// head counts of the sorted hashes into ps.spare; returns the number of distinct hashes (one host sync, shared with
 // the repair status)
-uint32_t sorted_head_counts(HashSort &hs, uint64_t n, hipStream_t stream)
+uint32_t sorted_head_counts(PaySort &ps, uint64_t n, hipStream_t stream)
 {
-    uint32_t *cum = hs.spare;
+    uint32_t *cum = ps.spare;
     uint32_t n_nodes = 0, status = 0;
     unsigned long long D = 0;
     for (int pass = 0; pass < 2; ++pass) {
         inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
-                                                       SplitHeadFlag{hs.key32, hs.val}),
+                                                       PayHeadFlag{ps.key32, ps.pay}),
                       cum, n, (uint32_t)0, stream);
         SW_HIP(hipMemcpyAsync(&n_nodes, cum + (n - 1), 4, hipMemcpyDeviceToHost, stream));
         if (pass == 0) {
-            SW_HIP(hipMemcpyAsync(&status, hs.rep.status.p, 4, hipMemcpyDeviceToHost, stream));
-            SW_HIP(hipMemcpyAsync(&D, hs.rep.n_desc.p, 8, hipMemcpyDeviceToHost, stream));
+            SW_HIP(hipMemcpyAsync(&status, ps.rep.status.p, 4, hipMemcpyDeviceToHost, stream));
+            SW_HIP(hipMemcpyAsync(&D, ps.rep.n_desc.p, 8, hipMemcpyDeviceToHost, stream));
         }
         SW_HIP(hipStreamSynchronize(stream));
-        if (pass == 1 || !sort_hashes_settle(hs, D, status, stream)) break;
+        if (pass == 1 || !sort_pay_settle(ps, D, status, stream)) break;
     }
+    return n_nodes;
+}
+
+// Sorted occurrences -> kmers, nodes (hash, start, stop; counts zero), node rank of every occurrence in ORIGINAL order
+// (rank_out, may be null), and -- with rec_flag -- the first-of-assembly bitmaps for the counts.  ps.key_a / ps.pay_a hold
+// the n occurrences on entry.  Returns the number of nodes.
+uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_t *rec_flag, hipStream_t stream, sw_index &ix,
+                           uint32_t *rank_out, DevArray<unsigned long long> *tbits, DevArray<unsigned long long> *nbits)
+{
+    sort_pay(n, stream, ps);
+    const uint32_t n_nodes = sorted_head_counts(ps, n, stream);   // into the spare key buffer
+    ix.n_nodes = n_nodes;
+    ix.nodes.alloc(n_nodes);
+    const bool direct = rank_out && n <= UNSORT_DIRECT_MAX;
+    DevArray<uint32_t> uk0, uk1;
+    DevArray<uint64_t> uv0, uv1;
+    if (rank_out && !direct) {
+        uk0.alloc(n);
+        uv0.alloc(n);
+    }
+    if (rec_flag) {
+        tbits->alloc((n + 63) / 64);
+        nbits->alloc((n + 63) / 64);
+    }
+    const unsigned blocks = (unsigned)((n + 256 * NODES_ITEMS - 1) / (256 * NODES_ITEMS));
+    if (rec_flag)
+        hipLaunchKernelGGL(k_nodes<true>, dim3(blocks), dim3(256), 0, stream, ps.key32, ps.pay, ps.spare, n, base, rec_flag,
+                           ix.kmers.p, ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uk0.p, uv0.p, tbits->p, nbits->p);
+    else
+        hipLaunchKernelGGL(k_nodes<false>, dim3(blocks), dim3(256), 0, stream, ps.key32, ps.pay, ps.spare, n, base,
+                           (const uint32_t *)nullptr, ix.kmers.p, ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uk0.p, uv0.p,
+                           (unsigned long long *)nullptr, (unsigned long long *)nullptr);
+    SW_HIP(hipGetLastError());
+    if (rank_out && !direct) {
+        unsigned nbit = 1;
+        while (nbit < 32 && (1ull << nbit) < n) ++nbit;          // indices < 2^nbit
+        uk1.alloc(n);
+        uv1.alloc(n);
+        uint32_t *k = uk0.p, *k_alt = uk1.p;
+        uint64_t *v = uv0.p, *v_alt = uv1.p;
+        sort_pairs(k, k_alt, v, v_alt, n, 0, nbit - UNSORT_BITS, stream);   // buckets of 2^14 consecutive indices
+        hipLaunchKernelGGL(k_unsort_bucket, dim3((unsigned)((n + UNSORT_RANGE - 1) / UNSORT_RANGE)), dim3(1024), 0, stream, v, n,
+                           rank_out);
+        SW_HIP(hipGetLastError());
+    }
+    // (the sort buffers go back to the pool here; later users are ordered after these kernels on this stream, or fenced)
     return n_nodes;
 }
 
 }  // namespace
 
-void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out)
+void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out, bool index_form)
 {
     out.n = sk.n_occ;
     if (out.n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
-    out.hash.alloc(out.n);
-    out.kmer.alloc(out.n);
-    out.key32.alloc(out.n);
-    out.val.alloc(out.n);
+    if (index_form) {
+        out.key32.alloc(out.n);
+        out.pay.alloc(out.n);
+        out.rec.alloc(out.n);
+    } else {
+        out.hash.alloc(out.n);
+        out.kmer.alloc(out.n);
+    }
     if (plan.n_tiles == 0 || out.n == 0) return;
     DevArray<uint64_t> dst_off(plan.n_tiles);
     exclusive_sum(rocprim::make_transform_iterator(sk.tile_count.p, U32ToU64()), dst_off.p, plan.n_tiles,
                   (uint64_t)0, stream);
     const uint64_t threads = (uint64_t)plan.n_tiles * 64;
-    hipLaunchKernelGGL(k_order, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
-                       sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult, out.hash.p, out.kmer.p, out.key32.p,
-                       out.val.p);
+    if (index_form)
+        hipLaunchKernelGGL(k_order<true>, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
+                           sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult, (uint64_t *)nullptr,
+                           (uint64_t *)nullptr, out.key32.p, out.pay.p, out.rec.p);
+    else
+        hipLaunchKernelGGL(k_order<false>, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
+                           sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult, out.hash.p, out.kmer.p,
+                           (uint32_t *)nullptr, (OccPay *)nullptr, (uint32_t *)nullptr);
     SW_HIP(hipGetLastError());
     // (dst_off goes back to the pool here; its next user is ordered after k_order on this stream)
 }
@@ -1219,27 +1425,9 @@ hipStream_t side_stream()   // one per (thread, current device); never destroyed
 }  // namespace
 
 namespace {
-// ---- packed edge keys: ((rank_lo << nb | rank_hi) << ab) | assembly in ONE 64-bit key when 2 nb + ab <= 64 ----
+// ---- packed edge keys: pair and assembly in ONE 64-bit key when 2 nb + ab <= 64 (k_adj_keys<true>) ----
 // (keys-only radix sort: 16 B instead of 24 B per element and pass; equal pairs of one assembly become adjacent
 // duplicates, so weight = number of distinct keys inside a pair's run)
-__global__ void k_adj_packed(const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ rank,
-                             const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, unsigned ab, uint64_t sentinel,
-                             bool asm_high, uint64_t *__restrict__ key)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i + 1 < n) {
-        const uint32_t r0 = (uint32_t)(kmer[i] >> 32), r1 = (uint32_t)(kmer[i + 1] >> 32);
-        if (r0 == r1) {
-            uint32_t u = rank[i], v = rank[i + 1];
-            if (v < u) { const uint32_t t = u; u = v; v = t; }
-            const uint64_t pair = ((uint64_t)u << nb) | v;
-            key[i] = asm_high ? (((uint64_t)rec_asm[r0] << (2 * nb)) | pair) : ((pair << ab) | rec_asm[r0]);
-        } else {
-            key[i] = sentinel;
-        }
-    }
-}
-
 struct PackedChangeAny {   // 1 where the whole key differs from its predecessor (first element: 1)
     const uint64_t *keys;
     __host__ __device__ uint32_t operator()(uint64_t s) const { return (s == 0 || keys[s] != keys[s - 1]) ? 1u : 0u; }
@@ -1381,8 +1569,8 @@ void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nod
     *err_flags_host = penalty_finish(job);
 }
 
-void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target, uint64_t n_targets,
-                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix)
+void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assemblies, OrderedOcc &occ,
+                 const uint8_t *d_is_target, uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, sw_index &ix)
 {
     const uint64_t n = occ.n;
     if (n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
@@ -1392,24 +1580,25 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
     ix.n_kmers = n;
     ix.kmers.alloc(n);
     DevArray<uint32_t> rank(n);
-    // -- nodes: stable radix sort of (out_hash -> original index), run-length heads ------------------
+    // The counts come from two first-of-assembly bitmaps written while the sorted occurrences stream by (k_nodes); the
+    // occurrence order is this library's own stable sort, so the validation flags of filter.cpp:103-123 are only produced
+    // under SEQWIN_AMD_CHECK_ORDER=1 (then the C-ABI get_penalty's flag / prefix-sum form runs instead).
+    const bool want_counts = d_is_target != nullptr;
+    const bool check_order = want_counts && getenv("SEQWIN_AMD_CHECK_ORDER") != nullptr;
+    DevArray<uint32_t> rec_flag;
+    DevArray<unsigned long long> tbits, nbits;
+    // -- nodes: stable radix sort of the occurrences by hash, run-length heads, ranks back in stream order ------
     if (n) {
-        // the first-phase key / identity-index arrays written by k_order are consumed in place
-        HashSort hs;
-        hs.key_a = std::move(occ.key32);
-        hs.val_a = std::move(occ.val);
-        sort_hashes(occ.hash.p, 1u, n, true, stream, hs);
-        const uint32_t n_nodes = sorted_head_counts(hs, n, stream);   // into the spare key buffer
-        const uint32_t *keys = hs.key32;
-        const uint64_t *vals = hs.val;
-        const uint32_t *cum = hs.spare;
-        ix.n_nodes = n_nodes;
-        ix.nodes.alloc(n_nodes);
-        hipLaunchKernelGGL(k_nodes, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, cum, occ.kmer.p, 1u, n,
-                           (uint64_t)0, ix.kmers.p, ix.nodes.p, rank.p);
-        SW_HIP(hipGetLastError());
-        // (the sort buffers go back to the pool here; later users are ordered after k_nodes: this stream, or the
-        //  counts stream, which waits for ev[1])
+        if (want_counts && !check_order) {
+            rec_flag.alloc(n_records);
+            hipLaunchKernelGGL(k_rec_flag, dim3(blocks_for(n_records)), dim3(TPB), 0, stream, d_rec_asm, d_is_target, n_records,
+                               rec_flag.p);
+            SW_HIP(hipGetLastError());
+        }
+        PaySort ps;   // the sort input written by k_order is consumed in place
+        ps.key_a = std::move(occ.key32);
+        ps.pay_a = std::move(occ.pay);
+        group_occurrences(ps, n, 0, rec_flag.p, stream, ix, rank.p, &tbits, &nbits);
     } else {
         ix.n_nodes = 0;
         ix.nodes.alloc(0);
@@ -1417,15 +1606,23 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
     SW_HIP(hipEventRecord(ev[1], stream));
 
     // -- per-node target / non-target assembly counts + penalty (filter.cpp:62-136), on a second stream
-    //    so that it overlaps the edge stage (both only read kmers / ranks; nodes fields are disjoint) -----
+    //    so that it overlaps the edge stage (nodes fields are disjoint) -----
     PenaltyJob pen;
     hipStream_t side = side_stream();
-    if (d_is_target && ix.n_nodes) {
+    bool forked = false;
+    if (want_counts && ix.n_nodes) {
         alloc_fork(side);   // blocks released from here on are fenced against the counts stream as well
+        forked = true;
         SW_HIP(hipStreamWaitEvent(side, ev[1], 0));
         SW_HIP(hipEventRecord(ev[4], side));
-        penalty_launch(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, b.d_rec_asm.p, b.n_records, d_is_target, n_targets,
-                       n_non_targets, side, pen, true);
+        if (check_order) {
+            penalty_launch(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, d_rec_asm, n_records, d_is_target, n_targets, n_non_targets,
+                           side, pen);
+        } else {
+            hipLaunchKernelGGL(k_pen_bits, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, side, ix.nodes.p, ix.n_nodes, (uint64_t)0,
+                               tbits.p, nbits.p, 1.0 / (double)n_targets, 1.0 / (double)n_non_targets);   // filter.cpp:89-90
+            SW_HIP(hipGetLastError());
+        }
         SW_HIP(hipEventRecord(ev[5], side));
     }
     SW_HIP(hipEventRecord(ev[2], stream));
@@ -1437,42 +1634,42 @@ void build_index(const sw_batch &b, OrderedOcc &occ, const uint8_t *d_is_target,
         unsigned nb = 1;
         while (((1ull << nb) - 1ull) < ix.n_nodes) ++nb;  // n_nodes <= 2^nb - 1, so (2^nb-1, 2^nb-1) is free
         unsigned ab = 1;
-        while ((1ull << ab) < b.host.n_assemblies) ++ab;     // assembly index < 2^ab
+        while ((1ull << ab) < n_assemblies) ++ab;            // assembly index < 2^ab
+        const unsigned adj_blocks = (unsigned)((n + 1023) / 1024);   // 4 occurrences per thread
         if (2 * nb + ab <= 64 && !getenv("SEQWIN_AMD_NO_PACKED_EDGES")) {
             // pair and assembly in one 64-bit key: keys-only sort
             const unsigned tb = 2 * nb + ab;
             const uint64_t sentinel = (tb == 64) ? ~0ull : ((1ull << tb) - 1ull);
             DevArray<uint64_t> k0(m), k1(m);
-            hipLaunchKernelGGL(k_adj_packed, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, b.d_rec_asm.p, n, nb,
-                               ab, sentinel, true, k0.p);
+            hipLaunchKernelGGL(k_adj_keys<true>, dim3(adj_blocks), dim3(256), 0, stream, occ.rec.p, rank.p, d_rec_asm, n, nb,
+                               sentinel, k0.p, (uint32_t *)nullptr);
             SW_HIP(hipGetLastError());
             edges_from_packed(k0.p, k1.p, m, sentinel, nb, ab, nullptr, stream, ix, true);
         } else {
             const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
             DevArray<uint64_t> k0(m), k1(m);
             DevArray<uint32_t> v0(m), v1(m);
-            hipLaunchKernelGGL(k_adj, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, b.d_rec_asm.p, n, nb,
+            hipLaunchKernelGGL(k_adj_keys<false>, dim3(adj_blocks), dim3(256), 0, stream, occ.rec.p, rank.p, d_rec_asm, n, nb,
                                sentinel, k0.p, v0.p);
             SW_HIP(hipGetLastError());
             edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, sentinel, nb, nullptr, stream, ix);
         }
     }
     if (ix.n_edges == 0) ix.edges.alloc(0);
-    const bool had_pen = pen.active;
-    if (had_pen) {
-        const uint64_t err = penalty_finish(pen);
+    if (forked) {
+        const uint64_t err = pen.active ? penalty_finish(pen) : 0;
         SW_HIP(hipStreamWaitEvent(stream, ev[5], 0));   // the build is complete on `stream` only after the counts
         alloc_join(side);
         if (err) raise(SW_ERR_RUNTIME, "internal error: inconsistent occurrence order in device index (%llu)",
                        (unsigned long long)err);
     }
     SW_HIP(hipEventRecord(ev[3], stream));
-    SW_HIP(hipEventSynchronize(ev[3]));
+    SW_HIP(hipEventSynchronize(ev[3]));   // (the bitmaps and the rank array are released after this)
     float ms = 0.f;
     SW_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
     ix.timings.nodes_ms = ms;
     ix.timings.counts_ms = 0;
-    if (had_pen) {
+    if (forked) {
         SW_HIP(hipEventElapsedTime(&ms, ev[4], ev[5]));
         ix.timings.counts_ms = ms;                       // overlaps edges_ms
     }
@@ -1519,17 +1716,13 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
     ix.kmers.alloc(n);
     ix.n_nodes = 0;
     if (n) {
-        HashSort hs;
-        sort_hashes(d_occ_rows, 2u, n, false, stream, hs);   // stable: ties keep source-rank order
-        const uint32_t n_nodes = sorted_head_counts(hs, n, stream);
-        const uint32_t *keys = hs.key32;
-        const uint64_t *vals = hs.val;
-        const uint32_t *cum = hs.spare;
-        ix.n_nodes = n_nodes;
-        ix.nodes.alloc(n_nodes);
-        hipLaunchKernelGGL(k_nodes, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, vals, cum, d_occ_rows + 1, 2u, n,
-                           (uint64_t)0, ix.kmers.p, ix.nodes.p, d_rank_out);
+        PaySort ps;
+        ps.key_a.alloc(n);
+        ps.pay_a.alloc(n);
+        hipLaunchKernelGGL(k_rows_to_pay, dim3(blocks_for(n)), dim3(TPB), 0, stream, d_occ_rows, n, ps.key_a.p, ps.pay_a.p);
         SW_HIP(hipGetLastError());
+        // stable: ties keep source-rank order; d_rank_out[j] = node rank of received row j
+        group_occurrences(ps, n, 0, nullptr, stream, ix, d_rank_out, nullptr, nullptr);
         SW_HIP(hipStreamSynchronize(stream));
     } else {
         ix.nodes.alloc(0);
