@@ -28,6 +28,11 @@ namespace {
 
 constexpr int TPB = 256;
 inline unsigned blocks_for(uint64_t n, int per = TPB) { return (unsigned)((n + per - 1) / per); }
+inline bool ranks_by_table()
+{
+    const char *e = getenv("SEQWIN_AMD_RANKS");
+    return e && !strcmp(e, "table");
+}
 
 // ---- rocPRIM wrappers (temp storage from the caching allocator) ------------------------------
 template <class K, class V>
@@ -120,6 +125,7 @@ __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t 
             p.idx = (uint32_t)(dst + i);
             pay[dst + i] = p;
             rec[dst + i] = p.rec;
+            if (hash) hash[dst + i] = h;   // (only for the hash-table rank lookup, SEQWIN_AMD_RANKS=table)
         } else {
             hash[dst + i] = h;
             kmer[dst + i] = km;
@@ -159,7 +165,9 @@ __global__ void k_iota(uint32_t *v, uint64_t n)
 constexpr int NODES_ITEMS = 8;
 constexpr uint32_t UNSORT_BITS = 14;                 // the unsort's last step handles 2^14 consecutive indices in LDS
 constexpr uint32_t UNSORT_RANGE = 1u << UNSORT_BITS;
-constexpr uint64_t UNSORT_DIRECT_MAX = 1ull << 20;   // up to here the rank array stays in L2: scatter directly
+constexpr uint64_t UNSORT_DIRECT_MAX = 1ull << 25;   // up to here (128 MiB of ranks) the array stays in the 256 MiB Infinity Cache and a
+                                                     // direct scatter is as fast (measured: 24 M occurrences 7.74 against 7.84 ms per build;
+                                                     // 745 M: 239.0 against 232.3 ms)
 
 template <bool BITS>
 __global__ __launch_bounds__(256) void k_nodes(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay,
@@ -271,6 +279,63 @@ __global__ void k_rec_flag(const uint32_t *__restrict__ rec_asm, const uint8_t *
     if (r < n_records) {
         const uint32_t a = rec_asm[r];
         rec_flag[r] = (a << 1) | (is_target[a] ? 1u : 0u);
+    }
+}
+
+// ---- open-addressing table hash -> node rank (the ankerl::unordered_dense role, build.cpp:66-73, 153-168) ----------
+// Linear probing over 16-B slots {hash, rank}, claimed with a 64-bit atomicCAS on the hash word, load <= 0.5.  Built
+// from the distinct node hashes once the sort has produced them, then probed once per occurrence to bring the node
+// rank to (record_idx, pos) order -- the alternative to the unsort below, kept behind SEQWIN_AMD_RANKS=table because
+// it measured slower (one random 128-B line per occurrence against two streaming passes).
+constexpr unsigned long long TABLE_EMPTY = ~0ull;
+__device__ __forceinline__ uint64_t table_mix(uint64_t x)   // the hashes are already uniform: a cheap fold is enough
+{
+    return x ^ (x >> 29);
+}
+
+__global__ void k_table_build(const sw_node *__restrict__ nodes, uint64_t n_nodes, ulonglong2 *__restrict__ slots, uint64_t mask,
+                              uint32_t *__restrict__ rank_of_empty_key)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_nodes) return;
+    const unsigned long long h = nodes[r].hash;
+    if (h == TABLE_EMPTY) {   // the one hash value that cannot be stored lives beside the table
+        *rank_of_empty_key = (uint32_t)r;
+        return;
+    }
+    uint64_t s = table_mix(h) & mask;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&slots[s].x, TABLE_EMPTY, h);
+        if (old == TABLE_EMPTY) {   // claimed (node hashes are distinct: `old == h` cannot happen)
+            slots[s].y = r;
+            return;
+        }
+        s = (s + 1) & mask;
+    }
+}
+
+__global__ void k_table_lookup(const uint64_t *__restrict__ hash, uint64_t n, const ulonglong2 *__restrict__ slots, uint64_t mask,
+                               const uint32_t *__restrict__ rank_of_empty_key, uint32_t *__restrict__ rank)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long h = hash[i];
+    if (h == TABLE_EMPTY) {
+        rank[i] = *rank_of_empty_key;
+        return;
+    }
+    uint64_t s = table_mix(h) & mask;
+    for (;;) {
+        const ulonglong2 e = slots[s];
+        if (e.x == h) {
+            rank[i] = (uint32_t)e.y;
+            return;
+        }
+        if (e.x == TABLE_EMPTY) {   // cannot happen for a hash of this index; never spin
+            rank[i] = 0xFFFFFFFFu;
+            return;
+        }
+        s = (s + 1) & mask;
     }
 }
 
@@ -1286,7 +1351,9 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     const uint32_t n_nodes = sorted_head_counts(ps, n, stream);   // into the spare key buffer
     ix.n_nodes = n_nodes;
     ix.nodes.alloc(n_nodes);
-    const bool direct = rank_out && n <= UNSORT_DIRECT_MAX;
+    uint64_t direct_max = UNSORT_DIRECT_MAX;
+    if (const char *e = getenv("SEQWIN_AMD_UNSORT_DIRECT")) direct_max = 1ull << std::min(40, std::max(0, atoi(e)));   // A/B, tests
+    const bool direct = rank_out && n <= direct_max;
     DevArray<uint32_t> uk0, uk1;
     DevArray<uint64_t> uv0, uv1;
     if (rank_out && !direct) {
@@ -1313,7 +1380,7 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
         uv1.alloc(n);
         uint32_t *k = uk0.p, *k_alt = uk1.p;
         uint64_t *v = uv0.p, *v_alt = uv1.p;
-        sort_pairs(k, k_alt, v, v_alt, n, 0, nbit - UNSORT_BITS, stream);   // buckets of 2^14 consecutive indices
+        if (nbit > UNSORT_BITS) sort_pairs(k, k_alt, v, v_alt, n, 0, nbit - UNSORT_BITS, stream);   // buckets of 2^14 consecutive indices
         hipLaunchKernelGGL(k_unsort_bucket, dim3((unsigned)((n + UNSORT_RANGE - 1) / UNSORT_RANGE)), dim3(1024), 0, stream, v, n,
                            rank_out);
         SW_HIP(hipGetLastError());
@@ -1322,16 +1389,35 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     return n_nodes;
 }
 
+// node rank of every occurrence through the open-addressing table (A/B alternative to the unsort)
+void ranks_from_table(const sw_index &ix, const uint64_t *hash, uint64_t n, hipStream_t stream, uint32_t *rank)
+{
+    uint64_t cap = 1024;
+    while (cap < 2 * ix.n_nodes) cap <<= 1;   // load <= 0.5
+    DevArray<ulonglong2> slots(cap);
+    DevArray<uint32_t> special(1);
+    SW_HIP(hipMemsetAsync(slots.p, 0xFF, cap * sizeof(ulonglong2), stream));
+    SW_HIP(hipMemsetAsync(special.p, 0xFF, 4, stream));
+    if (ix.n_nodes)
+        hipLaunchKernelGGL(k_table_build, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, slots.p, cap - 1,
+                           special.p);
+    hipLaunchKernelGGL(k_table_lookup, dim3(blocks_for(n)), dim3(TPB), 0, stream, hash, n, slots.p, cap - 1, special.p, rank);
+    SW_HIP(hipGetLastError());
+    SW_HIP(hipStreamSynchronize(stream));   // the table is released on return
+}
+
 }  // namespace
 
 void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out, bool index_form)
 {
     out.n = sk.n_occ;
     if (out.n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
+    const bool table_ranks = index_form && ranks_by_table();
     if (index_form) {
         out.key32.alloc(out.n);
         out.pay.alloc(out.n);
         out.rec.alloc(out.n);
+        if (table_ranks) out.hash.alloc(out.n);
     } else {
         out.hash.alloc(out.n);
         out.kmer.alloc(out.n);
@@ -1343,8 +1429,8 @@ void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, Ord
     const uint64_t threads = (uint64_t)plan.n_tiles * 64;
     if (index_form)
         hipLaunchKernelGGL(k_order<true>, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
-                           sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult, (uint64_t *)nullptr,
-                           (uint64_t *)nullptr, out.key32.p, out.pay.p, out.rec.p);
+                           sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult,
+                           table_ranks ? out.hash.p : (uint64_t *)nullptr, (uint64_t *)nullptr, out.key32.p, out.pay.p, out.rec.p);
     else
         hipLaunchKernelGGL(k_order<false>, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
                            sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult, out.hash.p, out.kmer.p,
@@ -1598,7 +1684,9 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
         PaySort ps;   // the sort input written by k_order is consumed in place
         ps.key_a = std::move(occ.key32);
         ps.pay_a = std::move(occ.pay);
-        group_occurrences(ps, n, 0, rec_flag.p, stream, ix, rank.p, &tbits, &nbits);
+        const bool by_table = occ.hash.p != nullptr;   // SEQWIN_AMD_RANKS=table (order_tuples then kept the hashes)
+        group_occurrences(ps, n, 0, rec_flag.p, stream, ix, by_table ? nullptr : rank.p, &tbits, &nbits);
+        if (by_table) ranks_from_table(ix, occ.hash.p, n, stream, rank.p);
     } else {
         ix.n_nodes = 0;
         ix.nodes.alloc(0);

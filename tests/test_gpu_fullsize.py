@@ -67,6 +67,9 @@ KNOBS = [
     {"SEQWIN_AMD_SORT_KEYBITS": "10"},                                     # many shared phase-1 keys: general repair
     {"SEQWIN_AMD_SORT_KEYBITS": "20", "SEQWIN_AMD_CHECK_ORDER": "1"},      # in-place repair + order validation flags
     {"SEQWIN_AMD_NO_PACKED_EDGES": "1", "SEQWIN_AMD_SORT_KEYBITS": "10", "SEQWIN_AMD_CHECK_ORDER": "1"},
+    {"SEQWIN_AMD_UNSORT_DIRECT": "4"},                                     # node ranks return through the bucketed unsort (default above 2^25 occurrences)
+    {"SEQWIN_AMD_UNSORT_DIRECT": "4", "SEQWIN_AMD_SORT_KEYBITS": "12", "SEQWIN_AMD_NO_PACKED_EDGES": "1"},
+    {"SEQWIN_AMD_RANKS": "table"},                                         # ... or through the open-addressing hash table (A/B path)
 ]
 
 
