@@ -78,8 +78,11 @@ int sw_set_device(int device);
  * (python_bindings.cpp:50-90) = seqwin::build (cpp/include/seqwin/build.hpp:22-28,
  * cpp/src/seqwin/build.cpp:330-394).  FASTA/gz files are read and 2-bit packed on `n_cpu` host
  * threads, sketched and indexed on the GPU, and the result is copied back into *out.
- * `low_memory` is accepted for interface compatibility; results are identical either way
- * (reference tests/smoke/test_graph.py:222-245).
+ * `low_memory` (build.cpp:264-325: the reference recomputes the sketches in a second pass to keep the peak down) streams the
+ * assemblies through HBM in consecutive chunks of SEQWIN_AMD_LOWMEM_CHUNK_MBP Mbp (default 4096): only 24 B per
+ * minimizer of a finished chunk stay resident, and the index is built once from the concatenated tuple stream -- results are
+ * identical either way (reference tests/smoke/test_graph.py:222-245).  The same route is taken without the flag when the
+ * files exceed SEQWIN_AMD_HBM_BUDGET_GB (if set).
  * Errors: k < 3, k > 65535, w < 1, w > SW_MAX_WINDOW -> SW_ERR_VALUE; unreadable file, FASTA
  * without header, > 2^32-1 records or bases per record -> SW_ERR_RUNTIME (build.cpp:136-147,337-339;
  * fasta_reader.cpp:69-71,99-102).
@@ -99,7 +102,14 @@ int sw_graph_sizes(const sw_graph *g, uint64_t *n_kmers, uint64_t *n_nodes, uint
 int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *edges,
                     uint32_t *record_offsets, char *ids_blob);
 
+/* Frees the graph handle.  The device index of an EXPORTED graph stays resident (one per process, replaced by the next
+ * sw_build): sw_get_penalty / sw_filter_kmers work on it instead of uploading the caller's arrays again when those are
+ * still the exported ones (same sizes and position-dependent checksums, verified on the host).  sw_release_resident()
+ * gives that HBM back at once; SEQWIN_AMD_NO_RESIDENT=1 disables the mechanism. */
 void sw_graph_free(sw_graph *g);
+void sw_release_resident(void);
+/* out[3] = { occurrences of the resident index (0: none), sw_get_penalty calls served from it, sw_filter_kmers calls served from it } */
+void sw_resident_stats(uint64_t *out);
 
 /*
  * Replaces `_get_penalty_native(kmers, nodes, record_offsets, is_targets, n_cpu)`
@@ -115,7 +125,8 @@ int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint6
 /*
  * Replaces `_filter_kmers_native(kmers, nodes, used_hashes)` (python_bindings.cpp:137-168) =
  * seqwin::filter_kmers (cpp/src/seqwin/filter.cpp:139-201).  Two-phase: call with kmers_out ==
- * nodes_out == NULL to obtain the output sizes, then again with buffers of those sizes.
+ * nodes_out == NULL to obtain the output sizes, then again with buffers of those sizes; the second call of the same
+ * thread with the same arguments only copies the result of the first out (one upload, one compute per pair).
  */
 int sw_filter_kmers(const sw_kmer *kmers, uint64_t n_kmers, const sw_node *nodes, uint64_t n_nodes,
                     const uint64_t *used_hashes, uint64_t n_used, sw_kmer *kmers_out, sw_node *nodes_out,

@@ -412,11 +412,61 @@ __global__ void k_synth(uint32_t *packed, uint64_t words_per_record, uint64_t n_
 }
 
 struct GraphHost {   // result of sw_build: arrays stay in HBM until sw_graph_export copies them into caller buffers
-    sw_index ix;
+    std::unique_ptr<sw_index> ixp{new sw_index};
+    sw_index &ix = *ixp;
     std::vector<uint32_t> record_offsets;
     std::string ids_blob;
     uint64_t n_assemblies = 0, total_bp = 0;
+    bool exported = false;          // sw_graph_export has filled caller arrays from this index
+    uint64_t identity[2] = {0, 0};  // device_identity at that moment
 };
+
+// ---- the index of the last exported sw_build stays resident --------------------------------------------------------
+// Seqwin calls get_penalty on the arrays build() has just returned (kmers.py:396-402).  Uploading them again is the
+// most expensive part of that call (6 GB of kmers at 15k genomes, from pageable memory), so sw_graph_free hands the
+// device index of an exported graph to this slot instead of releasing it, and sw_get_penalty works on it when the
+// caller's arrays are still the exported ones -- same sizes and the same position-dependent checksum of kmers and of
+// the nodes' hash / start / stop, computed on the host with the caller's n_cpu threads (reading 6 GB at memory speed
+// instead of pinning and copying it).  One index per process; replaced by the next sw_build's, dropped by
+// sw_release_resident(); SEQWIN_AMD_NO_RESIDENT=1 disables it.
+struct Resident {
+    std::mutex mu;
+    std::unique_ptr<sw_index> ix;
+    uint64_t kmer_sum = 0, node_sum = 0;
+    uint64_t penalty_hits = 0, filter_hits = 0;   // calls served from the resident arrays (sw_resident_stats)
+};
+Resident &resident()
+{
+    static Resident *r = new Resident;   // leaked on purpose (see pool())
+    return *r;
+}
+
+// the sums of k_identity (index.hip) over host arrays, on n_threads threads
+void host_identity(const sw_kmer *kmers, uint64_t nk, const sw_node *nodes, uint64_t nn, unsigned n_threads, uint64_t *sums2)
+{
+    const uint64_t G = 0x9E3779B97F4A7C15ULL;
+    n_threads = std::max(1u, std::min(n_threads, 64u));
+    if (nk + nn < (1u << 20)) n_threads = 1;
+    std::vector<uint64_t> pa(n_threads, 0), pb(n_threads, 0);
+    auto work = [&](unsigned t) {
+        uint64_t a = 0, b = 0;
+        for (uint64_t i = nk * t / n_threads, e = nk * (t + 1) / n_threads; i < e; ++i)
+            a += mix64(i * G + ((uint64_t)kmers[i].pos | ((uint64_t)kmers[i].record_idx << 32)));
+        for (uint64_t i = nn * t / n_threads, e = nn * (t + 1) / n_threads; i < e; ++i)
+            b += mix64(i * G + nodes[i].hash) + mix64(nodes[i].start * 3 + 1) + mix64(nodes[i].stop * 5 + 2);
+        pa[t] = a;
+        pb[t] = b;
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    sums2[0] = sums2[1] = 0;
+    for (unsigned t = 0; t < n_threads; ++t) {
+        sums2[0] += pa[t];
+        sums2[1] += pb[t];
+    }
+}
 
 void check_targets(const uint8_t *is_targets, uint64_t n, uint64_t *n_tar, uint64_t *n_neg)
 {
@@ -1000,10 +1050,82 @@ int sw_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *st
     });
 }
 
+// low_memory (build.cpp:264-325 keeps the peak down by recomputing the sketches in a second pass): here the assemblies
+// stream through HBM in consecutive chunks -- ingest, upload, sketch and order one chunk, keep only its 24 B per
+// minimizer, release its packed bases / stage slots / host buffers -- and the index is built once from the concatenated
+// tuple stream.  That stream is exactly what the one-shot build sorts, so the result is identical by construction.
+static void build_chunked(const char *const *paths, size_t n_paths, uint64_t k, uint64_t w, uint64_t n_cpu, uint64_t chunk_bp,
+                          GraphHost &g, double *ingest_ms, double *device_ms)
+{
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    StreamScope scope(nullptr);
+    std::vector<OrderedOcc> chunks;
+    std::vector<uint64_t> rec_base;
+    std::vector<uint32_t> rec_asm;
+    g.record_offsets.assign(1, 0);
+    uint64_t n_records = 0;
+    size_t a0 = 0;
+    while (a0 < n_paths) {
+        // consecutive assemblies up to ~chunk_bp bases, estimated from the file sizes (gz: x4), at least one
+        size_t a1 = a0;
+        uint64_t est = 0;
+        while (a1 < n_paths && (a1 == a0 || est < chunk_bp)) {
+            uint64_t sz = 0;
+            if (FILE *f = fopen(paths[a1], "rb")) {
+                if (fseek(f, 0, SEEK_END) == 0) { const long t = ftell(f); sz = t > 0 ? (uint64_t)t : 0; }
+                fclose(f);
+            }
+            const size_t len = strlen(paths[a1]);
+            if (len > 3 && !strcmp(paths[a1] + len - 3, ".gz")) sz *= 4;
+            if (a1 > a0 && est + sz > chunk_bp) break;
+            est += sz;
+            ++a1;
+        }
+        const auto t0 = now();
+        sw_batch b;
+        SW_HIP(hipGetDevice(&b.device));
+        ingest_to_device(paths + a0, a1 - a0, n_cpu, b);
+        const auto t1 = now();
+        *ingest_ms += ms(t0, t1);
+        Plan &plan = get_plan(b, k, w);
+        SketchOut sk;
+        run_sketch(b, plan, nullptr, sk, nullptr);
+        chunks.emplace_back();
+        order_tuples(sk, plan, nullptr, chunks.back(), true);
+        SW_HIP(hipStreamSynchronize(nullptr));   // the batch and the stage arrays go out of scope
+        *device_ms += ms(t1, now());
+        rec_base.push_back(n_records);
+        const HostBatch &h = b.host;
+        for (uint64_t a = 0; a < h.n_assemblies; ++a) {
+            const uint64_t nr = h.record_offsets[a + 1] - h.record_offsets[a];
+            if (n_records + nr > UINT32_MAX) raise(SW_ERR_RUNTIME, "Total number of FASTA records exceeds uint32 range");   // build.cpp:136-147
+            rec_asm.insert(rec_asm.end(), nr, (uint32_t)(a0 + a));
+            n_records += nr;
+            g.record_offsets.push_back((uint32_t)n_records);
+        }
+        g.ids_blob += h.ids_blob;
+        g.total_bp += h.total_bp;
+        a0 = a1;
+    }
+    g.n_assemblies = n_paths;
+    const auto t2 = now();
+    OrderedOcc occ;
+    concat_occ(chunks, rec_base, nullptr, occ);
+    DevArray<uint32_t> d_rec_asm(n_records);
+    if (n_records) SW_HIP(hipMemcpyAsync(d_rec_asm.p, rec_asm.data(), n_records * 4, hipMemcpyHostToDevice, nullptr));
+    g.ix.device = 0;
+    SW_HIP(hipGetDevice(&g.ix.device));
+    build_index(d_rec_asm.p, n_records, n_paths, occ, nullptr, 0, 0, nullptr, g.ix);
+    SW_HIP(hipStreamSynchronize(nullptr));
+    *device_ms += ms(t2, now());
+}
+
 int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t kmerlen, uint64_t windowsize, uint64_t n_cpu,
              int low_memory, sw_graph **out)
 {
-    (void)low_memory;  // same result either way (reference test_graph.py:222-245); HBM holds the whole batch
     return guarded([&] {
         check_kw(kmerlen, windowsize);
         require_device();
@@ -1012,27 +1134,58 @@ int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t km
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
             return std::chrono::duration<double, std::milli>(b - a).count();
         };
-        const auto t0 = now();
-        std::unique_ptr<sw_batch> b(new sw_batch);
-        SW_HIP(hipGetDevice(&b->device));
-        ingest_to_device(assembly_paths, n_assemblies, n_cpu, *b);
-        const auto t1 = now();
-        const auto t2 = t1;
+        {   // the previous build's resident index makes room
+            Resident &r = resident();
+            std::lock_guard<std::mutex> lock(r.mu);
+            r.ix.reset();
+        }
         std::unique_ptr<sw_graph> g(new sw_graph);
-        do_index_build(*b, kmerlen, windowsize, nullptr, 0, 0, g->g.ix);
-        const auto t3 = now();
-        g->g.record_offsets = b->host.record_offsets;
-        g->g.ids_blob = b->host.ids_blob;
-        g->g.n_assemblies = b->host.n_assemblies;
-        g->g.total_bp = b->host.total_bp;
-        const auto t4 = now();
-        log_message("info", "MI355X index: %llu assemblies, %.1f Mbp -> %llu minimizers, %llu nodes, %llu edges "
-                            "(ingest + upload %.1f ms, device %.1f ms)",
-                    (unsigned long long)b->host.n_assemblies, b->host.total_bp / 1e6, (unsigned long long)g->g.ix.n_kmers,
-                    (unsigned long long)g->g.ix.n_nodes, (unsigned long long)g->g.ix.n_edges, ms(t0, t1), ms(t2, t3));
+        double ingest_ms = 0, device_ms = 0;
+        // SEQWIN_AMD_LOWMEM_CHUNK_MBP: bases (in Mbp) per chunk of a low-memory build (default 4096: ~1 GiB packed);
+        // SEQWIN_AMD_HBM_BUDGET_GB: take the chunked route whenever the files' bases would not fit this budget
+        uint64_t chunk_bp = 4096ull << 20;
+        if (const char *e = getenv("SEQWIN_AMD_LOWMEM_CHUNK_MBP")) chunk_bp = (uint64_t)std::max(0ll, atoll(e)) << 20;
+        bool chunked = low_memory != 0 && n_assemblies > 1;
+        if (const char *e = getenv("SEQWIN_AMD_HBM_BUDGET_GB")) {
+            // working set of the one-shot build: ~1 B per base at w = 200 (packed bases + stage slots + tuples and their sort buffers)
+            const uint64_t budget = (uint64_t)std::max(1.0, atof(e) * 1073741824.0);
+            uint64_t est = 0;
+            for (size_t i = 0; i < n_assemblies; ++i)
+                if (FILE *f = fopen(assembly_paths[i], "rb")) {
+                    if (fseek(f, 0, SEEK_END) == 0) { const long t = ftell(f); est += t > 0 ? (uint64_t)t : 0; }
+                    fclose(f);
+                }
+            if (est > budget && n_assemblies > 1) {
+                chunked = true;
+                chunk_bp = std::min(chunk_bp, budget / 2);
+            }
+        }
+        const auto t0 = now();
+        if (chunked) {
+            build_chunked(assembly_paths, n_assemblies, kmerlen, windowsize, n_cpu, chunk_bp, g->g, &ingest_ms, &device_ms);
+        } else {
+            std::unique_ptr<sw_batch> b(new sw_batch);
+            SW_HIP(hipGetDevice(&b->device));
+            ingest_to_device(assembly_paths, n_assemblies, n_cpu, *b);
+            const auto t1 = now();
+            do_index_build(*b, kmerlen, windowsize, nullptr, 0, 0, g->g.ix);
+            ingest_ms = ms(t0, t1);
+            device_ms = ms(t1, now());
+            g->g.record_offsets = b->host.record_offsets;
+            g->g.ids_blob = b->host.ids_blob;
+            g->g.n_assemblies = b->host.n_assemblies;
+            g->g.total_bp = b->host.total_bp;
+        }
+        // the reference logs its stages from native code (build.cpp:358-392 through log_python); two lines here
+        log_message("info", "MI355X sketch + index: %llu assemblies, %.1f Mbp%s (ingest + upload %.1f ms, device %.1f ms)",
+                    (unsigned long long)g->g.n_assemblies, g->g.total_bp / 1e6, chunked ? ", streamed through HBM in chunks" : "",
+                    ingest_ms, device_ms);
+        log_message("info", "MI355X index: %llu assemblies -> %llu minimizers, %llu nodes, %llu edges",
+                    (unsigned long long)g->g.n_assemblies, (unsigned long long)g->g.ix.n_kmers, (unsigned long long)g->g.ix.n_nodes,
+                    (unsigned long long)g->g.ix.n_edges);
         if (dbg)
-            fprintf(stderr, "[seqwin_amd] sw_build: ingest+upload %.1f ms (+%.1f), device %.1f ms, rest %.1f ms (%.1f Mbp)\n",
-                    ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), b->host.total_bp / 1e6);
+            fprintf(stderr, "[seqwin_amd] sw_build: ingest+upload %.1f ms, device %.1f ms, total %.1f ms (%.1f Mbp%s)\n", ingest_ms,
+                    device_ms, ms(t0, now()), g->g.total_bp / 1e6, chunked ? ", chunked" : "");
         *out = g.release();
     });
 }
@@ -1065,6 +1218,11 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
         if (ix.n_edges) SW_HIP(hipMemcpy(edges, ix.edges.p, ix.n_edges * sizeof(sw_edge), hipMemcpyDeviceToHost));
         memcpy(record_offsets, h.record_offsets.data(), h.record_offsets.size() * 4);
         if (!h.ids_blob.empty()) memcpy(ids_blob, h.ids_blob.data(), h.ids_blob.size());
+        if (kmers && nodes && ix.n_kmers && !getenv("SEQWIN_AMD_NO_RESIDENT")) {
+            GraphHost &hm = const_cast<GraphHost &>(h);
+            device_identity(ix, 0, hm.identity);
+            hm.exported = true;
+        }
         if (getenv("SEQWIN_AMD_DEBUG_TIMING"))
             fprintf(stderr, "[seqwin_amd] sw_graph_export: %.1f ms for %.1f MB\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
@@ -1072,7 +1230,33 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
     });
 }
 
-void sw_graph_free(sw_graph *g) { delete g; }
+void sw_graph_free(sw_graph *g)
+{
+    if (g && g->g.exported) {   // the exported index stays resident for the get_penalty / filter_kmers calls that follow
+        Resident &r = resident();
+        std::lock_guard<std::mutex> lock(r.mu);
+        r.ix = std::move(g->g.ixp);
+        r.kmer_sum = g->g.identity[0];
+        r.node_sum = g->g.identity[1];
+    }
+    delete g;
+}
+
+void sw_resident_stats(uint64_t *out)
+{
+    Resident &r = resident();
+    std::lock_guard<std::mutex> lock(r.mu);
+    out[0] = r.ix ? r.ix->n_kmers : 0;
+    out[1] = r.penalty_hits;
+    out[2] = r.filter_hits;
+}
+
+void sw_release_resident(void)
+{
+    Resident &r = resident();
+    std::lock_guard<std::mutex> lock(r.mu);
+    r.ix.reset();
+}
 
 int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint64_t n_nodes, const uint32_t *record_offsets,
                    uint64_t n_record_offsets, const uint8_t *is_targets, uint64_t n_assemblies, uint64_t n_cpu)
@@ -1095,22 +1279,62 @@ int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint6
         std::vector<uint32_t> rec_asm(n_records);
         for (uint64_t a = 0; a < n_assemblies; ++a)  // filter.cpp:68-87
             for (uint32_t r = record_offsets[a]; r < record_offsets[a + 1]; ++r) rec_asm[r] = (uint32_t)a;
-        DevArray<sw_kmer> d_kmers(n_kmers);
-        DevArray<sw_node> d_nodes(n_nodes);
         DevArray<uint32_t> d_rec_asm(n_records);
         DevArray<uint8_t> d_tar(n_assemblies);
-        if (n_kmers) SW_HIP(hipMemcpy(d_kmers.p, kmers, n_kmers * sizeof(sw_kmer), hipMemcpyHostToDevice));
-        SW_HIP(hipMemcpy(d_nodes.p, nodes, n_nodes * sizeof(sw_node), hipMemcpyHostToDevice));
         if (n_records) SW_HIP(hipMemcpy(d_rec_asm.p, rec_asm.data(), (size_t)n_records * 4, hipMemcpyHostToDevice));
         SW_HIP(hipMemcpy(d_tar.p, is_targets, n_assemblies, hipMemcpyHostToDevice));
+        // the arrays of the last sw_build are usually still in HBM (Resident): use them when the caller's are the same
+        Resident &res = resident();
+        std::unique_lock<std::mutex> rlock(res.mu);
+        int dev = -1;
+        SW_HIP(hipGetDevice(&dev));
+        bool use_resident = false;
+        if (res.ix && res.ix->device == dev && res.ix->n_kmers == n_kmers && res.ix->n_nodes == n_nodes) {
+            uint64_t id[2];
+            host_identity(kmers, n_kmers, nodes, n_nodes, (unsigned)std::min<uint64_t>(std::max<uint64_t>(n_cpu, 1), 64), id);
+            use_resident = id[0] == res.kmer_sum && id[1] == res.node_sum;
+        }
+        DevArray<sw_kmer> d_kmers;
+        DevArray<sw_node> d_nodes;
+        const sw_kmer *dk;
+        sw_node *dn;
+        if (use_resident) {
+            dk = res.ix->kmers.p;
+            dn = res.ix->nodes.p;
+            ++res.penalty_hits;
+        } else {
+            rlock.unlock();
+            d_kmers.alloc(n_kmers);
+            d_nodes.alloc(n_nodes);
+            if (n_kmers) SW_HIP(hipMemcpy(d_kmers.p, kmers, n_kmers * sizeof(sw_kmer), hipMemcpyHostToDevice));
+            SW_HIP(hipMemcpy(d_nodes.p, nodes, n_nodes * sizeof(sw_node), hipMemcpyHostToDevice));
+            dk = d_kmers.p;
+            dn = d_nodes.p;
+        }
         uint64_t err = 0;
-        device_get_penalty(d_kmers.p, n_kmers, d_nodes.p, n_nodes, d_rec_asm.p, n_records, d_tar.p, n_tar, n_neg, 0, &err);
+        device_get_penalty(dk, n_kmers, dn, n_nodes, d_rec_asm.p, n_records, d_tar.p, n_tar, n_neg, 0, &err);
         if (err & 1) raise(SW_ERR_VALUE, "node range is outside kmers");
         if (err & 2) raise(SW_ERR_VALUE, "record_idx is outside record_offsets range");                    // filter.cpp:104-106,120-122
         if (err & 4) raise(SW_ERR_VALUE, "record_idx must be nondecreasing within each node range");        // filter.cpp:113-115
-        SW_HIP(hipMemcpy(nodes, d_nodes.p, n_nodes * sizeof(sw_node), hipMemcpyDeviceToHost));
+        const HostSpan span[1] = {{nodes, n_nodes * sizeof(sw_node)}};
+        (void)span;
+        SW_HIP(hipMemcpy(nodes, dn, n_nodes * sizeof(sw_node), hipMemcpyDeviceToHost));
     });
 }
+
+// sw_filter_kmers is called twice per logical call (sizes, then data): the size phase leaves its device result here and
+// the data phase only copies it out when it is called with the same arguments (same host pointers and sizes, same
+// used_hashes content) on the same thread -- one upload and one compute per logical call.
+namespace {
+struct FilterStash {
+    const void *kmers = nullptr, *nodes = nullptr;
+    uint64_t n_kmers = 0, n_nodes = 0, n_used = 0, used_sum = 0, nk = 0, nn = 0;
+    DevArray<sw_kmer> kout;
+    DevArray<sw_node> nout;
+    bool valid = false;
+};
+thread_local FilterStash g_filter_stash;
+}  // namespace
 
 int sw_filter_kmers(const sw_kmer *kmers, uint64_t n_kmers, const sw_node *nodes, uint64_t n_nodes,
                     const uint64_t *used_hashes, uint64_t n_used, sw_kmer *kmers_out, sw_node *nodes_out,
@@ -1118,22 +1342,69 @@ int sw_filter_kmers(const sw_kmer *kmers, uint64_t n_kmers, const sw_node *nodes
 {
     return guarded([&] {
         require_device();
+        uint64_t used_sum = 0;
+        for (uint64_t i = 0; i < n_used; ++i) used_sum += mix64(used_hashes[i]);   // order-independent, as the hash set is
+        FilterStash &st = g_filter_stash;
+        const bool data_phase = kmers_out || nodes_out;
+        if (data_phase && st.valid && st.kmers == kmers && st.nodes == nodes && st.n_kmers == n_kmers && st.n_nodes == n_nodes &&
+            st.n_used == n_used && st.used_sum == used_sum) {
+            *n_kmers_out = st.nk;
+            *n_nodes_out = st.nn;
+            if (kmers_out && st.nk) SW_HIP(hipMemcpy(kmers_out, st.kout.p, st.nk * sizeof(sw_kmer), hipMemcpyDeviceToHost));
+            if (nodes_out && st.nn) SW_HIP(hipMemcpy(nodes_out, st.nout.p, st.nn * sizeof(sw_node), hipMemcpyDeviceToHost));
+            st = FilterStash();
+            return;
+        }
+        st = FilterStash();
         for (uint64_t i = 0; i < n_nodes; ++i)
             if (nodes[i].start > nodes[i].stop || nodes[i].stop > n_kmers) raise(SW_ERR_VALUE, "node range is outside kmers");
         std::vector<uint64_t> used(used_hashes, used_hashes + n_used);
         std::sort(used.begin(), used.end());  // filter.cpp:145
-        DevArray<sw_kmer> d_kmers(n_kmers), d_kout;
+        // kmers: the resident copy of the last sw_build when the caller's array is that one (Resident)
+        Resident &res = resident();
+        std::unique_lock<std::mutex> rlock(res.mu);
+        int dev = -1;
+        SW_HIP(hipGetDevice(&dev));
+        bool use_resident = false;
+        if (res.ix && res.ix->device == dev && res.ix->n_kmers == n_kmers && n_kmers) {
+            uint64_t id[2];
+            host_identity(kmers, n_kmers, nullptr, 0, 16, id);
+            use_resident = id[0] == res.kmer_sum;
+        }
+        DevArray<sw_kmer> d_kmers, d_kout;
         DevArray<sw_node> d_nodes(n_nodes), d_nout;
         DevArray<uint64_t> d_used(n_used);
-        if (n_kmers) SW_HIP(hipMemcpy(d_kmers.p, kmers, n_kmers * sizeof(sw_kmer), hipMemcpyHostToDevice));
+        const sw_kmer *dk;
+        if (use_resident) {
+            dk = res.ix->kmers.p;
+            ++res.filter_hits;
+        } else {
+            rlock.unlock();
+            d_kmers.alloc(n_kmers);
+            if (n_kmers) SW_HIP(hipMemcpy(d_kmers.p, kmers, n_kmers * sizeof(sw_kmer), hipMemcpyHostToDevice));
+            dk = d_kmers.p;
+        }
         if (n_nodes) SW_HIP(hipMemcpy(d_nodes.p, nodes, n_nodes * sizeof(sw_node), hipMemcpyHostToDevice));
         if (n_used) SW_HIP(hipMemcpy(d_used.p, used.data(), n_used * 8, hipMemcpyHostToDevice));
         uint64_t nk = 0, nn = 0;
-        device_filter_kmers(d_kmers.p, n_kmers, d_nodes.p, n_nodes, d_used.p, n_used, 0, d_kout, d_nout, &nk, &nn);
+        device_filter_kmers(dk, n_kmers, d_nodes.p, n_nodes, d_used.p, n_used, 0, d_kout, d_nout, &nk, &nn);
         *n_kmers_out = nk;
         *n_nodes_out = nn;
         if (kmers_out && nk) SW_HIP(hipMemcpy(kmers_out, d_kout.p, nk * sizeof(sw_kmer), hipMemcpyDeviceToHost));
         if (nodes_out && nn) SW_HIP(hipMemcpy(nodes_out, d_nout.p, nn * sizeof(sw_node), hipMemcpyDeviceToHost));
+        if (!data_phase) {   // size phase: keep the result for the data phase
+            st.kmers = kmers;
+            st.nodes = nodes;
+            st.n_kmers = n_kmers;
+            st.n_nodes = n_nodes;
+            st.n_used = n_used;
+            st.used_sum = used_sum;
+            st.nk = nk;
+            st.nn = nn;
+            st.kout = std::move(d_kout);
+            st.nout = std::move(d_nout);
+            st.valid = true;
+        }
     });
 }
 

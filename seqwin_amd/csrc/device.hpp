@@ -197,6 +197,9 @@ struct OrderedOcc {
     uint64_t n = 0;
 };
 void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out, bool index_form = false);
+// index-form streams of consecutive assembly chunks -> one stream (chunk c's records follow rec_base[c] earlier ones);
+// the chunks are emptied
+void concat_occ(std::vector<OrderedOcc> &chunks, const std::vector<uint64_t> &rec_base, hipStream_t stream, OrderedOcc &out);
 void index_settle(sw_index &ix);   // finish deferred counts (no-op otherwise)
 // occ: index form (key32 / pay / rec); d_rec_asm[n_records] = assembly of every record of the stream
 void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assemblies, OrderedOcc &occ,
@@ -208,6 +211,7 @@ void device_filter_kmers(const sw_kmer *d_kmers, uint64_t n_kmers, const sw_node
                          const uint64_t *d_used_sorted, uint64_t n_used, hipStream_t stream,
                          DevArray<sw_kmer> &kmers_out, DevArray<sw_node> &nodes_out, uint64_t *n_kmers_out,
                          uint64_t *n_nodes_out);
+void device_identity(const sw_index &ix, hipStream_t stream, uint64_t *sums2);
 void device_checksums(const sw_index &ix, hipStream_t stream, uint64_t *sums3, uint64_t kbase = 0, uint64_t nbase = 0,
                       uint64_t ebase = 0);
 void index_threshold_sums(const sw_index &ix, hipStream_t stream, uint64_t *sums3);

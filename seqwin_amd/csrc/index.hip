@@ -1406,7 +1406,45 @@ void ranks_from_table(const sw_index &ix, const uint64_t *hash, uint64_t n, hipS
     SW_HIP(hipStreamSynchronize(stream));   // the table is released on return
 }
 
+// chunk c of a low-memory build: its occurrences take places [occ_base, occ_base + n) of the whole stream and its
+// records follow rec_base earlier ones (record re-basing: build_internals.cpp:334-355)
+__global__ void k_append_chunk(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay, const uint32_t *__restrict__ rec,
+                               uint64_t n, uint32_t occ_base, uint32_t rec_base, uint32_t *__restrict__ key32_out,
+                               OccPay *__restrict__ pay_out, uint32_t *__restrict__ rec_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    OccPay p = pay[i];
+    p.rec += rec_base;
+    p.idx += occ_base;
+    key32_out[occ_base + i] = key32[i];
+    pay_out[occ_base + i] = p;
+    rec_out[occ_base + i] = rec[i] + rec_base;
+}
+
 }  // namespace
+
+void concat_occ(std::vector<OrderedOcc> &chunks, const std::vector<uint64_t> &rec_base, hipStream_t stream, OrderedOcc &out)
+{
+    uint64_t n = 0;
+    for (const OrderedOcc &c : chunks) n += c.n;
+    if (n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
+    out.n = n;
+    out.key32.alloc(n);
+    out.pay.alloc(n);
+    out.rec.alloc(n);
+    uint64_t at = 0;
+    for (size_t c = 0; c < chunks.size(); ++c) {
+        OrderedOcc &ch = chunks[c];
+        if (ch.n) {
+            hipLaunchKernelGGL(k_append_chunk, dim3(blocks_for(ch.n)), dim3(TPB), 0, stream, ch.key32.p, ch.pay.p, ch.rec.p, ch.n,
+                               (uint32_t)at, (uint32_t)rec_base[c], out.key32.p, out.pay.p, out.rec.p);
+            SW_HIP(hipGetLastError());
+        }
+        at += ch.n;
+        ch = OrderedOcc();   // (released blocks are reused in stream order)
+    }
+}
 
 void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out, bool index_form)
 {
@@ -2226,6 +2264,41 @@ void index_verify(const sw_index &ix, uint64_t n_assemblies, bool scored, hipStr
     SW_HIP(hipStreamSynchronize(stream));
     if (ix.n_nodes == 0 && ix.n_kmers) h[1] += 1;
     for (int i = 0; i < 10; ++i) out10[i] = h[i];
+}
+
+// identity of an index's immutable part (kmers; nodes' hash / start / stop): what sw_get_penalty compares a caller's host
+// arrays with before it reuses the still-resident index of the last sw_build (api.hip: host_identity is the same sums)
+__global__ void k_identity(const sw_kmer *kmers, uint64_t nk, const sw_node *nodes, uint64_t nn, unsigned long long *sums)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t G = 0x9E3779B97F4A7C15ULL;
+    uint64_t a = 0, b = 0;
+    if (i < nk) a = mix64(i * G + ((uint64_t)kmers[i].pos | ((uint64_t)kmers[i].record_idx << 32)));
+    if (i < nn) b = mix64(i * G + nodes[i].hash) + mix64(nodes[i].start * 3 + 1) + mix64(nodes[i].stop * 5 + 2);
+    for (int d = 32; d; d >>= 1) {
+        a += __shfl_down(a, d, 64);
+        b += __shfl_down(b, d, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (a) atomicAdd(&sums[0], (unsigned long long)a);
+        if (b) atomicAdd(&sums[1], (unsigned long long)b);
+    }
+}
+
+void device_identity(const sw_index &ix, hipStream_t stream, uint64_t *sums2)
+{
+    DevArray<unsigned long long> sums(2);
+    SW_HIP(hipMemsetAsync(sums.p, 0, 16, stream));
+    const uint64_t n = std::max(ix.n_kmers, ix.n_nodes);
+    if (n) {
+        hipLaunchKernelGGL(k_identity, dim3(blocks_for(n)), dim3(TPB), 0, stream, ix.kmers.p, ix.n_kmers, ix.nodes.p, ix.n_nodes, sums.p);
+        SW_HIP(hipGetLastError());
+    }
+    unsigned long long h[2];
+    SW_HIP(hipMemcpyAsync(h, sums.p, 16, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    sums2[0] = h[0];
+    sums2[1] = h[1];
 }
 
 void device_checksums(const sw_index &ix, hipStream_t stream, uint64_t *sums3, uint64_t kbase, uint64_t nbase, uint64_t ebase)

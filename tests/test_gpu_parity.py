@@ -119,6 +119,57 @@ def test_build_empty_record_offsets(tmp_path: Path):   # test_graph.py:168-187
             assert ids == [()] * len(paths)
 
 
+@pytest.mark.parametrize("chunk_mbp", [None, "0", "1"])
+def test_low_memory_build_matches_standard(smoke_paths, tmp_path, monkeypatch, chunk_mbp):   # test_graph.py:222-245
+    """low_memory streams the assemblies through HBM in chunks (sw_build: build_chunked) and indexes the concatenated
+    tuple stream: one assembly per chunk (SEQWIN_AMD_LOWMEM_CHUNK_MBP=0), a few per chunk (1 Mbp), or the default
+    chunk size; also chosen automatically when the files exceed SEQWIN_AMD_HBM_BUDGET_GB."""
+    if chunk_mbp is not None:
+        monkeypatch.setenv("SEQWIN_AMD_LOWMEM_CHUNK_MBP", chunk_mbp)
+    for n_cpu in (1, 2, 99):
+        standard = _build(smoke_paths, kmerlen=7, windowsize=10, n_cpu=n_cpu, low_memory=False)
+        low = _build(smoke_paths, kmerlen=7, windowsize=10, n_cpu=n_cpu, low_memory=True)
+        for a, b in zip(standard[:4], low[:4]):
+            assert np.array_equal(a, b)
+        assert standard[4] == low[4]
+    # ragged inputs: multi-record assemblies, an empty file, records shorter than k, gz, N runs; chunks of ~1 Mbp
+    rng = np.random.default_rng(5)
+    paths = []
+    for a in range(9):
+        recs = []
+        for r in range(int(rng.integers(0, 4))):
+            n = int(rng.choice([0, 12, 5000, 300_000, 700_000]))
+            seq = rng.choice(np.frombuffer(b"ACGTN", np.uint8), n, p=[0.2475, 0.2475, 0.2475, 0.2475, 0.01]).tobytes()
+            recs.append(b">a%d_r%d x\n" % (a, r) + seq + b"\n")
+        p = tmp_path / (f"lm{a}.fa" + (".gz" if a % 4 == 3 else ""))
+        if a % 4 == 3:
+            with gzip.open(p, "wb") as f:
+                f.write(b"".join(recs))
+        else:
+            p.write_bytes(b"".join(recs))
+        paths.append(p)
+    for k, w in ((21, 200), (15, 10)):
+        exp = oracle.build(paths, k, w)
+        got = _build(paths, k, w, n_cpu=3, low_memory=True)
+        assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])), [list(t) for t in exp[4]])
+    exp = dict(zip(("kmers", "nodes", "edges", "record_offsets"), oracle.build(paths, 21, 200)[:4]))
+    import logging
+    for budget, streamed in (("1", False), ("0.001", True)):   # the ~4 MB of files fit 1 GB (one-shot) but not 1 MB (chunks)
+        monkeypatch.setenv("SEQWIN_AMD_HBM_BUDGET_GB", budget)
+        seen = []
+        h = logging.Handler()
+        h.emit = lambda rec: seen.append(rec.getMessage())
+        logging.getLogger().addHandler(h)
+        old = logging.getLogger().level
+        logging.getLogger().setLevel(logging.INFO)
+        try:
+            assert_graph_equal(_build(paths, 21, 200), exp)
+        finally:
+            logging.getLogger().removeHandler(h)
+            logging.getLogger().setLevel(old)
+        assert any("streamed through HBM in chunks" in m for m in seen) == streamed
+
+
 def test_filter_kmers():   # test_graph.py:190-219
     kmers = np.array([(10, 0), (11, 0), (20, 1), (30, 2), (31, 2), (32, 2)], dtype=KMER_DTYPE)
     nodes = np.array([(10, 0, 2, 1, 0, 0.1), (20, 2, 3, 1, 0, 0.2), (30, 3, 6, 1, 1, 0.3)], dtype=NODE_DTYPE)
@@ -572,3 +623,61 @@ def test_two_host_threads_two_streams_share_the_block_pool():
     for t in th:
         t.join()
     assert not errors, errors[:3]
+
+
+def _resident_stats():
+    import ctypes
+
+    from seqwin_amd._lib import lib
+    v = (ctypes.c_uint64 * 3)()
+    lib.sw_resident_stats.restype = None
+    lib.sw_resident_stats(v)
+    return [int(x) for x in v]
+
+
+def test_resident_index_serves_get_penalty_and_filter_kmers(tmp_path, monkeypatch):
+    """The index of the last build stays in HBM; get_penalty / filter_kmers use it instead of uploading the caller's arrays
+    when -- and only when -- those still are the exported ones (host checksums); the size phase of filter_kmers keeps its
+    device result for the data phase.  Results are the same on every route."""
+    paths = sorted((GOLDEN / "synth").glob("pan_*.fa"))
+    tar = [i % 2 == 0 for i in range(len(paths))]
+    ek, en, ee, eo, _ = oracle.build(paths, 15, 20)
+    scored = en.copy()
+    oracle.get_penalty(ek, scored, eo, tar)
+    g = KmerGraph(paths, kmerlen=15, windowsize=20, n_cpu=2)
+    s0 = _resident_stats()
+    assert s0[0] == len(g.kmers)
+    nodes = g.nodes.copy()
+    _get_penalty(g.kmers, nodes, g.record_offsets, tar)                     # a COPY of the exported nodes: same content -> resident
+    assert np.array_equal(nodes, scored) and _resident_stats()[1] == s0[1] + 1
+    _get_penalty(g.kmers, g.nodes, g.record_offsets, [not t for t in tar])  # again, other targets, already-scored nodes
+    inv = en.copy()
+    oracle.get_penalty(ek, inv, eo, [not t for t in tar])
+    assert np.array_equal(g.nodes, inv) and _resident_stats()[1] == s0[1] + 2
+    bad = g.kmers.copy()
+    bad[5]["record_idx"] = 10_000                                            # not the exported array any more: uploaded, validated
+    with pytest.raises(ValueError):
+        _get_penalty(bad, g.nodes.copy(), g.record_offsets, tar)
+    swapped = g.kmers.copy()
+    swapped[[0, 1]] = swapped[[1, 0]]
+    n2 = en.copy()
+    try:
+        _get_penalty(swapped, n2, g.record_offsets, tar)
+        e2 = en.copy()
+        oracle.get_penalty(swapped, e2, eo, tar)
+        assert np.array_equal(n2, e2)
+    except ValueError:
+        pass                                                                 # (the swap may break the record order of a node)
+    assert _resident_stats()[1] == s0[1] + 2
+    used = frozenset(np.uint64(h) for h in en["hash"][::3])
+    f1 = _filter_kmers(g.kmers, scored, used)
+    f2 = oracle.filter_kmers(ek, scored, used)
+    assert np.array_equal(f1[0], f2[0]) and np.array_equal(f1[1], f2[1])
+    assert _resident_stats()[2] == s0[2] + 1                                 # one compute for the two phases, on resident kmers
+    monkeypatch.setenv("SEQWIN_AMD_NO_RESIDENT", "1")
+    g2 = KmerGraph(paths, kmerlen=15, windowsize=20, n_cpu=2)
+    assert _resident_stats()[0] == 0
+    _get_penalty(g2.kmers, g2.nodes, g2.record_offsets, tar)
+    assert np.array_equal(g2.nodes, scored)
+    f3 = _filter_kmers(g2.kmers, scored, used)
+    assert np.array_equal(f3[0], f2[0]) and np.array_equal(f3[1], f2[1])
