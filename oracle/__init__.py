@@ -22,7 +22,8 @@ from pathlib import Path
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-_SO = _HERE / "libseqwin_oracle.so"
+# SEQWIN_ORACLE_LIB: another build of the same restatement (the sanitizer build, `make -C oracle asan`)
+_SO = Path(os.environ.get("SEQWIN_ORACLE_LIB", _HERE / "libseqwin_oracle.so"))
 
 # Same layouts as the reference's wire format (cpp/include/seqwin/graph.hpp:15-53,
 # src/seqwin/graph/__init__.py:40-58).
@@ -39,6 +40,8 @@ _lib = None
 def build_oracle_lib(force: bool = False) -> Path:
     """Compile the C restatement if needed (gcc + zlib; no reference sources involved)."""
     src = _HERE / "seqwin_oracle.c"
+    if "SEQWIN_ORACLE_LIB" in os.environ:
+        return _SO
     if force or not _SO.exists() or _SO.stat().st_mtime < src.stat().st_mtime:
         subprocess.check_call(["make", "-C", str(_HERE), "oracle"], stdout=subprocess.DEVNULL)
     return _SO

@@ -702,7 +702,7 @@ int so_build(const char *const *paths, size_t n_paths, uint64_t k, uint64_t w, s
 
     /* edges: weight = number of assemblies containing the unordered pair (build.cpp:177-189),
      * sorted by (first, second) (build_internals.cpp:253-291) */
-    qsort(adj, n_adj, sizeof *adj, cmp_adj);
+    if (n_adj) qsort(adj, n_adj, sizeof *adj, cmp_adj);   /* (qsort(NULL, 0, ...) is undefined: found by the UBSan build) */
     size_t n_edges = 0;
     for (size_t i = 0; i < n_adj; ++i)
         if (i == 0 || adj[i].first != adj[i - 1].first || adj[i].second != adj[i - 1].second) ++n_edges;
@@ -849,8 +849,8 @@ int so_filter_kmers(const so_kmer_t *kmers, const so_node_t *nodes, uint64_t n_n
 {
     uint64_t *used = (uint64_t *)malloc((n_used ? n_used : 1) * sizeof(uint64_t));
     if (!used) return fail(SO_ERR_RUNTIME, "out of memory");
-    memcpy(used, used_hashes, n_used * sizeof(uint64_t));
-    qsort(used, n_used, sizeof(uint64_t), cmp_u64);                              /* :145 */
+    if (n_used) memcpy(used, used_hashes, n_used * sizeof(uint64_t));
+    if (n_used) qsort(used, n_used, sizeof(uint64_t), cmp_u64);                              /* :145 */
     uint64_t ni = 0, ui = 0, nk = 0, nn = 0;
     while (ni < n_nodes && ui < n_used) {                                        /* :155-173 */
         if (nodes[ni].hash < used[ui]) { ++ni; continue; }

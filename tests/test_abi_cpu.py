@@ -145,15 +145,14 @@ def test_host_ingest_errors(tmp_path):
     assert _host_ingest([empty])[0].tolist() == [0, 0]
 
 
-def test_host_ingest_random_bytes_match_oracle_reader(tmp_path):
-    """The SIMD packer (32 bytes per step, low-nibble classification) against the oracle's reader on adversarial
-    content: every byte value except the refused control bytes, blanks inside lines, CRLF, lines of every length
-    around the 32-byte step, records shorter than a step, '>' inside sequence lines."""
-    rng = np.random.default_rng(7)
+def _byte_soup_files(tmp_path, seed=7, n_files=12):
+    """Adversarial FASTA: every byte value except the refused control bytes, blanks inside lines, CRLF, lines of every
+    length around the packer's 32-byte step, records shorter than a step, '>' inside sequence lines."""
+    rng = np.random.default_rng(seed)
     refused = {1, 3, 4, 5, 7}
     any_byte = np.array([b for b in range(1, 256) if b not in refused and b not in (10, 62)], np.uint8)   # (the oracle wrapper returns NUL-terminated strings)
     files = []
-    for f in range(12):
+    for f in range(n_files):
         parts = []
         for r in range(int(rng.integers(1, 6))):
             parts.append(b">rec%d some description\n" % r)
@@ -177,9 +176,15 @@ def test_host_ingest_random_bytes_match_oracle_reader(tmp_path):
                 parts.append(line + eol)
             if rng.random() < 0.3:
                 parts.append(b"\n   \n")
-        p = tmp_path / f"rnd{f}.fa"
+        p = tmp_path / f"rnd{seed}_{f}.fa"
         p.write_bytes(b"".join(parts))
         files.append(p)
+    return files
+
+
+def test_host_ingest_random_bytes_match_oracle_reader(tmp_path):
+    """The SIMD packer (32 bytes per step, low-nibble classification) against the oracle's reader on adversarial content."""
+    files = _byte_soup_files(tmp_path)
     for n_cpu in (1, 4):
         offs, ids, seqs, bp = _host_ingest(files, n_cpu)
         exp_ids, exp_seqs, exp_offs = [], [], [0]
@@ -190,6 +195,44 @@ def test_host_ingest_random_bytes_match_oracle_reader(tmp_path):
         assert ids == exp_ids and offs.tolist() == exp_offs
         assert seqs == exp_seqs
         assert bp == sum(len(s) for s in exp_seqs)
+
+
+def test_host_ingest_under_sanitizers(tmp_path):
+    """host_ingest.cpp (hand-written SIMD over hostile bytes, threads, zlib streams) rebuilt with AddressSanitizer + UBSan
+    (`make -C seqwin_amd/csrc asan`) and run on the byte soup, gzip members, truncated gzip, blank / header-only files and
+    refused inputs: no sanitizer report, and the same records as the regular library.  CPU only."""
+    import subprocess
+    if subprocess.run(["make", "-C", str(ROOT / "seqwin_amd" / "csrc"), "asan"], capture_output=True).returncode != 0:
+        pytest.skip("no sanitizer runtime for g++ here")
+    exe = ROOT / "seqwin_amd" / "csrc" / "build" / "ingest_san"
+    files = _byte_soup_files(tmp_path, seed=11, n_files=8)
+    gz = tmp_path / "two_members.fa.gz"
+    gz.write_bytes(gzip.compress(b">m1\nACGTNACGT\nAC") + gzip.compress(b"GT\n>m2 x\n" + b"ACGT" * 9000 + b"\n"))
+    hdr = tmp_path / "headers_only.fa"; hdr.write_bytes(b">a\n>b\r\n>c")
+    blank = tmp_path / "blank.fa"; blank.write_bytes(b"\n\n   \n")
+    # a truncated gzip stream yields what could be inflated, as with the reference's gzread loop (fasta_reader.cpp:134-150)
+    trunc = tmp_path / "trunc.fa.gz"
+    trunc.write_bytes(gzip.compress(b">t\n" + b"ACGTTGCA" * 5000 + b"\n>u\nACGTACGTACGTACGTACGTAAAA\n")[:-10])
+    assert [(i, len(q)) for i, q in oracle.read_fasta(trunc)] == [("t", 40000), ("u", 21)]
+    files += [gz, hdr, blank, trunc] + sorted((GOLDEN / "synth").glob("edge_*"))
+    env = dict(__import__("os").environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    for n_cpu, scalar in ((1, False), (3, False), (2, True)):
+        e = dict(env, **({"SEQWIN_AMD_SCALAR_INGEST": "1"} if scalar else {}))
+        dump = tmp_path / f"dump_{n_cpu}_{int(scalar)}.bin"
+        out = subprocess.run([str(exe), str(n_cpu), str(dump)] + [str(f) for f in files], capture_output=True, text=True, env=e)
+        assert out.returncode == 0 and "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
+        offs, ids, seqs, bp = _host_ingest(files, n_cpu)
+        blob = b"".join(i.encode() + b"\0" for i in ids)
+        lens = np.array([len(x) for x in seqs], np.uint32)
+        assert dump.read_bytes() == offs.astype(np.uint32).tobytes() + blob + lens.tobytes() + b"".join(seqs)
+        assert f"{len(files)} assemblies {len(seqs)} records {bp} bp" in out.stdout
+    # refused / broken inputs must fail cleanly under the sanitizers too (exit code 3, no report)
+    ctl = tmp_path / "ctl.fa"; ctl.write_bytes(b">r\nACGT\x01ACGT\n")
+    nohdr = tmp_path / "nohdr.fa"; nohdr.write_bytes(b"ACGT\n>r\nAC\n")
+    notgz = tmp_path / "notgz.fa.gz"; notgz.write_bytes(b"\x1f\x8b\x08\x00" + bytes(range(200)))
+    for bad in (ctl, nohdr, notgz, tmp_path / "missing.fa"):
+        out = subprocess.run([str(exe), "2", str(tmp_path / "x.bin"), str(files[0]), str(bad)], capture_output=True, text=True, env=env)
+        assert out.returncode == 3 and "refused" in out.stderr and "Sanitizer" not in out.stderr, (bad.name, out.returncode, out.stderr[-2000:])
 
 
 def test_half_word_rotate_formulas(tmp_path):

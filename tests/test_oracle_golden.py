@@ -117,3 +117,46 @@ def test_argument_errors(tmp_path):
     ctl.write_bytes(b">r\nACGT\x01ACGT\n")
     with pytest.raises(ValueError, match="control byte"):
         oracle.build([ctl], 3, 1)
+
+
+def test_oracle_under_sanitizers(tmp_path):
+    """The C restatement rebuilt with AddressSanitizer + UBSan (`make -C oracle asan`) reproduces the golden vectors and a
+    ragged fuzz set without a sanitizer report.  CPU only."""
+    import os
+    import subprocess
+    import sys
+    root = GOLDEN.parent.parent
+    if subprocess.run(["make", "-C", str(root / "oracle"), "asan"], capture_output=True).returncode != 0:
+        pytest.skip("no sanitizer runtime for gcc here")
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan):
+        pytest.skip("libasan.so not found")
+    script = r'''
+import json, sys, random
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import oracle
+from conftest import GOLDEN, load_case
+man = json.loads((GOLDEN / "manifest.json").read_text())
+for case in man["cases"]:
+    paths, z = load_case(case)
+    k, n, e, o, ids = oracle.build(paths, case["k"], case["w"])
+    assert np.array_equal(k, z["kmers"]) and np.array_equal(n, z["nodes"]) and np.array_equal(e, z["edges"]), case["name"]
+    if case["is_targets"] is not None and len(n):
+        oracle.get_penalty(k, n, o, case["is_targets"])
+        assert np.array_equal(n, z["nodes_scored"])
+        oracle.filter_kmers(k, n, frozenset(np.uint64(h) for h in n["hash"][::2]))
+rng = random.Random(3)
+for it in range(25):
+    p = sys.argv[2] + f"/f{it}.fa"
+    with open(p, "w") as f:
+        for r in range(rng.randrange(0, 4)):
+            f.write(f">r{r}\n" + "".join(rng.choice("ACGTNacgtRY") for _ in range(rng.choice([0, 3, 40, 700, 6000]))) + "\n")
+    oracle.build([p], rng.choice([3, 7, 21, 33]), rng.choice([1, 5, 50, 200]))
+print("SAN_OK")
+'''
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1",
+               SEQWIN_ORACLE_LIB=str(root / "oracle" / "libseqwin_oracle_asan.so"))
+    out = subprocess.run([sys.executable, "-c", script, str(root), str(tmp_path)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "SAN_OK" in out.stdout, out.stderr[-3000:]
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
