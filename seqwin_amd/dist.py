@@ -142,7 +142,8 @@ class HipEngine:
             tar, na = t.ctypes.data_as(c_vp), len(t)
         occ_rows = occ_rows.to(self.gpu).contiguous()
         edge_rows = edge_rows.to(self.gpu).contiguous()
-        self.torch.cuda.current_stream().synchronize()   # rows were produced by RCCL on its own stream
+        # (no host synchronisation: a collective's result is ordered before later work on the current stream by
+        #  torch.distributed, and the library launches on that same stream)
         h = c_vp()
         check(lib.sw_index_merge(c_vp(occ_rows.data_ptr()), c_u64(occ_rows.shape[0]), c_vp(edge_rows.data_ptr()),
                                  c_u64(edge_rows.shape[0]), c_u64(kmer_base), offs.ctypes.data_as(c_vp), tar, c_u64(na),
@@ -186,7 +187,6 @@ class HipEngine:
         else:
             tt = np.ascontiguousarray(np.asarray(is_targets, np.bool_)).view(np.uint8)
             tar, na = tt.ctypes.data_as(c_vp), len(tt)
-        t.cuda.current_stream().synchronize()
         h = c_vp()
         check(lib.sw_slice_build(c_vp(rows.data_ptr()), c_u64(rows.shape[0]), c_u64(kmer_base), offs.ctypes.data_as(c_vp),
                                  tar, c_u64(na), c_vp(ranks.data_ptr()), c_vp(self._stream()), ctypes.byref(h)))
@@ -197,7 +197,6 @@ class HipEngine:
         t = self.torch
         out = t.empty((ix.sizes()[1],), dtype=t.int64, device=self.gpu)
         check(lib.sw_index_node_hashes(ix._h, c_vp(out.data_ptr()), c_vp(self._stream())))
-        t.cuda.current_stream().synchronize()
         return out.to(self.device)
 
     def adjacency(self, occ, perm, ranks_by_row, n_bits: int, asm_bits: int, asm_base: int, rank_bounds):
@@ -209,7 +208,6 @@ class HipEngine:
         nb = len(rank_bounds)
         b = (c_u64 * max(nb, 1))(*rank_bounds)
         cnt = (c_u64 * (nb + 1))()
-        t.cuda.current_stream().synchronize()
         check(lib.sw_occ_adjacency(occ._h, c_vp(perm.data_ptr()), c_vp(ranks_by_row.data_ptr()), c_u64(n_bits),
                                    c_u64(asm_bits), c_u64(asm_base), b, c_u64(nb), c_vp(rows.data_ptr()), cnt, c_vp(self._stream())))
         counts = [int(x) for x in cnt]
@@ -219,7 +217,6 @@ class HipEngine:
         from ._lib import c_u64, c_vp, check, lib
         adj_rows = adj_rows.to(self.gpu).contiguous()
         rank_hash = rank_hash.to(self.gpu).contiguous()
-        self.torch.cuda.current_stream().synchronize()
         check(lib.sw_slice_edges(ix._h, c_vp(adj_rows.data_ptr()), c_u64(adj_rows.shape[0]), c_u64(n_bits),
                                  c_u64(asm_bits), c_vp(rank_hash.data_ptr()), c_vp(self._stream())))
 
