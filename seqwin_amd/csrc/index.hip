@@ -163,56 +163,127 @@ __global__ void k_iota(uint32_t *v, uint64_t n)
 // A workgroup takes NODES_ITEMS x 256 consecutive occurrences, 256 at a time (lane s of a wave = occurrence s of a
 // 64-aligned group: the bits of a group are one ballot).
 constexpr int NODES_ITEMS = 8;
+constexpr uint32_t NODES_TILE = 256 * NODES_ITEMS;
 constexpr uint32_t UNSORT_BITS = 14;                 // the unsort's last step handles 2^14 consecutive indices in LDS
 constexpr uint32_t UNSORT_RANGE = 1u << UNSORT_BITS;
 constexpr uint64_t UNSORT_DIRECT_MAX = 1ull << 25;   // up to here (128 MiB of ranks) the array stays in the 256 MiB Infinity Cache and a
                                                      // direct scatter is as fast (measured: 24 M occurrences 7.74 against 7.84 ms per build;
                                                      // 745 M: 239.0 against 232.3 ms)
 
+// The node of an occurrence is the number of run heads before it: a prefix sum over the whole array, done in the same pass
+// by chained tiles (decoupled look-back: a tile publishes the number of its heads at once, then adds up the published
+// numbers of its predecessors until it meets one that already knows its inclusive total).  Tiles take their number from a
+// ticket counter, so every predecessor of a running tile is itself running or finished: the look-back cannot wait for a
+// workgroup that has not started.  state = status << 62 | value; status 0 = nothing yet, 1 = own heads, 2 = all heads up to
+// and including the tile.
+constexpr unsigned long long TS_AGG = 1ull << 62, TS_INC = 2ull << 62;
+
 template <bool BITS>
-__global__ __launch_bounds__(256) void k_nodes(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay,
-                                               const uint32_t *__restrict__ cum, uint64_t n, uint64_t base,
-                                               const uint32_t *__restrict__ rec_flag, sw_kmer *__restrict__ kmers,
+__global__ __launch_bounds__(256) void k_nodes(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay, uint64_t n,
+                                               uint64_t base, const uint32_t *__restrict__ rec_flag, sw_kmer *__restrict__ kmers,
                                                sw_node *__restrict__ nodes, uint32_t *__restrict__ rank_direct,
                                                uint32_t *__restrict__ ukey, uint64_t *__restrict__ uval,
-                                               unsigned long long *__restrict__ tbits, unsigned long long *__restrict__ nbits)
+                                               unsigned long long *__restrict__ tbits, unsigned long long *__restrict__ nbits,
+                                               unsigned long long *__restrict__ tile_state, uint32_t *__restrict__ ticket,
+                                               uint32_t *__restrict__ n_nodes_out)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t s0 = (uint64_t)blockIdx.x * (256 * NODES_ITEMS);
-#pragma unroll 2
+    __shared__ uint32_t s_tile, s_excl;
+    __shared__ uint32_t s_row[NODES_ITEMS * 4 + 1];   // heads of (row j, wave): counts, then exclusive offsets; [32] = tile total
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint64_t s0 = (uint64_t)tile * NODES_TILE;
+    uint32_t k[NODES_ITEMS], within[NODES_ITEMS], headm = 0, prec[NODES_ITEMS];
+    OccPay p[NODES_ITEMS];
+#pragma unroll
     for (int j = 0; j < NODES_ITEMS; ++j) {
         const uint64_t s = s0 + (uint64_t)j * 256 + threadIdx.x;
         const bool live = s < n;
-        uint32_t k = 0, nid = 0;
-        OccPay p = {0, 0, 0, 0};
+        k[j] = 0;
+        p[j] = OccPay{0, 0, 0, 0};
         if (live) {
-            k = key32[s];
-            p = pay[s];
-            nid = cum[s] - 1;
+            k[j] = key32[s];
+            p[j] = pay[s];
         }
         // the previous occurrence: the lane below, or (lane 0) a load
-        uint32_t pk = __shfl_up(k, 1, 64), plow = __shfl_up(p.low, 1, 64), prec = __shfl_up(p.rec, 1, 64);
+        uint32_t pk = __shfl_up(k[j], 1, 64), plow = __shfl_up(p[j].low, 1, 64);
+        prec[j] = __shfl_up(p[j].rec, 1, 64);
         if (lane == 0 && live && s) {
             pk = key32[s - 1];
             const OccPay q = pay[s - 1];
             plow = q.low;
-            prec = q.rec;
+            prec[j] = q.rec;
         }
-        const bool head = live && (s == 0 || k != pk || p.low != plow);
+        const bool head = live && (s == 0 || k[j] != pk || p[j].low != plow);
+        const unsigned long long bal = __ballot(head);
+        within[j] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (head) headm |= 1u << j;
+        if (lane == 0) s_row[j * 4 + wave] = (uint32_t)__popcll(bal);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // exclusive offsets of the 32 (row, wave) groups, the tile's total, then the look-back
+        uint32_t c = (lane < NODES_ITEMS * 4) ? s_row[lane] : 0u, incl = c;
+        for (uint32_t d = 1; d < 32; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, NODES_ITEMS * 4 - 1, 64);
+        if (lane < NODES_ITEMS * 4) s_row[lane] = incl - c;
+        if (lane == 0)
+            __hip_atomic_store(&tile_state[tile], (tile == 0 ? TS_INC : TS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        if (tile) {
+            int64_t look = (int64_t)tile - 1;
+            for (;;) {
+                const int64_t idx = look - lane;   // lane 0 reads the nearest predecessor
+                const unsigned long long st = idx >= 0 ? __hip_atomic_load(&tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                       : TS_INC;   // before the first tile: nothing
+                const unsigned long long inc = __ballot((st >> 62) == 2), none = __ballot((st >> 62) == 0);
+                const uint32_t first_inc = inc ? (uint32_t)__builtin_ctzll(inc) : 64u;
+                const unsigned long long needed = first_inc >= 63 ? ~0ull : ((2ull << first_inc) - 1ull);
+                if (none & needed) {   // a predecessor in reach has not published yet (it is running: see above)
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                uint32_t v = (lane <= first_inc) ? (uint32_t)st : 0u;
+                for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
+                excl += v;
+                if (first_inc < 64) break;
+                look -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&tile_state[tile], TS_INC | (unsigned long long)(excl + total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_excl = excl;
+            if (s0 + NODES_TILE >= n) *n_nodes_out = excl + total;   // the last tile
+        }
+    }
+    __syncthreads();
+    const uint32_t excl = s_excl;
+#pragma unroll
+    for (int j = 0; j < NODES_ITEMS; ++j) {
+        const uint64_t s = s0 + (uint64_t)j * 256 + threadIdx.x;
+        const bool live = s < n;
+        const bool head = (headm >> j) & 1u;
+        const uint32_t nid = excl + s_row[j * 4 + wave] + within[j] + (head ? 1u : 0u) - 1u;   // heads up to and including s, - 1
         if (live) {
             sw_kmer km;
-            km.pos = p.pos;
-            km.record_idx = p.rec;
+            km.pos = p[j].pos;
+            km.record_idx = p[j].rec;
             kmers[s] = km;
             if (rank_direct) {
-                rank_direct[p.idx] = nid;
+                rank_direct[p[j].idx] = nid;
             } else if (ukey) {
-                ukey[s] = p.idx >> UNSORT_BITS;
-                uval[s] = ((uint64_t)nid << 32) | p.idx;
+                ukey[s] = p[j].idx >> UNSORT_BITS;
+                uval[s] = ((uint64_t)nid << 32) | p[j].idx;
             }
             if (head) {
                 // (stop is written by the next head / the last occurrence: two stores to one node never race on a field)
-                nodes[nid].hash = ((uint64_t)k << 32) | p.low;
+                nodes[nid].hash = ((uint64_t)k[j] << 32) | p[j].low;
                 nodes[nid].start = base + s;
                 nodes[nid].n_tar = 0;
                 nodes[nid].n_neg = 0;
@@ -223,9 +294,9 @@ __global__ __launch_bounds__(256) void k_nodes(const uint32_t *__restrict__ key3
         }
         if (BITS) {
             // rec_flag[r] = assembly << 1 | is_target
-            const uint32_t f = live ? rec_flag[p.rec] : 0u;
+            const uint32_t f = live ? rec_flag[p[j].rec] : 0u;
             uint32_t pf = __shfl_up(f, 1, 64);
-            if (lane == 0 && live && s) pf = rec_flag[prec];
+            if (lane == 0 && live && s) pf = rec_flag[prec[j]];
             const bool first_of_asm = live && (head || (f >> 1) != (pf >> 1));
             const unsigned long long tb = __ballot(first_of_asm && (f & 1u));
             const unsigned long long nb = __ballot(first_of_asm && !(f & 1u));
@@ -939,9 +1010,10 @@ struct PayView {   // key32[q] = top half of the hash, pay[q].low = its low half
 };
 
 template <class View>
-__device__ __forceinline__ uint32_t descents_of_thread(const View &V, uint32_t kmask, uint64_t n, uint64_t q0)
+__device__ __forceinline__ uint32_t descents_of_thread(const View &V, uint32_t kmask, uint64_t n, uint64_t q0, uint32_t *heads = nullptr)
 {
-    uint32_t m = 0;   // bit i: position q0 + i is a descent
+    uint32_t m = 0, hm = 0;   // bit i: position q0 + i is a descent / differs from its predecessor (a run head of this order)
+    if (heads) *heads = 0;
     if (q0 >= n) return 0;
     uint32_t kp = q0 ? V.key(q0 - 1) : 0;
     uint64_t lp = q0 ? V.low(q0 - 1) : 0;
@@ -952,21 +1024,26 @@ __device__ __forceinline__ uint32_t descents_of_thread(const View &V, uint32_t k
         const uint32_t kq = V.key(q);
         const uint64_t lq = V.low(q);
         if (q && (kq & kmask) == (kp & kmask) && (kq < kp || (kq == kp && lq < lp))) m |= 1u << i;
+        if (q == 0 || kq != kp || lq != lp) hm |= 1u << i;
         kp = kq;
         lp = lq;
     }
+    if (heads) *heads = (uint32_t)__popc(hm);
     return m;
 }
 
+// cnt[block] = run heads << 32 | descents.  The heads of the order BEFORE the repair bound the number of distinct hashes
+// from above (a repair only merges runs of equal hashes that a descent had split), closely: the nodes array is sized by it.
 template <class View>
-__global__ __launch_bounds__(256) void k_count_descents(const View V, uint32_t kmask, uint64_t n, uint32_t *__restrict__ cnt)
+__global__ __launch_bounds__(256) void k_count_descents(const View V, uint32_t kmask, uint64_t n, unsigned long long *__restrict__ cnt)
 {
     const uint64_t q0 = (uint64_t)blockIdx.x * DESC_BLOCK + threadIdx.x * 4u;
-    const uint32_t c = (uint32_t)__popc(descents_of_thread(V, kmask, n, q0));
-    __shared__ uint32_t s;
+    uint32_t heads = 0;
+    const uint32_t c = (uint32_t)__popc(descents_of_thread(V, kmask, n, q0, &heads));
+    __shared__ unsigned long long s;
     if (threadIdx.x == 0) s = 0;
     __syncthreads();
-    uint32_t w = c;
+    unsigned long long w = ((unsigned long long)heads << 32) | c;
     for (int d = 32; d; d >>= 1) w += __shfl_down(w, d, 64);
     if ((threadIdx.x & 63u) == 0 && w) atomicAdd(&s, w);
     __syncthreads();
@@ -975,14 +1052,18 @@ __global__ __launch_bounds__(256) void k_count_descents(const View V, uint32_t k
 
 template <class View>
 __global__ __launch_bounds__(256) void k_list_descents(const View V, uint32_t kmask, uint64_t n,
-                                                       const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ off,
-                                                       uint32_t n_blocks, uint32_t *__restrict__ bad, uint32_t cap,
-                                                       uint32_t *__restrict__ bad_q, uint32_t cap_q,
-                                                       unsigned long long *__restrict__ n_desc)
+                                                       const unsigned long long *__restrict__ cnt,
+                                                       const unsigned long long *__restrict__ off, uint32_t n_blocks,
+                                                       uint32_t *__restrict__ bad, uint32_t cap, uint32_t *__restrict__ bad_q,
+                                                       uint32_t cap_q, unsigned long long *__restrict__ n_desc)
 {
     const uint32_t b = blockIdx.x;
-    const uint32_t c_blk = cnt[b];
-    if (b == n_blocks - 1 && threadIdx.x == 0) *n_desc = (unsigned long long)off[b] + c_blk;
+    const uint32_t c_blk = (uint32_t)cnt[b];
+    if (b == n_blocks - 1 && threadIdx.x == 0) {
+        const unsigned long long tot = off[b] + cnt[b];
+        n_desc[0] = tot & 0xFFFFFFFFull;   // descents
+        n_desc[1] = tot >> 32;             // run heads before the repair
+    }
     if (c_blk == 0) return;
     const uint64_t q0 = (uint64_t)b * DESC_BLOCK + threadIdx.x * 4u;
     const uint32_t m = descents_of_thread(V, kmask, n, q0);
@@ -997,7 +1078,7 @@ __global__ __launch_bounds__(256) void k_list_descents(const View V, uint32_t km
     }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    uint32_t base = off[b] + (incl - c);
+    uint32_t base = (uint32_t)off[b] + (incl - c);
     for (uint32_t i = 0; i < wave; ++i) base += wsum[i];
     uint32_t mm = m;
     while (mm) {
@@ -1124,8 +1205,9 @@ __global__ __launch_bounds__(256) void k_repair_sort(const View V, const unsigne
 
 // Buffers of the in-place repair (kept by the caller until the stream has been synchronised).
 struct RepairState {
-    DevArray<unsigned long long> n_desc;
-    DevArray<uint32_t> bad_q, plan, status, blk_cnt, blk_off;
+    DevArray<unsigned long long> n_desc;   // [0] descents, [1] run heads before the repair
+    DevArray<unsigned long long> blk_cnt, blk_off;
+    DevArray<uint32_t> bad_q, plan, status;
 };
 
 // enqueue: list the descents of the phase-1 order, repair short runs in place.  `bad` (may be null) also receives the
@@ -1137,14 +1219,14 @@ void enqueue_repair(const View &V, uint32_t kmask, uint64_t n, uint32_t *bad, ui
     const uint32_t max_desc = (uint32_t)std::min<uint64_t>(REPAIR_MAX_DESC, std::max<uint64_t>(n, 1));
     r.bad_q.alloc(max_desc);
     r.plan.alloc(3 * (size_t)max_desc);
-    r.n_desc.alloc(1);
+    r.n_desc.alloc(2);
     r.status.alloc(1);
     r.blk_cnt.alloc(n_blocks);
     r.blk_off.alloc(n_blocks);
     SW_HIP(hipMemsetAsync(r.status.p, 0, 4, stream));
     hipLaunchKernelGGL(k_count_descents<View>, dim3(n_blocks), dim3(256), 0, stream, V, kmask, n, r.blk_cnt.p);
     SW_HIP(hipGetLastError());
-    exclusive_sum(r.blk_cnt.p, r.blk_off.p, n_blocks, (uint32_t)0, stream);
+    exclusive_sum(r.blk_cnt.p, r.blk_off.p, n_blocks, 0ull, stream);   // both halves at once: neither sum reaches 2^32
     hipLaunchKernelGGL(k_list_descents<View>, dim3(n_blocks), dim3(256), 0, stream, V, kmask, n, r.blk_cnt.p, r.blk_off.p,
                        n_blocks, bad, cap, r.bad_q.p, max_desc, r.n_desc.p);
     hipLaunchKernelGGL(k_repair_plan<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, kmask, n, r.bad_q.p, r.n_desc.p,
@@ -1214,21 +1296,11 @@ __global__ void k_scatter_sub(const uint64_t *__restrict__ sub_h, const OccPay *
     pay[q] = sub_v[t];   // (its low half is the hash's: it travelled with the element)
 }
 
-struct PayHeadFlag {   // head-of-run flag over the split (key32, pay.low) form of the sorted hashes
-    const uint32_t *key32;
-    const OccPay *pay;
-    __host__ __device__ uint32_t operator()(uint64_t s) const
-    {
-        return (s == 0 || key32[s] != key32[s - 1] || pay[s].low != pay[s - 1].low) ? 1u : 0u;
-    }
-};
-
 struct PaySort {
     DevArray<uint32_t> key_a, key_b;   // phase-1 double buffers; key_a / pay_a are handed in filled
     DevArray<OccPay> pay_a, pay_b;
     uint32_t *key32 = nullptr;         // result: top halves, ascending
     OccPay *pay = nullptr;             // result: low half, pos, record, original index (stable)
-    uint32_t *spare = nullptr;         // n free u32 for the caller (the other key buffer)
     uint64_t n_repaired = 0;
     // repair bookkeeping (device): keys of the descents for the general repair, and the in-place repair's state
     DevArray<uint32_t> bad;
@@ -1263,7 +1335,6 @@ void sort_pay(uint64_t n, hipStream_t stream, PaySort &o)
     }
     o.key32 = keys;
     o.pay = vals;
-    o.spare = keys_alt;
     o.cap = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(1u << 16, n / 16));
     o.bad.alloc(o.cap);
     enqueue_repair(PayView{keys, vals}, o.kmask, n, o.bad.p, o.cap, o.rep, stream);
@@ -1319,26 +1390,17 @@ bool sort_pay_settle(PaySort &o, unsigned long long D, uint32_t status, hipStrea
     return true;
 }
 
-// head counts of the sorted hashes into ps.spare; returns the number of distinct hashes (one host sync, shared with
-// the repair status)
-uint32_t sorted_head_counts(PaySort &ps, uint64_t n, hipStream_t stream)
+// wait for the sort and its in-place repair, run the general repair if something was left; returns an upper bound of the
+// number of distinct hashes (the run heads counted before the repair)
+uint64_t settle_sort(PaySort &ps, hipStream_t stream)
 {
-    uint32_t *cum = ps.spare;
-    uint32_t n_nodes = 0, status = 0;
-    unsigned long long D = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0),
-                                                       PayHeadFlag{ps.key32, ps.pay}),
-                      cum, n, (uint32_t)0, stream);
-        SW_HIP(hipMemcpyAsync(&n_nodes, cum + (n - 1), 4, hipMemcpyDeviceToHost, stream));
-        if (pass == 0) {
-            SW_HIP(hipMemcpyAsync(&status, ps.rep.status.p, 4, hipMemcpyDeviceToHost, stream));
-            SW_HIP(hipMemcpyAsync(&D, ps.rep.n_desc.p, 8, hipMemcpyDeviceToHost, stream));
-        }
-        SW_HIP(hipStreamSynchronize(stream));
-        if (pass == 1 || !sort_pay_settle(ps, D, status, stream)) break;
-    }
-    return n_nodes;
+    uint32_t status = 0;
+    unsigned long long dh[2] = {0, 0};
+    SW_HIP(hipMemcpyAsync(&status, ps.rep.status.p, 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipMemcpyAsync(dh, ps.rep.n_desc.p, 16, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    sort_pay_settle(ps, dh[0], status, stream);
+    return dh[1];
 }
 
 // Sorted occurrences -> kmers, nodes (hash, start, stop; counts zero), node rank of every occurrence in ORIGINAL order
@@ -1348,9 +1410,8 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
                            uint32_t *rank_out, DevArray<unsigned long long> *tbits, DevArray<unsigned long long> *nbits)
 {
     sort_pay(n, stream, ps);
-    const uint32_t n_nodes = sorted_head_counts(ps, n, stream);   // into the spare key buffer
-    ix.n_nodes = n_nodes;
-    ix.nodes.alloc(n_nodes);
+    const uint64_t node_cap = settle_sort(ps, stream);   // >= the number of nodes, within ~2 descents of it
+    ix.nodes.alloc(node_cap);
     uint64_t direct_max = UNSORT_DIRECT_MAX;
     if (const char *e = getenv("SEQWIN_AMD_UNSORT_DIRECT")) direct_max = 1ull << std::min(40, std::max(0, atoi(e)));   // A/B, tests
     const bool direct = rank_out && n <= direct_max;
@@ -1364,15 +1425,22 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
         tbits->alloc((n + 63) / 64);
         nbits->alloc((n + 63) / 64);
     }
-    const unsigned blocks = (unsigned)((n + 256 * NODES_ITEMS - 1) / (256 * NODES_ITEMS));
+    const unsigned blocks = (unsigned)((n + NODES_TILE - 1) / NODES_TILE);
+    DevArray<unsigned long long> tile_state(blocks);
+    DevArray<uint32_t> words(2);   // [0] tile tickets, [1] the number of nodes
+    SW_HIP(hipMemsetAsync(tile_state.p, 0, (size_t)blocks * 8, stream));
+    SW_HIP(hipMemsetAsync(words.p, 0, 8, stream));
     if (rec_flag)
-        hipLaunchKernelGGL(k_nodes<true>, dim3(blocks), dim3(256), 0, stream, ps.key32, ps.pay, ps.spare, n, base, rec_flag,
-                           ix.kmers.p, ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uk0.p, uv0.p, tbits->p, nbits->p);
+        hipLaunchKernelGGL(k_nodes<true>, dim3(blocks), dim3(256), 0, stream, ps.key32, ps.pay, n, base, rec_flag, ix.kmers.p,
+                           ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uk0.p, uv0.p, tbits->p, nbits->p, tile_state.p,
+                           words.p, words.p + 1);
     else
-        hipLaunchKernelGGL(k_nodes<false>, dim3(blocks), dim3(256), 0, stream, ps.key32, ps.pay, ps.spare, n, base,
-                           (const uint32_t *)nullptr, ix.kmers.p, ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uk0.p, uv0.p,
-                           (unsigned long long *)nullptr, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL(k_nodes<false>, dim3(blocks), dim3(256), 0, stream, ps.key32, ps.pay, n, base, (const uint32_t *)nullptr,
+                           ix.kmers.p, ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uk0.p, uv0.p,
+                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, tile_state.p, words.p, words.p + 1);
     SW_HIP(hipGetLastError());
+    uint32_t n_nodes = 0;
+    SW_HIP(hipMemcpyAsync(&n_nodes, words.p + 1, 4, hipMemcpyDeviceToHost, stream));
     if (rank_out && !direct) {
         unsigned nbit = 1;
         while (nbit < 32 && (1ull << nbit) < n) ++nbit;          // indices < 2^nbit
@@ -1385,6 +1453,9 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
                            rank_out);
         SW_HIP(hipGetLastError());
     }
+    SW_HIP(hipStreamSynchronize(stream));   // n_nodes has arrived
+    if (n_nodes > node_cap) raise(SW_ERR_RUNTIME, "internal error: %u nodes exceed the bound %llu", n_nodes, (unsigned long long)node_cap);
+    ix.n_nodes = n_nodes;
     // (the sort buffers go back to the pool here; later users are ordered after these kernels on this stream, or fenced)
     return n_nodes;
 }
