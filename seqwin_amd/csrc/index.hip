@@ -182,7 +182,7 @@ template <bool BITS>
 __global__ __launch_bounds__(256) void k_nodes(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay, uint64_t n,
                                                uint64_t base, const uint32_t *__restrict__ rec_flag, sw_kmer *__restrict__ kmers,
                                                sw_node *__restrict__ nodes, uint32_t *__restrict__ rank_direct,
-                                               uint32_t *__restrict__ ukey, uint64_t *__restrict__ uval,
+                                               uint64_t *__restrict__ uval,
                                                unsigned long long *__restrict__ tbits, unsigned long long *__restrict__ nbits,
                                                unsigned long long *__restrict__ tile_state, uint32_t *__restrict__ ticket,
                                                uint32_t *__restrict__ n_nodes_out)
@@ -277,9 +277,8 @@ __global__ __launch_bounds__(256) void k_nodes(const uint32_t *__restrict__ key3
             kmers[s] = km;
             if (rank_direct) {
                 rank_direct[p[j].idx] = nid;
-            } else if (ukey) {
-                ukey[s] = p[j].idx >> UNSORT_BITS;
-                uval[s] = ((uint64_t)nid << 32) | p[j].idx;
+            } else if (uval) {
+                uval[s] = ((uint64_t)p[j].idx << 32) | nid;   // the unsort's element: index above, node below
             }
             if (head) {
                 // (stop is written by the next head / the last occurrence: two stores to one node never race on a field)
@@ -412,10 +411,10 @@ __global__ void k_table_lookup(const uint64_t *__restrict__ hash, uint64_t n, co
 
 // ---- unsort: node rank of every occurrence, back in (record_idx, pos) order --------------------------------------
 // (index, rank) pairs arrive in hash order, i.e. with random indices: scattering 4 B to rank[index] costs a 128-B HBM
-// line each (26 ms for 745 M on MI355X).  Instead the pairs are first brought into buckets of 2^14 consecutive indices
-// (a stable radix sort on the index's high bits only -- the indices are a permutation of [0, n), so bucket b is
-// exactly positions [b * 2^14, (b + 1) * 2^14)), and one workgroup per bucket scatters its pairs inside LDS and writes
-// the 64 KiB of ranks out in order.
+// line each (26 ms for 745 M on MI355X).  Instead the pairs -- one 64-bit word, index << 32 | rank -- are first brought
+// into buckets of 2^14 consecutive indices (a keys-only radix sort on the index's high bits only; the indices are a
+// permutation of [0, n), so bucket b is exactly positions [b * 2^14, (b + 1) * 2^14)), and one workgroup per bucket
+// scatters its pairs inside LDS and writes the 64 KiB of ranks out in order.
 __global__ __launch_bounds__(1024) void k_unsort_bucket(const uint64_t *__restrict__ uval, uint64_t n, uint32_t *__restrict__ rank)
 {
     __shared__ uint32_t sr[UNSORT_RANGE];
@@ -423,7 +422,7 @@ __global__ __launch_bounds__(1024) void k_unsort_bucket(const uint64_t *__restri
     const uint32_t cnt = (uint32_t)min((uint64_t)UNSORT_RANGE, n - b0);
     for (uint32_t t = threadIdx.x; t < cnt; t += 1024) {
         const uint64_t v = uval[b0 + t];
-        sr[(uint32_t)v & (UNSORT_RANGE - 1u)] = (uint32_t)(v >> 32);
+        sr[(uint32_t)(v >> 32) & (UNSORT_RANGE - 1u)] = (uint32_t)v;
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < cnt; t += 1024) rank[b0 + t] = sr[t];
@@ -1032,6 +1031,41 @@ __device__ __forceinline__ uint32_t descents_of_thread(const View &V, uint32_t k
     return m;
 }
 
+// the same for the occurrence arrays, with 16-B loads (four consecutive keys; the payloads whole: their lines are read anyway)
+__device__ __forceinline__ uint32_t descents_of_thread(const PayView &V, uint32_t kmask, uint64_t n, uint64_t q0, uint32_t *heads = nullptr)
+{
+    uint32_t m = 0, hm = 0;
+    if (heads) *heads = 0;
+    if (q0 >= n) return 0;
+    uint32_t kq[4];
+    uint64_t lq[4];
+    if (q0 + 4 <= n) {
+        const uint4 kv = *reinterpret_cast<const uint4 *>(V.key32 + q0);
+        kq[0] = kv.x; kq[1] = kv.y; kq[2] = kv.z; kq[3] = kv.w;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) lq[i] = reinterpret_cast<const uint4 *>(V.pay + q0 + i)->x;   // OccPay::low
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            kq[i] = (q0 + i < n) ? V.key32[q0 + i] : 0u;
+            lq[i] = (q0 + i < n) ? V.pay[q0 + i].low : 0u;
+        }
+    }
+    uint32_t kp = q0 ? V.key32[q0 - 1] : 0;
+    uint64_t lp = q0 ? V.pay[q0 - 1].low : 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint64_t q = q0 + i;
+        if (q >= n) break;
+        if (q && (kq[i] & kmask) == (kp & kmask) && (kq[i] < kp || (kq[i] == kp && lq[i] < lp))) m |= 1u << i;
+        if (q == 0 || kq[i] != kp || lq[i] != lp) hm |= 1u << i;
+        kp = kq[i];
+        lp = lq[i];
+    }
+    if (heads) *heads = (uint32_t)__popc(hm);
+    return m;
+}
+
 // cnt[block] = run heads << 32 | descents.  The heads of the order BEFORE the repair bound the number of distinct hashes
 // from above (a repair only merges runs of equal hashes that a descent had split), closely: the nodes array is sized by it.
 template <class View>
@@ -1415,12 +1449,8 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     uint64_t direct_max = UNSORT_DIRECT_MAX;
     if (const char *e = getenv("SEQWIN_AMD_UNSORT_DIRECT")) direct_max = 1ull << std::min(40, std::max(0, atoi(e)));   // A/B, tests
     const bool direct = rank_out && n <= direct_max;
-    DevArray<uint32_t> uk0, uk1;
     DevArray<uint64_t> uv0, uv1;
-    if (rank_out && !direct) {
-        uk0.alloc(n);
-        uv0.alloc(n);
-    }
+    if (rank_out && !direct) uv0.alloc(n);
     if (rec_flag) {
         tbits->alloc((n + 63) / 64);
         nbits->alloc((n + 63) / 64);
@@ -1432,11 +1462,11 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     SW_HIP(hipMemsetAsync(words.p, 0, 8, stream));
     if (rec_flag)
         hipLaunchKernelGGL(k_nodes<true>, dim3(blocks), dim3(256), 0, stream, ps.key32, ps.pay, n, base, rec_flag, ix.kmers.p,
-                           ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uk0.p, uv0.p, tbits->p, nbits->p, tile_state.p,
+                           ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uv0.p, tbits->p, nbits->p, tile_state.p,
                            words.p, words.p + 1);
     else
         hipLaunchKernelGGL(k_nodes<false>, dim3(blocks), dim3(256), 0, stream, ps.key32, ps.pay, n, base, (const uint32_t *)nullptr,
-                           ix.kmers.p, ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uk0.p, uv0.p,
+                           ix.kmers.p, ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uv0.p,
                            (unsigned long long *)nullptr, (unsigned long long *)nullptr, tile_state.p, words.p, words.p + 1);
     SW_HIP(hipGetLastError());
     uint32_t n_nodes = 0;
@@ -1444,11 +1474,17 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     if (rank_out && !direct) {
         unsigned nbit = 1;
         while (nbit < 32 && (1ull << nbit) < n) ++nbit;          // indices < 2^nbit
-        uk1.alloc(n);
         uv1.alloc(n);
-        uint32_t *k = uk0.p, *k_alt = uk1.p;
-        uint64_t *v = uv0.p, *v_alt = uv1.p;
-        if (nbit > UNSORT_BITS) sort_pairs(k, k_alt, v, v_alt, n, 0, nbit - UNSORT_BITS, stream);   // buckets of 2^14 consecutive indices
+        uint64_t *v = uv0.p;
+        if (nbit > UNSORT_BITS) {   // buckets of 2^14 consecutive indices: sort on the index's bits above those
+            // (begin_bit > 0 of rocPRIM's radix sort is checked on this stack by scripts/micro/sort_beginbit.hip)
+            rocprim::double_buffer<uint64_t> dk(uv0.p, uv1.p);
+            size_t tmp_bytes = 0;
+            SW_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, dk, n, 32 + UNSORT_BITS, 32 + nbit, stream));
+            DevArray<unsigned char> tmp(tmp_bytes);
+            SW_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, n, 32 + UNSORT_BITS, 32 + nbit, stream));
+            v = dk.current();
+        }
         hipLaunchKernelGGL(k_unsort_bucket, dim3((unsigned)((n + UNSORT_RANGE - 1) / UNSORT_RANGE)), dim3(1024), 0, stream, v, n,
                            rank_out);
         SW_HIP(hipGetLastError());
