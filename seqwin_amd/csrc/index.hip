@@ -160,10 +160,14 @@ __global__ void k_iota(uint32_t *v, uint64_t n)
 // the unsort, which brings every occurrence's node rank back to (record_idx, pos) order; and -- when the counts are wanted --
 // one bit per occurrence says "first occurrence of a target (T) / non-target (N) assembly in its node" (the occurrences of
 // a node are in record order, records are assembly-major, filter.cpp:62-136), so a node's counts are two popcounts.
-// A workgroup takes NODES_ITEMS x 256 consecutive occurrences, 256 at a time (lane s of a wave = occurrence s of a
+// A workgroup takes NODES_TILE consecutive occurrences, NODES_THREADS at a time (lane s of a wave = occurrence s of a
 // 64-aligned group: the bits of a group are one ballot).
-constexpr int NODES_ITEMS = 8;
-constexpr uint32_t NODES_TILE = 256 * NODES_ITEMS;
+constexpr int NODES_ITEMS = 4;                       // occurrences per thread
+constexpr int NODES_THREADS = 512;                   // 8 waves: the same 2048-occurrence tile (one ticket, one look-back) at half
+                                                     // the registers per thread of 256 x 8 (100 VGPRs: 4 waves per SIMD)
+constexpr int NODES_WAVES = NODES_THREADS / 64;
+constexpr uint32_t NODES_TILE = NODES_THREADS * NODES_ITEMS;
+static_assert(NODES_ITEMS * NODES_WAVES == 32, "the (row, wave) group counts are scanned by half a wave");
 constexpr uint32_t UNSORT_BITS = 14;                 // the unsort's last step handles 2^14 consecutive indices in LDS
 constexpr uint32_t UNSORT_RANGE = 1u << UNSORT_BITS;
 constexpr uint64_t UNSORT_DIRECT_MAX = 1ull << 25;   // up to here (128 MiB of ranks) the array stays in the 256 MiB Infinity Cache and a
@@ -179,7 +183,7 @@ constexpr uint64_t UNSORT_DIRECT_MAX = 1ull << 25;   // up to here (128 MiB of r
 constexpr unsigned long long TS_AGG = 1ull << 62, TS_INC = 2ull << 62;
 
 template <bool BITS>
-__global__ __launch_bounds__(256) void k_nodes(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay, uint64_t n,
+__global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay, uint64_t n,
                                                uint64_t base, const uint32_t *__restrict__ rec_flag, sw_kmer *__restrict__ kmers,
                                                sw_node *__restrict__ nodes, uint32_t *__restrict__ rank_direct,
                                                uint64_t *__restrict__ uval,
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(256) void k_nodes(const uint32_t *__restrict__ key3
                                                uint32_t *__restrict__ n_nodes_out)
 {
     __shared__ uint32_t s_tile, s_excl;
-    __shared__ uint32_t s_row[NODES_ITEMS * 4 + 1];   // heads of (row j, wave): counts, then exclusive offsets; [32] = tile total
+    __shared__ uint32_t s_row[NODES_ITEMS * NODES_WAVES];   // heads of (row j, wave): counts, then exclusive offsets
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void k_nodes(const uint32_t *__restrict__ key3
     OccPay p[NODES_ITEMS];
 #pragma unroll
     for (int j = 0; j < NODES_ITEMS; ++j) {
-        const uint64_t s = s0 + (uint64_t)j * 256 + threadIdx.x;
+        const uint64_t s = s0 + (uint64_t)j * NODES_THREADS + threadIdx.x;
         const bool live = s < n;
         k[j] = 0;
         p[j] = OccPay{0, 0, 0, 0};
@@ -219,18 +223,18 @@ __global__ __launch_bounds__(256) void k_nodes(const uint32_t *__restrict__ key3
         const unsigned long long bal = __ballot(head);
         within[j] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
         if (head) headm |= 1u << j;
-        if (lane == 0) s_row[j * 4 + wave] = (uint32_t)__popcll(bal);
+        if (lane == 0) s_row[j * NODES_WAVES + wave] = (uint32_t)__popcll(bal);
     }
     __syncthreads();
     if (wave == 0) {
         // exclusive offsets of the 32 (row, wave) groups, the tile's total, then the look-back
-        uint32_t c = (lane < NODES_ITEMS * 4) ? s_row[lane] : 0u, incl = c;
+        uint32_t c = (lane < 32) ? s_row[lane] : 0u, incl = c;
         for (uint32_t d = 1; d < 32; d <<= 1) {
             const uint32_t up = __shfl_up(incl, d, 64);
             if (lane >= d) incl += up;
         }
-        const uint32_t total = __shfl(incl, NODES_ITEMS * 4 - 1, 64);
-        if (lane < NODES_ITEMS * 4) s_row[lane] = incl - c;
+        const uint32_t total = __shfl(incl, 31, 64);
+        if (lane < 32) s_row[lane] = incl - c;
         if (lane == 0)
             __hip_atomic_store(&tile_state[tile], (tile == 0 ? TS_INC : TS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t excl = 0;
@@ -266,10 +270,10 @@ __global__ __launch_bounds__(256) void k_nodes(const uint32_t *__restrict__ key3
     const uint32_t excl = s_excl;
 #pragma unroll
     for (int j = 0; j < NODES_ITEMS; ++j) {
-        const uint64_t s = s0 + (uint64_t)j * 256 + threadIdx.x;
+        const uint64_t s = s0 + (uint64_t)j * NODES_THREADS + threadIdx.x;
         const bool live = s < n;
         const bool head = (headm >> j) & 1u;
-        const uint32_t nid = excl + s_row[j * 4 + wave] + within[j] + (head ? 1u : 0u) - 1u;   // heads up to and including s, - 1
+        const uint32_t nid = excl + s_row[j * NODES_WAVES + wave] + within[j] + (head ? 1u : 0u) - 1u;   // heads up to and including s, - 1
         if (live) {
             sw_kmer km;
             km.pos = p[j].pos;
@@ -1461,11 +1465,11 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     SW_HIP(hipMemsetAsync(tile_state.p, 0, (size_t)blocks * 8, stream));
     SW_HIP(hipMemsetAsync(words.p, 0, 8, stream));
     if (rec_flag)
-        hipLaunchKernelGGL(k_nodes<true>, dim3(blocks), dim3(256), 0, stream, ps.key32, ps.pay, n, base, rec_flag, ix.kmers.p,
+        hipLaunchKernelGGL(k_nodes<true>, dim3(blocks), dim3(NODES_THREADS), 0, stream, ps.key32, ps.pay, n, base, rec_flag, ix.kmers.p,
                            ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uv0.p, tbits->p, nbits->p, tile_state.p,
                            words.p, words.p + 1);
     else
-        hipLaunchKernelGGL(k_nodes<false>, dim3(blocks), dim3(256), 0, stream, ps.key32, ps.pay, n, base, (const uint32_t *)nullptr,
+        hipLaunchKernelGGL(k_nodes<false>, dim3(blocks), dim3(NODES_THREADS), 0, stream, ps.key32, ps.pay, n, base, (const uint32_t *)nullptr,
                            ix.kmers.p, ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uv0.p,
                            (unsigned long long *)nullptr, (unsigned long long *)nullptr, tile_state.p, words.p, words.p + 1);
     SW_HIP(hipGetLastError());

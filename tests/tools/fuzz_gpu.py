@@ -11,6 +11,7 @@ from seqwin_amd import _core
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 replay = [int(x) for x in sys.argv[3:]]
+LOWMEM = os.environ.get("FUZZ_LOWMEM") == "1"      # sw_build's chunked low-memory route (set SEQWIN_AMD_LOWMEM_CHUNK_MBP=0: one assembly per chunk)
 DIST = os.environ.get("FUZZ_DIST") == "1"          # also push every case through the routed multi-GPU forms (P shards on one GPU)
 if DIST:
     sys.path.insert(0, str(ROOT / "tests"))
@@ -63,7 +64,7 @@ while time.time() < t_end and (not replay or it < len(replay)):
     k = rng.choice([3, 4, 5, 7, 11, 15, 16, 17, 19, 21, 31, 32, 33, 47, 64, 65, 100, 255, 256, 257])
     w = rng.choice([1, 2, 3, 5, 10, 15, 16, 17, 25, 31, 32, 33, 34, 50, 63, 64, 65, 100, 200, 201, 500, 1000, 4096])
     try:
-        got = _core._build_native(ps, k, w, rng.choice([1, 3]), False)
+        got = _core._build_native(ps, k, w, rng.choice([1, 3]), LOWMEM)
         exp = oracle.build(ps, k, w)
         ok = all(np.array_equal(x, y) for x, y in zip(got[:4], exp[:4])) and [tuple(t) for t in got[4]] == [tuple(t) for t in exp[4]]
         if ok and len(got[1]) and len(ps) >= 2:
