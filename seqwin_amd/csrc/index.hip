@@ -162,12 +162,11 @@ __global__ void k_iota(uint32_t *v, uint64_t n)
 // a node are in record order, records are assembly-major, filter.cpp:62-136), so a node's counts are two popcounts.
 // A workgroup takes NODES_TILE consecutive occurrences, NODES_THREADS at a time (lane s of a wave = occurrence s of a
 // 64-aligned group: the bits of a group are one ballot).
-constexpr int NODES_ITEMS = 4;                       // occurrences per thread
-constexpr int NODES_THREADS = 512;                   // 8 waves: the same 2048-occurrence tile (one ticket, one look-back) at half
-                                                     // the registers per thread of 256 x 8 (100 VGPRs: 4 waves per SIMD)
+constexpr int NODES_ROWS = 2;                        // rows per tile; a row = NODES_THREADS lanes x 2 consecutive occurrences
+constexpr int NODES_THREADS = 512;                   // 8 waves
 constexpr int NODES_WAVES = NODES_THREADS / 64;
-constexpr uint32_t NODES_TILE = NODES_THREADS * NODES_ITEMS;
-static_assert(NODES_ITEMS * NODES_WAVES == 32, "the (row, wave) group counts are scanned by half a wave");
+constexpr uint32_t NODES_ROW = NODES_THREADS * 2;
+constexpr uint32_t NODES_TILE = NODES_ROW * NODES_ROWS;   // 2048 occurrences: one ticket, one look-back
 constexpr uint32_t UNSORT_BITS = 14;                 // the unsort's last step handles 2^14 consecutive indices in LDS
 constexpr uint32_t UNSORT_RANGE = 1u << UNSORT_BITS;
 constexpr uint64_t UNSORT_DIRECT_MAX = 1ull << 25;   // up to here (128 MiB of ranks) the array stays in the 256 MiB Infinity Cache and a
@@ -182,6 +181,21 @@ constexpr uint64_t UNSORT_DIRECT_MAX = 1ull << 25;   // up to here (128 MiB of r
 // and including the tile.
 constexpr unsigned long long TS_AGG = 1ull << 62, TS_INC = 2ull << 62;
 
+// bits of a (lanes 0..31's even positions) and b (odd positions) interleaved: result bit 2 l + e = e ? b[l] : a[l]
+__device__ __forceinline__ unsigned long long interleave32(uint32_t a, uint32_t b)
+{
+    unsigned long long x = a, y = b;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull; y = (y | (y << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;  y = (y | (y << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;  y = (y | (y << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;  y = (y | (y << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;  y = (y | (y << 1)) & 0x5555555555555555ull;
+    return x | (y << 1);
+}
+
+// Every lane takes TWO consecutive occurrences per row (16-B stores of kmers and of the unsort words, one 8-B load of
+// the keys, 32 B of payload), a wave 128, so the bits of a wave's row are two 64-bit words: ballots of the even and of the
+// odd occurrences, interleaved (wave-uniform values: scalar ALU).
 template <bool BITS>
 __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay, uint64_t n,
                                                uint64_t base, const uint32_t *__restrict__ rec_flag, sw_kmer *__restrict__ kmers,
@@ -192,49 +206,57 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
                                                uint32_t *__restrict__ n_nodes_out)
 {
     __shared__ uint32_t s_tile, s_excl;
-    __shared__ uint32_t s_row[NODES_ITEMS * NODES_WAVES];   // heads of (row j, wave): counts, then exclusive offsets
+    __shared__ uint32_t s_row[NODES_ROWS * NODES_WAVES];   // heads of (row, wave): counts, then exclusive offsets
+    static_assert(NODES_ROWS * NODES_WAVES <= 32, "the (row, wave) group counts are scanned by half a wave");
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint64_t s0 = (uint64_t)tile * NODES_TILE;
-    uint32_t k[NODES_ITEMS], within[NODES_ITEMS], headm = 0, prec[NODES_ITEMS];
-    OccPay p[NODES_ITEMS];
+    uint32_t k[NODES_ROWS][2], within[NODES_ROWS], headm = 0, prec[NODES_ROWS];
+    OccPay p[NODES_ROWS][2];
 #pragma unroll
-    for (int j = 0; j < NODES_ITEMS; ++j) {
-        const uint64_t s = s0 + (uint64_t)j * NODES_THREADS + threadIdx.x;
-        const bool live = s < n;
-        k[j] = 0;
-        p[j] = OccPay{0, 0, 0, 0};
-        if (live) {
-            k[j] = key32[s];
-            p[j] = pay[s];
+    for (int r = 0; r < NODES_ROWS; ++r) {
+        const uint64_t s = s0 + (uint64_t)r * NODES_ROW + 2 * threadIdx.x;   // occurrences s, s + 1
+        k[r][0] = k[r][1] = 0;
+        p[r][0] = p[r][1] = OccPay{0, 0, 0, 0};
+        if (s + 1 < n) {
+            const uint2 kk = *reinterpret_cast<const uint2 *>(key32 + s);
+            k[r][0] = kk.x;
+            k[r][1] = kk.y;
+            p[r][0] = pay[s];
+            p[r][1] = pay[s + 1];
+        } else if (s < n) {
+            k[r][0] = key32[s];
+            p[r][0] = pay[s];
         }
-        // the previous occurrence: the lane below, or (lane 0) a load
-        uint32_t pk = __shfl_up(k[j], 1, 64), plow = __shfl_up(p[j].low, 1, 64);
-        prec[j] = __shfl_up(p[j].rec, 1, 64);
-        if (lane == 0 && live && s) {
+        // the occurrence before s: the odd one of the lane below, or (lane 0) a load
+        uint32_t pk = __shfl_up(k[r][1], 1, 64), plow = __shfl_up(p[r][1].low, 1, 64);
+        prec[r] = __shfl_up(p[r][1].rec, 1, 64);
+        if (lane == 0 && s < n && s) {
             pk = key32[s - 1];
             const OccPay q = pay[s - 1];
             plow = q.low;
-            prec[j] = q.rec;
+            prec[r] = q.rec;
         }
-        const bool head = live && (s == 0 || k[j] != pk || p[j].low != plow);
-        const unsigned long long bal = __ballot(head);
-        within[j] = (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-        if (head) headm |= 1u << j;
-        if (lane == 0) s_row[j * NODES_WAVES + wave] = (uint32_t)__popcll(bal);
+        const bool h0 = s < n && (s == 0 || k[r][0] != pk || p[r][0].low != plow);
+        const bool h1 = s + 1 < n && (k[r][1] != k[r][0] || p[r][1].low != p[r][0].low);
+        const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1), lt = (1ull << lane) - 1ull;
+        within[r] = (uint32_t)__popcll(b0 & lt) + (uint32_t)__popcll(b1 & lt);   // heads of the wave's row before occurrence s
+        if (h0) headm |= 1u << (2 * r);
+        if (h1) headm |= 2u << (2 * r);
+        if (lane == 0) s_row[r * NODES_WAVES + wave] = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
     }
     __syncthreads();
     if (wave == 0) {
-        // exclusive offsets of the 32 (row, wave) groups, the tile's total, then the look-back
-        uint32_t c = (lane < 32) ? s_row[lane] : 0u, incl = c;
+        // exclusive offsets of the (row, wave) groups, the tile's total, then the look-back
+        uint32_t c = (lane < NODES_ROWS * NODES_WAVES) ? s_row[lane] : 0u, incl = c;
         for (uint32_t d = 1; d < 32; d <<= 1) {
             const uint32_t up = __shfl_up(incl, d, 64);
             if (lane >= d) incl += up;
         }
         const uint32_t total = __shfl(incl, 31, 64);
-        if (lane < 32) s_row[lane] = incl - c;
+        if (lane < NODES_ROWS * NODES_WAVES) s_row[lane] = incl - c;
         if (lane == 0)
             __hip_atomic_store(&tile_state[tile], (tile == 0 ? TS_INC : TS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t excl = 0;
@@ -269,43 +291,62 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
     __syncthreads();
     const uint32_t excl = s_excl;
 #pragma unroll
-    for (int j = 0; j < NODES_ITEMS; ++j) {
-        const uint64_t s = s0 + (uint64_t)j * NODES_THREADS + threadIdx.x;
-        const bool live = s < n;
-        const bool head = (headm >> j) & 1u;
-        const uint32_t nid = excl + s_row[j * NODES_WAVES + wave] + within[j] + (head ? 1u : 0u) - 1u;   // heads up to and including s, - 1
-        if (live) {
+    for (int r = 0; r < NODES_ROWS; ++r) {
+        const uint64_t s = s0 + (uint64_t)r * NODES_ROW + 2 * threadIdx.x;
+        const bool live0 = s < n, live1 = s + 1 < n;
+        const bool h0 = (headm >> (2 * r)) & 1u, h1 = (headm >> (2 * r + 1)) & 1u;
+        // node = heads up to and including the occurrence, - 1
+        const uint32_t nid0 = excl + s_row[r * NODES_WAVES + wave] + within[r] + (h0 ? 1u : 0u) - 1u;
+        const uint32_t nid1 = nid0 + (h1 ? 1u : 0u);
+        if (live1) {
+            *reinterpret_cast<uint4 *>(kmers + s) = make_uint4(p[r][0].pos, p[r][0].rec, p[r][1].pos, p[r][1].rec);
+            if (uval)
+                *reinterpret_cast<ulonglong2 *>(uval + s) = make_ulonglong2(((uint64_t)p[r][0].idx << 32) | nid0,
+                                                                          ((uint64_t)p[r][1].idx << 32) | nid1);
+        } else if (live0) {
             sw_kmer km;
-            km.pos = p[j].pos;
-            km.record_idx = p[j].rec;
+            km.pos = p[r][0].pos;
+            km.record_idx = p[r][0].rec;
             kmers[s] = km;
-            if (rank_direct) {
-                rank_direct[p[j].idx] = nid;
-            } else if (uval) {
-                uval[s] = ((uint64_t)p[j].idx << 32) | nid;   // the unsort's element: index above, node below
-            }
-            if (head) {
+            if (uval) uval[s] = ((uint64_t)p[r][0].idx << 32) | nid0;   // the unsort's element: index above, node below
+        }
+        if (rank_direct) {
+            if (live0) rank_direct[p[r][0].idx] = nid0;
+            if (live1) rank_direct[p[r][1].idx] = nid1;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool head = e ? h1 : h0;
+            if (head) {   // (heads are live)
+                const uint32_t nid = e ? nid1 : nid0;
                 // (stop is written by the next head / the last occurrence: two stores to one node never race on a field)
-                nodes[nid].hash = ((uint64_t)k[j] << 32) | p[j].low;
-                nodes[nid].start = base + s;
+                nodes[nid].hash = ((uint64_t)k[r][e] << 32) | p[r][e].low;
+                nodes[nid].start = base + s + e;
                 nodes[nid].n_tar = 0;
                 nodes[nid].n_neg = 0;
                 nodes[nid].penalty = 0.0;
-                if (s) nodes[nid - 1].stop = base + s;
+                if (s + e) nodes[nid - 1].stop = base + s + e;
             }
-            if (s == n - 1) nodes[nid].stop = base + n;
         }
+        if (live0 && s == n - 1) nodes[nid0].stop = base + n;
+        if (live1 && s + 1 == n - 1) nodes[nid1].stop = base + n;
         if (BITS) {
             // rec_flag[r] = assembly << 1 | is_target
-            const uint32_t f = live ? rec_flag[p[j].rec] : 0u;
-            uint32_t pf = __shfl_up(f, 1, 64);
-            if (lane == 0 && live && s) pf = rec_flag[prec[j]];
-            const bool first_of_asm = live && (head || (f >> 1) != (pf >> 1));
-            const unsigned long long tb = __ballot(first_of_asm && (f & 1u));
-            const unsigned long long nb = __ballot(first_of_asm && !(f & 1u));
-            if (lane == 0 && live) {   // (lane 0 holds the group's first occurrence: dead there = the whole group is past the end)
-                tbits[s >> 6] = tb;
-                nbits[s >> 6] = nb;
+            const uint32_t f0 = live0 ? rec_flag[p[r][0].rec] : 0u, f1 = live1 ? rec_flag[p[r][1].rec] : 0u;
+            uint32_t pf = __shfl_up(f1, 1, 64);
+            if (lane == 0 && live0 && s) pf = rec_flag[prec[r]];
+            const bool first0 = live0 && (h0 || (f0 >> 1) != (pf >> 1)), first1 = live1 && (h1 || (f1 >> 1) != (f0 >> 1));
+            const unsigned long long t0 = __ballot(first0 && (f0 & 1u)), t1 = __ballot(first1 && (f1 & 1u));
+            const unsigned long long g0 = __ballot(first0 && !(f0 & 1u)), g1 = __ballot(first1 && !(f1 & 1u));
+            // the wave's 128 occurrences start at a multiple of 128: words (s >> 6) and (s >> 6) + 1 of lane 0's s
+            if (lane == 0 && live0) {
+                const uint64_t wd = s >> 6;
+                tbits[wd] = interleave32((uint32_t)t0, (uint32_t)t1);
+                nbits[wd] = interleave32((uint32_t)g0, (uint32_t)g1);
+                if (s + 64 < n) {
+                    tbits[wd + 1] = interleave32((uint32_t)(t0 >> 32), (uint32_t)(t1 >> 32));
+                    nbits[wd + 1] = interleave32((uint32_t)(g0 >> 32), (uint32_t)(g1 >> 32));
+                }
             }
         }
     }
