@@ -274,7 +274,8 @@ int sw_occ_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void
 int sw_occ_size(const sw_occ *o, uint64_t *n, double *sketch_ms);
 void sw_occ_free(sw_occ *o);
 /* Stable partition by owner = number of ascending bounds <= out_hash.  DEVICE outputs: rows[n][2] =
- * {out_hash, pos | (record_idx + rec_offset) << 32} grouped by owner, perm[n] (u32: original index of row j).
+ * {out_hash, pos | (record_idx + rec_offset) << 32} grouped by owner, perm[n] (u32: original index of row j; may be
+ * NULL -- the handle remembers the partition and sw_occ_adjacency walks it again instead of scattering through perm).
  * HOST output: counts[n_bounds + 1]. */
 int sw_occ_partition(const sw_occ *o, const uint64_t *bounds, uint64_t n_bounds, uint64_t rec_offset, void *rows_dev,
                      void *perm_dev, uint64_t *counts, void *stream);
@@ -286,7 +287,8 @@ int sw_slice_build(const void *rows_dev, uint64_t n, uint64_t kmer_base, const u
 /* Copy the node hashes (u64[n_nodes]) of an index into a DEVICE buffer. */
 int sw_index_node_hashes(const sw_index *ix, void *dst_dev, void *stream);
 /* Source: adjacency rows of consecutive minimizers of a record, from the GLOBAL node rank of every partitioned row
- * (rank_by_row_dev, u32[n]) and perm; grouped by edge owner = number of ascending rank_bounds <= rank_lo.
+ * (rank_by_row_dev, u32[n]; perm_dev is only read when the handle was not partitioned by sw_occ_partition and may be NULL
+ * otherwise); grouped by edge owner = number of ascending rank_bounds <= rank_lo.
  * asm_bits == 0: DEVICE rows[<= n-1][2] = {(rank_lo << n_bits) | rank_hi, global assembly};
  * asm_bits  > 0 (requires 2 n_bits + asm_bits <= 64): DEVICE rows[<= n-1] = one packed key
  *               (((rank_lo << n_bits) | rank_hi) << asm_bits) | global assembly  -- half the exchange volume.

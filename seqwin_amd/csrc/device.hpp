@@ -186,6 +186,8 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
 struct alignas(16) OccPay {
     uint32_t low, pos, rec, idx;
 };
+struct PartState;                       // index.hip: offsets of the last tuple partition (the way back walks them again)
+void part_state_delete(PartState *p);
 struct OrderedOcc {
     // exchange form (multi-GPU tuple exchange, sw_sketch): the tuples themselves
     DevArray<uint64_t> hash;   // out_hash in (record_idx, pos) order
@@ -195,6 +197,19 @@ struct OrderedOcc {
     DevArray<OccPay> pay;
     DevArray<uint32_t> rec;    // record_idx in (record_idx, pos) order
     uint64_t n = 0;
+    PartState *part = nullptr;
+    OrderedOcc() = default;
+    OrderedOcc(OrderedOcc &&o) noexcept { *this = std::move(o); }
+    OrderedOcc &operator=(OrderedOcc &&o) noexcept
+    {
+        if (this != &o) {
+            hash = std::move(o.hash); kmer = std::move(o.kmer); key32 = std::move(o.key32); pay = std::move(o.pay);
+            rec = std::move(o.rec); n = o.n; o.n = 0;
+            part_state_delete(part); part = o.part; o.part = nullptr;
+        }
+        return *this;
+    }
+    ~OrderedOcc() { part_state_delete(part); }
 };
 void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out, bool index_form = false);
 // index-form streams of consecutive assembly chunks -> one stream (chunk c's records follow rec_base[c] earlier ones);

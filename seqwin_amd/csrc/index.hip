@@ -2127,6 +2127,16 @@ struct PartArgs {
     uint32_t cols;       // output columns per row: 2, or 1 for packed keys
 };
 
+}  // namespace
+struct PartState {   // what a tuple partition leaves behind for the way back (OrderedOcc::part)
+    PartArgs args;
+    DevArray<uint32_t> offs;
+    uint64_t rec_off = 0;
+    bool valid = false;
+};
+void part_state_delete(PartState *p) { delete p; }
+namespace {
+
 __device__ __forceinline__ uint32_t owner_of(const PartArgs &P, uint64_t kx)
 {
     uint32_t o = 0;
@@ -2146,11 +2156,16 @@ __device__ __forceinline__ uint64_t match5(uint32_t v, uint64_t active)
     return m;
 }
 
-template <class Src, bool WRITE>
+// MODE 0 counts, 1 writes the rows (and perm), 2 walks the same positions again and brings a 32-bit value per partitioned row
+// back to the original order: gather_out[i] = gather_in[dst(i)] -- one sequential read cursor per owner instead of a
+// random scatter through perm (26 ms for 745 M rows).
+template <class Src, int MODE>
 __global__ __launch_bounds__(256) void k_partition(const Src src, const PartArgs P, uint32_t *__restrict__ hist,
                                                    const uint32_t *__restrict__ offsets, uint64_t *__restrict__ rows_out,
-                                                   uint32_t *__restrict__ perm_out)
+                                                   uint32_t *__restrict__ perm_out, const uint32_t *__restrict__ gather_in = nullptr,
+                                                   uint32_t *__restrict__ gather_out = nullptr)
 {
+    constexpr bool WRITE = MODE != 0;
     __shared__ uint32_t cnt[4][PART_BUCKETS];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint64_t wave = (uint64_t)blockIdx.x * 4 + wv;
@@ -2169,7 +2184,9 @@ __global__ __launch_bounds__(256) void k_partition(const Src src, const PartArgs
         if (live) {
             const uint32_t before = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
             const uint32_t start = cnt[wv][o];               // all lanes of a group read before the leader adds
-            if (WRITE) {
+            if (MODE == 2) {
+                gather_out[i] = gather_in[(uint64_t)start + before];
+            } else if (MODE == 1) {
                 const uint64_t dst = (uint64_t)start + before;
                 uint64_t r0, r1;
                 src.row(i, r0, r1);
@@ -2201,7 +2218,8 @@ __global__ void k_part_counts(const uint32_t *__restrict__ offsets, const uint32
 
 template <class Src>
 void stable_partition(const Src &src, uint64_t n, const uint64_t *bounds, uint32_t n_bounds, bool has_drop, uint64_t drop_key,
-                      uint64_t *d_rows_out, uint32_t *d_perm_out, uint64_t *counts_host, hipStream_t stream, uint32_t cols = 2)
+                      uint64_t *d_rows_out, uint32_t *d_perm_out, uint64_t *counts_host, hipStream_t stream, uint32_t cols = 2,
+                      PartState *keep = nullptr)
 {
     if (n_bounds > 15) raise(SW_ERR_VALUE, "at most 16 owners are supported");
     for (uint32_t j = 0; j < n_bounds + 2; ++j) counts_host[j] = 0;
@@ -2219,11 +2237,11 @@ void stable_partition(const Src &src, uint64_t n, const uint64_t *bounds, uint32
     DevArray<uint32_t> hist(nh), offs(nh);
     DevArray<unsigned long long> counts(PART_BUCKETS);
     const unsigned blocks = (P.n_waves + 3) / 4;
-    hipLaunchKernelGGL((k_partition<Src, false>), dim3(blocks), dim3(256), 0, stream, src, P, hist.p, (const uint32_t *)nullptr,
+    hipLaunchKernelGGL((k_partition<Src, 0>), dim3(blocks), dim3(256), 0, stream, src, P, hist.p, (const uint32_t *)nullptr,
                        (uint64_t *)nullptr, (uint32_t *)nullptr);
     SW_HIP(hipGetLastError());
     exclusive_sum(hist.p, offs.p, nh, (uint32_t)0, stream);
-    hipLaunchKernelGGL((k_partition<Src, true>), dim3(blocks), dim3(256), 0, stream, src, P, (uint32_t *)nullptr, offs.p,
+    hipLaunchKernelGGL((k_partition<Src, 1>), dim3(blocks), dim3(256), 0, stream, src, P, (uint32_t *)nullptr, offs.p,
                        d_rows_out, d_perm_out);
     hipLaunchKernelGGL(k_part_counts, dim3(1), dim3(64), 0, stream, offs.p, hist.p, P.n_waves, counts.p);
     SW_HIP(hipGetLastError());
@@ -2231,6 +2249,11 @@ void stable_partition(const Src &src, uint64_t n, const uint64_t *bounds, uint32
     SW_HIP(hipMemcpyAsync(h, counts.p, sizeof h, hipMemcpyDeviceToHost, stream));
     SW_HIP(hipStreamSynchronize(stream));
     for (uint32_t j = 0; j < n_bounds + 2; ++j) counts_host[j] = h[j];
+    if (keep) {   // the way back (MODE 2) walks the same offsets
+        keep->args = P;
+        keep->offs = std::move(offs);
+        keep->valid = true;
+    }
 }
 }  // namespace
 
@@ -2238,8 +2261,12 @@ void occ_partition(const OrderedOcc &occ, const uint64_t *bounds, uint32_t n_bou
                    uint32_t *d_perm, uint64_t *counts_host, hipStream_t stream)
 {
     uint64_t counts[18];
+    OrderedOcc &o = const_cast<OrderedOcc &>(occ);
+    if (!o.part) o.part = new PartState;
+    o.part->valid = false;
+    o.part->rec_off = rec_offset;
     stable_partition(TupleSrc{occ.hash.p, occ.kmer.p, rec_offset}, occ.n, bounds, n_bounds, false, 0, d_rows, d_perm, counts,
-                     stream);
+                     stream, 2, o.part);
     for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = counts[j];
 }
 
@@ -2256,7 +2283,16 @@ void occ_adjacency(const OrderedOcc &occ, const uint32_t *d_rec_asm, const uint3
     const uint64_t sentinel = (tb >= 64) ? ~0ull : ((1ull << tb) - 1ull);
     DevArray<uint32_t> rank(n);
     DevArray<uint64_t> rows(ab ? m : 2 * m);
-    hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(n)), dim3(TPB), 0, stream, d_perm, d_rank_by_row, n, rank.p);
+    if (occ.part && occ.part->valid) {
+        // ranks arrive in partitioned-row order; the partition was stable, so walking it again reads them back in order
+        const PartArgs &P = occ.part->args;
+        hipLaunchKernelGGL((k_partition<TupleSrc, 2>), dim3((P.n_waves + 3) / 4), dim3(256), 0, stream,
+                           TupleSrc{occ.hash.p, occ.kmer.p, occ.part->rec_off}, P, (uint32_t *)nullptr, occ.part->offs.p,
+                           (uint64_t *)nullptr, (uint32_t *)nullptr, d_rank_by_row, rank.p);
+    } else {
+        if (!d_perm) raise(SW_ERR_VALUE, "sw_occ_adjacency needs perm when the tuples were not partitioned by sw_occ_partition");
+        hipLaunchKernelGGL(k_unpermute, dim3(blocks_for(n)), dim3(TPB), 0, stream, d_perm, d_rank_by_row, n, rank.p);
+    }
     if (ab)
         hipLaunchKernelGGL(k_adj_rows_packed, dim3(blocks_for(m)), dim3(TPB), 0, stream, occ.kmer.p, rank.p, d_rec_asm, n, nb, ab,
                            sentinel, asm_base, rows.p);

@@ -165,13 +165,13 @@ class HipEngine:
         from ._lib import c_u64, c_vp, check, lib
         t = self.torch
         rows = t.empty((occ.n, 2), dtype=t.int64, device=self.gpu)
-        perm = t.empty((occ.n,), dtype=t.int32, device=self.gpu)
         nb = len(bounds)
         b = (c_u64 * max(nb, 1))(*bounds)
         cnt = (c_u64 * (nb + 1))()
-        check(lib.sw_occ_partition(occ._h, b, c_u64(nb), c_u64(rec_offset), c_vp(rows.data_ptr()), c_vp(perm.data_ptr()),
-                                   cnt, c_vp(self._stream())))
-        return rows.to(self.device), perm, [int(x) for x in cnt]
+        # no permutation array: the partition is stable, the occ handle keeps its offsets and sw_occ_adjacency walks them
+        # again to read the returned ranks back in stream order
+        check(lib.sw_occ_partition(occ._h, b, c_u64(nb), c_u64(rec_offset), c_vp(rows.data_ptr()), None, cnt, c_vp(self._stream())))
+        return rows.to(self.device), None, [int(x) for x in cnt]
 
     def slice_build(self, rows, kmer_base: int, record_offsets: np.ndarray, is_targets):
         import ctypes
@@ -208,7 +208,7 @@ class HipEngine:
         nb = len(rank_bounds)
         b = (c_u64 * max(nb, 1))(*rank_bounds)
         cnt = (c_u64 * (nb + 1))()
-        check(lib.sw_occ_adjacency(occ._h, c_vp(perm.data_ptr()), c_vp(ranks_by_row.data_ptr()), c_u64(n_bits),
+        check(lib.sw_occ_adjacency(occ._h, c_vp(perm.data_ptr()) if perm is not None else None, c_vp(ranks_by_row.data_ptr()), c_u64(n_bits),
                                    c_u64(asm_bits), c_u64(asm_base), b, c_u64(nb), c_vp(rows.data_ptr()), cnt, c_vp(self._stream())))
         counts = [int(x) for x in cnt]
         return rows[:sum(counts)].to(self.device), counts
