@@ -576,9 +576,8 @@ __global__ void k_lower_bounds(const sw_node *__restrict__ nodes, uint64_t n_nod
 // ---- get_penalty ------------------------------------------------------------------------------------
 // X[s] = (target-assembly change << 32) | non-target-assembly change, between occurrence s-1 and s.
 // Y[s] = (record_idx decreased << 32) | record_idx out of range.
-// TRUSTED: the occurrences come from this library's own stable sort (build_index), the validation flags Y of
-// filter.cpp:103-123 are not produced (their array, its prefix sum and the per-node test are a third of the traffic)
-template <bool TRUSTED>
+// (For occurrences that come from outside: the C-ABI get_penalty, the multi-GPU merges, SEQWIN_AMD_CHECK_ORDER=1.  The
+//  single-GPU build's own counts come from the bitmaps k_nodes writes: k_pen_bits.)
 __global__ void k_pen_flags(const sw_kmer *__restrict__ kmers, uint64_t n, const uint32_t *__restrict__ rec_asm,
                             uint64_t n_records, const uint8_t *__restrict__ is_target, uint64_t *__restrict__ X,
                             uint64_t *__restrict__ Y)
@@ -598,10 +597,9 @@ __global__ void k_pen_flags(const sw_kmer *__restrict__ kmers, uint64_t n, const
         }
     }
     X[s] = x;
-    if (!TRUSTED) Y[s] = y;
+    Y[s] = y;
 }
 
-template <bool TRUSTED>
 __global__ void k_pen_nodes(const sw_kmer *__restrict__ kmers, uint64_t n_kmers, sw_node *__restrict__ nodes,
                             uint64_t n_nodes, const uint32_t *__restrict__ rec_asm, uint64_t n_records,
                             const uint8_t *__restrict__ is_target, const uint64_t *__restrict__ XS,
@@ -621,7 +619,7 @@ __global__ void k_pen_nodes(const sw_kmer *__restrict__ kmers, uint64_t n_kmers,
         atomicOr(err, 1u);
         return;
     }
-    if (!TRUSTED) {
+    {
         const uint64_t y = YS[stop - 1] - (start ? YS[start - 1] : 0ull);
         // out-of-range anywhere in [start, stop); decreasing strictly inside (start, stop)
         if ((uint32_t)y) {
@@ -1642,40 +1640,28 @@ struct PenaltyJob {   // buffers of an in-flight get_penalty (asynchronous on `s
 
 void penalty_launch(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
                     const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target, uint64_t n_targets,
-                    uint64_t n_non_targets, hipStream_t stream, PenaltyJob &job, bool trusted = false)
+                    uint64_t n_non_targets, hipStream_t stream, PenaltyJob &job)
 {
     job.stream = stream;
     job.active = n_nodes != 0;
     if (!job.active) return;
-    if (getenv("SEQWIN_AMD_CHECK_ORDER")) trusted = false;
     job.X.alloc(n_kmers);
-    if (!trusted) job.Y.alloc(n_kmers);
+    job.Y.alloc(n_kmers);
     job.err.alloc(1);
     DevArray<uint64_t> &X = job.X, &Y = job.Y;
     DevArray<uint32_t> &err = job.err;
     SW_HIP(hipMemsetAsync(err.p, 0, 4, stream));
     const double inv_tar = 1.0 / (double)n_targets;        // filter.cpp:89-90
     const double inv_neg = 1.0 / (double)n_non_targets;
-    if (trusted) {
-        if (n_kmers) {
-            hipLaunchKernelGGL(k_pen_flags<true>, dim3(blocks_for(n_kmers)), dim3(TPB), 0, stream, d_kmers, n_kmers, d_rec_asm,
-                               n_records, d_is_target, X.p, (uint64_t *)nullptr);
-            SW_HIP(hipGetLastError());
-            inclusive_sum_keep(X.p, X.p, n_kmers, (uint64_t)0, stream, job.tmp_x);
-        }
-        hipLaunchKernelGGL(k_pen_nodes<true>, dim3(blocks_for(n_nodes)), dim3(TPB), 0, stream, d_kmers, n_kmers, d_nodes, n_nodes,
-                           d_rec_asm, n_records, d_is_target, X.p, (const uint64_t *)nullptr, inv_tar, inv_neg, err.p);
-    } else {
-        if (n_kmers) {
-            hipLaunchKernelGGL(k_pen_flags<false>, dim3(blocks_for(n_kmers)), dim3(TPB), 0, stream, d_kmers, n_kmers, d_rec_asm,
-                               n_records, d_is_target, X.p, Y.p);
-            SW_HIP(hipGetLastError());
-            inclusive_sum_keep(X.p, X.p, n_kmers, (uint64_t)0, stream, job.tmp_x);
-            inclusive_sum_keep(Y.p, Y.p, n_kmers, (uint64_t)0, stream, job.tmp_y);
-        }
-        hipLaunchKernelGGL(k_pen_nodes<false>, dim3(blocks_for(n_nodes)), dim3(TPB), 0, stream, d_kmers, n_kmers, d_nodes, n_nodes,
-                           d_rec_asm, n_records, d_is_target, X.p, Y.p, inv_tar, inv_neg, err.p);
+    if (n_kmers) {
+        hipLaunchKernelGGL(k_pen_flags, dim3(blocks_for(n_kmers)), dim3(TPB), 0, stream, d_kmers, n_kmers, d_rec_asm, n_records,
+                           d_is_target, X.p, Y.p);
+        SW_HIP(hipGetLastError());
+        inclusive_sum_keep(X.p, X.p, n_kmers, (uint64_t)0, stream, job.tmp_x);
+        inclusive_sum_keep(Y.p, Y.p, n_kmers, (uint64_t)0, stream, job.tmp_y);
     }
+    hipLaunchKernelGGL(k_pen_nodes, dim3(blocks_for(n_nodes)), dim3(TPB), 0, stream, d_kmers, n_kmers, d_nodes, n_nodes, d_rec_asm,
+                       n_records, d_is_target, X.p, Y.p, inv_tar, inv_neg, err.p);
     SW_HIP(hipGetLastError());
 }
 
