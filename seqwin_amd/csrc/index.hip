@@ -196,7 +196,11 @@ __device__ __forceinline__ unsigned long long interleave32(uint32_t a, uint32_t 
 // Every lane takes TWO consecutive occurrences per row (16-B stores of kmers and of the unsort words, one 8-B load of
 // the keys, 32 B of payload), a wave 128, so the bits of a wave's row are two 64-bit words: ballots of the even and of the
 // odd occurrences, interleaved (wave-uniform values: scalar ALU).
-template <bool BITS>
+// REP: bit 31 of the rank word marks an occurrence whose node occurs more than once in its assembly (its neighbour in this
+// order has the same node and assembly) -- only adjacencies touching such an occurrence can repeat a pair inside one
+// assembly (k_adj_pairs).  Needs rec_flag and fewer than 2^31 nodes.
+constexpr uint32_t RANK_REP = 0x80000000u;
+template <bool BITS, bool REP>
 __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay, uint64_t n,
                                                uint64_t base, const uint32_t *__restrict__ rec_flag, sw_kmer *__restrict__ kmers,
                                                sw_node *__restrict__ nodes, uint32_t *__restrict__ rank_direct,
@@ -298,21 +302,49 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
         // node = heads up to and including the occurrence, - 1
         const uint32_t nid0 = excl + s_row[r * NODES_WAVES + wave] + within[r] + (h0 ? 1u : 0u) - 1u;
         const uint32_t nid1 = nid0 + (h1 ? 1u : 0u);
+        uint32_t w0 = nid0, w1 = nid1;   // the rank words handed to the adjacency
+        uint32_t f0 = 0, f1 = 0, pf = 0;
+        if (BITS || REP) {
+            // rec_flag[r] = assembly << 1 | is_target
+            f0 = live0 ? rec_flag[p[r][0].rec] : 0u;
+            f1 = live1 ? rec_flag[p[r][1].rec] : 0u;
+            pf = __shfl_up(f1, 1, 64);
+            if (lane == 0 && live0 && s) pf = rec_flag[prec[r]];
+        }
+        if (REP) {
+            // the occurrence after s + 1: the even one of the lane above, or (lane 63) loads
+            uint32_t nk = __shfl_down(k[r][0], 1, 64), nlow = __shfl_down(p[r][0].low, 1, 64), nf = __shfl_down(f0, 1, 64);
+            bool nlive = __shfl_down((int)live0, 1, 64) != 0;
+            if (lane == 63) {
+                nlive = s + 2 < n;
+                if (nlive) {
+                    nk = key32[s + 2];
+                    const OccPay q = pay[s + 2];
+                    nlow = q.low;
+                    nf = rec_flag[q.rec];
+                }
+            }
+            const bool same01 = live1 && !h1 && (f1 >> 1) == (f0 >> 1);
+            const bool same_p0 = live0 && !h0 && (f0 >> 1) == (pf >> 1);
+            const bool same_1n = live1 && nlive && nk == k[r][1] && nlow == p[r][1].low && (nf >> 1) == (f1 >> 1);
+            if (same_p0 || same01) w0 |= RANK_REP;
+            if (same01 || same_1n) w1 |= RANK_REP;
+        }
         if (live1) {
             *reinterpret_cast<uint4 *>(kmers + s) = make_uint4(p[r][0].pos, p[r][0].rec, p[r][1].pos, p[r][1].rec);
             if (uval)
-                *reinterpret_cast<ulonglong2 *>(uval + s) = make_ulonglong2(((uint64_t)p[r][0].idx << 32) | nid0,
-                                                                          ((uint64_t)p[r][1].idx << 32) | nid1);
+                *reinterpret_cast<ulonglong2 *>(uval + s) = make_ulonglong2(((uint64_t)p[r][0].idx << 32) | w0,
+                                                                          ((uint64_t)p[r][1].idx << 32) | w1);
         } else if (live0) {
             sw_kmer km;
             km.pos = p[r][0].pos;
             km.record_idx = p[r][0].rec;
             kmers[s] = km;
-            if (uval) uval[s] = ((uint64_t)p[r][0].idx << 32) | nid0;   // the unsort's element: index above, node below
+            if (uval) uval[s] = ((uint64_t)p[r][0].idx << 32) | w0;   // the unsort's element: index above, node below
         }
         if (rank_direct) {
-            if (live0) rank_direct[p[r][0].idx] = nid0;
-            if (live1) rank_direct[p[r][1].idx] = nid1;
+            if (live0) rank_direct[p[r][0].idx] = w0;
+            if (live1) rank_direct[p[r][1].idx] = w1;
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -331,10 +363,6 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
         if (live0 && s == n - 1) nodes[nid0].stop = base + n;
         if (live1 && s + 1 == n - 1) nodes[nid1].stop = base + n;
         if (BITS) {
-            // rec_flag[r] = assembly << 1 | is_target
-            const uint32_t f0 = live0 ? rec_flag[p[r][0].rec] : 0u, f1 = live1 ? rec_flag[p[r][1].rec] : 0u;
-            uint32_t pf = __shfl_up(f1, 1, 64);
-            if (lane == 0 && live0 && s) pf = rec_flag[prec[r]];
             const bool first0 = live0 && (h0 || (f0 >> 1) != (pf >> 1)), first1 = live1 && (h1 || (f1 >> 1) != (f0 >> 1));
             const unsigned long long t0 = __ballot(first0 && (f0 & 1u)), t1 = __ballot(first1 && (f1 & 1u));
             const unsigned long long g0 = __ballot(first0 && !(f0 & 1u)), g1 = __ballot(first1 && !(f1 & 1u));
@@ -393,7 +421,7 @@ __global__ void k_rec_flag(const uint32_t *__restrict__ rec_asm, const uint8_t *
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n_records) {
         const uint32_t a = rec_asm[r];
-        rec_flag[r] = (a << 1) | (is_target[a] ? 1u : 0u);
+        rec_flag[r] = (a << 1) | ((is_target && is_target[a]) ? 1u : 0u);
     }
 }
 
@@ -654,10 +682,9 @@ __global__ void k_pen_nodes(const sw_kmer *__restrict__ kmers, uint64_t n_kmers,
 
 // ---- edges --------------------------------------------------------------------------------------------
 // Adjacency keys of consecutive minimizers of a record (build.cpp:177-189) from the node rank and the record of every
-// occurrence, both in (record_idx, pos) order: key = (rank_lo << nb) | rank_hi, record boundaries -> sentinel (sorts last).
-// PACKED: the assembly sits above the pair in the same 64-bit key (keys-only sort), else it is a 32-bit value next to it.
+// occurrence, both in (record_idx, pos) order: key = (rank_lo << nb) | rank_hi, record boundaries -> sentinel (sorts last);
+// the assembly is a 32-bit value next to the key (the (pair, assembly) form: SEQWIN_AMD_NO_PACKED_EDGES=1, 2^31 nodes or more).
 // Four consecutive occurrences per thread: 16-B loads of ranks and records, 2 x 16-B stores of keys.
-template <bool PACKED>
 __global__ __launch_bounds__(256) void k_adj_keys(const uint32_t *__restrict__ rec, const uint32_t *__restrict__ rank,
                                                   const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, uint64_t sentinel,
                                                   uint64_t *__restrict__ key, uint32_t *__restrict__ val)
@@ -685,21 +712,110 @@ __global__ __launch_bounds__(256) void k_adj_keys(const uint32_t *__restrict__ r
         if (v < u) { const uint32_t t = u; u = v; v = t; }
         const uint32_t a = pair ? rec_asm[r[j]] : 0xFFFFFFFFu;
         const uint64_t pk = ((uint64_t)u << nb) | v;
-        out[j] = pair ? (PACKED ? (((uint64_t)a << (2 * nb)) | pk) : pk) : sentinel;
+        out[j] = pair ? pk : sentinel;
         asmv[j] = a;
     }
     if (i0 + 4 < n) {   // all four keys exist (m = n - 1 keys): vector stores
         *reinterpret_cast<ulonglong2 *>(key + i0) = make_ulonglong2(out[0], out[1]);
         *reinterpret_cast<ulonglong2 *>(key + i0 + 2) = make_ulonglong2(out[2], out[3]);
-        if (!PACKED) *reinterpret_cast<uint4 *>(val + i0) = make_uint4(asmv[0], asmv[1], asmv[2], asmv[3]);
+        *reinterpret_cast<uint4 *>(val + i0) = make_uint4(asmv[0], asmv[1], asmv[2], asmv[3]);
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (i0 + j + 1 < n) {
                 key[i0 + j] = out[j];
-                if (!PACKED) val[i0 + j] = asmv[j];
+                val[i0 + j] = asmv[j];
             }
     }
+}
+
+// The same keys without any assembly: the weight of a pair is the NUMBER of its adjacency records minus the records that
+// repeat the pair inside one assembly, and only records touching an occurrence marked RANK_REP can do that (two records
+// of one pair in one assembly contain two occurrences of one of its nodes there).  Those candidates -- none on random
+// genomes, a few per cent on real ones (repeats) -- are also appended to a side list with their assembly
+// (subtract_repeats); everything else needs no assembly at all: keys-only sort, run lengths.
+__global__ __launch_bounds__(256) void k_adj_pairs(const uint32_t *__restrict__ rec, const uint32_t *__restrict__ rank,
+                                                   const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, uint64_t sentinel,
+                                                   uint64_t *__restrict__ key, uint64_t *__restrict__ cand_key,
+                                                   uint32_t *__restrict__ cand_asm, unsigned long long *__restrict__ n_cand)
+{
+    const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t r[5], k[5];
+    uint64_t out[4];
+    uint32_t cm = 0;   // bit j: record i0 + j is a candidate
+    if (i0 + 1 < n) {
+        if (i0 + 4 < n) {
+            const uint4 rv = *reinterpret_cast<const uint4 *>(rec + i0), kv = *reinterpret_cast<const uint4 *>(rank + i0);
+            r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w; r[4] = rec[i0 + 4];
+            k[0] = kv.x; k[1] = kv.y; k[2] = kv.z; k[3] = kv.w; k[4] = rank[i0 + 4];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                r[j] = (i0 + j < n) ? rec[i0 + j] : 0xFFFFFFFFu;
+                k[j] = (i0 + j < n) ? rank[i0 + j] : 0u;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pair = i0 + j + 1 < n && r[j] == r[j + 1];
+            uint32_t u = k[j] & ~RANK_REP, v = k[j + 1] & ~RANK_REP;
+            if (v < u) { const uint32_t t = u; u = v; v = t; }
+            out[j] = pair ? (((uint64_t)u << nb) | v) : sentinel;
+            if (pair && ((k[j] | k[j + 1]) & RANK_REP)) cm |= 1u << j;
+        }
+        if (i0 + 4 < n) {   // all four keys exist (m = n - 1 keys): vector stores
+            *reinterpret_cast<ulonglong2 *>(key + i0) = make_ulonglong2(out[0], out[1]);
+            *reinterpret_cast<ulonglong2 *>(key + i0 + 2) = make_ulonglong2(out[2], out[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j + 1 < n) key[i0 + j] = out[j];
+        }
+    }
+    if (__any(cm != 0)) {   // rare: one atomic per wave that has candidates
+        const uint32_t c = (uint32_t)__popc(cm);
+        uint32_t incl = c;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        unsigned long long base = 0;
+        if (lane == 63) base = atomicAdd(n_cand, (unsigned long long)total);
+        base = __shfl(base, 63, 64) + (incl - c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((cm >> j) & 1u) {
+                cand_key[base] = out[j];
+                cand_asm[base] = rec_asm[r[j]];
+                ++base;
+            }
+    }
+}
+
+struct RepeatFlag {   // 1 where a sorted candidate row repeats the (pair, assembly) of its predecessor
+    const uint64_t *keys;
+    const uint32_t *vals;
+    __host__ __device__ uint32_t operator()(uint64_t s) const
+    {
+        return (s && keys[s] == keys[s - 1] && vals[s] == vals[s - 1]) ? 1u : 0u;
+    }
+};
+
+// one thread per candidate pair with repeats: find its edge (the run-length keys are sorted) and take the repeats off
+__global__ void k_subtract_repeats(const uint64_t *__restrict__ rkeys, const uint32_t *__restrict__ rdups, uint32_t n_runs,
+                                   const uint64_t *__restrict__ ukeys, uint64_t n_edges, sw_edge *__restrict__ edges)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_runs || rdups[i] == 0) return;
+    const uint64_t key = rkeys[i];
+    uint64_t lo = 0, hi = n_edges;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (ukeys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    if (lo < n_edges && ukeys[lo] == key) edges[lo].weight -= rdups[i];   // (every candidate is also a record of the main sort)
 }
 
 // 1 at the first row of every (pair, assembly) combination of the sorted adjacency rows (first row: 1)
@@ -1481,10 +1597,12 @@ uint64_t settle_sort(PaySort &ps, hipStream_t stream)
 }
 
 // Sorted occurrences -> kmers, nodes (hash, start, stop; counts zero), node rank of every occurrence in ORIGINAL order
-// (rank_out, may be null), and -- with rec_flag -- the first-of-assembly bitmaps for the counts.  ps.key_a / ps.pay_a hold
-// the n occurrences on entry.  Returns the number of nodes.
+// (rank_out, may be null), and -- with rec_flag -- the first-of-assembly bitmaps for the counts (tbits / nbits non-null)
+// and / or the repeated-in-assembly mark in bit 31 of the rank words (*rep_marked, if the node count allows it).
+// ps.key_a / ps.pay_a hold the n occurrences on entry.  Returns the number of nodes.
 uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_t *rec_flag, hipStream_t stream, sw_index &ix,
-                           uint32_t *rank_out, DevArray<unsigned long long> *tbits, DevArray<unsigned long long> *nbits)
+                           uint32_t *rank_out, DevArray<unsigned long long> *tbits, DevArray<unsigned long long> *nbits,
+                           bool *rep_marked = nullptr)
 {
     sort_pay(n, stream, ps);
     const uint64_t node_cap = settle_sort(ps, stream);   // >= the number of nodes, within ~2 descents of it
@@ -1494,7 +1612,10 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     const bool direct = rank_out && n <= direct_max;
     DevArray<uint64_t> uv0, uv1;
     if (rank_out && !direct) uv0.alloc(n);
-    if (rec_flag) {
+    const bool bits = rec_flag && tbits && nbits;
+    const bool rep = rec_flag && rep_marked && rank_out && node_cap < (1ull << 31);
+    if (rep_marked) *rep_marked = rep;
+    if (bits) {
         tbits->alloc((n + 63) / 64);
         nbits->alloc((n + 63) / 64);
     }
@@ -1503,14 +1624,17 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     DevArray<uint32_t> words(2);   // [0] tile tickets, [1] the number of nodes
     SW_HIP(hipMemsetAsync(tile_state.p, 0, (size_t)blocks * 8, stream));
     SW_HIP(hipMemsetAsync(words.p, 0, 8, stream));
-    if (rec_flag)
-        hipLaunchKernelGGL(k_nodes<true>, dim3(blocks), dim3(NODES_THREADS), 0, stream, ps.key32, ps.pay, n, base, rec_flag, ix.kmers.p,
-                           ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uv0.p, tbits->p, nbits->p, tile_state.p,
-                           words.p, words.p + 1);
-    else
-        hipLaunchKernelGGL(k_nodes<false>, dim3(blocks), dim3(NODES_THREADS), 0, stream, ps.key32, ps.pay, n, base, (const uint32_t *)nullptr,
-                           ix.kmers.p, ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uv0.p,
-                           (unsigned long long *)nullptr, (unsigned long long *)nullptr, tile_state.p, words.p, words.p + 1);
+    {
+        auto launch = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(blocks), dim3(NODES_THREADS), 0, stream, ps.key32, ps.pay, n, base, rec_flag, ix.kmers.p,
+                               ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uv0.p, bits ? tbits->p : (unsigned long long *)nullptr,
+                               bits ? nbits->p : (unsigned long long *)nullptr, tile_state.p, words.p, words.p + 1);
+        };
+        if (bits && rep) launch(k_nodes<true, true>);
+        else if (bits) launch(k_nodes<true, false>);
+        else if (rep) launch(k_nodes<false, true>);
+        else launch(k_nodes<false, false>);
+    }
     SW_HIP(hipGetLastError());
     uint32_t n_nodes = 0;
     SW_HIP(hipMemcpyAsync(&n_nodes, words.p + 1, 4, hipMemcpyDeviceToHost, stream));
@@ -1687,7 +1811,7 @@ hipStream_t side_stream()   // one per (thread, current device); never destroyed
 }  // namespace
 
 namespace {
-// ---- packed edge keys: pair and assembly in ONE 64-bit key when 2 nb + ab <= 64 (k_adj_keys<true>) ----
+// ---- packed edge keys of the multi-GPU slices: pair and assembly in ONE 64-bit key when 2 nb + ab <= 64 ----
 // (keys-only radix sort: 16 B instead of 24 B per element and pass; equal pairs of one assembly become adjacent
 // duplicates, so weight = number of distinct keys inside a pair's run)
 struct PackedChangeAny {   // 1 where the whole key differs from its predecessor (first element: 1)
@@ -1699,18 +1823,16 @@ struct PackedPairEq {      // same (rank_lo, rank_hi) pair
     uint64_t pmask;
     __host__ __device__ bool operator()(uint64_t a, uint64_t b) const { return ((a >> pshift) & pmask) == ((b >> pshift) & pmask); }
 };
-// asm_high: keys are (assembly << 2 nb) | pair and arrive in assembly order (the single-GPU build emits them in
-// (record, pos) order, records are assembly-major): a STABLE sort on the 2 nb pair bits alone leaves every pair's run in
-// assembly order, so the assembly bits are never sorted (one radix pass fewer at the default workload: 44 instead of 53 bits).
+// keys = (pair << ab) | assembly (rows of the multi-GPU exchange, routed by key value)
 void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t sentinel, unsigned nb, unsigned ab,
-                       const uint64_t *rank_hash, hipStream_t stream, sw_index &ix, bool asm_high = false)
+                       const uint64_t *rank_hash, hipStream_t stream, sw_index &ix)
 {
     ix.n_edges = 0;
     if (m == 0) return;
-    const unsigned pshift = asm_high ? 0u : ab;
-    const uint64_t pmask = asm_high ? ((2 * nb >= 64) ? ~0ull : ((1ull << (2 * nb)) - 1ull)) : ~0ull;
+    const unsigned pshift = ab;
+    const uint64_t pmask = ~0ull;
     {
-        const unsigned sort_bits = asm_high ? 2 * nb : 2 * nb + ab;
+        const unsigned sort_bits = 2 * nb + ab;
         rocprim::double_buffer<uint64_t> dk(keys, keys_alt);
         size_t tmp_bytes = 0;
         SW_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, dk, m, 0, sort_bits, stream));
@@ -1751,6 +1873,74 @@ void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t 
 }  // namespace
 
 namespace {
+// keys[m] = (rank_lo << nb) | rank_hi of every adjacency record (sentinels sort last), no assemblies: a keys-only sort and
+// the run lengths give the number of records of every pair; the candidates (records that may repeat their pair inside one
+// assembly: ck / ca, *d_n_cand of them, unordered) are sorted by (pair, assembly) and the repeats taken off.
+void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t sentinel, unsigned nb, unsigned ab,
+                      DevArray<uint64_t> &ck, DevArray<uint32_t> &ca, const unsigned long long *d_n_cand, hipStream_t stream,
+                      sw_index &ix)
+{
+    ix.n_edges = 0;
+    if (m == 0) return;
+    {
+        rocprim::double_buffer<uint64_t> dk(keys, keys_alt);
+        size_t tmp_bytes = 0;
+        SW_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, dk, m, 0, 2 * nb, stream));
+        DevArray<unsigned char> tmp(tmp_bytes);
+        SW_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, m, 0, 2 * nb, stream));
+        keys = dk.current();
+    }
+    DevArray<uint64_t> ukeys(m);
+    DevArray<uint32_t> ucnt(m), ucount(1);
+    unsigned long long n_cand = 0;
+    {
+        size_t tmp_bytes = 0;
+        SW_HIP(rocprim::run_length_encode(nullptr, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
+        DevArray<unsigned char> tmp(tmp_bytes);
+        SW_HIP(rocprim::run_length_encode(tmp.p, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
+        hipLaunchKernelGGL(k_drop_sentinel_run, dim3(1), dim3(1), 0, stream, ukeys.p, sentinel, ucount.p);
+        SW_HIP(hipGetLastError());
+        uint32_t n_edges = 0;
+        SW_HIP(hipMemcpyAsync(&n_edges, ucount.p, 4, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipMemcpyAsync(&n_cand, d_n_cand, 8, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));   // (tmp is released here, after the pass has finished)
+        ix.n_edges = n_edges;
+    }
+    if (ix.n_edges == 0) return;
+    ix.edges.alloc(ix.n_edges);
+    hipLaunchKernelGGL(k_edges_runs, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, ucnt.p, 0u, ~0ull,
+                       (uint64_t)ix.n_edges, nb, ix.nodes.p, (const uint64_t *)nullptr, ix.edges.p);
+    SW_HIP(hipGetLastError());
+    if (n_cand) {
+        const uint64_t c = n_cand;
+        // (pair, assembly) order: least significant key first, both sorts stable
+        DevArray<uint64_t> ck1(c);
+        DevArray<uint32_t> ca1(c);
+        uint32_t *a = ca.p, *a_alt = ca1.p;
+        uint64_t *k = ck.p, *k_alt = ck1.p;
+        sort_pairs(a, a_alt, k, k_alt, c, 0, ab, stream);
+        sort_pairs(k, k_alt, a, a_alt, c, 0, 2 * nb, stream);
+        DevArray<uint64_t> rkeys(c);
+        DevArray<uint32_t> rdups(c), rcount(1);
+        auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), RepeatFlag{k, a});
+        size_t tmp_bytes = 0;
+        SW_HIP(rocprim::reduce_by_key(nullptr, tmp_bytes, k, flags, c, rkeys.p, rdups.p, rcount.p, rocprim::plus<uint32_t>(),
+                                      rocprim::equal_to<uint64_t>(), stream));
+        DevArray<unsigned char> tmp(tmp_bytes);
+        SW_HIP(rocprim::reduce_by_key(tmp.p, tmp_bytes, k, flags, c, rkeys.p, rdups.p, rcount.p, rocprim::plus<uint32_t>(),
+                                      rocprim::equal_to<uint64_t>(), stream));
+        uint32_t n_runs = 0;
+        SW_HIP(hipMemcpyAsync(&n_runs, rcount.p, 4, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));
+        if (n_runs) {
+            hipLaunchKernelGGL(k_subtract_repeats, dim3(blocks_for(n_runs)), dim3(TPB), 0, stream, rkeys.p, rdups.p, n_runs, ukeys.p,
+                               (uint64_t)ix.n_edges, ix.edges.p);
+            SW_HIP(hipGetLastError());
+        }
+    }
+    SW_HIP(hipStreamSynchronize(stream));
+}
+
 // keys[m] = (rank_lo << nb) | rank_hi (sentinels sort last), vals[m] = assembly; stable sort keeps equal
 // pairs in assembly order, so weight = number of assembly changes inside a run (+1).
 void edges_from_adjacency(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, uint32_t *vals_alt, uint64_t m,
@@ -1847,21 +2037,28 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
     // under SEQWIN_AMD_CHECK_ORDER=1 (then the C-ABI get_penalty's flag / prefix-sum form runs instead).
     const bool want_counts = d_is_target != nullptr;
     const bool check_order = want_counts && getenv("SEQWIN_AMD_CHECK_ORDER") != nullptr;
+    // The edges are counted without assemblies (keys-only pair sort + a side list of the records that can repeat a pair
+    // inside one assembly, k_adj_pairs) unless SEQWIN_AMD_NO_PACKED_EDGES=1 asks for the (pair, assembly) sort that the
+    // multi-GPU slices use, or the rank words have no spare bit (2^31 nodes or more).
+    const bool by_table = occ.hash.p != nullptr;   // SEQWIN_AMD_RANKS=table (order_tuples then kept the hashes)
+    const bool pair_edges = !getenv("SEQWIN_AMD_NO_PACKED_EDGES") && !by_table;
+    bool rep_marked = false;
     DevArray<uint32_t> rec_flag;
     DevArray<unsigned long long> tbits, nbits;
     // -- nodes: stable radix sort of the occurrences by hash, run-length heads, ranks back in stream order ------
     if (n) {
-        if (want_counts && !check_order) {
+        const bool bits = want_counts && !check_order;
+        if (bits || pair_edges) {
             rec_flag.alloc(n_records);
-            hipLaunchKernelGGL(k_rec_flag, dim3(blocks_for(n_records)), dim3(TPB), 0, stream, d_rec_asm, d_is_target, n_records,
-                               rec_flag.p);
+            hipLaunchKernelGGL(k_rec_flag, dim3(blocks_for(n_records)), dim3(TPB), 0, stream, d_rec_asm, bits ? d_is_target : nullptr,
+                               n_records, rec_flag.p);
             SW_HIP(hipGetLastError());
         }
         PaySort ps;   // the sort input written by k_order is consumed in place
         ps.key_a = std::move(occ.key32);
         ps.pay_a = std::move(occ.pay);
-        const bool by_table = occ.hash.p != nullptr;   // SEQWIN_AMD_RANKS=table (order_tuples then kept the hashes)
-        group_occurrences(ps, n, 0, rec_flag.p, stream, ix, by_table ? nullptr : rank.p, &tbits, &nbits);
+        group_occurrences(ps, n, 0, rec_flag.p, stream, ix, by_table ? nullptr : rank.p, bits ? &tbits : nullptr,
+                          bits ? &nbits : nullptr, pair_edges ? &rep_marked : nullptr);
         if (by_table) ranks_from_table(ix, occ.hash.p, n, stream, rank.p);
     } else {
         ix.n_nodes = 0;
@@ -1900,20 +2097,21 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
         unsigned ab = 1;
         while ((1ull << ab) < n_assemblies) ++ab;            // assembly index < 2^ab
         const unsigned adj_blocks = (unsigned)((n + 1023) / 1024);   // 4 occurrences per thread
-        if (2 * nb + ab <= 64 && !getenv("SEQWIN_AMD_NO_PACKED_EDGES")) {
-            // pair and assembly in one 64-bit key: keys-only sort
-            const unsigned tb = 2 * nb + ab;
-            const uint64_t sentinel = (tb == 64) ? ~0ull : ((1ull << tb) - 1ull);
-            DevArray<uint64_t> k0(m), k1(m);
-            hipLaunchKernelGGL(k_adj_keys<true>, dim3(adj_blocks), dim3(256), 0, stream, occ.rec.p, rank.p, d_rec_asm, n, nb,
-                               sentinel, k0.p, (uint32_t *)nullptr);
+        const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
+        DevArray<uint64_t> k0(m), k1(m);
+        if (rep_marked) {
+            // weight = records of the pair - records that repeat it inside one assembly
+            DevArray<uint64_t> ck(m);
+            DevArray<uint32_t> ca(m);
+            DevArray<unsigned long long> n_cand(1);
+            SW_HIP(hipMemsetAsync(n_cand.p, 0, 8, stream));
+            hipLaunchKernelGGL(k_adj_pairs, dim3(adj_blocks), dim3(256), 0, stream, occ.rec.p, rank.p, d_rec_asm, n, nb, sentinel,
+                               k0.p, ck.p, ca.p, n_cand.p);
             SW_HIP(hipGetLastError());
-            edges_from_packed(k0.p, k1.p, m, sentinel, nb, ab, nullptr, stream, ix, true);
+            edges_from_pairs(k0.p, k1.p, m, sentinel, nb, ab, ck, ca, n_cand.p, stream, ix);
         } else {
-            const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
-            DevArray<uint64_t> k0(m), k1(m);
             DevArray<uint32_t> v0(m), v1(m);
-            hipLaunchKernelGGL(k_adj_keys<false>, dim3(adj_blocks), dim3(256), 0, stream, occ.rec.p, rank.p, d_rec_asm, n, nb,
+            hipLaunchKernelGGL(k_adj_keys, dim3(adj_blocks), dim3(256), 0, stream, occ.rec.p, rank.p, d_rec_asm, n, nb,
                                sentinel, k0.p, v0.p);
             SW_HIP(hipGetLastError());
             edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, sentinel, nb, nullptr, stream, ix);
