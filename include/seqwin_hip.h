@@ -301,6 +301,25 @@ int sw_occ_adjacency(const sw_occ *o, const void *perm_dev, const void *rank_by_
 int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t n_bits, uint64_t asm_bits,
                    const void *rank_hash_dev, void *stream);
 
+/* ---- pairs form of the adjacency exchange (half the volume when pair + assembly do not fit one 64-bit key) ----------
+ * The weight of an edge is the number of its adjacency records minus the records that repeat the pair inside one
+ * assembly, and only records touching an occurrence whose node occurs more than once in its assembly can do that.  A slice
+ * build with a record table and fewer than 2^31 nodes marks those occurrences in bit 31 of the ranks it returns
+ * (sw_index_ranks_marked); when every slice did and the job has fewer than 2^31 nodes, the sources send ONE 64-bit pair key
+ * per adjacency record plus the few candidate records with their assembly, and the owners count. */
+int sw_index_ranks_marked(const sw_index *ix, int *marked);
+/* Source: keys_dev[<= n-1] (u64, DEVICE) = (rank_lo << n_bits) | rank_hi of every adjacency record, grouped by edge owner
+ * (counts[n_bounds + 1]); the candidate records stay in the handle as rows {key, global assembly} grouped by owner
+ * (cand_counts[n_bounds + 1]) until sw_occ_candidates copies them (sum of cand_counts rows of 2 u64) to a DEVICE buffer.
+ * rank_by_row_dev: GLOBAL ranks with the repeat mark in bit 31. */
+int sw_occ_adjacency_pairs(const sw_occ *o, const void *rank_by_row_dev, uint64_t n_bits, uint64_t asm_base,
+                           const uint64_t *rank_bounds, uint64_t n_bounds, void *keys_dev, uint64_t *counts, uint64_t *cand_counts,
+                           void *stream);
+int sw_occ_candidates(const sw_occ *o, void *rows_dev, void *stream);
+/* Owner: edges of its rank range from the received pair keys and candidate rows (source-rank order). */
+int sw_slice_edges_pairs(sw_index *ix, const void *keys_dev, uint64_t m, const void *cand_rows_dev, uint64_t n_cand, uint64_t n_bits,
+                         uint64_t asm_bits, const void *rank_hash_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -767,7 +767,6 @@ int sw_index_timings(const sw_index *ix, sw_timings *t)
 int sw_index_export(const sw_index *ix, sw_kmer *kmers, sw_node *nodes, sw_edge *edges)
 {
     return guarded([&] {
-        index_settle(*const_cast<sw_index *>(ix));
         require_current_device(ix->device, "the index");
         const HostSpan spans[3] = {{kmers, ix->n_kmers * sizeof(sw_kmer)}, {nodes, ix->n_nodes * sizeof(sw_node)},
                                    {edges, ix->n_edges * sizeof(sw_edge)}};
@@ -781,7 +780,6 @@ int sw_index_export(const sw_index *ix, sw_kmer *kmers, sw_node *nodes, sw_edge 
 int sw_index_checksums(const sw_index *ix, uint64_t *kmers_sum, uint64_t *nodes_sum, uint64_t *edges_sum)
 {
     return guarded([&] {
-        index_settle(*const_cast<sw_index *>(ix));
         uint64_t s[3];
         device_checksums(*ix, 0, s);
         *kmers_sum = s[0];
@@ -793,7 +791,6 @@ int sw_index_checksums(const sw_index *ix, uint64_t *kmers_sum, uint64_t *nodes_
 int sw_index_checksums_at(const sw_index *ix, uint64_t kmer_base, uint64_t node_base, uint64_t edge_base, uint64_t *sums)
 {
     return guarded([&] {
-        index_settle(*const_cast<sw_index *>(ix));
         device_checksums(*ix, 0, sums, kmer_base, node_base, edge_base);
     });
 }
@@ -801,7 +798,6 @@ int sw_index_checksums_at(const sw_index *ix, uint64_t kmer_base, uint64_t node_
 int sw_index_verify(const sw_index *ix, uint64_t n_assemblies, int scored, uint64_t *out)
 {
     return guarded([&] {
-        index_settle(*const_cast<sw_index *>(ix));
         require_current_device(ix->device, "the index");
         index_verify(*ix, n_assemblies, scored != 0, 0, out);
     });
@@ -811,14 +807,12 @@ void sw_index_free(sw_index *ix) { delete ix; }
 
 int sw_index_threshold_sums(const sw_index *ix, uint64_t *sums)
 {
-    return guarded([&] {
-        index_settle(*const_cast<sw_index *>(ix)); index_threshold_sums(*ix, 0, sums); });
+    return guarded([&] { index_threshold_sums(*ix, 0, sums); });
 }
 
 int sw_index_filter_graph(const sw_index *ix, uint64_t edge_weight_th, sw_index **out)
 {
     return guarded([&] {
-        index_settle(*const_cast<sw_index *>(ix));
         std::unique_ptr<sw_index> o(new sw_index);
         o->device = ix->device;
         index_filter_graph(*ix, edge_weight_th, 0, *o);
@@ -833,8 +827,6 @@ int sw_index_filter_kmers(const sw_index *ix, const sw_index *nodes_from, const 
         const sw_index *nf = nodes_from ? nodes_from : ix;   // NULL: the index's own nodes
         require_current_device(ix->device, "the index");
         if (nf->device != ix->device) raise(SW_ERR_VALUE, "the two indexes live on different devices (%d, %d)", ix->device, nf->device);
-        index_settle(*const_cast<sw_index *>(ix));
-        index_settle(*const_cast<sw_index *>(nf));
         std::vector<uint64_t> used(used_hashes, used_hashes + n_used);
         std::sort(used.begin(), used.end());
         DevArray<uint64_t> d_used(n_used);
@@ -912,7 +904,48 @@ int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t 
         SW_HIP(hipEventRecord(e0, (hipStream_t)stream));
         slice_edges(*ix, (const uint64_t *)adj_rows_dev, m, (unsigned)n_bits, (unsigned)asm_bits,
                     (const uint64_t *)rank_hash_dev, (hipStream_t)stream);
-        index_settle(*ix);   // the counts launched by sw_slice_build
+        SW_HIP(hipEventRecord(e1, (hipStream_t)stream));
+        SW_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SW_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ix->timings.edges_ms = ms;
+    });
+}
+
+int sw_index_ranks_marked(const sw_index *ix, int *marked)
+{
+    return guarded([&] { *marked = ix->ranks_marked ? 1 : 0; });
+}
+
+int sw_occ_adjacency_pairs(const sw_occ *o, const void *rank_by_row_dev, uint64_t n_bits, uint64_t asm_base,
+                           const uint64_t *rank_bounds, uint64_t n_bounds, void *keys_dev, uint64_t *counts, uint64_t *cand_counts,
+                           void *stream)
+{
+    return guarded([&] {
+        if (n_bits < 1 || n_bits > 31) raise(SW_ERR_VALUE, "n_bits must be in [1, 31] (bit 31 of a rank word is the repeat mark)");
+        StreamScope scope((hipStream_t)stream);
+        occ_adjacency_pairs(*o->occ, o->batch->d_rec_asm.p, (const uint32_t *)rank_by_row_dev, (unsigned)n_bits, asm_base, rank_bounds,
+                            (uint32_t)n_bounds, (uint64_t *)keys_dev, counts, cand_counts, (hipStream_t)stream);
+    });
+}
+
+int sw_occ_candidates(const sw_occ *o, void *rows_dev, void *stream)
+{
+    return guarded([&] {
+        if (o->occ->cand_rows.n)
+            SW_HIP(hipMemcpyAsync(rows_dev, o->occ->cand_rows.p, o->occ->cand_rows.n * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    });
+}
+
+int sw_slice_edges_pairs(sw_index *ix, const void *keys_dev, uint64_t m, const void *cand_rows_dev, uint64_t n_cand, uint64_t n_bits,
+                         uint64_t asm_bits, const void *rank_hash_dev, void *stream)
+{
+    return guarded([&] {
+        StreamScope scope((hipStream_t)stream);
+        Event e0, e1;
+        SW_HIP(hipEventRecord(e0, (hipStream_t)stream));
+        slice_edges_pairs(*ix, (const uint64_t *)keys_dev, m, (const uint64_t *)cand_rows_dev, n_cand, (unsigned)n_bits,
+                          (unsigned)asm_bits, (const uint64_t *)rank_hash_dev, (hipStream_t)stream);
         SW_HIP(hipEventRecord(e1, (hipStream_t)stream));
         SW_HIP(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -932,7 +965,6 @@ int sw_index_node_hashes(const sw_index *ix, void *dst_dev, void *stream)
 int sw_index_device_ptrs(const sw_index *ix, void **kmers, void **nodes, void **edges)
 {
     return guarded([&] {
-        index_settle(*const_cast<sw_index *>(ix));
         if (kmers) *kmers = ix->kmers.p;
         if (nodes) *nodes = ix->nodes.p;
         if (edges) *edges = ix->edges.p;
@@ -943,7 +975,6 @@ int sw_index_occ_rows(const sw_index *ix, uint64_t rec_offset, void *rows_dev, v
 {
     return guarded([&] {
         StreamScope scope((hipStream_t)stream);
-        index_settle(*const_cast<sw_index *>(ix));
         index_occ_rows(*ix, rec_offset, (uint64_t *)rows_dev, (hipStream_t)stream);
     });
 }
@@ -962,7 +993,6 @@ int sw_index_splits(const sw_index *ix, const uint64_t *node_bounds, const uint6
 {
     return guarded([&] {
         StreamScope scope((hipStream_t)stream);
-        index_settle(*const_cast<sw_index *>(ix));
         index_splits(*ix, node_bounds, edge_bounds, (uint32_t)n_bounds, occ_split, edge_split, (hipStream_t)stream);
     });
 }
@@ -1004,23 +1034,24 @@ static void merge_like(const void *occ_rows_dev, uint64_t n_occ, const void *edg
         DevArray<uint8_t> d_tar;
         DevArray<uint32_t> d_rec_asm;
         uint32_t n_records = 0;
-        if (is_targets) {
-            check_targets(is_targets, n_assemblies, &n_tar, &n_neg);
+        if (is_targets) check_targets(is_targets, n_assemblies, &n_tar, &n_neg);
+        if (record_offsets && (is_targets || d_rank_out)) {   // the record -> assembly table: counts, repeat marks of a slice build
             n_records = record_offsets[n_assemblies];
             std::vector<uint32_t> rec_asm(n_records);
             for (uint64_t a = 0; a < n_assemblies; ++a)
                 for (uint32_t r = record_offsets[a]; r < record_offsets[a + 1]; ++r) rec_asm[r] = (uint32_t)a;
             d_rec_asm.alloc(n_records);
-            d_tar.alloc(n_assemblies);
             if (n_records) SW_HIP(hipMemcpyAsync(d_rec_asm.p, rec_asm.data(), (size_t)n_records * 4, hipMemcpyHostToDevice, st));
-            SW_HIP(hipMemcpyAsync(d_tar.p, is_targets, n_assemblies, hipMemcpyHostToDevice, st));
+            if (is_targets) {
+                d_tar.alloc(n_assemblies);
+                SW_HIP(hipMemcpyAsync(d_tar.p, is_targets, n_assemblies, hipMemcpyHostToDevice, st));
+            }
             SW_HIP(hipStreamSynchronize(st));
         }
         Event e0, e1;
         SW_HIP(hipEventRecord(e0, st));
         merge_build((const uint64_t *)occ_rows_dev, n_occ, (const uint64_t *)edge_rows_dev, n_edge_rows, kmer_base,
-                    d_rec_asm.p, n_records, is_targets ? d_tar.p : nullptr, n_tar, n_neg, st, *ix, d_rank_out,
-                    d_rank_out ? &d_rec_asm : nullptr, d_rank_out ? &d_tar : nullptr);   // slice build: counts stay in flight
+                    d_rec_asm.p, n_records, is_targets ? d_tar.p : nullptr, n_tar, n_neg, st, *ix, d_rank_out);
         SW_HIP(hipEventRecord(e1, st));
         SW_HIP(hipEventSynchronize(e1));
         float ms = 0.f;

@@ -143,11 +143,6 @@ struct sw_occ {   // ordered tuple stream of one shard (tuple-exchange form of t
     ~sw_occ();
 };
 
-namespace sw {
-struct PendingCounts;                          // index.hip: counts of a slice build still running on the side stream
-void pending_counts_delete(PendingCounts *p);
-}
-
 struct sw_index {
     int device = 0;
     uint64_t n_kmers = 0, n_nodes = 0, n_edges = 0;
@@ -155,10 +150,7 @@ struct sw_index {
     sw::DevArray<sw_node> nodes;
     sw::DevArray<sw_edge> edges;
     sw_timings timings{};
-    // sw_slice_build leaves its target / non-target counts in flight (they overlap the exchanges that follow); every
-    // reader of nodes[].start / stop / n_tar / n_neg / penalty goes through sw::index_settle first
-    sw::PendingCounts *pending = nullptr;
-    ~sw_index() { sw::pending_counts_delete(pending); }
+    bool ranks_marked = false;   // slice build: the returned ranks carry "node recurs in its assembly" in bit 31
 };
 
 namespace sw {
@@ -196,6 +188,7 @@ struct OrderedOcc {
     DevArray<uint32_t> key32;  // out_hash >> 32: first-phase sort key
     DevArray<OccPay> pay;
     DevArray<uint32_t> rec;    // record_idx in (record_idx, pos) order
+    DevArray<uint64_t> cand_rows;   // pairs form of the adjacency exchange: {pair key, assembly} of the candidate records, by owner
     uint64_t n = 0;
     PartState *part = nullptr;
     OrderedOcc() = default;
@@ -204,7 +197,7 @@ struct OrderedOcc {
     {
         if (this != &o) {
             hash = std::move(o.hash); kmer = std::move(o.kmer); key32 = std::move(o.key32); pay = std::move(o.pay);
-            rec = std::move(o.rec); n = o.n; o.n = 0;
+            rec = std::move(o.rec); cand_rows = std::move(o.cand_rows); n = o.n; o.n = 0;
             part_state_delete(part); part = o.part; o.part = nullptr;
         }
         return *this;
@@ -215,7 +208,6 @@ void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, Ord
 // index-form streams of consecutive assembly chunks -> one stream (chunk c's records follow rec_base[c] earlier ones);
 // the chunks are emptied
 void concat_occ(std::vector<OrderedOcc> &chunks, const std::vector<uint64_t> &rec_base, hipStream_t stream, OrderedOcc &out);
-void index_settle(sw_index &ix);   // finish deferred counts (no-op otherwise)
 // occ: index form (key32 / pay / rec); d_rec_asm[n_records] = assembly of every record of the stream
 void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assemblies, OrderedOcc &occ,
                  const uint8_t *d_is_target, uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, sw_index &ix);
@@ -237,8 +229,7 @@ void index_splits(const sw_index &ix, const uint64_t *node_bounds, const uint64_
                   uint64_t *occ_split, uint64_t *edge_split, hipStream_t stream);
 void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_rows, uint64_t m, uint64_t kmer_base,
                  const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target, uint64_t n_targets,
-                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix, uint32_t *d_rank_out = nullptr,
-                 DevArray<uint32_t> *defer_rec_asm = nullptr, DevArray<uint8_t> *defer_is_target = nullptr);
+                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix, uint32_t *d_rank_out = nullptr);
 void occ_partition(const OrderedOcc &occ, const uint64_t *bounds, uint32_t n_bounds, uint64_t rec_offset, uint64_t *d_rows,
                    uint32_t *d_perm, uint64_t *counts_host, hipStream_t stream);
 void occ_adjacency(const OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_perm, const uint32_t *d_rank_by_row,
@@ -246,6 +237,11 @@ void occ_adjacency(const OrderedOcc &occ, const uint32_t *d_rec_asm, const uint3
                    uint64_t *d_rows_out, uint64_t *counts_host, hipStream_t stream);
 void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned nb, unsigned ab, const uint64_t *d_rank_hash,
                  hipStream_t stream);
+void occ_adjacency_pairs(OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_rank_by_row, unsigned nb, uint64_t asm_base,
+                         const uint64_t *rank_bounds, uint32_t n_bounds, uint64_t *d_keys_out, uint64_t *counts_host,
+                         uint64_t *cand_counts_host, hipStream_t stream);
+void slice_edges_pairs(sw_index &ix, const uint64_t *d_keys, uint64_t m, const uint64_t *d_cand_rows, uint64_t c, unsigned nb,
+                       unsigned ab, const uint64_t *d_rank_hash, hipStream_t stream);
 void index_node_hashes(const sw_index &ix, uint64_t *d_out, hipStream_t stream);
 
 }  // namespace sw

@@ -734,9 +734,29 @@ __global__ __launch_bounds__(256) void k_adj_keys(const uint32_t *__restrict__ r
 // of one pair in one assembly contain two occurrences of one of its nodes there).  Those candidates -- none on random
 // genomes, a few per cent on real ones (repeats) -- are also appended to a side list with their assembly
 // (subtract_repeats); everything else needs no assembly at all: keys-only sort, run lengths.
-__global__ __launch_bounds__(256) void k_adj_pairs(const uint32_t *__restrict__ rec, const uint32_t *__restrict__ rank,
-                                                   const uint32_t *__restrict__ rec_asm, uint64_t n, unsigned nb, uint64_t sentinel,
-                                                   uint64_t *__restrict__ key, uint64_t *__restrict__ cand_key,
+struct RecArray {    // record of every occurrence as its own array (single-GPU build)
+    const uint32_t *rec;
+    __device__ void load4(uint64_t i0, uint32_t *r) const
+    {
+        const uint4 rv = *reinterpret_cast<const uint4 *>(rec + i0);
+        r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w;
+    }
+    __device__ uint32_t at(uint64_t i) const { return rec[i]; }
+};
+struct RecOfKmer {   // record = top half of pos | record << 32 (exchange form)
+    const uint64_t *kmer;
+    __device__ void load4(uint64_t i0, uint32_t *r) const
+    {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(kmer + i0), b = *reinterpret_cast<const ulonglong2 *>(kmer + i0 + 2);
+        r[0] = (uint32_t)(a.x >> 32); r[1] = (uint32_t)(a.y >> 32); r[2] = (uint32_t)(b.x >> 32); r[3] = (uint32_t)(b.y >> 32);
+    }
+    __device__ uint32_t at(uint64_t i) const { return (uint32_t)(kmer[i] >> 32); }
+};
+
+template <class Rec>
+__global__ __launch_bounds__(256) void k_adj_pairs(const Rec rec, const uint32_t *__restrict__ rank,
+                                                   const uint32_t *__restrict__ rec_asm, uint32_t asm_base, uint64_t n, unsigned nb,
+                                                   uint64_t sentinel, uint64_t *__restrict__ key, uint64_t *__restrict__ cand_key,
                                                    uint32_t *__restrict__ cand_asm, unsigned long long *__restrict__ n_cand)
 {
     const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -746,13 +766,14 @@ __global__ __launch_bounds__(256) void k_adj_pairs(const uint32_t *__restrict__ 
     uint32_t cm = 0;   // bit j: record i0 + j is a candidate
     if (i0 + 1 < n) {
         if (i0 + 4 < n) {
-            const uint4 rv = *reinterpret_cast<const uint4 *>(rec + i0), kv = *reinterpret_cast<const uint4 *>(rank + i0);
-            r[0] = rv.x; r[1] = rv.y; r[2] = rv.z; r[3] = rv.w; r[4] = rec[i0 + 4];
+            const uint4 kv = *reinterpret_cast<const uint4 *>(rank + i0);
+            rec.load4(i0, r);
+            r[4] = rec.at(i0 + 4);
             k[0] = kv.x; k[1] = kv.y; k[2] = kv.z; k[3] = kv.w; k[4] = rank[i0 + 4];
         } else {
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                r[j] = (i0 + j < n) ? rec[i0 + j] : 0xFFFFFFFFu;
+                r[j] = (i0 + j < n) ? rec.at(i0 + j) : 0xFFFFFFFFu;
                 k[j] = (i0 + j < n) ? rank[i0 + j] : 0u;
             }
         }
@@ -788,7 +809,7 @@ __global__ __launch_bounds__(256) void k_adj_pairs(const uint32_t *__restrict__ 
         for (int j = 0; j < 4; ++j)
             if ((cm >> j) & 1u) {
                 cand_key[base] = out[j];
-                cand_asm[base] = rec_asm[r[j]];
+                cand_asm[base] = asm_base + rec_asm[r[j]];
                 ++base;
             }
     }
@@ -1876,9 +1897,10 @@ namespace {
 // keys[m] = (rank_lo << nb) | rank_hi of every adjacency record (sentinels sort last), no assemblies: a keys-only sort and
 // the run lengths give the number of records of every pair; the candidates (records that may repeat their pair inside one
 // assembly: ck / ca, *d_n_cand of them, unordered) are sorted by (pair, assembly) and the repeats taken off.
+// (d_n_cand == nullptr: the caller knows the number of candidates, host_n_cand.)
 void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t sentinel, unsigned nb, unsigned ab,
-                      DevArray<uint64_t> &ck, DevArray<uint32_t> &ca, const unsigned long long *d_n_cand, hipStream_t stream,
-                      sw_index &ix)
+                      uint64_t *ck, uint32_t *ca, const unsigned long long *d_n_cand, uint64_t host_n_cand,
+                      const uint64_t *rank_hash, hipStream_t stream, sw_index &ix)
 {
     ix.n_edges = 0;
     if (m == 0) return;
@@ -1892,7 +1914,7 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
     }
     DevArray<uint64_t> ukeys(m);
     DevArray<uint32_t> ucnt(m), ucount(1);
-    unsigned long long n_cand = 0;
+    unsigned long long n_cand = host_n_cand;
     {
         size_t tmp_bytes = 0;
         SW_HIP(rocprim::run_length_encode(nullptr, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
@@ -1902,22 +1924,22 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
         SW_HIP(hipGetLastError());
         uint32_t n_edges = 0;
         SW_HIP(hipMemcpyAsync(&n_edges, ucount.p, 4, hipMemcpyDeviceToHost, stream));
-        SW_HIP(hipMemcpyAsync(&n_cand, d_n_cand, 8, hipMemcpyDeviceToHost, stream));
+        if (d_n_cand) SW_HIP(hipMemcpyAsync(&n_cand, d_n_cand, 8, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipStreamSynchronize(stream));   // (tmp is released here, after the pass has finished)
         ix.n_edges = n_edges;
     }
     if (ix.n_edges == 0) return;
     ix.edges.alloc(ix.n_edges);
     hipLaunchKernelGGL(k_edges_runs, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, ucnt.p, 0u, ~0ull,
-                       (uint64_t)ix.n_edges, nb, ix.nodes.p, (const uint64_t *)nullptr, ix.edges.p);
+                       (uint64_t)ix.n_edges, nb, ix.nodes.p, rank_hash, ix.edges.p);
     SW_HIP(hipGetLastError());
     if (n_cand) {
         const uint64_t c = n_cand;
         // (pair, assembly) order: least significant key first, both sorts stable
         DevArray<uint64_t> ck1(c);
         DevArray<uint32_t> ca1(c);
-        uint32_t *a = ca.p, *a_alt = ca1.p;
-        uint64_t *k = ck.p, *k_alt = ck1.p;
+        uint32_t *a = ca, *a_alt = ca1.p;
+        uint64_t *k = ck, *k_alt = ck1.p;
         sort_pairs(a, a_alt, k, k_alt, c, 0, ab, stream);
         sort_pairs(k, k_alt, a, a_alt, c, 0, 2 * nb, stream);
         DevArray<uint64_t> rkeys(c);
@@ -1976,40 +1998,6 @@ void edges_from_adjacency(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, ui
     SW_HIP(hipStreamSynchronize(stream));
 }
 }  // namespace
-
-struct PendingCounts {
-    PenaltyJob job;
-    DevArray<uint32_t> rec_asm;
-    DevArray<uint8_t> is_target;
-    hipEvent_t ev = nullptr;       // recorded on the side stream after the counts
-    hipStream_t stream = nullptr;  // the build's stream
-    uint64_t kmer_base = 0;
-};
-
-void pending_counts_delete(PendingCounts *p)
-{
-    if (!p) return;
-    if (p->job.active) (void)hipStreamSynchronize(p->job.stream);   // nothing may still use the buffers
-    if (p->ev) (void)hipEventDestroy(p->ev);
-    delete p;
-}
-
-void index_settle(sw_index &ix)
-{
-    if (!ix.pending) return;
-    std::unique_ptr<PendingCounts, void (*)(PendingCounts *)> pc(ix.pending, pending_counts_delete);
-    ix.pending = nullptr;
-    const uint64_t err = penalty_finish(pc->job);
-    SW_HIP(hipStreamWaitEvent(pc->stream, pc->ev, 0));
-    if (err) raise(SW_ERR_RUNTIME, "internal error: inconsistent occurrence order in merged index (%llu)",
-                   (unsigned long long)err);
-    if (pc->kmer_base && ix.n_nodes) {
-        hipLaunchKernelGGL(k_rebase_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, pc->stream, ix.nodes.p, ix.n_nodes,
-                           pc->kmer_base);
-        SW_HIP(hipGetLastError());
-        SW_HIP(hipStreamSynchronize(pc->stream));
-    }
-}
 
 void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
                         const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,
@@ -2105,10 +2093,10 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
             DevArray<uint32_t> ca(m);
             DevArray<unsigned long long> n_cand(1);
             SW_HIP(hipMemsetAsync(n_cand.p, 0, 8, stream));
-            hipLaunchKernelGGL(k_adj_pairs, dim3(adj_blocks), dim3(256), 0, stream, occ.rec.p, rank.p, d_rec_asm, n, nb, sentinel,
-                               k0.p, ck.p, ca.p, n_cand.p);
+            hipLaunchKernelGGL(k_adj_pairs<RecArray>, dim3(adj_blocks), dim3(256), 0, stream, RecArray{occ.rec.p}, rank.p, d_rec_asm, 0u,
+                               n, nb, sentinel, k0.p, ck.p, ca.p, n_cand.p);
             SW_HIP(hipGetLastError());
-            edges_from_pairs(k0.p, k1.p, m, sentinel, nb, ab, ck, ca, n_cand.p, stream, ix);
+            edges_from_pairs(k0.p, k1.p, m, sentinel, nb, ab, ck.p, ca.p, n_cand.p, 0, nullptr, stream, ix);
         } else {
             DevArray<uint32_t> v0(m), v1(m);
             hipLaunchKernelGGL(k_adj_keys, dim3(adj_blocks), dim3(256), 0, stream, occ.rec.p, rank.p, d_rec_asm, n, nb,
@@ -2170,50 +2158,54 @@ void index_splits(const sw_index &ix, const uint64_t *node_bounds, const uint64_
 // with globally rebased record indices), edge rows as (first, second, partial weight).
 void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_rows, uint64_t m, uint64_t kmer_base,
                  const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target, uint64_t n_targets,
-                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix, uint32_t *d_rank_out,
-                 DevArray<uint32_t> *defer_rec_asm, DevArray<uint8_t> *defer_is_target)
+                 uint64_t n_non_targets, hipStream_t stream, sw_index &ix, uint32_t *d_rank_out)
 {
     if (n >= 0xFFFFFFFFull || m >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 rows on one device");
     ix.n_kmers = n;
     ix.kmers.alloc(n);
     ix.n_nodes = 0;
+    ix.n_edges = 0;
+    // Slice build of the tuple-exchange form (ranks wanted, no partial edges): the rows are this library's own tuples,
+    // concatenated in source-rank = (record, pos) order, so the counts come from k_nodes' bitmaps as in the single-GPU build
+    // (no flag arrays, no prefix sums, nothing left running) and the ranks carry the repeat marks.  SEQWIN_AMD_CHECK_ORDER=1
+    // keeps the validating form below.
+    const bool slice = d_rank_out && m == 0 && d_rec_asm && n_records && !getenv("SEQWIN_AMD_CHECK_ORDER");
     if (n) {
         PaySort ps;
         ps.key_a.alloc(n);
         ps.pay_a.alloc(n);
         hipLaunchKernelGGL(k_rows_to_pay, dim3(blocks_for(n)), dim3(TPB), 0, stream, d_occ_rows, n, ps.key_a.p, ps.pay_a.p);
         SW_HIP(hipGetLastError());
-        // stable: ties keep source-rank order; d_rank_out[j] = node rank of received row j
-        group_occurrences(ps, n, 0, nullptr, stream, ix, d_rank_out, nullptr, nullptr);
-        SW_HIP(hipStreamSynchronize(stream));
+        // stable: ties keep source-rank order; d_rank_out[j] = node rank of received row j -- with RANK_REP in bit 31 where the
+        // node recurs in the occurrence's assembly (record table given, fewer than 2^31 nodes)
+        DevArray<uint32_t> rec_flag;
+        DevArray<unsigned long long> tbits, nbits;
+        bool marked = false;
+        if (d_rank_out && d_rec_asm && n_records) {
+            rec_flag.alloc(n_records);
+            hipLaunchKernelGGL(k_rec_flag, dim3(blocks_for(n_records)), dim3(TPB), 0, stream, d_rec_asm,
+                               slice ? d_is_target : (const uint8_t *)nullptr, n_records, rec_flag.p);
+            SW_HIP(hipGetLastError());
+        }
+        const bool bits = slice && d_is_target;
+        group_occurrences(ps, n, slice ? kmer_base : 0, rec_flag.p, stream, ix, d_rank_out, bits ? &tbits : nullptr,
+                          bits ? &nbits : nullptr, rec_flag.p ? &marked : nullptr);
+        ix.ranks_marked = marked;
+        if (bits && ix.n_nodes) {
+            hipLaunchKernelGGL(k_pen_bits, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, kmer_base, tbits.p,
+                               nbits.p, 1.0 / (double)n_targets, 1.0 / (double)n_non_targets);   // filter.cpp:89-90
+            SW_HIP(hipGetLastError());
+        }
+        SW_HIP(hipStreamSynchronize(stream));   // (the bitmaps are released here)
     } else {
         ix.nodes.alloc(0);
     }
-    // counts on slice-local ranges, on the side stream so that they overlap the partial-edge merge below;
-    // ranges are re-based after both are done
-    if (defer_rec_asm && defer_is_target && d_is_target && ix.n_nodes && m == 0) {
-        // slice build of the tuple-exchange form: the counts keep running on the side stream while the caller goes on
-        // with the rank / adjacency exchanges; index_settle() collects them (and re-bases the ranges)
-        std::unique_ptr<PendingCounts> pc(new PendingCounts);
-        pc->rec_asm = std::move(*defer_rec_asm);
-        pc->is_target = std::move(*defer_is_target);
-        pc->kmer_base = kmer_base;
-        pc->stream = stream;
-        hipStream_t side = side_stream();
-        Event ev_nodes(false);
-        SW_HIP(hipEventCreateWithFlags(&pc->ev, hipEventDisableTiming));
-        SW_HIP(hipEventRecord(ev_nodes, stream));
-        SW_HIP(hipStreamWaitEvent(side, ev_nodes, 0));
-        // (the job keeps every buffer it uses -- held by PendingCounts until index_settle -- and only reads the index's own
-        //  kmers / nodes, so nothing released later needs a fence against this stream)
-        penalty_launch(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, pc->rec_asm.p, n_records, pc->is_target.p, n_targets,
-                       n_non_targets, side, pc->job);
-        SW_HIP(hipEventRecord(pc->ev, side));
-        ix.n_edges = 0;
+    if (slice) {
         ix.edges.alloc(0);
-        ix.pending = pc.release();
         return;
     }
+    // counts on slice-local ranges, on the side stream so that they overlap the partial-edge merge below;
+    // ranges are re-based after both are done
     PenaltyJob pen;
     Event ev_nodes(false), ev_pen(false);
     hipStream_t side = nullptr;
@@ -2510,6 +2502,74 @@ void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned 
         hipLaunchKernelGGL(k_split_rows2, dim3(blocks_for(m)), dim3(TPB), 0, stream, d_adj_rows, m, k0.p, v0.p);
         SW_HIP(hipGetLastError());
         edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, ~0ull, nb, d_rank_hash, stream, ix);
+    }
+    if (ix.n_edges == 0) ix.edges.alloc(0);
+}
+
+namespace {
+struct PairSrc {   // candidate rows as two arrays: key, assembly
+    const uint64_t *key_;
+    const uint32_t *asm_;
+    __device__ uint64_t key(uint64_t i) const { return key_[i]; }
+    __device__ void row(uint64_t i, uint64_t &r0, uint64_t &r1) const { r0 = key_[i]; r1 = asm_[i]; }
+};
+}  // namespace
+
+// Pairs form of the adjacency exchange (ranks carry RANK_REP): d_keys_out[<= n - 1] = one pair key per adjacency record,
+// grouped by edge owner; the candidates (records that may repeat a pair inside one assembly) as {key, global assembly} rows,
+// grouped by owner, stay in occ.cand_rows.  counts_host / cand_counts_host [n_bounds + 1].
+void occ_adjacency_pairs(OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_rank_by_row, unsigned nb, uint64_t asm_base,
+                         const uint64_t *rank_bounds, uint32_t n_bounds, uint64_t *d_keys_out, uint64_t *counts_host,
+                         uint64_t *cand_counts_host, hipStream_t stream)
+{
+    for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = cand_counts_host[j] = 0;
+    occ.cand_rows.alloc(0);
+    const uint64_t n = occ.n;
+    if (n < 2) return;
+    if (!occ.part || !occ.part->valid) raise(SW_ERR_VALUE, "sw_occ_adjacency_pairs needs the tuples partitioned by sw_occ_partition");
+    const uint64_t m = n - 1;
+    const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
+    DevArray<uint32_t> rank(n), ca(m);
+    DevArray<uint64_t> keys(m), ck(m);
+    DevArray<unsigned long long> n_cand(1);
+    SW_HIP(hipMemsetAsync(n_cand.p, 0, 8, stream));
+    const PartArgs &P = occ.part->args;
+    hipLaunchKernelGGL((k_partition<TupleSrc, 2>), dim3((P.n_waves + 3) / 4), dim3(256), 0, stream,
+                       TupleSrc{occ.hash.p, occ.kmer.p, occ.part->rec_off}, P, (uint32_t *)nullptr, occ.part->offs.p,
+                       (uint64_t *)nullptr, (uint32_t *)nullptr, d_rank_by_row, rank.p);
+    hipLaunchKernelGGL(k_adj_pairs<RecOfKmer>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, RecOfKmer{occ.kmer.p}, rank.p,
+                       d_rec_asm, (uint32_t)asm_base, n, nb, sentinel, keys.p, ck.p, ca.p, n_cand.p);
+    SW_HIP(hipGetLastError());
+    std::vector<uint64_t> kb(n_bounds);
+    for (uint32_t j = 0; j < n_bounds; ++j) kb[j] = rank_bounds[j] << nb;   // key is monotone in rank_lo
+    uint64_t counts[18];
+    // dropped (sentinel) rows land after the last owner; the output buffer holds all m keys
+    stable_partition(KeySrc{keys.p}, m, kb.data(), n_bounds, true, sentinel, d_keys_out, (uint32_t *)nullptr, counts, stream, 1);
+    for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = counts[j];
+    unsigned long long c = 0;
+    SW_HIP(hipMemcpyAsync(&c, n_cand.p, 8, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    if (c) {
+        occ.cand_rows.alloc(2 * c);
+        stable_partition(PairSrc{ck.p, ca.p}, c, kb.data(), n_bounds, false, 0, occ.cand_rows.p, (uint32_t *)nullptr, counts, stream);
+        for (uint32_t j = 0; j <= n_bounds; ++j) cand_counts_host[j] = counts[j];
+    }
+}
+
+void slice_edges_pairs(sw_index &ix, const uint64_t *d_keys, uint64_t m, const uint64_t *d_cand_rows, uint64_t c, unsigned nb,
+                       unsigned ab, const uint64_t *d_rank_hash, hipStream_t stream)
+{
+    ix.n_edges = 0;
+    if (m >= 0xFFFFFFFFull || c >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 adjacency rows on one device");
+    if (m) {
+        DevArray<uint64_t> k0(m), k1(m), ck(c);
+        DevArray<uint32_t> ca(c);
+        SW_HIP(hipMemcpyAsync(k0.p, d_keys, m * 8, hipMemcpyDeviceToDevice, stream));
+        if (c) {
+            hipLaunchKernelGGL(k_split_rows2, dim3(blocks_for(c)), dim3(TPB), 0, stream, d_cand_rows, c, ck.p, ca.p);
+            SW_HIP(hipGetLastError());
+        }
+        edges_from_pairs(k0.p, k1.p, m, ~0ull, nb, ab, ck.p, ca.p, nullptr, c, d_rank_hash, stream, ix);   // rows carry no sentinels
     }
     if (ix.n_edges == 0) ix.edges.alloc(0);
 }

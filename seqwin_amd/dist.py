@@ -220,6 +220,40 @@ class HipEngine:
         check(lib.sw_slice_edges(ix._h, c_vp(adj_rows.data_ptr()), c_u64(adj_rows.shape[0]), c_u64(n_bits),
                                  c_u64(asm_bits), c_vp(rank_hash.data_ptr()), c_vp(self._stream())))
 
+    # ---- pairs form of the adjacency exchange (include/seqwin_hip.h: sw_occ_adjacency_pairs) ---------------------
+    def ranks_marked(self, ix) -> bool:
+        import ctypes
+
+        from ._lib import check, lib
+        m = ctypes.c_int()
+        check(lib.sw_index_ranks_marked(ix._h, ctypes.byref(m)))
+        return bool(m.value)
+
+    def adjacency_pairs(self, occ, ranks_by_row, n_bits: int, asm_base: int, rank_bounds):
+        from ._lib import c_u64, c_vp, check, lib
+        t = self.torch
+        ranks_by_row = ranks_by_row.to(self.gpu).contiguous()
+        m = max(occ.n - 1, 0)
+        keys = t.empty((m,), dtype=t.int64, device=self.gpu)
+        nb = len(rank_bounds)
+        b = (c_u64 * max(nb, 1))(*rank_bounds)
+        cnt, ccnt = (c_u64 * (nb + 1))(), (c_u64 * (nb + 1))()
+        check(lib.sw_occ_adjacency_pairs(occ._h, c_vp(ranks_by_row.data_ptr()), c_u64(n_bits), c_u64(asm_base), b, c_u64(nb),
+                                         c_vp(keys.data_ptr()), cnt, ccnt, c_vp(self._stream())))
+        counts, cand_counts = [int(x) for x in cnt], [int(x) for x in ccnt]
+        cand = t.empty((sum(cand_counts), 2), dtype=t.int64, device=self.gpu)
+        check(lib.sw_occ_candidates(occ._h, c_vp(cand.data_ptr()), c_vp(self._stream())))
+        return keys[:sum(counts)].to(self.device), counts, cand.to(self.device), cand_counts
+
+    def slice_edges_pairs(self, ix, keys, cand, n_bits: int, asm_bits: int, rank_hash) -> None:
+        from ._lib import c_u64, c_vp, check, lib
+        keys = keys.to(self.gpu).contiguous()
+        cand = cand.to(self.gpu).contiguous()
+        rank_hash = rank_hash.to(self.gpu).contiguous()
+        check(lib.sw_slice_edges_pairs(ix._h, c_vp(keys.data_ptr()), c_u64(keys.shape[0]), c_vp(cand.data_ptr()),
+                                       c_u64(cand.shape[0]), c_u64(n_bits), c_u64(asm_bits), c_vp(rank_hash.data_ptr()),
+                                       c_vp(self._stream())))
+
     def free_occ(self, occ) -> None:
         occ.close()
 
@@ -420,10 +454,11 @@ def _exchange_rows(rows, counts, dev, group):
     return out, recv_l, matrix
 
 
-def _gather_ints(value: int, dev, group) -> list[int]:
+def _gather_ints(values, dev, group) -> list[int]:
+    """all_gather of a few ints per rank -> flat list in rank order."""
     import torch
     import torch.distributed as dist
-    t = torch.tensor([value], dtype=torch.int64, device=dev)
+    t = torch.tensor([int(v) for v in (values if isinstance(values, (list, tuple)) else [values])], dtype=torch.int64, device=dev)
     parts = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
     dist.all_gather(parts, t, group=group)
     return [int(x) for x in torch.cat(parts).tolist()]   # one device-to-host copy
@@ -485,13 +520,25 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     t3 = time.perf_counter()
 
     # C2: node ranks back to the sources; C3: rank -> hash table everywhere
+    # A slice build may have marked, in bit 31 of the ranks, the occurrences whose node recurs in their assembly: if every
+    # slice did and the job has fewer than 2^31 nodes, the adjacency travels in its pairs form (one 64-bit key per record
+    # plus the few records that can repeat a pair inside an assembly) instead of {pair, assembly} rows.
+    marked = bool(getattr(engine, "ranks_marked", lambda ix: False)(ix))
+    REP = 0x80000000
     if multi:
-        node_cnt = _gather_ints(n_nodes, dev, group)
+        info = _gather_ints([n_nodes, 1 if marked else 0], dev, group)          # [n_nodes, marked] of every rank
+        node_cnt, all_marked = info[0::2], all(info[1::2])
         node_base, total_nodes = sum(node_cnt[:rank]), sum(node_cnt)
         if total_nodes >= 0xFFFFFFFF:
             raise RuntimeError("more than 2^32-2 nodes")
-        # slice-local ranks are uint32 bit patterns held in int32: widen UNSIGNED before adding the base
-        r_ranks = ((r_ranks.to(torch.int64) & 0xFFFFFFFF) + node_base).to(torch.int32)
+        pairs = all_marked and total_nodes < REP and not os.environ.get("SEQWIN_AMD_NO_PACKED_EDGES")
+        # slice-local ranks are uint32 bit patterns held in int32: widen UNSIGNED, add the base below the mark
+        rr = r_ranks.to(torch.int64) & 0xFFFFFFFF
+        if marked:
+            rr = ((rr & (REP - 1)) + node_base) | ((rr & REP) if pairs else 0)
+        else:
+            rr = rr + node_base
+        r_ranks = rr.to(torch.int32)
         ranks_by_row = torch.empty((occ.n,), dtype=torch.int32, device=dev)
         dist.all_to_all_single(ranks_by_row, r_ranks.contiguous(), [int(c) for c in cnt], recv_cnt, group=group)
         hashes = engine.node_hashes(ix)
@@ -502,19 +549,32 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
         hash_work = dist.all_gather(parts, mine, group=group, async_op=True)   # overlaps the adjacency build below
         rank_hash = None
     else:
-        total_nodes, ranks_by_row, rank_hash, hash_work = n_nodes, r_ranks, engine.node_hashes(ix), None
+        total_nodes, rank_hash, hash_work = n_nodes, engine.node_hashes(ix), None
+        pairs = marked and total_nodes < REP and not os.environ.get("SEQWIN_AMD_NO_PACKED_EDGES")
+        ranks_by_row = r_ranks if (pairs or not marked) else (r_ranks.to(torch.int64) & (REP - 1)).to(torch.int32)
     n_bits = max(1, (total_nodes).bit_length())     # total_nodes <= 2^n_bits - 1
-    asm_bits = adjacency_asm_bits(n_bits, shard.n_assemblies_total)
-    adj, acnt = engine.adjacency(occ, perm, ranks_by_row, n_bits, asm_bits, shard.first_assembly,
-                                 rank_bounds(world, total_nodes))
+    if pairs:
+        asm_bits = max(1, int(shard.n_assemblies_total).bit_length())
+        adj, acnt, cand, ccnt = engine.adjacency_pairs(occ, ranks_by_row, n_bits, shard.first_assembly,
+                                                       rank_bounds(world, total_nodes))
+        if multi:
+            r_adj, _, _ = _exchange_rows(adj, acnt, dev, group)
+            r_cand, _, _ = _exchange_rows(cand, ccnt, dev, group)
+        else:
+            r_adj, r_cand = adj, cand
+    else:
+        asm_bits = adjacency_asm_bits(n_bits, shard.n_assemblies_total)
+        adj, acnt = engine.adjacency(occ, perm, ranks_by_row, n_bits, asm_bits, shard.first_assembly,
+                                     rank_bounds(world, total_nodes))
+        r_adj = _exchange_rows(adj, acnt, dev, group)[0] if multi else adj
     if multi:
-        r_adj, _, _ = _exchange_rows(adj, acnt, dev, group)
         hash_work.wait()
         rank_hash = torch.cat([p[:c] for p, c in zip(parts, node_cnt)])
-    else:
-        r_adj = adj
     t4 = time.perf_counter()
-    engine.slice_edges(ix, r_adj, n_bits, asm_bits, rank_hash)
+    if pairs:
+        engine.slice_edges_pairs(ix, r_adj, r_cand, n_bits, asm_bits, rank_hash)
+    else:
+        engine.slice_edges(ix, r_adj, n_bits, asm_bits, rank_hash)
     tm.update(engine.timings(ix))
     t5 = time.perf_counter()
     tm.update(sketch_ms=occ.sketch_ms, n_occ_local=occ.n, sketch_wall_ms=(t1 - t0) * 1e3, tuple_exchange_wall_ms=(t2 - t1) * 1e3,

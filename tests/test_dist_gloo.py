@@ -112,12 +112,62 @@ class NumpyEngine:
         perm = np.argsort(owner, kind="stable")
         rows = np.stack([occ.hash[perm], occ.kmer[perm] + (U64(rec_offset) << U64(32))], axis=1)
         counts = np.bincount(owner, minlength=len(bounds) + 1).tolist()
+        occ.perm = perm   # (the HIP engine's handle remembers its partition the same way)
         return torch.from_numpy(rows.view(np.int64).copy()), torch.from_numpy(perm.astype(np.int32)), counts
 
     def slice_build(self, rows, kmer_base, record_offsets, is_targets):
         ix = self.merge(rows, torch.zeros((0, 3), dtype=torch.int64), kmer_base, record_offsets, is_targets)
-        ranks = np.searchsorted(ix["nodes"]["hash"], rows.numpy().view(U64)[:, 0]).astype(np.uint32)
+        r = rows.numpy().view(U64)
+        ranks = np.searchsorted(ix["nodes"]["hash"], r[:, 0]).astype(np.uint32)
+        if self.mark_repeats and len(r):
+            # bit 31: the row's node occurs more than once in the row's assembly
+            asm = np.searchsorted(np.asarray(record_offsets, np.uint64), r[:, 1] >> U64(32), side="right") - 1
+            both = np.stack([ranks.astype(np.int64), asm.astype(np.int64)], axis=1)
+            _, inv, cnt = np.unique(both, axis=0, return_inverse=True, return_counts=True)
+            ranks = ranks | np.where(cnt[inv.ravel()] > 1, np.uint32(0x80000000), np.uint32(0))
+        ix["marked"] = bool(self.mark_repeats)
         return ix, torch.from_numpy(ranks.view(np.int32).copy())
+
+    mark_repeats = True
+
+    def ranks_marked(self, ix):
+        return ix.get("marked", False)
+
+    def adjacency_pairs(self, occ, ranks_by_row, n_bits, asm_base, rank_bounds):
+        w = np.zeros(occ.n, U64)
+        w[occ.perm] = ranks_by_row.numpy().view(np.uint32).astype(U64)
+        rank, rep = w & U64(0x7FFFFFFF), (w >> U64(31)).astype(bool)
+        rec = (occ.kmer >> U64(32)).astype(np.int64)
+        ok = rec[1:] == rec[:-1] if occ.n > 1 else np.zeros(0, bool)
+        u, v = rank[:-1][ok], rank[1:][ok]
+        key = (np.minimum(u, v) << U64(n_bits)) | np.maximum(u, v)
+        asm = (occ.rec_asm[rec[:-1][ok]] + asm_base).astype(U64)
+        cand = (rep[:-1] | rep[1:])[ok] if occ.n > 1 else np.zeros(0, bool)
+        kb = np.array([b << n_bits for b in rank_bounds], dtype=U64)
+        owner = np.searchsorted(kb, key, side="right")
+        p = np.argsort(owner, kind="stable")
+        co = owner[cand]
+        cp = np.argsort(co, kind="stable")
+        crows = np.stack([key[cand][cp], asm[cand][cp]], axis=1) if cand.any() else np.zeros((0, 2), U64)
+        return (torch.from_numpy(key[p].view(np.int64).copy()), np.bincount(owner, minlength=len(rank_bounds) + 1).tolist(),
+                torch.from_numpy(crows.view(np.int64).copy()), np.bincount(co, minlength=len(rank_bounds) + 1).tolist())
+
+    def slice_edges_pairs(self, ix, keys, cand, n_bits, asm_bits, rank_hash):
+        k = keys.numpy().view(U64)
+        table = rank_hash.numpy().view(U64)
+        edges = np.zeros(0, oracle.EDGE_DTYPE)
+        if len(k):
+            uk, cnt = np.unique(k, return_counts=True)
+            w = cnt.astype(np.int64)
+            c = cand.numpy().view(U64)
+            if len(c):   # records that repeat their (pair, assembly) do not count
+                rows, rc = np.unique(c, axis=0, return_counts=True)
+                np.subtract.at(w, np.searchsorted(uk, rows[:, 0]), rc - 1)
+            edges = np.zeros(len(uk), oracle.EDGE_DTYPE)
+            edges["first"] = table[(uk >> U64(n_bits)).astype(np.int64)]
+            edges["second"] = table[(uk & U64((1 << n_bits) - 1)).astype(np.int64)]
+            edges["weight"] = w.astype(np.uint64)
+        ix["edges"] = edges
 
     def node_hashes(self, ix):
         return torch.from_numpy(ix["nodes"]["hash"].view(np.int64).copy())
@@ -176,9 +226,10 @@ def _worker(rank, world, port, paths, k, w, tar, out_path, mode):
     try:
         start, end = swdist.partition_assemblies(len(paths), world)[rank]
         eng = NumpyEngine()
+        eng.mark_repeats = mode != "tuples_rows"   # "tuples": adjacency in its pairs form; "tuples_rows": {pair, assembly} rows
         mine = paths[start:end]
         eng._offs = oracle.build(mine, k, w)[3]
-        build = swdist.build_sharded_index if mode == "tuples" else swdist.build_sharded_index_merge
+        build = swdist.build_sharded_index if mode.startswith("tuples") else swdist.build_sharded_index_merge
         sharded = build(swdist.Shard(mine, start, len(paths)), k, w, tar, engine=eng)
         sums = sharded.global_checksums()   # every rank: shares of the slices add up to the checksums of the whole
         full = sharded.gather(0)
@@ -192,7 +243,7 @@ def _worker(rank, world, port, paths, k, w, tar, out_path, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["tuples", "merge"])
+@pytest.mark.parametrize("mode", ["tuples", "tuples_rows", "merge"])
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("case", ["smoke", "pan", "edge"])
 def test_sharded_build_equals_single(tmp_path, world, case, mode):

@@ -155,8 +155,10 @@ def test_rccl_collectives_world1(tmp_path):
     assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
 
 
-def routed_tuple_exchange(paths, world, k, w, tar, packed=True):
-    """The tuple-exchange form with the all-to-all steps done by hand on ONE GPU (P shards, one after another)."""
+def routed_tuple_exchange(paths, world, k, w, tar, packed=True, pairs=None):
+    """The tuple-exchange form with the all-to-all steps done by hand on ONE GPU (P shards, one after another).
+    pairs (default: whenever the slices marked their ranks, as dist.py decides): adjacency as pair keys + candidate rows;
+    else packed keys (when they fit) or {pair, assembly} rows."""
     eng = swdist.HipEngine()
     parts = swdist.partition_assemblies(len(paths), world)
     shards = [swdist.Shard(Batch.from_fasta(paths[a:b], n_cpu=2), a, len(paths)) for a, b in parts]
@@ -179,9 +181,19 @@ def routed_tuple_exchange(paths, world, k, w, tar, packed=True):
         kbase += r_rows.shape[0]
     node_cnt = [s[0].sizes()[1] for s in slices]
     total_nodes = sum(node_cnt)
+    REP = 0x80000000
+    marked = [eng.ranks_marked(s[0]) for s in slices]
+    if pairs is None:
+        pairs = all(marked) and total_nodes < REP
+    assert not pairs or (all(marked) and total_nodes < REP)
     for owner in range(world):
         ix, r_ranks = slices[owner]
-        g = (r_ranks.to(torch.int64) + sum(node_cnt[:owner])).to(torch.int32)
+        rr = r_ranks.to(torch.int64) & 0xFFFFFFFF
+        if marked[owner]:   # the mark in bit 31 stays above the re-based rank (pairs form) or is dropped
+            rr = ((rr & (REP - 1)) + sum(node_cnt[:owner])) | ((rr & REP) if pairs else 0)
+        else:
+            rr = rr + sum(node_cnt[:owner])
+        g = rr.to(torch.int32)
         o = 0
         for r in range(world):
             c = int(cnts[r][owner])
@@ -191,18 +203,29 @@ def routed_tuple_exchange(paths, world, k, w, tar, packed=True):
     n_bits = max(1, total_nodes.bit_length())
     rb = swdist.rank_bounds(world, total_nodes)
     asm_bits = swdist.adjacency_asm_bits(n_bits, shards[0].n_assemblies_total) if packed else 0
+    if pairs:
+        asm_bits = max(1, int(shards[0].n_assemblies_total).bit_length())
     adj = []
     for r in range(world):
         by_row = torch.cat(ranks_back[r]) if occs[r].n else torch.zeros(0, dtype=torch.int32, device=eng.gpu)
-        adj.append(eng.adjacency(occs[r], perms[r], by_row, n_bits, asm_bits, shards[r].first_assembly, rb))
+        if pairs:
+            adj.append(eng.adjacency_pairs(occs[r], by_row, n_bits, shards[r].first_assembly, rb))
+        else:
+            adj.append(eng.adjacency(occs[r], perms[r], by_row, n_bits, asm_bits, shards[r].first_assembly, rb))
     kmers, nodes, edges = [], [], []
     for owner in range(world):
-        pieces = []
+        pieces, cpieces = [], []
         for r in range(world):
-            a_rows, a_cnt = adj[r]
+            a_rows, a_cnt = adj[r][0], adj[r][1]
             c = np.concatenate([[0], np.cumsum(a_cnt)])
             pieces.append(a_rows[c[owner]:c[owner + 1]])
-        eng.slice_edges(slices[owner][0], torch.cat(pieces), n_bits, asm_bits, rank_hash)
+            if pairs:
+                cc = np.concatenate([[0], np.cumsum(adj[r][3])])
+                cpieces.append(adj[r][2][cc[owner]:cc[owner + 1]])
+        if pairs:
+            eng.slice_edges_pairs(slices[owner][0], torch.cat(pieces), torch.cat(cpieces), n_bits, asm_bits, rank_hash)
+        else:
+            eng.slice_edges(slices[owner][0], torch.cat(pieces), n_bits, asm_bits, rank_hash)
         K, N, E = slices[owner][0].export()
         kmers.append(K); nodes.append(N); edges.append(E)
     return np.concatenate(kmers), np.concatenate(nodes), np.concatenate(edges), record_offsets
@@ -215,10 +238,11 @@ def test_routed_tuple_exchange_equals_single_batch(world):
     for k, w in [(15, 20), (21, 200), (11, 5)]:
         ek, en, ee, eo, _ = oracle.build(paths, k, w)
         oracle.get_penalty(ek, en, eo, tar)
-        for packed in (True, False):    # one 64-bit key per adjacency row, or {key, assembly} pairs
-            got = routed_tuple_exchange(paths, world, k, w, tar, packed)
-            assert np.array_equal(got[0], ek) and np.array_equal(got[1], en), (world, k, w, packed)
-            assert np.array_equal(got[2], ee) and np.array_equal(got[3], eo), (world, k, w, packed)
+        # pair keys + candidate rows (what dist.py chooses); one packed 64-bit key per row; {key, assembly} rows
+        for packed, pairs in ((True, None), (True, False), (False, False)):
+            got = routed_tuple_exchange(paths, world, k, w, tar, packed, pairs)
+            assert np.array_equal(got[0], ek) and np.array_equal(got[1], en), (world, k, w, packed, pairs)
+            assert np.array_equal(got[2], ee) and np.array_equal(got[3], eo), (world, k, w, packed, pairs)
 
 
 @pytest.mark.parametrize("case", ["few_tops_random_lows", "pairs_sharing_top", "ascending_lows", "random", "one_top_long_runs",
@@ -268,7 +292,12 @@ def test_two_phase_hash_sort_repairs_shared_top_halves(case):
     uh, start, cnt = np.unique(h[order], return_index=True, return_counts=True)
     assert np.array_equal(N["hash"], uh) and np.array_equal(N["start"], start.astype(np.uint64))
     assert np.array_equal(N["stop"], (start + cnt).astype(np.uint64))
-    assert np.array_equal(ranks.cpu().numpy().view(np.uint32), np.searchsorted(uh, h).astype(np.uint32))
+    got = ranks.cpu().numpy().view(np.uint32)
+    node_of = np.searchsorted(uh, h)
+    assert np.array_equal(got & np.uint32(0x7FFFFFFF), node_of.astype(np.uint32))
+    # bit 31 (sw_index_ranks_marked): the row's node occurs more than once in the row's assembly (here: one assembly)
+    assert eng.ranks_marked(ix)
+    assert np.array_equal(got >> np.uint32(31), (cnt[node_of] > 1).astype(np.uint32))
 
 
 @pytest.mark.parametrize("workload,extra", [("tiny", []), ("salmonella500", ["--scaling", "strong", "--genomes", "48"])])
