@@ -301,6 +301,14 @@ int sw_occ_adjacency(const sw_occ *o, const void *perm_dev, const void *rank_by_
 int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t n_bits, uint64_t asm_bits,
                    const void *rank_hash_dev, void *stream);
 
+/* ---- the sort primitive of the index stage, on its own (tests, timing) ------------------------------------------------
+ * Stable LSD radix sort of n DEVICE u64 keys by bits [begin_bit, end_bit) -- lsd_radix_sort_key
+ * (cpp/src/seqwin/build_internals.cpp:76-144) on the device: the hand-written onesweep of csrc/radix.hip (rocPRIM's under
+ * SEQWIN_AMD_SORT=rocprim).  keys_dev / alt_dev are a double buffer of n keys each; *sorted_in_alt tells which one holds the
+ * result; *ms (may be NULL) the device time. */
+int sw_sort_keys64(void *keys_dev, void *alt_dev, uint64_t n, uint64_t begin_bit, uint64_t end_bit, void *stream, int *sorted_in_alt,
+                   double *ms);
+
 /* ---- pairs form of the adjacency exchange (half the volume when pair + assembly do not fit one 64-bit key) ----------
  * The weight of an edge is the number of its adjacency records minus the records that repeat the pair inside one
  * assembly, and only records touching an occurrence whose node occurs more than once in its assembly can do that.  A slice

@@ -912,6 +912,32 @@ int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t 
     });
 }
 
+int sw_sort_keys64(void *keys_dev, void *alt_dev, uint64_t n, uint64_t begin_bit, uint64_t end_bit, void *stream, int *sorted_in_alt,
+                   double *ms)
+{
+    return guarded([&] {
+        require_device();
+        if (begin_bit > end_bit || end_bit > 64) raise(SW_ERR_VALUE, "bit range must be inside [0, 64]");
+        StreamScope scope((hipStream_t)stream);
+        uint64_t *k = (uint64_t *)keys_dev, *a = (uint64_t *)alt_dev;
+        DevArray<uint32_t> fail(1);
+        SW_HIP(hipMemsetAsync(fail.p, 0, 4, (hipStream_t)stream));
+        Event e0, e1;
+        SW_HIP(hipEventRecord(e0, (hipStream_t)stream));
+        sort_keys64(k, a, n, (unsigned)begin_bit, (unsigned)end_bit, (hipStream_t)stream, fail.p);
+        SW_HIP(hipEventRecord(e1, (hipStream_t)stream));
+        uint32_t failed = 0;
+        SW_HIP(hipMemcpyAsync(&failed, fail.p, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        SW_HIP(hipEventSynchronize(e1));
+        SW_HIP(hipStreamSynchronize((hipStream_t)stream));
+        check_sort_failed(failed);
+        float t = 0.f;
+        SW_HIP(hipEventElapsedTime(&t, e0, e1));
+        if (ms) *ms = t;
+        *sorted_in_alt = (k == (uint64_t *)alt_dev) ? 1 : 0;
+    });
+}
+
 int sw_index_ranks_marked(const sw_index *ix, int *marked)
 {
     return guarded([&] { *marked = ix->ranks_marked ? 1 : 0; });

@@ -171,6 +171,16 @@ struct SketchOut {
 };
 void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchOut &out, float *sketch_ms);
 
+// radix.hip: stable LSD radix sort of 64-bit keys by bits [begin_bit, end_bit); (keys, alt) is a double buffer, on return
+// `keys` points at the sorted data; *d_fail (device word, zeroed by the caller) becomes non-zero if a pass gave up
+void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
+                       uint32_t *d_fail);
+
+// index.hip: radix.hip or rocPRIM; d_fail: zeroed device word, to be read back and handed to check_sort_failed
+void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
+                 uint32_t *d_fail);
+void check_sort_failed(uint32_t fail_word);
+
 // index.hip
 // What the node sort moves with every occurrence (16 B): the low half of its hash (the high half is the sort key), its
 // (pos, record_idx) -- so that `kmers` comes out of the sort in order, without a gather -- and its place in the

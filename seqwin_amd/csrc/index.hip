@@ -51,6 +51,41 @@ void sort_pairs(K *&keys, K *&keys_alt, V *&vals, V *&vals_alt, size_t n, unsign
     vals_alt = dv.alternate();
 }
 
+}  // namespace
+
+// keys-only stable sort of 64-bit keys on bits [begin_bit, end_bit): the hand-written onesweep of radix.hip for large
+// inputs, rocPRIM's for small ones; SEQWIN_AMD_SORT=own|rocprim forces one (A/B, tests).  On return `keys` is the sorted buffer.  d_fail: a zeroed device word the caller
+// reads back at its next host synchronisation -- non-zero means a pass of radix.hip gave up waiting for a lower-numbered
+// workgroup (it relies on in-order dispatch, like rocPRIM's onesweep; never seen) and the result is not sorted:
+// check_sort_failed() then raises instead of the device hanging.
+void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
+                 uint32_t *d_fail)
+{
+    // measured per build: 745 M keys 211.1 against 214.5 ms with rocPRIM; 24 M keys 7.90 against 7.68 ms (the
+    // per-pass state resets and launches weigh more on few tiles) -> the own passes from 2^26 keys on
+    const char *e = getenv("SEQWIN_AMD_SORT");
+    const bool own = e ? !strcmp(e, "own") : n >= (1ull << 26);
+    if (own && !(e && !strcmp(e, "rocprim"))) {
+        radix_sort_keys64(keys, keys_alt, n, begin_bit, end_bit, stream, d_fail);
+        return;
+    }
+    rocprim::double_buffer<uint64_t> dk(keys, keys_alt);
+    size_t tmp_bytes = 0;
+    SW_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, dk, n, begin_bit, end_bit, stream));
+    DevArray<unsigned char> tmp(tmp_bytes);
+    SW_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, n, begin_bit, end_bit, stream));
+    keys = dk.current();
+    keys_alt = dk.alternate();
+}
+
+void check_sort_failed(uint32_t fail_word)
+{
+    if (fail_word)
+        raise(SW_ERR_RUNTIME, "internal error: a radix pass gave up waiting for a lower-numbered workgroup (set SEQWIN_AMD_SORT=rocprim)");
+}
+
+namespace {
+
 // NOTE: the temp storage goes back to the caching allocator when the wrapper returns, while the scan / sort may
 // still be running.  That is safe only because every later user of the block is ordered after it on the SAME
 // stream; work on a second stream must keep its temp storage alive itself (inclusive_sum_keep).
@@ -1642,9 +1677,9 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     }
     const unsigned blocks = (unsigned)((n + NODES_TILE - 1) / NODES_TILE);
     DevArray<unsigned long long> tile_state(blocks);
-    DevArray<uint32_t> words(2);   // [0] tile tickets, [1] the number of nodes
+    DevArray<uint32_t> words(3);   // [0] tile tickets, [1] the number of nodes, [2] the unsort's radix passes gave up
     SW_HIP(hipMemsetAsync(tile_state.p, 0, (size_t)blocks * 8, stream));
-    SW_HIP(hipMemsetAsync(words.p, 0, 8, stream));
+    SW_HIP(hipMemsetAsync(words.p, 0, 12, stream));
     {
         auto launch = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(blocks), dim3(NODES_THREADS), 0, stream, ps.key32, ps.pay, n, base, rec_flag, ix.kmers.p,
@@ -1657,8 +1692,7 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
         else launch(k_nodes<false, false>);
     }
     SW_HIP(hipGetLastError());
-    uint32_t n_nodes = 0;
-    SW_HIP(hipMemcpyAsync(&n_nodes, words.p + 1, 4, hipMemcpyDeviceToHost, stream));
+    uint32_t back[2] = {0, 0};   // the number of nodes, the sort's failure word (read after the unsort has been enqueued)
     if (rank_out && !direct) {
         unsigned nbit = 1;
         while (nbit < 32 && (1ull << nbit) < n) ++nbit;          // indices < 2^nbit
@@ -1666,18 +1700,17 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
         uint64_t *v = uv0.p;
         if (nbit > UNSORT_BITS) {   // buckets of 2^14 consecutive indices: sort on the index's bits above those
             // (begin_bit > 0 of rocPRIM's radix sort is checked on this stack by scripts/micro/sort_beginbit.hip)
-            rocprim::double_buffer<uint64_t> dk(uv0.p, uv1.p);
-            size_t tmp_bytes = 0;
-            SW_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, dk, n, 32 + UNSORT_BITS, 32 + nbit, stream));
-            DevArray<unsigned char> tmp(tmp_bytes);
-            SW_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, n, 32 + UNSORT_BITS, 32 + nbit, stream));
-            v = dk.current();
+            uint64_t *v_alt = uv1.p;
+            sort_keys64(v, v_alt, n, 32 + UNSORT_BITS, 32 + nbit, stream, words.p + 2);
         }
         hipLaunchKernelGGL(k_unsort_bucket, dim3((unsigned)((n + UNSORT_RANGE - 1) / UNSORT_RANGE)), dim3(1024), 0, stream, v, n,
                            rank_out);
         SW_HIP(hipGetLastError());
     }
+    SW_HIP(hipMemcpyAsync(back, words.p + 1, 8, hipMemcpyDeviceToHost, stream));
     SW_HIP(hipStreamSynchronize(stream));   // n_nodes has arrived
+    const uint32_t n_nodes = back[0];
+    check_sort_failed(back[1]);
     if (n_nodes > node_cap) raise(SW_ERR_RUNTIME, "internal error: %u nodes exceed the bound %llu", n_nodes, (unsigned long long)node_cap);
     ix.n_nodes = n_nodes;
     // (the sort buffers go back to the pool here; later users are ordered after these kernels on this stream, or fenced)
@@ -1852,14 +1885,11 @@ void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t 
     if (m == 0) return;
     const unsigned pshift = ab;
     const uint64_t pmask = ~0ull;
+    DevArray<uint32_t> sort_fail(1);
+    SW_HIP(hipMemsetAsync(sort_fail.p, 0, 4, stream));
     {
         const unsigned sort_bits = 2 * nb + ab;
-        rocprim::double_buffer<uint64_t> dk(keys, keys_alt);
-        size_t tmp_bytes = 0;
-        SW_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, dk, m, 0, sort_bits, stream));
-        DevArray<unsigned char> tmp(tmp_bytes);
-        SW_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, m, 0, sort_bits, stream));
-        keys = dk.current();
+        sort_keys64(keys, keys_alt, m, 0, sort_bits, stream, sort_fail.p);
     }
     // One run-length pass over the sorted keys (rocprim::reduce_by_key, decoupled look-back): runs = equal pairs, value of
     // an element = 1 where the whole key (pair, assembly) differs from its predecessor, so a run's sum is the number of
@@ -1879,9 +1909,11 @@ void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t 
                                       stream));
         hipLaunchKernelGGL(k_drop_sentinel_run, dim3(1), dim3(1), 0, stream, ukeys.p, sentinel, ucount.p);
         SW_HIP(hipGetLastError());
-        uint32_t n_edges = 0;
+        uint32_t n_edges = 0, failed = 0;
         SW_HIP(hipMemcpyAsync(&n_edges, ucount.p, 4, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipMemcpyAsync(&failed, sort_fail.p, 4, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipStreamSynchronize(stream));   // (tmp is released here, after the pass has finished)
+        check_sort_failed(failed);
         ix.n_edges = n_edges;
     }
     if (ix.n_edges == 0) return;
@@ -1904,14 +1936,9 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
 {
     ix.n_edges = 0;
     if (m == 0) return;
-    {
-        rocprim::double_buffer<uint64_t> dk(keys, keys_alt);
-        size_t tmp_bytes = 0;
-        SW_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, dk, m, 0, 2 * nb, stream));
-        DevArray<unsigned char> tmp(tmp_bytes);
-        SW_HIP(rocprim::radix_sort_keys(tmp.p, tmp_bytes, dk, m, 0, 2 * nb, stream));
-        keys = dk.current();
-    }
+    DevArray<uint32_t> sort_fail(1);
+    SW_HIP(hipMemsetAsync(sort_fail.p, 0, 4, stream));
+    sort_keys64(keys, keys_alt, m, 0, 2 * nb, stream, sort_fail.p);
     DevArray<uint64_t> ukeys(m);
     DevArray<uint32_t> ucnt(m), ucount(1);
     unsigned long long n_cand = host_n_cand;
@@ -1922,10 +1949,12 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
         SW_HIP(rocprim::run_length_encode(tmp.p, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
         hipLaunchKernelGGL(k_drop_sentinel_run, dim3(1), dim3(1), 0, stream, ukeys.p, sentinel, ucount.p);
         SW_HIP(hipGetLastError());
-        uint32_t n_edges = 0;
+        uint32_t n_edges = 0, failed = 0;
         SW_HIP(hipMemcpyAsync(&n_edges, ucount.p, 4, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipMemcpyAsync(&failed, sort_fail.p, 4, hipMemcpyDeviceToHost, stream));
         if (d_n_cand) SW_HIP(hipMemcpyAsync(&n_cand, d_n_cand, 8, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipStreamSynchronize(stream));   // (tmp is released here, after the pass has finished)
+        check_sort_failed(failed);
         ix.n_edges = n_edges;
     }
     if (ix.n_edges == 0) return;

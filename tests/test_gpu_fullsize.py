@@ -70,6 +70,8 @@ KNOBS = [
     {"SEQWIN_AMD_UNSORT_DIRECT": "4"},                                     # node ranks return through the bucketed unsort (default above 2^25 occurrences)
     {"SEQWIN_AMD_UNSORT_DIRECT": "4", "SEQWIN_AMD_SORT_KEYBITS": "12", "SEQWIN_AMD_NO_PACKED_EDGES": "1"},
     {"SEQWIN_AMD_RANKS": "table"},                                         # ... or through the open-addressing hash table (A/B path)
+    {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_UNSORT_DIRECT": "4"},           # csrc/radix.hip for the keys-only sorts (default from 2^26 keys on)
+    {"SEQWIN_AMD_SORT": "rocprim"},
 ]
 
 

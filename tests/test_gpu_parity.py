@@ -681,3 +681,24 @@ def test_resident_index_serves_get_penalty_and_filter_kmers(tmp_path, monkeypatc
     assert np.array_equal(g2.nodes, scored)
     f3 = _filter_kmers(g2.kmers, scored, used)
     assert np.array_equal(f3[0], f2[0]) and np.array_equal(f3[1], f2[1])
+
+
+@pytest.mark.parametrize("impl", ["own", "rocprim"])
+def test_sort_keys64_is_a_stable_radix_sort(impl, monkeypatch):
+    """sw_sort_keys64 = lsd_radix_sort_key (build_internals.cpp:76-144) on the device: csrc/radix.hip (hand-written onesweep,
+    8192-key tiles, ballot ranking, decoupled look-back) or rocPRIM; any bit range, sizes around the tile, heavy ties."""
+    import ctypes
+
+    import torch
+    from seqwin_amd._lib import c_u64, c_vp, check, lib
+    monkeypatch.setenv("SEQWIN_AMD_SORT", impl)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n, begin, end, hi in [(0, 0, 8, 2**20), (1, 0, 64, 2**62), (63, 5, 9, 2**12), (8191, 0, 16, 2**16), (8192, 3, 27, 2**30),
+                              (8193, 0, 54, 2**54), (1_000_003, 46, 62, 2**62), (3_000_000, 0, 64, 2**62), (500_000, 0, 24, 4)]:
+        keys = torch.randint(0, hi, (n,), dtype=torch.int64, device="cuda", generator=g)
+        a, b = keys.clone(), torch.empty_like(keys)
+        flag = ctypes.c_int()
+        check(lib.sw_sort_keys64(c_vp(a.data_ptr()), c_vp(b.data_ptr()), c_u64(n), c_u64(begin), c_u64(end), c_vp(0), ctypes.byref(flag), None))
+        out = b if flag.value else a
+        field = (keys >> begin) & ((1 << (end - begin)) - 1) if end - begin < 64 else keys
+        assert torch.equal(out, keys[torch.sort(field, stable=True).indices]), (n, begin, end)
