@@ -14,58 +14,44 @@
 namespace sw {
 namespace {
 
-#ifndef RS_THREADS_
-#define RS_THREADS_ 512
-#endif
-constexpr int RS_THREADS = RS_THREADS_;
 constexpr int RS_ITEMS = 16;
-constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr uint32_t RS_TILE = RS_THREADS * RS_ITEMS;   // 8192 keys = 64 KiB of LDS (256 threads: 4096 keys)
 constexpr int RS_MAX_PASSES = 8;
 
-// digit histograms of all passes in one sweep over the keys
-__global__ __launch_bounds__(256) void k_rs_hist(const uint64_t *__restrict__ keys, uint64_t n, unsigned begin_bit, unsigned end_bit,
-                                                 unsigned n_passes, unsigned long long *__restrict__ hist)
+// digit histogram of one pass (the first: every pass counts the next digit of the keys it holds anyway)
+template <int BITS>
+__global__ __launch_bounds__(256) void k_rs_hist(const uint64_t *__restrict__ keys, uint64_t n, unsigned shift, unsigned bits,
+                                                 unsigned long long *__restrict__ hist)
 {
-    __shared__ uint32_t h[RS_MAX_PASSES][256];
-    for (uint32_t i = threadIdx.x; i < RS_MAX_PASSES * 256; i += 256) (&h[0][0])[i] = 0;
+    constexpr uint32_t RADIX = 1u << BITS;
+    __shared__ uint32_t h[RADIX];
+    for (uint32_t i = threadIdx.x; i < RADIX; i += 256) h[i] = 0;
     __syncthreads();
-    const uint64_t chunk = (uint64_t)RS_TILE * 4;   // a workgroup's share, small enough for 32-bit counters
+    const uint64_t chunk = 32768;   // a workgroup's share, small enough for 32-bit counters
     const uint64_t i0 = (uint64_t)blockIdx.x * chunk, i1 = min(n, i0 + chunk);
+    const uint32_t mask = (1u << bits) - 1u;
     for (uint64_t i = i0 + 2 * threadIdx.x; i < i1; i += 512) {
-        uint64_t k[2];
-        int cnt = 1;
         if (i + 1 < i1) {
             const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(keys + i);
-            k[0] = kk.x;
-            k[1] = kk.y;
-            cnt = 2;
+            atomicAdd(&h[(uint32_t)(kk.x >> shift) & mask], 1u);
+            atomicAdd(&h[(uint32_t)(kk.y >> shift) & mask], 1u);
         } else {
-            k[0] = keys[i];
-            k[1] = 0;
+            atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
         }
-        for (int e = 0; e < cnt; ++e)
-            for (unsigned p = 0; p < n_passes; ++p) {
-                const unsigned sh = begin_bit + 8 * p, bits = min(8u, end_bit - sh);
-                atomicAdd(&h[p][(uint32_t)(k[e] >> sh) & ((1u << bits) - 1u)], 1u);
-            }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n_passes * 256; i += 256) {
-        const uint32_t v = (&h[0][0])[i];
-        if (v) atomicAdd(&hist[i], (unsigned long long)v);
-    }
+    for (uint32_t i = threadIdx.x; i < RADIX; i += 256)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
-// exclusive scan of each pass's 256 digit counts (one workgroup per pass)
-__global__ __launch_bounds__(256) void k_rs_scan(unsigned long long *__restrict__ hist)
+// exclusive scan of a pass's digit counts (one workgroup of RADIX threads)
+template <int BITS> __global__ void k_rs_scan(unsigned long long *__restrict__ h)
 {
-    __shared__ unsigned long long s[256];
-    unsigned long long *h = hist + (size_t)blockIdx.x * 256;
+    constexpr uint32_t RADIX = 1u << BITS;
+    __shared__ unsigned long long s[RADIX];
     const unsigned long long v = h[threadIdx.x];
     s[threadIdx.x] = v;
     __syncthreads();
-    for (uint32_t d = 1; d < 256; d <<= 1) {
+    for (uint32_t d = 1; d < RADIX; d <<= 1) {
         const unsigned long long add = threadIdx.x >= d ? s[threadIdx.x - d] : 0;
         __syncthreads();
         s[threadIdx.x] += add;
@@ -76,30 +62,35 @@ __global__ __launch_bounds__(256) void k_rs_scan(unsigned long long *__restrict_
 
 constexpr unsigned long long RS_AGG = 1ull << 62, RS_INC = 2ull << 62, RS_VAL = (1ull << 62) - 1ull;
 
-// One pass: tile t = workgroup t takes keys [t * 4096, ...), wave w of it the w-th quarter, lane l item i the key
-// w * 1024 + i * 64 + l.  The look-back waits for lower-numbered workgroups: like rocPRIM's onesweep it relies on the
-// dispatcher starting workgroups in index order (a single-address ticket would cap a pass at ~88 tiles per microsecond:
-// 2 ms for the 182 k tiles of 745 M keys); should a wait ever outlast RS_SPIN_LIMIT polls, the workgroup gives up and raises
-// *fail -- the host then sorts again with rocPRIM -- instead of hanging the device.
+// One pass: tile t = workgroup t takes THREADS x 16 consecutive keys, wave w of it the w-th 1024 of them, lane l item i the
+// key w * 1024 + i * 64 + l.  Two shapes: 512 threads with 8-bit digits (8192-key tiles, 72 KiB of LDS, two workgroups per CU)
+// and 1024 threads with 9-bit digits (16384-key tiles, 150 KiB: the same 32 keys per digit and tile, one pass fewer for the
+// 54 bits of the edge pairs).  The look-back waits for lower-numbered workgroups: like rocPRIM's onesweep it relies on the
+// dispatcher starting workgroups in index order (a single-address ticket would cap a pass at ~88 tiles per microsecond);
+// should a wait ever outlast RS_SPIN_LIMIT polls, the workgroup gives up and raises *fail -- the caller then reports an
+// error -- instead of hanging the device.
 constexpr uint32_t RS_SPIN_LIMIT = 1u << 24;
-__global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n,
-                                                        unsigned shift, unsigned bits, const unsigned long long *__restrict__ digit_base,
-                                                        unsigned long long *__restrict__ state, uint32_t *__restrict__ fail,
-                                                        unsigned long long *__restrict__ next_hist, unsigned next_shift,
-                                                        unsigned next_bits)
+template <int THREADS, int BITS>
+__global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n,
+                                                     unsigned shift, unsigned bits, const unsigned long long *__restrict__ digit_base,
+                                                     unsigned long long *__restrict__ state, uint32_t *__restrict__ fail,
+                                                     unsigned long long *__restrict__ next_hist, unsigned next_shift, unsigned next_bits)
 {
-    __shared__ uint64_t sk[RS_TILE];
-    __shared__ uint32_t whist[RS_WAVES][256];        // per wave: running digit counts, then the wave's base inside the tile's digit
-    __shared__ uint32_t lstart[256];                 // first local position of a digit in the tile
-    __shared__ unsigned long long goff[256];         // global position of local position 0 of a digit: out[goff[d] + local]
-    __shared__ uint32_t nh[256];                     // the tile's histogram of the NEXT pass's digit (the keys are here anyway)
+    constexpr uint32_t RADIX = 1u << BITS, WAVES = THREADS / 64, TILE = THREADS * RS_ITEMS;
+    static_assert(RADIX <= (uint32_t)THREADS, "one thread per digit");
+    __shared__ uint64_t sk[TILE];
+    __shared__ uint16_t whist[WAVES][RADIX];         // per wave: running digit counts (<= 1024), then the wave's base inside the tile's digit
+    __shared__ uint32_t lstart[RADIX];               // first local position of a digit in the tile
+    __shared__ unsigned long long goff[RADIX];       // global position of local position 0 of a digit: out[goff[d] + local]
+    __shared__ uint32_t nh[RADIX];                   // the tile's histogram of the NEXT pass's digit (the keys are here anyway)
+    __shared__ uint32_t wsum[RADIX / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    for (uint32_t i = tid; i < RS_WAVES * 256; i += RS_THREADS) (&whist[0][0])[i] = 0;
-    if (tid < 256) nh[tid] = 0;
+    for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) (&whist[0][0])[i] = 0;
+    if (tid < RADIX) nh[tid] = 0;
     __syncthreads();
     const uint32_t tile = blockIdx.x;
-    const uint64_t t0 = (uint64_t)tile * RS_TILE;
-    const uint32_t cnt_tile = (uint32_t)min((uint64_t)RS_TILE, n - t0);
+    const uint64_t t0 = (uint64_t)tile * TILE;
+    const uint32_t cnt_tile = (uint32_t)min((uint64_t)TILE, n - t0);
     const uint32_t dmask = (1u << bits) - 1u;
 
     uint64_t key[RS_ITEMS];
@@ -108,8 +99,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const uint64_t *__restri
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; ++i) {
         const uint32_t li = wave * (64 * RS_ITEMS) + i * 64 + lane;
-        const bool live = li < cnt_tile;
-        key[i] = live ? in[t0 + li] : ~0ull;
+        key[i] = li < cnt_tile ? in[t0 + li] : ~0ull;
     }
     if (next_hist) {
         const uint32_t nmask = (1u << next_bits) - 1u;
@@ -124,7 +114,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const uint64_t *__restri
         const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
         uint64_t m = __ballot(live);                       // lanes with the same digit (among the live ones)
 #pragma unroll
-        for (unsigned b = 0; b < 8; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const uint64_t bal = __ballot((d >> b) & 1u);
             m &= ((d >> b) & 1u) ? bal : ~bal;
         }
@@ -132,20 +122,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const uint64_t *__restri
         if (live) prior = whist[wave][d];                  // every lane of a group reads before its leader adds
         rank[i] = prior + (uint32_t)__popcll(m & lt);
         __builtin_amdgcn_wave_barrier();
-        if (live && (m & lt) == 0) whist[wave][d] = prior + (uint32_t)__popcll(m);   // the group's first lane
+        if (live && (m & lt) == 0) whist[wave][d] = (uint16_t)(prior + (uint32_t)__popcll(m));   // the group's first lane
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // thread d < 256: the digit's counts per wave -> bases, total; publish; scan over the digits; look back
-    __shared__ uint32_t wsum[4];
+    // thread d < RADIX: the digit's counts per wave -> bases, total; publish; scan over the digits; look back
     uint32_t total = 0, incl = 0;
-    unsigned long long *st = state + (size_t)tile * 256;
-    if (tid < 256) {
+    unsigned long long *st = state + (size_t)tile * RADIX;
+    if (tid < RADIX) {
         const uint32_t d = tid;
 #pragma unroll
-        for (int w = 0; w < RS_WAVES; ++w) {
+        for (uint32_t w = 0; w < WAVES; ++w) {
             const uint32_t c = whist[w][d];
-            whist[w][d] = total;
+            whist[w][d] = (uint16_t)total;
             total += c;
         }
         __hip_atomic_store(&st[d], (tile == 0 ? RS_INC : RS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -157,7 +146,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const uint64_t *__restri
         if (lane == 63) wsum[wave] = incl;
     }
     __syncthreads();
-    if (tid < 256) {
+    if (tid < RADIX) {
         const uint32_t d = tid;
         uint32_t before = incl - total;
         for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
@@ -168,7 +157,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const uint64_t *__restri
                 unsigned long long v;
                 uint32_t spins = 0;
                 for (;;) {
-                    v = __hip_atomic_load(&state[(size_t)t * 256 + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = __hip_atomic_load(&state[(size_t)t * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if ((v >> 62) != 0) break;           // the predecessor started earlier: it will publish
                     if (++spins > RS_SPIN_LIMIT) {         // (never seen; see above)
                         atomicOr(fail, 1u);
@@ -197,7 +186,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const uint64_t *__restri
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
-        const uint32_t t = j * RS_THREADS + tid;
+        const uint32_t t = j * THREADS + tid;
         if (t < cnt_tile) {
             const uint64_t k = sk[t];
             out[goff[(uint32_t)(k >> shift) & dmask] + t] = k;
@@ -205,37 +194,47 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_pass(const uint64_t *__restri
     }
 }
 
-}  // namespace
-
-// Stable sort of keys[0, n) by bits [begin_bit, end_bit); keys / alt are a double buffer, on return `keys` points at the
-// sorted data and `alt` at the other buffer.  Returns a device word that is non-zero if a pass gave up waiting (the caller
-// checks it at its next host synchronisation and repeats the sort with rocPRIM: sort_keys64 in index.hip).
-void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                       uint32_t *d_fail)
+template <int THREADS, int BITS>
+void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream, uint32_t *d_fail)
 {
-    if (n == 0 || end_bit <= begin_bit) return;
-    const unsigned n_passes = (end_bit - begin_bit + 7) / 8;
-    if (n_passes > RS_MAX_PASSES) raise(SW_ERR_RUNTIME, "radix_sort_keys64: more than 64 key bits");
-    const uint64_t n_tiles = (n + RS_TILE - 1) / RS_TILE;
-    DevArray<unsigned long long> hist((size_t)RS_MAX_PASSES * 256), state((size_t)n_tiles * 256);
+    constexpr uint32_t RADIX = 1u << BITS, TILE = THREADS * RS_ITEMS;
+    const unsigned n_passes = (end_bit - begin_bit + BITS - 1) / BITS;
+    const uint64_t n_tiles = (n + TILE - 1) / TILE;
+    DevArray<unsigned long long> hist((size_t)n_passes * RADIX), state((size_t)n_tiles * RADIX);
     SW_HIP(hipMemsetAsync(hist.p, 0, hist.bytes(), stream));
-    // the first digit's histogram by a sweep of its own; every pass counts the next digit of the keys it holds anyway
-    hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)((n + RS_TILE * 4 - 1) / (RS_TILE * 4))), dim3(256), 0, stream, keys, n, begin_bit,
-                       std::min(end_bit, begin_bit + 8), 1u, hist.p);
+    hipLaunchKernelGGL(k_rs_hist<BITS>, dim3((unsigned)((n + 32767) / 32768)), dim3(256), 0, stream, keys, n, begin_bit,
+                       std::min<unsigned>(BITS, end_bit - begin_bit), hist.p);
     SW_HIP(hipGetLastError());
     for (unsigned p = 0; p < n_passes; ++p) {
-        const unsigned sh = begin_bit + 8 * p, bits = std::min(8u, end_bit - sh);
+        const unsigned sh = begin_bit + BITS * p, bits = std::min<unsigned>(BITS, end_bit - sh);
         const bool more = p + 1 < n_passes;
-        const unsigned nsh = sh + 8, nbits = more ? std::min(8u, end_bit - nsh) : 0u;
-        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(256), 0, stream, hist.p + (size_t)p * 256);
+        const unsigned nsh = sh + BITS, nbits = more ? std::min<unsigned>(BITS, end_bit - nsh) : 0u;
+        hipLaunchKernelGGL(k_rs_scan<BITS>, dim3(1), dim3(RADIX), 0, stream, hist.p + (size_t)p * RADIX);
         SW_HIP(hipMemsetAsync(state.p, 0, state.bytes(), stream));
-        hipLaunchKernelGGL(k_rs_pass, dim3((unsigned)n_tiles), dim3(RS_THREADS), 0, stream, keys, alt, n, sh, bits,
-                           hist.p + (size_t)p * 256, state.p, d_fail, more ? hist.p + (size_t)(p + 1) * 256 : (unsigned long long *)nullptr,
-                           nsh, nbits);
+        hipLaunchKernelGGL((k_rs_pass<THREADS, BITS>), dim3((unsigned)n_tiles), dim3(THREADS), 0, stream, keys, alt, n, sh, bits,
+                           hist.p + (size_t)p * RADIX, state.p, d_fail,
+                           more ? hist.p + (size_t)(p + 1) * RADIX : (unsigned long long *)nullptr, nsh, nbits);
         SW_HIP(hipGetLastError());
         std::swap(keys, alt);
     }
     // (hist / state go back to the pool here; their next user is ordered after these kernels on this stream)
+}
+
+}  // namespace
+
+// Stable sort of keys[0, n) by bits [begin_bit, end_bit); keys / alt are a double buffer, on return `keys` points at the
+// sorted data and `alt` at the other buffer.  *d_fail (device word, zeroed by the caller) becomes non-zero if a pass gave
+// up waiting (the caller checks it at its next host synchronisation: check_sort_failed in index.hip).
+void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
+                       uint32_t *d_fail)
+{
+    if (n == 0 || end_bit <= begin_bit) return;
+    if (end_bit - begin_bit > 64) raise(SW_ERR_RUNTIME, "radix_sort_keys64: more than 64 key bits");
+    const unsigned bits = end_bit - begin_bit;
+    const char *e = getenv("SEQWIN_AMD_RADIX_BITS");   // A/B: 8 or 9
+    const bool nine = e ? atoi(e) == 9 : (bits + 8) / 9 < (bits + 7) / 8;   // 9-bit digits where they save a pass (54 bits: 6 for 7)
+    if (nine) sort_passes<1024, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail);
+    else sort_passes<512, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail);
 }
 
 }  // namespace sw
