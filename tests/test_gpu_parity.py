@@ -674,6 +674,13 @@ def test_resident_index_serves_get_penalty_and_filter_kmers(tmp_path, monkeypatc
     f2 = oracle.filter_kmers(ek, scored, used)
     assert np.array_equal(f1[0], f2[0]) and np.array_equal(f1[1], f2[1])
     assert _resident_stats()[2] == s0[2] + 1                                 # one compute for the two phases, on resident kmers
+    from seqwin_amd._lib import lib
+    lib.sw_release_resident.restype = None
+    lib.sw_release_resident()                                                # the HBM goes back at once; later calls upload
+    assert _resident_stats()[0] == 0
+    n3 = en.copy()
+    _get_penalty(g.kmers, n3, g.record_offsets, tar)
+    assert np.array_equal(n3, scored) and _resident_stats()[1] == s0[1] + 2
     monkeypatch.setenv("SEQWIN_AMD_NO_RESIDENT", "1")
     g2 = KmerGraph(paths, kmerlen=15, windowsize=20, n_cpu=2)
     assert _resident_stats()[0] == 0
