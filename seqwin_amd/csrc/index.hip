@@ -1340,100 +1340,103 @@ __global__ __launch_bounds__(256) void k_list_descents(const View V, uint32_t km
 }
 
 // ---- in-place repair (the common case: short runs) -- no host round trip -----------------------------------
-// Workgroups stride over the descents.  k_repair_plan (reads only) finds the run [a, a + len) of a descent -- galloping
-// outwards from it, runs are short -- and whether it is the FIRST descent of that run (the owner); k_repair_sort lets
-// the owner rank-sort the run in LDS by (key, low, position), a total order, so the result is the stable sort.
+// One WAVE per descent (k_repair_wave).  The descents are listed in position order, so the first descent of a run --
+// its owner -- is the one whose predecessor in the list lies in another run; the test reads only the masked keys, which
+// no repair changes, so owners of other runs may be writing meanwhile.  The owner finds its run [a, e), 64 positions
+// per step, and rank-sorts it by (key, low, position) -- a total order, so the result is the stable sort: a run of up
+// to 64 elements in registers (one element per lane, the others read with v_readlane), a longer one is listed for
+// k_repair_sort (a workgroup per run, in LDS).
 // Anything the fast path does not take (more than REPAIR_MAX_DESC descents, a run longer than REPAIR_MAX_RUN)
 // raises `status` and is left to the general repair of the caller.
 constexpr uint32_t REPAIR_MAX_DESC = 1u << 22;   // 15k genomes: 7.3e5 descents (79 M nodes); 2^22 covers ~190 M nodes
 constexpr uint32_t REPAIR_MAX_RUN = 2048;
 constexpr uint32_t REPAIR_GRID = 2048;
 
-template <class View>
-__global__ __launch_bounds__(256) void k_repair_plan(const View V, uint32_t kmask, uint64_t n, const uint32_t *__restrict__ bad_q,
-                                                     const unsigned long long *__restrict__ n_desc,
-                                                     uint32_t *__restrict__ plan, uint32_t *__restrict__ status)
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t lane)   // `lane` is wave-uniform
 {
-    __shared__ uint32_t sh[3];
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)lane);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)lane);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <class View>
+__global__ __launch_bounds__(256) void k_repair_wave(const View V, uint32_t kmask, uint64_t n, const uint32_t *__restrict__ bad_q,
+                                                     const unsigned long long *__restrict__ n_desc, uint32_t *__restrict__ big,
+                                                     uint32_t *__restrict__ n_big, uint32_t *__restrict__ status)
+{
     const unsigned long long D = *n_desc;
-    const uint32_t tid = threadIdx.x;
     if (D > REPAIR_MAX_DESC) {
-        if (blockIdx.x == 0 && tid == 0) *status = 1u;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *status = 1u;
         return;
     }
-    for (uint32_t b = blockIdx.x; b < D; b += gridDim.x) {
-        __syncthreads();                      // sh is reused
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < D; b += n_waves) {   // (wave-uniform)
         const uint32_t q = bad_q[b];
-        if (tid == 0) {
-            const uint32_t k = V.key(q) & kmask;
-            // first position of the run: gallop left from q, then bisect
-            uint64_t step = 1, hi = q, lo;
-            for (;;) {
-                if (step > hi) { lo = 0; break; }
-                if ((V.key(hi - step) & kmask) != k) { lo = hi - step + 1; break; }
-                hi -= step;
-                step <<= 1;
+        const uint32_t k = V.key(q) & kmask;
+        if (b && (V.key(bad_q[b - 1]) & kmask) == k) continue;   // an earlier descent of the same run owns it
+        uint64_t a = q, e = (uint64_t)q + 1;                     // [a, e) belongs to the run
+        bool too_long = false;
+        for (;;) {                                               // leftwards: positions a-1, a-2, ..
+            const bool match = a >= 1 + (uint64_t)lane && (V.key(a - 1 - lane) & kmask) == k;
+            const unsigned long long miss = ~__ballot(match);
+            if (miss) {
+                a -= (uint64_t)__builtin_ctzll(miss);
+                break;
             }
-            // key(hi) == k and [hi, q] belongs to the run; the start lies in [lo, hi]
-            while (lo < hi) {
-                const uint64_t mid = (lo + hi) >> 1;
-                if ((V.key(mid) & kmask) == k) hi = mid; else lo = mid + 1;
-            }
-            sh[0] = (uint32_t)lo;
-            // first position after the run: gallop right
-            uint64_t lo2 = q, hi2;
-            step = 1;
-            for (;;) {
-                if (lo2 + step >= n) { hi2 = n; break; }
-                if ((V.key(lo2 + step) & kmask) != k) { hi2 = lo2 + step; break; }
-                lo2 += step;
-                step <<= 1;
-            }
-            ++lo2;                            // key(lo2 - 1) == k; the end lies in [lo2, hi2]
-            while (lo2 < hi2) {
-                const uint64_t mid = (lo2 + hi2) >> 1;
-                if ((V.key(mid) & kmask) == k) lo2 = mid + 1; else hi2 = mid;
-            }
-            sh[1] = (uint32_t)lo2;
-            sh[2] = 0xFFFFFFFFu;
+            a -= 64;
+            if (e - a > REPAIR_MAX_RUN) { too_long = true; break; }
         }
-        __syncthreads();
-        const uint32_t a = sh[0], len = sh[1] - sh[0];
-        if (len > REPAIR_MAX_RUN) {
-            if (tid == 0) {
-                *status = 1u;
-                plan[3 * b + 2] = 0u;
+        while (!too_long) {                                      // rightwards: positions e, e+1, ..
+            const bool match = e + lane < n && (V.key(e + lane) & kmask) == k;
+            const unsigned long long miss = ~__ballot(match);
+            if (miss) {
+                e += (uint64_t)__builtin_ctzll(miss);
+                break;
+            }
+            e += 64;
+            if (e - a > REPAIR_MAX_RUN) too_long = true;
+        }
+        const uint32_t len = (uint32_t)(e - a);
+        if (too_long || len > REPAIR_MAX_RUN) {
+            if (lane == 0) *status = 1u;
+            continue;
+        }
+        if (len > 64) {
+            if (lane == 0) {
+                const uint32_t s = atomicAdd(n_big, 1u);         // (at most one entry per owner: <= D <= the list's size)
+                big[2 * s] = (uint32_t)a;
+                big[2 * s + 1] = len;
             }
             continue;
         }
-        for (uint32_t p = a + 1 + tid; p <= q; p += blockDim.x) {   // first descent of the run (q itself is one)
-            const uint32_t kq = V.key(p), kp = V.key(p - 1);
-            if (kq < kp || (kq == kp && V.low(p) < V.low(p - 1))) {
-                atomicMin(&sh[2], p);
-                break;
-            }
+        uint32_t ki = 0;
+        typename View::Elem vi;
+        uint64_t li = 0;
+        const bool have = lane < len;
+        if (have) {
+            V.load(a + lane, ki, vi);
+            li = View::low_of(vi);
         }
-        __syncthreads();
-        if (tid == 0) {
-            plan[3 * b] = a;
-            plan[3 * b + 1] = len;
-            plan[3 * b + 2] = (sh[2] == q) ? 1u : 0u;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < len; ++j) {
+            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)ki, (int)j);
+            const uint64_t lj = readlane64(li, j);
+            rank += (kj < ki || (kj == ki && (lj < li || (lj == li && j < lane)))) ? 1u : 0u;
         }
+        if (have) V.store(a + rank, ki, vi);   // (every load of the run has returned: the ranks depend on them)
     }
 }
 
 template <class View>
-__global__ __launch_bounds__(256) void k_repair_sort(const View V, const unsigned long long *__restrict__ n_desc,
-                                                     const uint32_t *__restrict__ plan)
+__global__ __launch_bounds__(256) void k_repair_sort(const View V, const uint32_t *__restrict__ n_big, const uint32_t *__restrict__ big)
 {
     __shared__ typename View::Elem sv[REPAIR_MAX_RUN];
     __shared__ uint32_t sk[REPAIR_MAX_RUN];
-    const unsigned long long D = *n_desc;
+    const uint32_t B = *n_big;
     const uint32_t tid = threadIdx.x;
-    if (D > REPAIR_MAX_DESC) return;
-    for (uint32_t b = blockIdx.x; b < D; b += gridDim.x) {
-        if (plan[3 * b + 2] == 0u) continue;
-        const uint32_t a = plan[3 * b], len = plan[3 * b + 1];
+    for (uint32_t b = blockIdx.x; b < B; b += gridDim.x) {
+        const uint32_t a = big[2 * b], len = big[2 * b + 1];
         __syncthreads();                      // the previous run has been written out
         for (uint32_t i = tid; i < len; i += blockDim.x) V.load(a + i, sk[i], sv[i]);
         __syncthreads();
@@ -1456,7 +1459,7 @@ __global__ __launch_bounds__(256) void k_repair_sort(const View V, const unsigne
 struct RepairState {
     DevArray<unsigned long long> n_desc;   // [0] descents, [1] run heads before the repair
     DevArray<unsigned long long> blk_cnt, blk_off;
-    DevArray<uint32_t> bad_q, plan, status;
+    DevArray<uint32_t> bad_q, big, status;   // status: [0] leftovers for the general repair, [1] the number of listed long runs
 };
 
 // enqueue: list the descents of the phase-1 order, repair short runs in place.  `bad` (may be null) also receives the
@@ -1467,20 +1470,20 @@ void enqueue_repair(const View &V, uint32_t kmask, uint64_t n, uint32_t *bad, ui
     const uint32_t n_blocks = (uint32_t)((n + DESC_BLOCK - 1) / DESC_BLOCK);
     const uint32_t max_desc = (uint32_t)std::min<uint64_t>(REPAIR_MAX_DESC, std::max<uint64_t>(n, 1));
     r.bad_q.alloc(max_desc);
-    r.plan.alloc(3 * (size_t)max_desc);
+    r.big.alloc(2 * (size_t)max_desc);
     r.n_desc.alloc(2);
-    r.status.alloc(1);
+    r.status.alloc(2);
     r.blk_cnt.alloc(n_blocks);
     r.blk_off.alloc(n_blocks);
-    SW_HIP(hipMemsetAsync(r.status.p, 0, 4, stream));
+    SW_HIP(hipMemsetAsync(r.status.p, 0, 8, stream));
     hipLaunchKernelGGL(k_count_descents<View>, dim3(n_blocks), dim3(256), 0, stream, V, kmask, n, r.blk_cnt.p);
     SW_HIP(hipGetLastError());
     exclusive_sum(r.blk_cnt.p, r.blk_off.p, n_blocks, 0ull, stream);   // both halves at once: neither sum reaches 2^32
     hipLaunchKernelGGL(k_list_descents<View>, dim3(n_blocks), dim3(256), 0, stream, V, kmask, n, r.blk_cnt.p, r.blk_off.p,
                        n_blocks, bad, cap, r.bad_q.p, max_desc, r.n_desc.p);
-    hipLaunchKernelGGL(k_repair_plan<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, kmask, n, r.bad_q.p, r.n_desc.p,
-                       r.plan.p, r.status.p);
-    hipLaunchKernelGGL(k_repair_sort<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, r.n_desc.p, r.plan.p);
+    hipLaunchKernelGGL(k_repair_wave<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, kmask, n, r.bad_q.p, r.n_desc.p,
+                       r.big.p, r.status.p + 1, r.status.p);
+    hipLaunchKernelGGL(k_repair_sort<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, r.status.p + 1, r.big.p);
     SW_HIP(hipGetLastError());
 }
 
