@@ -1,6 +1,7 @@
+# five processes: with six sharing the card, four of them crawled (30 x fewer cases)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r2p; mkdir -p $O; cd $R; T=${1:-280}
 python3 tests/tools/fuzz_gpu.py $T 21 > $O/fuzz_default.log 2>&1 &
-SEQWIN_AMD_SORT=own SEQWIN_AMD_UNSORT_DIRECT=4 python3 tests/tools/fuzz_gpu.py $T 22 > $O/fuzz_unsort.log 2>&1 &
+SEQWIN_AMD_SORT=own SEQWIN_AMD_UNSORT_DIRECT=4 SEQWIN_AMD_WINDOW_SPLIT=8,4 python3 tests/tools/fuzz_gpu.py $T 22 > $O/fuzz_unsort_winsplit.log 2>&1 &
 SEQWIN_AMD_UNSORT_DIRECT=4 SEQWIN_AMD_SORT_KEYBITS=10 SEQWIN_AMD_NO_PACKED_EDGES=1 SEQWIN_AMD_CHECK_ORDER=1 python3 tests/tools/fuzz_gpu.py $T 23 > $O/fuzz_knobs.log 2>&1 &
 FUZZ_DIST=1 SEQWIN_AMD_SORT=own SEQWIN_AMD_RADIX_BITS=9 SEQWIN_AMD_UNSORT_DIRECT=6 python3 tests/tools/fuzz_gpu.py $T 24 > $O/fuzz_dist.log 2>&1 &
 FUZZ_LOWMEM=1 SEQWIN_AMD_LOWMEM_CHUNK_MBP=0 SEQWIN_AMD_RANKS=table python3 tests/tools/fuzz_gpu.py $T 25 > $O/fuzz_lowmem_table.log 2>&1 &

@@ -1100,6 +1100,7 @@ int sw_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *st
         if (!out_hash || !kmers || cap < sk.n_occ) return;
         OrderedOcc occ;
         order_tuples(sk, plan, (hipStream_t)stream, occ);
+        *n_out = occ.n;   // (a window above SW_MAX_WINDOW: fewer than the size query's upper bound)
         if (occ.n) {
             SW_HIP(hipMemcpy(out_hash, occ.hash.p, occ.n * 8, hipMemcpyDeviceToHost));
             SW_HIP(hipMemcpy(kmers, occ.kmer.p, occ.n * 8, hipMemcpyDeviceToHost));  // pos | rec << 32 == sw_kmer layout

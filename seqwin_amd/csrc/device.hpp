@@ -83,6 +83,8 @@ template <class T> struct DevArray {
 // run_len-k+1 consecutive idx values.  A tile is TW consecutive window ends of one record.
 struct Plan {
     uint32_t k = 0, w = 0;
+    uint32_t w_full = 0;   // the caller's window; > w when it exceeds SW_MAX_WINDOW: the tile kernels then sketch with the
+                           // smaller w (a superset of the answer) and order_tuples selects the minimizers of w_full from it
     uint32_t L = 0;        // k-mers hashed per thread (odd, <= w)
     uint32_t NE = 0;       // elements per tile = 256 * L
     uint32_t TW = 0;       // window ends per tile = NE - w

@@ -37,9 +37,7 @@ void check_kw(uint64_t k, uint64_t w)
     if (k < 3) raise(SW_ERR_VALUE, "kmerlen must be >= 3 (got %llu)", (unsigned long long)k);
     if (k > 65535) raise(SW_ERR_VALUE, "kmerlen must be <= 65535 (got %llu)", (unsigned long long)k);
     if (w < 1) raise(SW_ERR_VALUE, "windowsize must be >= 1 (got %llu)", (unsigned long long)w);
-    if (w > SW_MAX_WINDOW)
-        raise(SW_ERR_VALUE, "windowsize must be <= %u on the GPU path (got %llu)", SW_MAX_WINDOW,
-              (unsigned long long)w);
+    // (any w: windows above SW_MAX_WINDOW take the two-step route of index.hip's select_large_windows)
 }
 
 namespace {

@@ -140,7 +140,7 @@ __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t 
                         const uint32_t *__restrict__ tile_count, const uint64_t *__restrict__ tile_offset,
                         const uint64_t *__restrict__ dst_off, uint32_t n_tiles, uint64_t mult, uint64_t *__restrict__ hash,
                         uint64_t *__restrict__ kmer, uint32_t *__restrict__ key32, OccPay *__restrict__ pay,
-                        uint32_t *__restrict__ rec)
+                        uint32_t *__restrict__ rec, bool raw = false)
 {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
@@ -148,8 +148,11 @@ __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t 
     const uint32_t c = tile_count[wave];
     const uint64_t src = tile_offset[wave], dst = dst_off[wave];
     for (uint32_t i = lane; i < c; i += 64) {
-        uint64_t h = stage_hash[src + i] * mult;
-        h ^= h >> 27;
+        uint64_t h = stage_hash[src + i];
+        if (!raw) {   // extend_hashes, hashing_internals.hpp:89-103 (raw: the canonical hash, what the windows compare)
+            h *= mult;
+            h ^= h >> 27;
+        }
         const uint64_t km = stage_kmer[src + i];
         if (INDEX) {
             key32[dst + i] = (uint32_t)(h >> 32);
@@ -1777,33 +1780,290 @@ void concat_occ(std::vector<OrderedOcc> &chunks, const std::vector<uint64_t> &re
     }
 }
 
+namespace {
+
+// ---- windows above SW_MAX_WINDOW -------------------------------------------------------------------------
+// The tile kernels ran with a smaller window w' (get_plan); their output C -- the minimizers of w', canonical hashes, in
+// (record, position) order -- contains every minimizer of w, and the rightmost minimum of a w-window is the rightmost
+// minimum of the members of C inside it.  So candidate i (valid-k-mer index g_i of its record, n valid k-mers) is a
+// minimizer of w iff some window [x, x + w - 1], 0 <= x <= n - w, holds it with no strictly smaller candidate to its
+// left and no smaller-or-equal one to its right (minimizer.cpp:36,40: '<=', the rightmost wins):
+//     max(Lg + 1, g_i - w + 1, 0) <= min(Rg - w, g_i, n - w),
+// Lg = index of the nearest candidate to the left with a smaller hash (-1: none), Rg = of the nearest to the right
+// with a smaller or equal hash (n: none), both within the record.  The two neighbours come from a 64-ary tree of
+// minima over C (level t + 1 = minima of 64 consecutive entries of level t): climb until a sibling's minimum
+// qualifies, descend to the nearest element -- at most 128 reads per level whatever the input (a homopolymer makes
+// every k-mer a candidate and every comparison a tie).
+struct MinTree {
+    const uint64_t *lvl[7];
+    uint64_t size[7];
+    int levels;
+};
+constexpr uint64_t LW_NONE = ~0ull;
+
+// nodes of level t + 1 from level t: one wave per node
+__global__ void k_lw_level(const uint64_t *__restrict__ in, uint64_t n_in, uint64_t *__restrict__ out, uint64_t n_out)
+{
+    const uint64_t node = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (node >= n_out) return;
+    const uint64_t i = node * 64 + lane;
+    uint64_t v = i < n_in ? in[i] : ~0ull;
+    for (int d = 32; d; d >>= 1) {
+        const uint64_t o = __shfl_xor(v, d, 64);
+        v = o < v ? o : v;
+    }
+    if (lane == 0) out[node] = v;
+}
+
+// largest j in [lo, i) with hash[j] < h
+__device__ uint64_t lw_nearest_left(const MinTree &T, uint64_t i, uint64_t lo, uint64_t h)
+{
+    uint64_t pos = i, q = 0;
+    int t = 0;
+    for (;;) {   // climb: the siblings left of `pos` at level t; nodes below lo >> 6t lie entirely before lo
+        const uint64_t gstart = pos & ~63ull, lo_t = lo >> (6 * t), stop = gstart > lo_t ? gstart : lo_t;
+        bool found = false;
+        for (q = pos; q > stop;) {
+            --q;
+            if (T.lvl[t][q] < h) {
+                found = true;
+                break;
+            }
+        }
+        if (found) break;
+        if (gstart <= lo_t || t + 1 >= T.levels) return LW_NONE;
+        pos >>= 6;
+        ++t;
+    }
+    while (t > 0) {   // descend: the rightmost child that qualifies (only the leftmost admissible child can straddle lo,
+                      // so a failure below it means there is nothing)
+        const uint64_t cfirst = q << 6, clo = lo >> (6 * (t - 1));
+        uint64_t c = cfirst + 64 < T.size[t - 1] ? cfirst + 64 : T.size[t - 1];   // one past the last child
+        const uint64_t stop = cfirst > clo ? cfirst : clo;
+        bool found = false;
+        while (c > stop) {
+            --c;
+            if (T.lvl[t - 1][c] < h) {
+                found = true;
+                break;
+            }
+        }
+        if (!found) return LW_NONE;
+        q = c;
+        --t;
+    }
+    return q;
+}
+
+// smallest j in (i, hi) with hash[j] <= h
+__device__ uint64_t lw_nearest_right(const MinTree &T, uint64_t i, uint64_t hi, uint64_t h)
+{
+    uint64_t pos = i, q = 0;
+    int t = 0;
+    for (;;) {   // nodes from (hi + 64^t - 1) >> 6t on lie entirely at or behind hi
+        const uint64_t gend = (pos | 63ull) + 1, hi_t = (hi + ((1ull << (6 * t)) - 1)) >> (6 * t);
+        uint64_t stop = gend < hi_t ? gend : hi_t;
+        if (T.size[t] < stop) stop = T.size[t];
+        bool found = false;
+        for (q = pos + 1; q < stop; ++q)
+            if (T.lvl[t][q] <= h) {
+                found = true;
+                break;
+            }
+        if (found) break;
+        if (gend >= hi_t || gend >= T.size[t] || t + 1 >= T.levels) return LW_NONE;
+        pos >>= 6;
+        ++t;
+    }
+    while (t > 0) {
+        const uint64_t cfirst = q << 6, chi = (hi + ((1ull << (6 * (t - 1))) - 1)) >> (6 * (t - 1));
+        uint64_t stop = cfirst + 64 < T.size[t - 1] ? cfirst + 64 : T.size[t - 1];
+        if (chi < stop) stop = chi;
+        uint64_t c = cfirst;
+        bool found = false;
+        for (; c < stop; ++c)
+            if (T.lvl[t - 1][c] <= h) {
+                found = true;
+                break;
+            }
+        if (!found) return LW_NONE;
+        q = c;
+        --t;
+    }
+    return q;
+}
+
+// valid-k-mer index of every candidate: its segment is the last one starting at or before its position
+__global__ void k_lw_index(const uint64_t *__restrict__ kmer, uint64_t c, const uint32_t *__restrict__ rec_seg_off,
+                           const uint32_t *__restrict__ seg_pos, const uint32_t *__restrict__ seg_idx, uint32_t *__restrict__ g)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const uint32_t pos = (uint32_t)kmer[i], rec = (uint32_t)(kmer[i] >> 32);
+    uint32_t a = rec_seg_off[rec], b = rec_seg_off[rec + 1];
+    while (b - a > 1) {
+        const uint32_t mid = (a + b) >> 1;
+        if (seg_pos[mid] <= pos) a = mid; else b = mid;
+    }
+    g[i] = seg_idx[a] + (pos - seg_pos[a]);
+}
+
+__global__ void k_lw_select(const MinTree T, const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ g, uint64_t c,
+                            const uint32_t *__restrict__ rec_nvalid, uint32_t w, uint32_t *__restrict__ keep)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const uint64_t h = T.lvl[0][i];
+    const uint32_t rec = (uint32_t)(kmer[i] >> 32);
+    const int64_t n = rec_nvalid[rec], gi = g[i];
+    uint32_t k = 0;
+    if (n >= (int64_t)w && h != ~0ull) {   // (minimizer.cpp:44-45: a window whose minimum is 2^64 - 1 emits nothing)
+        uint64_t lo = 0, hi = i;           // the record's candidates are [lo, hi): first entry of rec / first of a later record
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if ((uint32_t)(kmer[mid] >> 32) < rec) lo = mid + 1; else hi = mid;
+        }
+        uint64_t a = i + 1;
+        hi = c;
+        while (a < hi) {
+            const uint64_t mid = (a + hi) >> 1;
+            if ((uint32_t)(kmer[mid] >> 32) <= rec) a = mid + 1; else hi = mid;
+        }
+        const uint64_t jl = lw_nearest_left(T, i, lo, h), jr = lw_nearest_right(T, i, hi, h);
+        const int64_t Lg = jl == LW_NONE ? -1 : (int64_t)g[jl], Rg = jr == LW_NONE ? n : (int64_t)g[jr];
+        int64_t x_lo = Lg + 1, x_hi = Rg - (int64_t)w;
+        if (gi - (int64_t)w + 1 > x_lo) x_lo = gi - (int64_t)w + 1;
+        if (x_lo < 0) x_lo = 0;
+        if (gi < x_hi) x_hi = gi;
+        if (n - (int64_t)w < x_hi) x_hi = n - (int64_t)w;
+        k = x_lo <= x_hi ? 1u : 0u;
+    }
+    keep[i] = k;
+}
+
+template <bool INDEX>
+__global__ void k_lw_emit(const uint64_t *__restrict__ canon, const uint64_t *__restrict__ kmer, const uint32_t *__restrict__ keep,
+                          const uint64_t *__restrict__ dst, uint64_t c, uint64_t mult, uint64_t *__restrict__ hash,
+                          uint64_t *__restrict__ kmer_out, uint32_t *__restrict__ key32, OccPay *__restrict__ pay,
+                          uint32_t *__restrict__ rec, unsigned long long *__restrict__ total)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    if (i == c - 1) *total = dst[i] + keep[i];
+    if (!keep[i]) return;
+    const uint64_t d = dst[i], km = kmer[i];
+    uint64_t h = canon[i] * mult;   // extend_hashes, hashing_internals.hpp:89-103
+    h ^= h >> 27;
+    if (INDEX) {
+        key32[d] = (uint32_t)(h >> 32);
+        OccPay p;
+        p.low = (uint32_t)h;
+        p.pos = (uint32_t)km;
+        p.rec = (uint32_t)(km >> 32);
+        p.idx = (uint32_t)d;
+        pay[d] = p;
+        rec[d] = p.rec;
+        if (hash) hash[d] = h;
+    } else {
+        hash[d] = h;
+        kmer_out[d] = km;
+    }
+}
+
+}  // namespace
+
 void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out, bool index_form)
 {
+    const bool large = plan.w_full > plan.w;   // the stage holds a superset: the minimizers of plan.w (see above)
     out.n = sk.n_occ;
-    if (out.n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
+    if (!large && out.n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
     const bool table_ranks = index_form && ranks_by_table();
-    if (index_form) {
-        out.key32.alloc(out.n);
-        out.pay.alloc(out.n);
-        out.rec.alloc(out.n);
-        if (table_ranks) out.hash.alloc(out.n);
-    } else {
-        out.hash.alloc(out.n);
-        out.kmer.alloc(out.n);
+    auto alloc_out = [&](uint64_t n) {
+        if (index_form) {
+            out.key32.alloc(n);
+            out.pay.alloc(n);
+            out.rec.alloc(n);
+            if (table_ranks) out.hash.alloc(n);
+        } else {
+            out.hash.alloc(n);
+            out.kmer.alloc(n);
+        }
+    };
+    if (!large) alloc_out(out.n);
+    if (plan.n_tiles == 0 || sk.n_occ == 0) {
+        out.n = 0;
+        if (large) alloc_out(0);
+        return;
     }
-    if (plan.n_tiles == 0 || out.n == 0) return;
     DevArray<uint64_t> dst_off(plan.n_tiles);
     exclusive_sum(rocprim::make_transform_iterator(sk.tile_count.p, U32ToU64()), dst_off.p, plan.n_tiles,
                   (uint64_t)0, stream);
     const uint64_t threads = (uint64_t)plan.n_tiles * 64;
+    if (large) {
+        const uint64_t c = sk.n_occ;
+        if (c >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 window candidates on one device");
+        DevArray<uint64_t> canon(c), kmer(c), keep_off(c);
+        DevArray<uint32_t> g(c), keep(c);
+        DevArray<unsigned long long> total(1);
+        hipLaunchKernelGGL(k_order<false>, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
+                           sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult, canon.p, kmer.p,
+                           (uint32_t *)nullptr, (OccPay *)nullptr, (uint32_t *)nullptr, true);
+        hipLaunchKernelGGL(k_lw_index, dim3(blocks_for(c)), dim3(TPB), 0, stream, kmer.p, c, plan.rec_seg_off.p, plan.seg_pos.p,
+                           plan.seg_idx.p, g.p);
+        SW_HIP(hipGetLastError());
+        MinTree T;
+        std::vector<DevArray<uint64_t>> levels;
+        levels.reserve(7);
+        T.lvl[0] = canon.p;
+        T.size[0] = c;
+        T.levels = 1;
+        while (T.size[T.levels - 1] > 64) {   // c < 2^32 candidates: at most 6 levels
+            const int t = T.levels;
+            if (t >= 7) raise(SW_ERR_RUNTIME, "internal error: more than 2^36 window candidates");
+            const uint64_t n_in = T.size[t - 1], n_out = (n_in + 63) / 64;
+            levels.emplace_back(n_out);
+            hipLaunchKernelGGL(k_lw_level, dim3(blocks_for(n_out * 64)), dim3(TPB), 0, stream, T.lvl[t - 1], n_in, levels.back().p,
+                               n_out);
+            SW_HIP(hipGetLastError());
+            T.lvl[t] = levels.back().p;
+            T.size[t] = n_out;
+            T.levels = t + 1;
+        }
+        for (int t = T.levels; t < 7; ++t) {
+            T.lvl[t] = nullptr;
+            T.size[t] = 0;
+        }
+        hipLaunchKernelGGL(k_lw_select, dim3(blocks_for(c)), dim3(TPB), 0, stream, T, kmer.p, g.p, c, plan.rec_nvalid.p, plan.w_full,
+                           keep.p);
+        SW_HIP(hipGetLastError());
+        exclusive_sum(rocprim::make_transform_iterator(keep.p, U32ToU64()), keep_off.p, c, (uint64_t)0, stream);
+        // the survivors are at most the candidates: emit into arrays of that size, shrink the count afterwards
+        alloc_out(c);
+        if (index_form)
+            hipLaunchKernelGGL(k_lw_emit<true>, dim3(blocks_for(c)), dim3(TPB), 0, stream, canon.p, kmer.p, keep.p, keep_off.p, c,
+                               plan.mult, table_ranks ? out.hash.p : (uint64_t *)nullptr, (uint64_t *)nullptr, out.key32.p,
+                               out.pay.p, out.rec.p, total.p);
+        else
+            hipLaunchKernelGGL(k_lw_emit<false>, dim3(blocks_for(c)), dim3(TPB), 0, stream, canon.p, kmer.p, keep.p, keep_off.p, c,
+                               plan.mult, out.hash.p, out.kmer.p, (uint32_t *)nullptr, (OccPay *)nullptr, (uint32_t *)nullptr,
+                               total.p);
+        SW_HIP(hipGetLastError());
+        unsigned long long n_keep = 0;
+        SW_HIP(hipMemcpyAsync(&n_keep, total.p, 8, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));   // (the side arrays are released on return)
+        out.n = n_keep;
+        if (out.n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
+        return;
+    }
     if (index_form)
         hipLaunchKernelGGL(k_order<true>, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
                            sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult,
-                           table_ranks ? out.hash.p : (uint64_t *)nullptr, (uint64_t *)nullptr, out.key32.p, out.pay.p, out.rec.p);
+                           table_ranks ? out.hash.p : (uint64_t *)nullptr, (uint64_t *)nullptr, out.key32.p, out.pay.p, out.rec.p, false);
     else
         hipLaunchKernelGGL(k_order<false>, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
                            sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult, out.hash.p, out.kmer.p,
-                           (uint32_t *)nullptr, (OccPay *)nullptr, (uint32_t *)nullptr);
+                           (uint32_t *)nullptr, (OccPay *)nullptr, (uint32_t *)nullptr, false);
     SW_HIP(hipGetLastError());
     // (dst_off goes back to the pool here; its next user is ordered after k_order on this stream)
 }

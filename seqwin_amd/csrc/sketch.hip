@@ -913,9 +913,22 @@ size_t lds_bytes_for(uint32_t L)
 Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
 {
     check_kw(k64, w64);
-    const uint32_t k = (uint32_t)k64, w = (uint32_t)w64;
+    // A window above SW_MAX_WINDOW does not fit the tiles (a tile holds w elements of halo).  The minimizers of w are a
+    // subset of those of any smaller window w' (the rightmost minimum of a window is the rightmost minimum of every
+    // sub-window that contains it), so the tile kernels run with w' and index.hip: select_large_windows picks the
+    // minimizers of w out of that sparse set.  SEQWIN_AMD_WINDOW_SPLIT="T,B" (tests): windows above T go through base B.
+    uint32_t split_at = SW_MAX_WINDOW, split_base = 1024;
+    if (const char *e = getenv("SEQWIN_AMD_WINDOW_SPLIT")) {
+        unsigned t = 0, bs = 0;
+        if (sscanf(e, "%u,%u", &t, &bs) == 2 && bs >= 1 && bs <= t && t <= SW_MAX_WINDOW) {
+            split_at = t;
+            split_base = bs;
+        }
+    }
+    const uint32_t k = (uint32_t)k64, w_full = (uint32_t)std::min<uint64_t>(w64, 0xFFFFFFFFull);   // (no record has 2^32 k-mers)
+    const uint32_t w = w_full > split_at ? split_base : w_full;
     std::lock_guard<std::mutex> lock(b.plan_mu);
-    auto key = std::make_pair(k, w);
+    auto key = std::make_pair(k, w_full);
     auto it = b.plans.find(key);
     if (cached) *cached = it != b.plans.end();
     if (it != b.plans.end()) return it->second;
@@ -924,6 +937,7 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
     Plan p;
     p.k = k;
     p.w = w;
+    p.w_full = w_full;
     // generic class: any record; run length odd (conflict-free 64-bit LDS accesses at stride L)
     uint32_t L = std::min<uint32_t>(w, L_MAX);
     if ((L & 1u) == 0) --L;

@@ -85,7 +85,7 @@ class Batch:
         km = np.empty(n.value, KMER_DTYPE)
         check(lib.sw_sketch(self._h, c_u64(kmerlen), c_u64(windowsize), c_vp(stream), _ptr(oh), _ptr(km),
                             c_u64(n.value), ctypes.byref(n)))
-        return oh, km
+        return oh[:n.value], km[:n.value]
 
     def build_index(self, kmerlen: int, windowsize: int, is_targets=None, stream: int = 0) -> "Index":
         h = c_vp()

@@ -39,8 +39,6 @@ def test_argument_validation_happens_without_a_device(smoke_paths):
         KmerGraph(smoke_paths, kmerlen=2, windowsize=10)
     with pytest.raises(ValueError):
         KmerGraph(smoke_paths, kmerlen=21, windowsize=0)
-    with pytest.raises(ValueError):
-        KmerGraph(smoke_paths, kmerlen=21, windowsize=5000)
     with pytest.raises(TypeError):
         KmerGraph(smoke_paths, kmerlen=7, windowsize=10, is_targets=[True, False])   # test_graph.py:130-141
     with pytest.raises(TypeError):

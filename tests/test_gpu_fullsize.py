@@ -72,6 +72,8 @@ KNOBS = [
     {"SEQWIN_AMD_RANKS": "table"},                                         # ... or through the open-addressing hash table (A/B path)
     {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_UNSORT_DIRECT": "4"},           # csrc/radix.hip for the keys-only sorts (default from 2^26 keys on)
     {"SEQWIN_AMD_SORT": "rocprim"},
+    {"SEQWIN_AMD_WINDOW_SPLIT": "8,4"},                                    # windows above 8 as if above SW_MAX_WINDOW: sketch with w' = 4, select
+    {"SEQWIN_AMD_WINDOW_SPLIT": "100,64", "SEQWIN_AMD_RANKS": "table"},
 ]
 
 

@@ -289,7 +289,7 @@ def test_fuzz_build_matches_oracle(tmp_path):
                 p.write_text(txt)
             ps.append(p)
         k = rng.choice([3, 4, 5, 7, 15, 16, 17, 18, 19, 21, 31, 32, 33, 40, 100, 255, 256, 257, 300])
-        w = rng.choice([1, 2, 3, 5, 10, 15, 16, 17, 25, 31, 32, 33, 34, 50, 66, 200, 1000, 4096])
+        w = rng.choice([1, 2, 3, 5, 10, 15, 16, 17, 25, 31, 32, 33, 34, 50, 66, 200, 1000, 4096, 4097, 6000, 20000, 10**6])
         got = _build(ps, k, w, n_cpu=rng.choice([1, 3]))
         exp = oracle.build(ps, k, w)
         assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])), [list(t) for t in exp[4]])
@@ -308,7 +308,7 @@ def test_low_complexity_and_ties(tmp_path):
     p = tmp_path / "lc.fa"
     p.write_text(">polyA\n" + "A" * 20000 + "\n>at\n" + "AT" * 9000 + "\n>rep7\n" + "ACGGTCA" * 3000 + "\n>mix\n" +
                  "A" * 500 + "N" + "C" * 700 + "ACGT" * 300 + "\n")
-    for k, w in [(21, 200), (5, 33), (15, 10), (31, 1000)]:
+    for k, w in [(21, 200), (5, 33), (15, 10), (31, 1000), (21, 4097), (5, 8000), (15, 17990)]:
         got = _build([p], k, w)
         exp = oracle.build([p], k, w)
         assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
@@ -326,7 +326,7 @@ def test_tile_seams_and_many_gaps(tmp_path):
     gap = "".join(arr)
     p = tmp_path / "seams.fa"
     p.write_text(f">long\n{s}\n>gappy\n{gap}\n>dense_gaps\n" + "N".join(s[i:i + 23] for i in range(0, 60000, 23)) + "\n")
-    for k, w in [(21, 200), (21, 50), (23, 7), (24, 3), (17, 4096)]:
+    for k, w in [(21, 200), (21, 50), (23, 7), (24, 3), (17, 4096), (17, 4097), (21, 30000), (23, 100000), (15, 119986), (15, 119987)]:
         got = _build([p], k, w)
         exp = oracle.build([p], k, w)
         assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
@@ -350,7 +350,7 @@ def _oracle_for_batch(b: Batch, k, w, tar, tmp_path):
 
 
 @pytest.mark.parametrize("shape,k,w", [((12, 5, 60000), 21, 200), ((5, 2, 150000), 15, 200), ((4, 1, 200000), 31, 200),
-                                       ((6, 3, 20000), 19, 10)])
+                                       ((6, 3, 20000), 19, 10), ((4, 1, 200000), 21, 5000), ((4, 2, 150000), 15, 100000)])
 def test_synthetic_batch_index_matches_oracle(tmp_path, shape, k, w):
     ng, rpg, rl = shape
     b = Batch.synthetic(ng, rpg, rl, n_ancestors=3, snp_ppm=10000, seed=20260821)
@@ -369,6 +369,25 @@ def test_synthetic_batch_index_matches_oracle(tmp_path, shape, k, w):
     assert t["total_bp"] == ng * rpg * rl and t["sketch_launches"] == 1
     # idempotence: a second build of the same batch is identical
     assert b.build_index(k, w, tar).checksums() == ix.checksums()
+
+
+def test_window_split_route_at_full_size(monkeypatch):
+    """Windows above SW_MAX_WINDOW are sketched with a smaller window and selected from that superset (index.hip:
+    select in order_tuples).  The test knob sends w = 200 down that route on a configs[1]-sized batch -- sketch with
+    w' = 16, 2.9e8 candidates, a five-level tree of minima -- and the arrays must be those of the direct route."""
+    ng, rpg, rl, k, w = 512, 50, 96000, 21, 200
+    tar = np.arange(ng) < ng // 2
+    b = Batch.synthetic(ng, rpg, rl, n_ancestors=5, snp_ppm=10000, seed=20260821)
+    ix = b.build_index(k, w, tar)
+    want, sizes = ix.checksums(), ix.sizes()
+    ix.close()
+    b.close()
+    monkeypatch.setenv("SEQWIN_AMD_WINDOW_SPLIT", "64,16")
+    b2 = Batch.synthetic(ng, rpg, rl, n_ancestors=5, snp_ppm=10000, seed=20260821)   # (plans are cached per batch)
+    ix2 = b2.build_index(k, w, tar)
+    assert ix2.sizes() == sizes and ix2.checksums() == want
+    oh, km = b2.sketch(k, w)
+    assert len(oh) == sizes[0] == len(km)
 
 
 def test_full_size_properties():

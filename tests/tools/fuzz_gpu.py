@@ -62,10 +62,15 @@ while time.time() < t_end and (not replay or it < len(replay)):
                 f.write(data)
         ps.append(p)
     k = rng.choice([3, 4, 5, 7, 11, 15, 16, 17, 19, 21, 31, 32, 33, 47, 64, 65, 100, 255, 256, 257])
-    w = rng.choice([1, 2, 3, 5, 10, 15, 16, 17, 25, 31, 32, 33, 34, 50, 63, 64, 65, 100, 200, 201, 500, 1000, 4096])
+    w = rng.choice([1, 2, 3, 5, 10, 15, 16, 17, 25, 31, 32, 33, 34, 50, 63, 64, 65, 100, 200, 201, 500, 1000, 4096, 4097, 5000, 20000])
     try:
+        t_a = time.time()
         got = _core._build_native(ps, k, w, rng.choice([1, 3]), LOWMEM)
+        t_b = time.time()
         exp = oracle.build(ps, k, w)
+        if os.environ.get("FUZZ_SLOW") and time.time() - t_a > float(os.environ["FUZZ_SLOW"]):
+            print(f"slow case seed={seed} k={k} w={w}: build {t_b - t_a:.2f} s, oracle {time.time() - t_b:.2f} s, "
+                  f"kmers {len(exp[0])}, files {[os.path.getsize(p) for p in ps]}", flush=True)
         ok = all(np.array_equal(x, y) for x, y in zip(got[:4], exp[:4])) and [tuple(t) for t in got[4]] == [tuple(t) for t in exp[4]]
         if ok and len(got[1]) and len(ps) >= 2:
             tar = [i % 2 == 0 for i in range(len(ps))]
