@@ -83,7 +83,9 @@ int sw_set_device(int device);
  * minimizer of a finished chunk stay resident, and the index is built once from the concatenated tuple stream -- results are
  * identical either way (reference tests/smoke/test_graph.py:222-245).  The same route is taken without the flag when the
  * files exceed SEQWIN_AMD_HBM_BUDGET_GB (if set).
- * Errors: k < 3, k > 65535, w < 1, w > SW_MAX_WINDOW -> SW_ERR_VALUE; unreadable file, FASTA
+ * Any windowsize >= 1 is taken (minimizer.cpp:53-90 has no upper limit either; a window longer than a record's k-mers
+ * gives no minimizer for it, :56-58).
+ * Errors: k < 3, k > 65535, w < 1 -> SW_ERR_VALUE; unreadable file, FASTA
  * without header, > 2^32-1 records or bases per record -> SW_ERR_RUNTIME (build.cpp:136-147,337-339;
  * fasta_reader.cpp:69-71,99-102).
  */
@@ -147,7 +149,8 @@ void sw_hostbatch_free(sw_hostbatch *hb);
 
 /* ---- device-resident pipeline (what sw_build is made of; used by bench.py and multi-GPU) --- */
 
-#define SW_MAX_WINDOW 4096u
+#define SW_MAX_WINDOW 4096u   /* largest window the tile kernels take directly */
+#define SW_WINDOW_SPLIT 2048u /* windows above this are sketched with w' = 1024 and selected from that superset (sketch.hip: get_plan) */
 
 /* Host ingest: read + pack FASTA files (fasta_reader.cpp:207-213 semantics) on n_cpu host threads and upload them
  * as one device-resident batch (assembly i of the batch = assembly_paths[i]). */

@@ -314,8 +314,12 @@ def test_low_complexity_and_ties(tmp_path):
         assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
 
 
-def test_tile_seams_and_many_gaps(tmp_path):
-    """Records spanning many tiles, with valid stretches of every length around k (idx space != pos space)."""
+@pytest.mark.parametrize("split", [None, "4096,1024", "16,5"], ids=["default", "direct-to-4096", "two-step-above-16"])
+def test_tile_seams_and_many_gaps(tmp_path, monkeypatch, split):
+    """Records spanning many tiles, with valid stretches of every length around k (idx space != pos space); windows up to
+    the tile limit taken directly, and the two-step route for longer ones (default from SW_WINDOW_SPLIT on)."""
+    if split:
+        monkeypatch.setenv("SEQWIN_AMD_WINDOW_SPLIT", split)
     rng = np.random.default_rng(11)
     s = "".join(rng.choice(list("ACGT"), 120000))
     cuts = sorted(rng.choice(len(s), 400, replace=False).tolist())
@@ -326,7 +330,7 @@ def test_tile_seams_and_many_gaps(tmp_path):
     gap = "".join(arr)
     p = tmp_path / "seams.fa"
     p.write_text(f">long\n{s}\n>gappy\n{gap}\n>dense_gaps\n" + "N".join(s[i:i + 23] for i in range(0, 60000, 23)) + "\n")
-    for k, w in [(21, 200), (21, 50), (23, 7), (24, 3), (17, 4096), (17, 4097), (21, 30000), (23, 100000), (15, 119986), (15, 119987)]:
+    for k, w in [(21, 200), (21, 50), (23, 7), (24, 3), (17, 2048), (19, 2049), (17, 4096), (17, 4097), (21, 30000), (23, 100000), (15, 119986), (15, 119987)]:
         got = _build([p], k, w)
         exp = oracle.build([p], k, w)
         assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
