@@ -1,13 +1,16 @@
-// radix.hip -- stable LSD radix sort of 64-bit keys (keys only), one pass per 8-bit digit, for gfx950.
+// radix.hip -- stable LSD radix sort of 64-bit keys (keys only), 8- or 9-bit digits, for gfx950.
 //
-// The index stage sorts 8-byte keys nine times per build (the edge pairs over 2 ceil(log2 n_nodes) bits, the unsort words over
+// The index stage sorts 8-byte keys eight times per build (the edge pairs over 2 ceil(log2 n_nodes) bits, the unsort words over
 // the index bits above 2^14: DESIGN.md 3.2) -- the reference's lsd_radix_sort_key (cpp/src/seqwin/build_internals.cpp:76-144)
-// on the device.  rocPRIM's onesweep moves such keys at ~3.1 TB/s (3.9 ms per pass of 745 M keys); a pass here follows the same
-// scheme -- all digit histograms in one sweep, then per pass one kernel that ranks a tile's keys, learns the tile's global
-// digit offsets by decoupled look-back and writes the keys out through LDS in digit order -- with 4096-key tiles and a
-// ballot-based rank (no LDS atomics in the ranking, so the order inside a digit is the input order: stable).
+// on the device.  A pass follows the onesweep scheme -- the first digit's histogram in one sweep (every pass counts the next
+// digit of the keys it holds anyway), then per pass one kernel that ranks a tile's keys, learns the tile's global digit
+// offsets by decoupled look-back and writes the keys out through LDS in digit order -- with a ballot-based rank (no LDS
+// atomics in the ranking, so the order inside a digit is the input order: stable).  745 M 54-bit keys: 26.3 ms against 31.2
+// for rocPRIM's onesweep (scripts/dbg/sort_time.py); with loads, stores and look-back switched off a pass still takes 70 % of
+// its time (ranking, LDS traffic, five barriers per tile with one 150 KiB workgroup per CU): the passes are bound on chip.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "device.hpp"
 
@@ -15,7 +18,6 @@ namespace sw {
 namespace {
 
 constexpr int RS_ITEMS = 16;
-constexpr int RS_MAX_PASSES = 8;
 
 // digit histogram of one pass (the first: every pass counts the next digit of the keys it holds anyway)
 template <int BITS>
@@ -62,14 +64,36 @@ template <int BITS> __global__ void k_rs_scan(unsigned long long *__restrict__ h
 
 constexpr unsigned long long RS_AGG = 1ull << 62, RS_INC = 2ull << 62, RS_VAL = (1ull << 62) - 1ull;
 
+// Lanes of the wave whose digit equals this lane's (among the live ones), as two 32-bit halves: per digit bit one ballot and,
+// per half, one three-input bit operation  m & ~(ballot ^ -bit)  (the compiler's own form of  m &= bit ? bal : ~bal  was nine
+// VALU instructions per bit on 64-bit lane masks -- 107 per key at 9 bits, a third of a pass).
+template <int BITS>
+__device__ __forceinline__ void match_digit(uint32_t d, bool live, uint32_t &mlo, uint32_t &mhi)
+{
+    const uint64_t lv = __ballot(live);
+    mlo = (uint32_t)lv;
+    mhi = (uint32_t)(lv >> 32);
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+        const uint32_t sx = (uint32_t)(-(int32_t)((d >> b) & 1u));   // all ones / zero
+        const uint64_t bal = __ballot(sx != 0);
+        const uint32_t blo = (uint32_t)bal, bhi = (uint32_t)(bal >> 32);
+        uint32_t nlo, nhi;
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x90" : "=v"(nlo) : "v"(mlo), "s"(blo), "v"(sx));   // src0 & ~(src1 ^ src2)
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x90" : "=v"(nhi) : "v"(mhi), "s"(bhi), "v"(sx));
+        mlo = nlo;
+        mhi = nhi;
+    }
+}
+
 // One pass: tile t = workgroup t takes THREADS x 16 consecutive keys, wave w of it the w-th 1024 of them, lane l item i the
 // key w * 1024 + i * 64 + l.  Two shapes: 512 threads with 8-bit digits (8192-key tiles, 72 KiB of LDS, two workgroups per CU)
 // and 1024 threads with 9-bit digits (16384-key tiles, 150 KiB: the same 32 keys per digit and tile, one pass fewer for the
-// 54 bits of the edge pairs).  The look-back waits for lower-numbered workgroups: like rocPRIM's onesweep it relies on the
-// dispatcher starting workgroups in index order (a single-address ticket would cap a pass at ~88 tiles per microsecond);
-// should a wait ever outlast RS_SPIN_LIMIT polls, the workgroup gives up and raises *fail -- the caller then reports an
-// error -- instead of hanging the device.
-constexpr uint32_t RS_SPIN_LIMIT = 1u << 24;
+// 54 bits of the edge pairs).  This one-tile-per-workgroup form (SEQWIN_AMD_RADIX_KERNEL=classic; the default is the
+// persistent form below) waits for lower-numbered workgroups: like rocPRIM's onesweep it relies on the dispatcher starting
+// workgroups in index order.  Should a wait ever outlast RS_SPIN_LIMIT polls, the workgroup gives up and raises *fail --
+// the caller then reports an error -- instead of hanging the device.
+constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
 template <int THREADS, int BITS>
 __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n,
                                                      unsigned shift, unsigned bits, const unsigned long long *__restrict__ digit_base,
@@ -95,7 +119,6 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict_
 
     uint64_t key[RS_ITEMS];
     uint32_t rank[RS_ITEMS];   // position of the item among the items of its digit in its wave
-    const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; ++i) {
         const uint32_t li = wave * (64 * RS_ITEMS) + i * 64 + lane;
@@ -112,17 +135,14 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict_
         const uint32_t li = wave * (64 * RS_ITEMS) + i * 64 + lane;
         const bool live = li < cnt_tile;
         const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
-        uint64_t m = __ballot(live);                       // lanes with the same digit (among the live ones)
-#pragma unroll
-        for (int b = 0; b < BITS; ++b) {
-            const uint64_t bal = __ballot((d >> b) & 1u);
-            m &= ((d >> b) & 1u) ? bal : ~bal;
-        }
+        uint32_t mlo, mhi;                                 // lanes with the same digit (among the live ones)
+        match_digit<BITS>(d, live, mlo, mhi);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));   // ... in lower lanes
         uint32_t prior = 0;
         if (live) prior = whist[wave][d];                  // every lane of a group reads before its leader adds
-        rank[i] = prior + (uint32_t)__popcll(m & lt);
+        rank[i] = prior + below;
         __builtin_amdgcn_wave_barrier();
-        if (live && (m & lt) == 0) whist[wave][d] = (uint16_t)(prior + (uint32_t)__popcll(m));   // the group's first lane
+        if (live && below == 0) whist[wave][d] = (uint16_t)(prior + (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi));   // the group's first lane
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
@@ -194,14 +214,202 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict_
     }
 }
 
+// The same pass as a PERSISTENT kernel: a workgroup takes tiles from a ticket counter until none are left, and the keys of
+// its next tile are already on their way (registers) while it ranks, scans and writes the current one -- with one workgroup
+// of 150 KiB per CU the one-tile-per-workgroup form leaves the memory pipe idle during ranking and look-back and the ALUs idle
+// during the loads (2.7 TB/s of moved bytes against 4.5 for rocPRIM's 20-byte pair passes).  Tickets also make the look-back
+// independent of the dispatch order: the lowest unfinished tile is always the CURRENT tile of a running workgroup (every
+// workgroup takes its tickets in increasing order and holds at most the current and the next one), so the waits terminate
+// whatever the residency.  The next tile's loads are issued once the current keys sit in LDS -- into the same registers -- and
+// are in flight during the look-back and the write-out; the look-back reads four predecessors per step (independent loads).
+template <int THREADS, int BITS>
+__global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n,
+                                                       uint32_t n_tiles, unsigned shift, unsigned bits,
+                                                       const unsigned long long *__restrict__ digit_base,
+                                                       unsigned long long *__restrict__ state, uint32_t *__restrict__ ticket,
+                                                       uint32_t *__restrict__ fail, unsigned long long *__restrict__ next_hist,
+                                                       unsigned next_shift, unsigned next_bits, uint32_t dbg)
+{
+    constexpr uint32_t RADIX = 1u << BITS, WAVES = THREADS / 64, TILE = THREADS * RS_ITEMS;
+    static_assert(RADIX <= (uint32_t)THREADS, "one thread per digit");
+    __shared__ uint64_t sk[TILE];
+    __shared__ uint16_t whist[WAVES][RADIX];
+    __shared__ uint32_t lstart[RADIX];
+    __shared__ unsigned long long goff[RADIX];
+    __shared__ uint32_t nh[RADIX];                   // histogram of the NEXT pass's digit over all tiles of this workgroup
+    __shared__ uint32_t wsum[RADIX / 64];
+    __shared__ uint32_t s_tile;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t dmask = (1u << bits) - 1u, nmask = (1u << next_bits) - 1u;
+    if (tid < RADIX) nh[tid] = 0;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    uint32_t tile = s_tile;
+    uint64_t key[RS_ITEMS];
+    uint32_t rank[RS_ITEMS];
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; ++i) {
+        const uint64_t g = (uint64_t)tile * TILE + wave * (64 * RS_ITEMS) + i * 64 + lane;
+        key[i] = (tile < n_tiles && g < n) ? in[g] : ~0ull;
+    }
+    const uint32_t tid0 = threadIdx.x;
+    while (tile < n_tiles) {
+        // (opaque per iteration: otherwise the 16 + 16 + 16 load / LDS / store addresses derived from the thread index are
+        // hoisted out of the loop and kept in ~100 registers across it)
+        uint32_t tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+        uint32_t fut = 0;
+        if (tid == 0) fut = atomicAdd(ticket, 1u);      // the next tile (the atomic's latency hides behind the ranking)
+        for (uint32_t i = tid; i < WAVES * RADIX / 2; i += THREADS) (reinterpret_cast<uint32_t *>(&whist[0][0]))[i] = 0;
+        __syncthreads();
+        const uint64_t t0 = (uint64_t)tile * TILE;
+        const uint32_t cnt_tile = (uint32_t)min((uint64_t)TILE, n - t0);
+        if (next_hist) {
+#pragma unroll
+            for (int i = 0; i < RS_ITEMS; ++i)
+                if (wave * (64 * RS_ITEMS) + i * 64 + lane < cnt_tile) atomicAdd(&nh[(uint32_t)(key[i] >> next_shift) & nmask], 1u);
+        }
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; ++i) {
+            const uint32_t li = wave * (64 * RS_ITEMS) + i * 64 + lane;
+            const bool live = li < cnt_tile;
+            const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
+            uint32_t mlo = 1u << (lane & 31u), mhi = 0;
+            if (!(dbg & 8u)) match_digit<BITS>(d, live, mlo, mhi);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+            uint32_t prior = 0;
+            if (live) prior = whist[wave][d];
+            rank[i] = prior + below;
+            __builtin_amdgcn_wave_barrier();
+            if (live && below == 0) whist[wave][d] = (uint16_t)(prior + (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi));
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        uint32_t total = 0, incl = 0;
+        unsigned long long pre[4] = {0, 0, 0, 0};
+        unsigned long long *st = state + (size_t)tile * RADIX;
+        if (tid < RADIX) {
+            const uint32_t d = tid;
+#pragma unroll
+            for (uint32_t w = 0; w < WAVES; ++w) {
+                const uint32_t c = whist[w][d];
+                whist[w][d] = (uint16_t)total;
+                total += c;
+            }
+            __hip_atomic_store(&st[d], (tile == 0 ? RS_INC : RS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)   // the first look-back step: requested now, examined after the keys are placed in LDS
+                pre[j] = (int64_t)tile - 1 - j >= 0
+                             ? __hip_atomic_load(&state[(size_t)(tile - 1 - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : RS_INC;
+            incl = total;
+            for (uint32_t dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t up = __shfl_up(incl, dd, 64);
+                if (lane >= dd) incl += up;
+            }
+            if (lane == 63) wsum[wave] = incl;
+        }
+        __syncthreads();
+        uint32_t before = 0;
+        if (tid < RADIX) {
+            before = incl - total;
+            for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
+            lstart[tid] = before;
+        }
+        if (tid == 0) s_tile = fut;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; ++i) {            // the tile in digit order, in LDS
+            const uint32_t li = wave * (64 * RS_ITEMS) + i * 64 + lane;
+            if (li < cnt_tile) {
+                const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
+                sk[lstart[d] + whist[wave][d] + rank[i]] = key[i];
+            }
+        }
+        const uint32_t ntile = s_tile;
+#pragma unroll
+        for (int i = 0; i < RS_ITEMS; ++i) {            // the next tile's keys are on their way during the look-back and the write-out
+            const uint64_t g = (uint64_t)ntile * TILE + wave * (64 * RS_ITEMS) + i * 64 + lane;
+            key[i] = (ntile < n_tiles && g < n && !(dbg & 4u)) ? in[g] : (dbg & 4u ? g * 0x9E3779B97F4A7C15ull : ~0ull);
+        }
+        if (tid < RADIX) {                              // look-back, four predecessors per step
+            const uint32_t d = tid;
+            unsigned long long excl = 0;
+            if (tile) {
+                int64_t t = (int64_t)tile - 1;
+                uint32_t spins = 0;
+                bool done = false;
+                bool first_step = true;
+                while (!done && t >= 0 && !(dbg & 1u)) {
+                    unsigned long long v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        v[j] = first_step ? pre[j]
+                               : t - j >= 0 ? __hip_atomic_load(&state[(size_t)(t - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                            : RS_INC;   // before the first tile: nothing
+                    first_step = false;
+                    int j = 0;
+                    for (; j < 4; ++j) {
+                        if ((v[j] >> 62) == 0) break;   // not published yet: poll again from here
+                        excl += v[j] & RS_VAL;
+                        if ((v[j] >> 62) == 2) {
+                            done = true;
+                            break;
+                        }
+                    }
+                    if (done) break;
+                    t -= j;
+                    if (j < 4) {
+                        if (++spins > RS_SPIN_LIMIT) {  // (never seen; the tile's owner is running, see above)
+                            atomicOr(fail, 1u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                __hip_atomic_store(&st[d], RS_INC | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            goff[d] = digit_base[d] + excl - before;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) {
+            const uint32_t t = j * THREADS + tid;
+            if (t < cnt_tile) {
+                const uint64_t k = sk[t];
+                if (!(dbg & 2u)) out[goff[(uint32_t)(k >> shift) & dmask] + t] = k;
+            }
+        }
+        // (no barrier here: the next iteration touches sk / goff / s_tile only behind its own barriers)
+        tile = ntile;
+    }
+    if (next_hist && tid < RADIX && nh[tid]) atomicAdd(&next_hist[tid], (unsigned long long)nh[tid]);
+}
+
 template <int THREADS, int BITS>
 void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream, uint32_t *d_fail)
 {
     constexpr uint32_t RADIX = 1u << BITS, TILE = THREADS * RS_ITEMS;
     const unsigned n_passes = (end_bit - begin_bit + BITS - 1) / BITS;
     const uint64_t n_tiles = (n + TILE - 1) / TILE;
+    const char *kind = getenv("SEQWIN_AMD_RADIX_KERNEL");   // A/B: "classic" = one tile per workgroup
+    const bool persistent = !(kind && !strcmp(kind, "classic"));
+    uint32_t dbg = 0;        // timing experiments only (scripts/dbg/sort_time.sh): 1 no look-back, 2 no stores, 4 no loads, 8 no ranking
+    if (const char *e = getenv("SEQWIN_AMD_RADIX_DEBUG")) dbg = (uint32_t)atoi(e);
+    static int grid_p = 0;   // (per template instance)   // resident workgroups of the persistent form on this device (any number would be correct)
+    if (persistent && !grid_p) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        SW_HIP(hipGetDevice(&dev));
+        SW_HIP(hipGetDeviceProperties(&prop, dev));
+        SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pass_p<THREADS, BITS>, THREADS, 0));
+        grid_p = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+    }
     DevArray<unsigned long long> hist((size_t)n_passes * RADIX), state((size_t)n_tiles * RADIX);
+    DevArray<uint32_t> tickets(n_passes);
     SW_HIP(hipMemsetAsync(hist.p, 0, hist.bytes(), stream));
+    SW_HIP(hipMemsetAsync(tickets.p, 0, tickets.bytes(), stream));
     hipLaunchKernelGGL(k_rs_hist<BITS>, dim3((unsigned)((n + 32767) / 32768)), dim3(256), 0, stream, keys, n, begin_bit,
                        std::min<unsigned>(BITS, end_bit - begin_bit), hist.p);
     SW_HIP(hipGetLastError());
@@ -211,9 +419,14 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
         const unsigned nsh = sh + BITS, nbits = more ? std::min<unsigned>(BITS, end_bit - nsh) : 0u;
         hipLaunchKernelGGL(k_rs_scan<BITS>, dim3(1), dim3(RADIX), 0, stream, hist.p + (size_t)p * RADIX);
         SW_HIP(hipMemsetAsync(state.p, 0, state.bytes(), stream));
-        hipLaunchKernelGGL((k_rs_pass<THREADS, BITS>), dim3((unsigned)n_tiles), dim3(THREADS), 0, stream, keys, alt, n, sh, bits,
-                           hist.p + (size_t)p * RADIX, state.p, d_fail,
-                           more ? hist.p + (size_t)(p + 1) * RADIX : (unsigned long long *)nullptr, nsh, nbits);
+        unsigned long long *next = more ? hist.p + (size_t)(p + 1) * RADIX : (unsigned long long *)nullptr;
+        if (persistent)
+            hipLaunchKernelGGL((k_rs_pass_p<THREADS, BITS>), dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)grid_p)), dim3(THREADS), 0,
+                               stream, keys, alt, n, (uint32_t)n_tiles, sh, bits, hist.p + (size_t)p * RADIX, state.p, tickets.p + p, d_fail,
+                               next, nsh, nbits, dbg);
+        else
+            hipLaunchKernelGGL((k_rs_pass<THREADS, BITS>), dim3((unsigned)n_tiles), dim3(THREADS), 0, stream, keys, alt, n, sh, bits,
+                               hist.p + (size_t)p * RADIX, state.p, d_fail, next, nsh, nbits);
         SW_HIP(hipGetLastError());
         std::swap(keys, alt);
     }
@@ -233,7 +446,10 @@ void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned beg
     const unsigned bits = end_bit - begin_bit;
     const char *e = getenv("SEQWIN_AMD_RADIX_BITS");   // A/B: 8 or 9
     const bool nine = e ? atoi(e) == 9 : (bits + 8) / 9 < (bits + 7) / 8;   // 9-bit digits where they save a pass (54 bits: 6 for 7)
-    if (nine) sort_passes<1024, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail);
+    const char *shape = getenv("SEQWIN_AMD_RADIX_SHAPE");   // A/B
+    if (shape && !strcmp(shape, "1024x8")) sort_passes<1024, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail);
+    else if (shape && !strcmp(shape, "512x9")) sort_passes<512, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail);
+    else if (nine) sort_passes<1024, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail);
     else sort_passes<512, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail);
 }
 
