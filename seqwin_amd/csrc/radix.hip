@@ -18,30 +18,39 @@ namespace sw {
 namespace {
 
 constexpr int RS_ITEMS = 16;
+#ifndef RS_LOOK
+#define RS_LOOK 4   // predecessors read per look-back step (independent loads; 8: more registers and state traffic, 29.0 against 25.1 ms)
+#endif
 
-// digit histogram of one pass (the first: every pass counts the next digit of the keys it holds anyway)
+// digit histograms of ALL passes in one sweep over the keys (in LDS; the 16 LDS atomics per thread and tile that counted the
+// next pass's digit inside a pass cost more there: the passes are bound by their LDS traffic, this sweep by HBM)
 template <int BITS>
-__global__ __launch_bounds__(256) void k_rs_hist(const uint64_t *__restrict__ keys, uint64_t n, unsigned shift, unsigned bits,
-                                                 unsigned long long *__restrict__ hist)
+__global__ __launch_bounds__(256) void k_rs_hist(const uint64_t *__restrict__ keys, uint64_t n, unsigned begin_bit, unsigned end_bit,
+                                                 unsigned n_passes, unsigned long long *__restrict__ hist)
 {
-    constexpr uint32_t RADIX = 1u << BITS;
-    __shared__ uint32_t h[RADIX];
-    for (uint32_t i = threadIdx.x; i < RADIX; i += 256) h[i] = 0;
+    constexpr uint32_t RADIX = 1u << BITS, MAXP = (64 + BITS - 1) / BITS;
+    __shared__ uint32_t h[MAXP * RADIX];
+    for (uint32_t i = threadIdx.x; i < n_passes * RADIX; i += 256) h[i] = 0;
     __syncthreads();
     const uint64_t chunk = 32768;   // a workgroup's share, small enough for 32-bit counters
     const uint64_t i0 = (uint64_t)blockIdx.x * chunk, i1 = min(n, i0 + chunk);
-    const uint32_t mask = (1u << bits) - 1u;
+    auto count = [&](uint64_t k) {
+        for (unsigned p = 0; p < n_passes; ++p) {
+            const unsigned sh = begin_bit + BITS * p, bits = min((unsigned)BITS, end_bit - sh);
+            atomicAdd(&h[p * RADIX + ((uint32_t)(k >> sh) & ((1u << bits) - 1u))], 1u);
+        }
+    };
     for (uint64_t i = i0 + 2 * threadIdx.x; i < i1; i += 512) {
         if (i + 1 < i1) {
             const ulonglong2 kk = *reinterpret_cast<const ulonglong2 *>(keys + i);
-            atomicAdd(&h[(uint32_t)(kk.x >> shift) & mask], 1u);
-            atomicAdd(&h[(uint32_t)(kk.y >> shift) & mask], 1u);
+            count(kk.x);
+            count(kk.y);
         } else {
-            atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
+            count(keys[i]);
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < RADIX; i += 256)
+    for (uint32_t i = threadIdx.x; i < n_passes * RADIX; i += 256)
         if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict_
 // independent of the dispatch order: the lowest unfinished tile is always the CURRENT tile of a running workgroup (every
 // workgroup takes its tickets in increasing order and holds at most the current and the next one), so the waits terminate
 // whatever the residency.  The next tile's loads are issued once the current keys sit in LDS -- into the same registers -- and
-// are in flight during the look-back and the write-out; the look-back reads four predecessors per step (independent loads).
+// are in flight during the look-back and the write-out; the look-back reads RS_LOOK predecessors per step (independent loads).
 template <int THREADS, int BITS>
 __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n,
                                                        uint32_t n_tiles, unsigned shift, unsigned bits,
@@ -287,7 +296,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
         }
         __syncthreads();
         uint32_t total = 0, incl = 0;
-        unsigned long long pre[4] = {0, 0, 0, 0};
+        unsigned long long pre[RS_LOOK];
         unsigned long long *st = state + (size_t)tile * RADIX;
         if (tid < RADIX) {
             const uint32_t d = tid;
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
             }
             __hip_atomic_store(&st[d], (tile == 0 ? RS_INC : RS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)   // the first look-back step: requested now, examined after the keys are placed in LDS
+            for (int j = 0; j < RS_LOOK; ++j)   // the first look-back step: requested now, examined after the keys are placed in LDS
                 pre[j] = (int64_t)tile - 1 - j >= 0
                              ? __hip_atomic_load(&state[(size_t)(tile - 1 - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                              : RS_INC;
@@ -342,15 +351,16 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                 bool done = false;
                 bool first_step = true;
                 while (!done && t >= 0 && !(dbg & 1u)) {
-                    unsigned long long v[4];
+                    unsigned long long v[RS_LOOK];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < RS_LOOK; ++j)
                         v[j] = first_step ? pre[j]
                                : t - j >= 0 ? __hip_atomic_load(&state[(size_t)(t - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                             : RS_INC;   // before the first tile: nothing
                     first_step = false;
                     int j = 0;
-                    for (; j < 4; ++j) {
+#pragma unroll
+                    for (; j < RS_LOOK; ++j) {
                         if ((v[j] >> 62) == 0) break;   // not published yet: poll again from here
                         excl += v[j] & RS_VAL;
                         if ((v[j] >> 62) == 2) {
@@ -360,7 +370,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                     }
                     if (done) break;
                     t -= j;
-                    if (j < 4) {
+                    if (j < RS_LOOK) {
                         if (++spins > RS_SPIN_LIMIT) {  // (never seen; the tile's owner is running, see above)
                             atomicOr(fail, 1u);
                             break;
@@ -410,8 +420,8 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
     DevArray<uint32_t> tickets(n_passes);
     SW_HIP(hipMemsetAsync(hist.p, 0, hist.bytes(), stream));
     SW_HIP(hipMemsetAsync(tickets.p, 0, tickets.bytes(), stream));
-    hipLaunchKernelGGL(k_rs_hist<BITS>, dim3((unsigned)((n + 32767) / 32768)), dim3(256), 0, stream, keys, n, begin_bit,
-                       std::min<unsigned>(BITS, end_bit - begin_bit), hist.p);
+    hipLaunchKernelGGL(k_rs_hist<BITS>, dim3((unsigned)((n + 32767) / 32768)), dim3(256), 0, stream, keys, n, begin_bit, end_bit,
+                       n_passes, hist.p);
     SW_HIP(hipGetLastError());
     for (unsigned p = 0; p < n_passes; ++p) {
         const unsigned sh = begin_bit + BITS * p, bits = std::min<unsigned>(BITS, end_bit - sh);
@@ -419,7 +429,8 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
         const unsigned nsh = sh + BITS, nbits = more ? std::min<unsigned>(BITS, end_bit - nsh) : 0u;
         hipLaunchKernelGGL(k_rs_scan<BITS>, dim3(1), dim3(RADIX), 0, stream, hist.p + (size_t)p * RADIX);
         SW_HIP(hipMemsetAsync(state.p, 0, state.bytes(), stream));
-        unsigned long long *next = more ? hist.p + (size_t)(p + 1) * RADIX : (unsigned long long *)nullptr;
+        unsigned long long *next = nullptr;   // (all histograms come from k_rs_hist; the in-pass count stays available: A/B)
+        (void)more;
         if (persistent)
             hipLaunchKernelGGL((k_rs_pass_p<THREADS, BITS>), dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)grid_p)), dim3(THREADS), 0,
                                stream, keys, alt, n, (uint32_t)n_tiles, sh, bits, hist.p + (size_t)p * RADIX, state.p, tickets.p + p, d_fail,
