@@ -135,12 +135,12 @@ struct HeadFlag {
 // One wave per tile: the tile's tuples move from its stage slot to their place in (record_idx, pos) order; the staged
 // canonical hash becomes out_hash = extend_hashes (hashing_internals.hpp:89-103).  INDEX form writes the node sort's
 // input (key32, OccPay) and the record of every occurrence; exchange form writes the tuples (hash, pos | record << 32).
-template <bool INDEX>
+template <bool INDEX, bool RAW = false>
 __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t *__restrict__ stage_kmer,
                         const uint32_t *__restrict__ tile_count, const uint64_t *__restrict__ tile_offset,
                         const uint64_t *__restrict__ dst_off, uint32_t n_tiles, uint64_t mult, uint64_t *__restrict__ hash,
                         uint64_t *__restrict__ kmer, uint32_t *__restrict__ key32, OccPay *__restrict__ pay,
-                        uint32_t *__restrict__ rec, bool raw = false)
+                        uint32_t *__restrict__ rec)
 {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
@@ -149,7 +149,7 @@ __global__ void k_order(const uint64_t *__restrict__ stage_hash, const uint64_t 
     const uint64_t src = tile_offset[wave], dst = dst_off[wave];
     for (uint32_t i = lane; i < c; i += 64) {
         uint64_t h = stage_hash[src + i];
-        if (!raw) {   // extend_hashes, hashing_internals.hpp:89-103 (raw: the canonical hash, what the windows compare)
+        if (!RAW) {   // extend_hashes, hashing_internals.hpp:89-103 (RAW: the canonical hash, what the windows compare)
             h *= mult;
             h ^= h >> 27;
         }
@@ -2006,9 +2006,9 @@ void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, Ord
         DevArray<uint64_t> canon(c), kmer(c), keep_off(c);
         DevArray<uint32_t> g(c), keep(c);
         DevArray<unsigned long long> total(1);
-        hipLaunchKernelGGL(k_order<false>, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
+        hipLaunchKernelGGL((k_order<false, true>), dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
                            sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult, canon.p, kmer.p,
-                           (uint32_t *)nullptr, (OccPay *)nullptr, (uint32_t *)nullptr, true);
+                           (uint32_t *)nullptr, (OccPay *)nullptr, (uint32_t *)nullptr);
         hipLaunchKernelGGL(k_lw_index, dim3(blocks_for(c)), dim3(TPB), 0, stream, kmer.p, c, plan.rec_seg_off.p, plan.seg_pos.p,
                            plan.seg_idx.p, g.p);
         SW_HIP(hipGetLastError());
@@ -2059,11 +2059,11 @@ void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, Ord
     if (index_form)
         hipLaunchKernelGGL(k_order<true>, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
                            sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult,
-                           table_ranks ? out.hash.p : (uint64_t *)nullptr, (uint64_t *)nullptr, out.key32.p, out.pay.p, out.rec.p, false);
+                           table_ranks ? out.hash.p : (uint64_t *)nullptr, (uint64_t *)nullptr, out.key32.p, out.pay.p, out.rec.p);
     else
         hipLaunchKernelGGL(k_order<false>, dim3(blocks_for(threads)), dim3(TPB), 0, stream, sk.stage_hash.p, sk.stage_kmer.p,
                            sk.tile_count.p, sk.tile_offset.p, dst_off.p, plan.n_tiles, plan.mult, out.hash.p, out.kmer.p,
-                           (uint32_t *)nullptr, (OccPay *)nullptr, (uint32_t *)nullptr, false);
+                           (uint32_t *)nullptr, (OccPay *)nullptr, (uint32_t *)nullptr);
     SW_HIP(hipGetLastError());
     // (dst_off goes back to the pool here; its next user is ordered after k_order on this stream)
 }
