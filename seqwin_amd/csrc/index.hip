@@ -200,11 +200,11 @@ __global__ void k_iota(uint32_t *v, uint64_t n)
 // a node are in record order, records are assembly-major, filter.cpp:62-136), so a node's counts are two popcounts.
 // A workgroup takes NODES_TILE consecutive occurrences, NODES_THREADS at a time (lane s of a wave = occurrence s of a
 // 64-aligned group: the bits of a group are one ballot).
-constexpr int NODES_ROWS = 2;                        // rows per tile; a row = NODES_THREADS lanes x 2 consecutive occurrences
-constexpr int NODES_THREADS = 512;                   // 8 waves
+constexpr int NODES_ROWS = 4;                        // rows per tile; a row = NODES_THREADS lanes x 2 consecutive occurrences
+constexpr int NODES_THREADS = 1024;                  // 16 waves: one workgroup per CU
 constexpr int NODES_WAVES = NODES_THREADS / 64;
 constexpr uint32_t NODES_ROW = NODES_THREADS * 2;
-constexpr uint32_t NODES_TILE = NODES_ROW * NODES_ROWS;   // 2048 occurrences: one ticket, one look-back
+constexpr uint32_t NODES_TILE = NODES_ROW * NODES_ROWS;   // 8192 occurrences: one ticket, one look-back
 constexpr uint32_t UNSORT_BITS = 14;                 // the unsort's last step handles 2^14 consecutive indices in LDS
 constexpr uint32_t UNSORT_RANGE = 1u << UNSORT_BITS;
 constexpr uint64_t UNSORT_DIRECT_MAX = 1ull << 25;   // up to here (128 MiB of ranks) the array stays in the 256 MiB Infinity Cache and a
@@ -216,7 +216,10 @@ constexpr uint64_t UNSORT_DIRECT_MAX = 1ull << 25;   // up to here (128 MiB of r
 // numbers of its predecessors until it meets one that already knows its inclusive total).  Tiles take their number from a
 // ticket counter, so every predecessor of a running tile is itself running or finished: the look-back cannot wait for a
 // workgroup that has not started.  state = status << 62 | value; status 0 = nothing yet, 1 = own heads, 2 = all heads up to
-// and including the tile.
+// and including the tile.  A walk passes every tile that is in flight (none of them knows its total yet), 64 per step and
+// a round trip to the memory side per step: with 2048-occurrence tiles and four workgroups per CU that was 1024 tiles = 16
+// steps per tile and the kernel's bound (13.4 ms at 745 M occurrences); 8192-occurrence tiles of 1024 threads, one workgroup
+// per CU, walk 4 steps (nodes stage 58.3 -> 54.0 ms; 1024 x 2 rows 56.4, 1024 x 6 rows 53.7, 1024 x 8 rows spills).
 constexpr unsigned long long TS_AGG = 1ull << 62, TS_INC = 2ull << 62;
 
 // bits of a (lanes 0..31's even positions) and b (odd positions) interleaved: result bit 2 l + e = e ? b[l] : a[l]
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
 {
     __shared__ uint32_t s_tile, s_excl;
     __shared__ uint32_t s_row[NODES_ROWS * NODES_WAVES];   // heads of (row, wave): counts, then exclusive offsets
-    static_assert(NODES_ROWS * NODES_WAVES <= 32, "the (row, wave) group counts are scanned by half a wave");
+    static_assert(NODES_ROWS * NODES_WAVES <= 128, "the (row, wave) group counts are scanned by one wave, two per lane");
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
@@ -291,14 +294,17 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
     }
     __syncthreads();
     if (wave == 0) {
-        // exclusive offsets of the (row, wave) groups, the tile's total, then the look-back
-        uint32_t c = (lane < NODES_ROWS * NODES_WAVES) ? s_row[lane] : 0u, incl = c;
-        for (uint32_t d = 1; d < 32; d <<= 1) {
+        // exclusive offsets of the (row, wave) groups (two per lane), the tile's total, then the look-back
+        constexpr uint32_t GROUPS = NODES_ROWS * NODES_WAVES;
+        const uint32_t c0 = (2 * lane < GROUPS) ? s_row[2 * lane] : 0u, c1 = (2 * lane + 1 < GROUPS) ? s_row[2 * lane + 1] : 0u;
+        uint32_t incl = c0 + c1;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
             const uint32_t up = __shfl_up(incl, d, 64);
             if (lane >= d) incl += up;
         }
-        const uint32_t total = __shfl(incl, 31, 64);
-        if (lane < NODES_ROWS * NODES_WAVES) s_row[lane] = incl - c;
+        const uint32_t total = __shfl(incl, 63, 64);
+        if (2 * lane < GROUPS) s_row[2 * lane] = incl - c0 - c1;
+        if (2 * lane + 1 < GROUPS) s_row[2 * lane + 1] = incl - c1;
         if (lane == 0)
             __hip_atomic_store(&tile_state[tile], (tile == 0 ? TS_INC : TS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t excl = 0;
@@ -389,17 +395,12 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
             const bool head = e ? h1 : h0;
             if (head) {   // (heads are live)
                 const uint32_t nid = e ? nid1 : nid0;
-                // (stop is written by the next head / the last occurrence: two stores to one node never race on a field)
-                nodes[nid].hash = ((uint64_t)k[r][e] << 32) | p[r][e].low;
-                nodes[nid].start = base + s + e;
-                nodes[nid].n_tar = 0;
-                nodes[nid].n_neg = 0;
-                nodes[nid].penalty = 0.0;
-                if (s + e) nodes[nid - 1].stop = base + s + e;
+                // hash and start in ONE 16-byte store; stop (= the next node's start) and the zeroed counts are filled in by
+                // k_pen_bits / k_node_stops, which stream over the nodes anyway (six scattered stores per head cost ~2 ms here)
+                static_assert(offsetof(sw_node, hash) == 0 && offsetof(sw_node, start) == 8, "hash, start lead the node");
+                *reinterpret_cast<ulonglong2 *>(&nodes[nid]) = make_ulonglong2(((uint64_t)k[r][e] << 32) | p[r][e].low, base + s + e);
             }
         }
-        if (live0 && s == n - 1) nodes[nid0].stop = base + n;
-        if (live1 && s + 1 == n - 1) nodes[nid1].stop = base + n;
         if (BITS) {
             const bool first0 = live0 && (h0 || (f0 >> 1) != (pf >> 1)), first1 = live1 && (h1 || (f1 >> 1) != (f0 >> 1));
             const unsigned long long t0 = __ballot(first0 && (f0 & 1u)), t1 = __ballot(first1 && (f1 & 1u));
@@ -431,13 +432,17 @@ __device__ __forceinline__ uint32_t popc_range(const unsigned long long *__restr
 }
 
 // per-node distinct target / non-target assemblies from the two bitmaps + penalty (filter.cpp:89-90, 125-134)
-__global__ void k_pen_bits(sw_node *__restrict__ nodes, uint64_t n_nodes, uint64_t base, const unsigned long long *__restrict__ tbits,
-                           const unsigned long long *__restrict__ nbits, double inv_tar, double inv_neg)
+// (also completes the node: stop = the next node's start, `end` for the last one -- k_nodes writes hash and start only)
+__global__ void k_pen_bits(sw_node *__restrict__ nodes, uint64_t n_nodes, uint64_t base, uint64_t end,
+                           const unsigned long long *__restrict__ tbits, const unsigned long long *__restrict__ nbits, double inv_tar,
+                           double inv_neg)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
-    const uint64_t a = nodes[i].start - base, b = nodes[i].stop - base;
+    const uint64_t stop = i + 1 < n_nodes ? nodes[i + 1].start : end;
+    const uint64_t a = nodes[i].start - base, b = stop - base;
     const uint32_t n_tar = popc_range(tbits, a, b), n_neg = popc_range(nbits, a, b);
+    nodes[i].stop = stop;
     nodes[i].n_tar = n_tar;
     nodes[i].n_neg = n_neg;
     {
@@ -451,6 +456,17 @@ __global__ void k_pen_bits(sw_node *__restrict__ nodes, uint64_t n_nodes, uint64
         const double sum = aa + bb;
         nodes[i].penalty = __dsqrt_rn(sum);
     }
+}
+
+// the same without counts: stop, and the count fields zeroed (python_bindings.cpp:50-90 hands out n_tar = n_neg = penalty = 0)
+__global__ void k_node_stops(sw_node *__restrict__ nodes, uint64_t n_nodes, uint64_t end)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    nodes[i].stop = i + 1 < n_nodes ? nodes[i + 1].start : end;
+    nodes[i].n_tar = 0;
+    nodes[i].n_neg = 0;
+    nodes[i].penalty = 0.0;
 }
 
 __global__ void k_rec_flag(const uint32_t *__restrict__ rec_asm, const uint8_t *__restrict__ is_target, uint64_t n_records,
@@ -1719,6 +1735,10 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     check_sort_failed(back[1]);
     if (n_nodes > node_cap) raise(SW_ERR_RUNTIME, "internal error: %u nodes exceed the bound %llu", n_nodes, (unsigned long long)node_cap);
     ix.n_nodes = n_nodes;
+    if (!bits && n_nodes) {   // (with the bitmaps the caller runs k_pen_bits, which completes the nodes as well)
+        hipLaunchKernelGGL(k_node_stops, dim3(blocks_for(n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, (uint64_t)n_nodes, base + n);
+        SW_HIP(hipGetLastError());
+    }
     // (the sort buffers go back to the pool here; later users are ordered after these kernels on this stream, or fenced)
     return n_nodes;
 }
@@ -2360,7 +2380,7 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
             penalty_launch(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, d_rec_asm, n_records, d_is_target, n_targets, n_non_targets,
                            side, pen);
         } else {
-            hipLaunchKernelGGL(k_pen_bits, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, side, ix.nodes.p, ix.n_nodes, (uint64_t)0,
+            hipLaunchKernelGGL(k_pen_bits, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, side, ix.nodes.p, ix.n_nodes, (uint64_t)0, n,
                                tbits.p, nbits.p, 1.0 / (double)n_targets, 1.0 / (double)n_non_targets);   // filter.cpp:89-90
             SW_HIP(hipGetLastError());
         }
@@ -2484,8 +2504,8 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
                           bits ? &nbits : nullptr, rec_flag.p ? &marked : nullptr);
         ix.ranks_marked = marked;
         if (bits && ix.n_nodes) {
-            hipLaunchKernelGGL(k_pen_bits, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, kmer_base, tbits.p,
-                               nbits.p, 1.0 / (double)n_targets, 1.0 / (double)n_non_targets);   // filter.cpp:89-90
+            hipLaunchKernelGGL(k_pen_bits, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, kmer_base,
+                               kmer_base + n, tbits.p, nbits.p, 1.0 / (double)n_targets, 1.0 / (double)n_non_targets);   // filter.cpp:89-90
             SW_HIP(hipGetLastError());
         }
         SW_HIP(hipStreamSynchronize(stream));   // (the bitmaps are released here)
