@@ -1447,29 +1447,109 @@ __global__ __launch_bounds__(256) void k_repair_wave(const View V, uint32_t kmas
     }
 }
 
+// A long run is almost always the occurrences of two or three hashes interleaved in input order.  Its stable sort is found
+// value by value: the smallest (key, low) not yet placed (a workgroup minimum), then its elements in input order (a
+// workgroup scan over contiguous chunks of the run) -- a handful of reductions instead of len^2 comparisons (1.9 -> 0.x ms at
+// 15k genomes, where a node has up to 500 occurrences); a run with more than REPAIR_MAX_VALUES distinct values falls back to
+// ranking every element against every other.
+constexpr uint32_t REPAIR_MAX_VALUES = 12;
 template <class View>
 __global__ __launch_bounds__(256) void k_repair_sort(const View V, const uint32_t *__restrict__ n_big, const uint32_t *__restrict__ big)
 {
     __shared__ typename View::Elem sv[REPAIR_MAX_RUN];
     __shared__ uint32_t sk[REPAIR_MAX_RUN];
+    __shared__ uint16_t srank[REPAIR_MAX_RUN];
+    __shared__ uint32_t w_k[4], w_cnt[4];
+    __shared__ uint64_t w_l[4];
     const uint32_t B = *n_big;
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t b = blockIdx.x; b < B; b += gridDim.x) {
         const uint32_t a = big[2 * b], len = big[2 * b + 1];
         __syncthreads();                      // the previous run has been written out
         for (uint32_t i = tid; i < len; i += blockDim.x) V.load(a + i, sk[i], sv[i]);
         __syncthreads();
-        for (uint32_t i = tid; i < len; i += blockDim.x) {
-            const uint32_t ki = sk[i];
-            const typename View::Elem vi = sv[i];
-            const uint64_t li = View::low_of(vi);
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < len; ++j) {
-                const uint32_t kj = sk[j];
-                const uint64_t lj = View::low_of(sv[j]);
-                rank += (kj < ki || (kj == ki && (lj < li || (lj == li && j < i)))) ? 1u : 0u;
+        const uint32_t per = (len + 255u) / 256u, i0 = min(len, tid * per), i1 = min(len, i0 + per);   // this thread's chunk
+        uint32_t placed = 0, last_k = 0;
+        uint64_t last_l = 0;
+        bool have_last = false;
+        for (uint32_t it = 0; it < REPAIR_MAX_VALUES && placed < len; ++it) {
+            // the smallest (key, low) above the last one placed
+            uint32_t mk = ~0u;
+            uint64_t ml = ~0ull;
+            bool any = false;
+            for (uint32_t i = i0; i < i1; ++i) {
+                const uint32_t k = sk[i];
+                const uint64_t l = View::low_of(sv[i]);
+                if (have_last && !(k > last_k || (k == last_k && l > last_l))) continue;
+                if (!any || k < mk || (k == mk && l < ml)) {
+                    mk = k;
+                    ml = l;
+                    any = true;
+                }
             }
-            V.store(a + rank, ki, vi);
+            for (int d = 32; d; d >>= 1) {
+                const uint32_t ok = __shfl_xor(mk, d, 64);
+                const uint64_t ol = __shfl_xor(ml, d, 64);
+                const bool oany = __shfl_xor((int)any, d, 64) != 0;
+                if (oany && (!any || ok < mk || (ok == mk && ol < ml))) {
+                    mk = ok;
+                    ml = ol;
+                    any = true;
+                }
+            }
+            __syncthreads();                  // (w_* of the previous round have been read)
+            if (lane == 0) {
+                w_k[wave] = mk;
+                w_l[wave] = ml;
+                w_cnt[wave] = any ? 1u : 0u;
+            }
+            __syncthreads();
+            any = false;
+            for (uint32_t w = 0; w < 4; ++w)
+                if (w_cnt[w] && (!any || w_k[w] < mk || (w_k[w] == mk && w_l[w] < ml))) {
+                    mk = w_k[w];
+                    ml = w_l[w];
+                    any = true;
+                }
+            // (placed < len: some element is above the last value, so `any` holds for the workgroup)
+            uint32_t c = 0;
+            for (uint32_t i = i0; i < i1; ++i) c += (sk[i] == mk && View::low_of(sv[i]) == ml) ? 1u : 0u;
+            uint32_t incl = c;
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += up;
+            }
+            __syncthreads();                  // (w_* have been read)
+            if (lane == 63) w_cnt[wave] = incl;
+            __syncthreads();
+            uint32_t before = placed + incl - c, total = 0;
+            for (uint32_t w = 0; w < 4; ++w) {
+                if (w < wave) before += w_cnt[w];
+                total += w_cnt[w];
+            }
+            for (uint32_t i = i0; i < i1; ++i)
+                if (sk[i] == mk && View::low_of(sv[i]) == ml) srank[i] = (uint16_t)before++;
+            placed += total;
+            last_k = mk;
+            last_l = ml;
+            have_last = true;
+        }
+        __syncthreads();
+        if (placed == len) {                  // (workgroup-uniform)
+            for (uint32_t i = tid; i < len; i += blockDim.x) V.store(a + srank[i], sk[i], sv[i]);
+        } else {
+            for (uint32_t i = tid; i < len; i += blockDim.x) {
+                const uint32_t ki = sk[i];
+                const typename View::Elem vi = sv[i];
+                const uint64_t li = View::low_of(vi);
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < len; ++j) {
+                    const uint32_t kj = sk[j];
+                    const uint64_t lj = View::low_of(sv[j]);
+                    rank += (kj < ki || (kj == ki && (lj < li || (lj == li && j < i)))) ? 1u : 0u;
+                }
+                V.store(a + rank, ki, vi);
+            }
         }
     }
 }
