@@ -1302,20 +1302,54 @@ __device__ __forceinline__ uint32_t descents_of_thread(const PayView &V, uint32_
 
 // cnt[block] = run heads << 32 | descents.  The heads of the order BEFORE the repair bound the number of distinct hashes
 // from above (a repair only merges runs of equal hashes that a descent had split), closely: the nodes array is sized by it.
+// (A block with 1..DESC_SLOT descents -- the rule: 7e5 descents over 7e5 blocks -- also leaves them, in position order, in
+// its slot, so that the listing pass need not read the block's 20 KB again.)
+constexpr uint32_t DESC_SLOT = 4;
 template <class View>
-__global__ __launch_bounds__(256) void k_count_descents(const View V, uint32_t kmask, uint64_t n, unsigned long long *__restrict__ cnt)
+__global__ __launch_bounds__(256) void k_count_descents(const View V, uint32_t kmask, uint64_t n, unsigned long long *__restrict__ cnt,
+                                                        uint32_t *__restrict__ slot_q, uint32_t *__restrict__ slot_k)
 {
     const uint64_t q0 = (uint64_t)blockIdx.x * DESC_BLOCK + threadIdx.x * 4u;
     uint32_t heads = 0;
-    const uint32_t c = (uint32_t)__popc(descents_of_thread(V, kmask, n, q0, &heads));
+    const uint32_t m = descents_of_thread(V, kmask, n, q0, &heads);
+    const uint32_t c = (uint32_t)__popc(m);
     __shared__ unsigned long long s;
-    if (threadIdx.x == 0) s = 0;
+    __shared__ uint32_t s_n, s_q[DESC_SLOT], s_kk[DESC_SLOT];
+    if (threadIdx.x == 0) {
+        s = 0;
+        s_n = 0;
+    }
     __syncthreads();
     unsigned long long w = ((unsigned long long)heads << 32) | c;
     for (int d = 32; d; d >>= 1) w += __shfl_down(w, d, 64);
     if ((threadIdx.x & 63u) == 0 && w) atomicAdd(&s, w);
     __syncthreads();
+    const uint32_t dc = (uint32_t)s;          // (workgroup-uniform)
     if (threadIdx.x == 0) cnt[blockIdx.x] = s;
+    if (dc == 0 || dc > DESC_SLOT) return;
+    uint32_t mm = m;
+    while (mm) {
+        const uint32_t i = (uint32_t)__builtin_ctz(mm);
+        mm &= mm - 1;
+        const uint32_t at = atomicAdd(&s_n, 1u);
+        s_q[at] = (uint32_t)(q0 + i);
+        s_kk[at] = V.key(q0 + i) & kmask;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t i = 1; i < dc; ++i)     // ascending positions (at most DESC_SLOT entries)
+            for (uint32_t j = i; j > 0 && s_q[j] < s_q[j - 1]; --j) {
+                const uint32_t tq = s_q[j], tk = s_kk[j];
+                s_q[j] = s_q[j - 1];
+                s_kk[j] = s_kk[j - 1];
+                s_q[j - 1] = tq;
+                s_kk[j - 1] = tk;
+            }
+        for (uint32_t i = 0; i < dc; ++i) {
+            slot_q[(size_t)blockIdx.x * DESC_SLOT + i] = s_q[i];
+            slot_k[(size_t)blockIdx.x * DESC_SLOT + i] = s_kk[i];
+        }
+    }
 }
 
 template <class View>
@@ -1323,7 +1357,8 @@ __global__ __launch_bounds__(256) void k_list_descents(const View V, uint32_t km
                                                        const unsigned long long *__restrict__ cnt,
                                                        const unsigned long long *__restrict__ off, uint32_t n_blocks,
                                                        uint32_t *__restrict__ bad, uint32_t cap, uint32_t *__restrict__ bad_q,
-                                                       uint32_t cap_q, unsigned long long *__restrict__ n_desc)
+                                                       uint32_t cap_q, unsigned long long *__restrict__ n_desc,
+                                                       const uint32_t *__restrict__ slot_q, const uint32_t *__restrict__ slot_k)
 {
     const uint32_t b = blockIdx.x;
     const uint32_t c_blk = (uint32_t)cnt[b];
@@ -1333,6 +1368,14 @@ __global__ __launch_bounds__(256) void k_list_descents(const View V, uint32_t km
         n_desc[1] = tot >> 32;             // run heads before the repair
     }
     if (c_blk == 0) return;
+    if (c_blk <= DESC_SLOT) {              // the counting pass left them in the block's slot
+        if (threadIdx.x < c_blk) {
+            const uint32_t at = (uint32_t)off[b] + threadIdx.x;
+            if (bad && at < cap) bad[at] = slot_k[(size_t)b * DESC_SLOT + threadIdx.x];
+            if (at < cap_q) bad_q[at] = slot_q[(size_t)b * DESC_SLOT + threadIdx.x];
+        }
+        return;
+    }
     const uint64_t q0 = (uint64_t)b * DESC_BLOCK + threadIdx.x * 4u;
     const uint32_t m = descents_of_thread(V, kmask, n, q0);
     const uint32_t c = (uint32_t)__popc(m);
@@ -1558,6 +1601,7 @@ __global__ __launch_bounds__(256) void k_repair_sort(const View V, const uint32_
 struct RepairState {
     DevArray<unsigned long long> n_desc;   // [0] descents, [1] run heads before the repair
     DevArray<unsigned long long> blk_cnt, blk_off;
+    DevArray<uint32_t> slot_q, slot_k;   // per block of the descent passes: its first DESC_SLOT descents (position, masked key)
     DevArray<uint32_t> bad_q, big, status;   // status: [0] leftovers for the general repair, [1] the number of listed long runs
 };
 
@@ -1574,12 +1618,14 @@ void enqueue_repair(const View &V, uint32_t kmask, uint64_t n, uint32_t *bad, ui
     r.status.alloc(2);
     r.blk_cnt.alloc(n_blocks);
     r.blk_off.alloc(n_blocks);
+    r.slot_q.alloc((size_t)n_blocks * DESC_SLOT);
+    r.slot_k.alloc((size_t)n_blocks * DESC_SLOT);
     SW_HIP(hipMemsetAsync(r.status.p, 0, 8, stream));
-    hipLaunchKernelGGL(k_count_descents<View>, dim3(n_blocks), dim3(256), 0, stream, V, kmask, n, r.blk_cnt.p);
+    hipLaunchKernelGGL(k_count_descents<View>, dim3(n_blocks), dim3(256), 0, stream, V, kmask, n, r.blk_cnt.p, r.slot_q.p, r.slot_k.p);
     SW_HIP(hipGetLastError());
     exclusive_sum(r.blk_cnt.p, r.blk_off.p, n_blocks, 0ull, stream);   // both halves at once: neither sum reaches 2^32
     hipLaunchKernelGGL(k_list_descents<View>, dim3(n_blocks), dim3(256), 0, stream, V, kmask, n, r.blk_cnt.p, r.blk_off.p,
-                       n_blocks, bad, cap, r.bad_q.p, max_desc, r.n_desc.p);
+                       n_blocks, bad, cap, r.bad_q.p, max_desc, r.n_desc.p, r.slot_q.p, r.slot_k.p);
     hipLaunchKernelGGL(k_repair_wave<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, kmask, n, r.bad_q.p, r.n_desc.p,
                        r.big.p, r.status.p + 1, r.status.p);
     hipLaunchKernelGGL(k_repair_sort<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, r.status.p + 1, r.big.p);
