@@ -175,12 +175,14 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
 
 // radix.hip: stable LSD radix sort of 64-bit keys by bits [begin_bit, end_bit); (keys, alt) is a double buffer, on return
 // `keys` points at the sorted data; *d_fail (device word, zeroed by the caller) becomes non-zero if a pass gave up
+// perm_hi32: the keys' upper halves are a permutation of 0 .. n-1 (the unsort's words): the digit histograms of a sort on
+// bits >= 32 then follow from n alone and the sweep that counts them is skipped
 void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                       uint32_t *d_fail);
+                       uint32_t *d_fail, bool perm_hi32 = false);
 
 // index.hip: radix.hip or rocPRIM; d_fail: zeroed device word, to be read back and handed to check_sort_failed
 void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                 uint32_t *d_fail);
+                 uint32_t *d_fail, bool perm_hi32 = false);
 void check_sort_failed(uint32_t fail_word);
 
 // index.hip

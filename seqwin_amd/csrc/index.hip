@@ -59,14 +59,14 @@ void sort_pairs(K *&keys, K *&keys_alt, V *&vals, V *&vals_alt, size_t n, unsign
 // workgroup (it relies on in-order dispatch, like rocPRIM's onesweep; never seen) and the result is not sorted:
 // check_sort_failed() then raises instead of the device hanging.
 void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                 uint32_t *d_fail)
+                 uint32_t *d_fail, bool perm_hi32)
 {
     // measured per build: 745 M keys 211.1 against 214.5 ms with rocPRIM; 24 M keys 7.90 against 7.68 ms (the
     // per-pass state resets and launches weigh more on few tiles) -> the own passes from 2^26 keys on
     const char *e = getenv("SEQWIN_AMD_SORT");
     const bool own = e ? !strcmp(e, "own") : n >= (1ull << 26);
     if (own && !(e && !strcmp(e, "rocprim"))) {
-        radix_sort_keys64(keys, keys_alt, n, begin_bit, end_bit, stream, d_fail);
+        radix_sort_keys64(keys, keys_alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32);
         return;
     }
     rocprim::double_buffer<uint64_t> dk(keys, keys_alt);
@@ -1849,7 +1849,7 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
         if (nbit > UNSORT_BITS) {   // buckets of 2^14 consecutive indices: sort on the index's bits above those
             // (begin_bit > 0 of rocPRIM's radix sort is checked on this stack by scripts/micro/sort_beginbit.hip)
             uint64_t *v_alt = uv1.p;
-            sort_keys64(v, v_alt, n, 32 + UNSORT_BITS, 32 + nbit, stream, words.p + 2);
+            sort_keys64(v, v_alt, n, 32 + UNSORT_BITS, 32 + nbit, stream, words.p + 2, true);   // (the indices are a permutation)
         }
         hipLaunchKernelGGL(k_unsort_bucket, dim3((unsigned)((n + UNSORT_RANGE - 1) / UNSORT_RANGE)), dim3(1024), 0, stream, v, n,
                            rank_out);

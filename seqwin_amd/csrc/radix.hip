@@ -54,6 +54,22 @@ __global__ __launch_bounds__(256) void k_rs_hist(const uint64_t *__restrict__ ke
         if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
+// The same histograms without reading a key, for keys whose upper halves are a permutation of 0 .. n-1 sorted on bits >= 32:
+// the values of a digit at index bits [sh, sh + b) repeat with period 2^(sh+b), 2^sh times each per period.
+template <int BITS>
+__global__ void k_rs_perm_hist(uint64_t n, unsigned begin_bit, unsigned end_bit, unsigned long long *__restrict__ hist)
+{
+    constexpr uint32_t RADIX = 1u << BITS;
+    const unsigned p = blockIdx.x, at = begin_bit + BITS * p, sh = at - 32u, bits = min((unsigned)BITS, end_bit - at);
+    const uint64_t v = threadIdx.x, block = 1ull << sh, period = block << bits;
+    unsigned long long c = 0;
+    if (v < (1ull << bits)) {
+        const uint64_t q = n / period, r = n % period, lo = v * block;
+        c = q * block + (r > lo ? (r - lo < block ? r - lo : block) : 0ull);
+    }
+    hist[(size_t)p * RADIX + threadIdx.x] = c;
+}
+
 // exclusive scan of a pass's digit counts (one workgroup of RADIX threads)
 template <int BITS> __global__ void k_rs_scan(unsigned long long *__restrict__ h)
 {
@@ -398,7 +414,8 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
 }
 
 template <int THREADS, int BITS>
-void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream, uint32_t *d_fail)
+void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream, uint32_t *d_fail,
+                 bool perm_hi32)
 {
     constexpr uint32_t RADIX = 1u << BITS, TILE = THREADS * RS_ITEMS;
     const unsigned n_passes = (end_bit - begin_bit + BITS - 1) / BITS;
@@ -418,10 +435,14 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
     }
     DevArray<unsigned long long> hist((size_t)n_passes * RADIX), state((size_t)n_tiles * RADIX);
     DevArray<uint32_t> tickets(n_passes);
-    SW_HIP(hipMemsetAsync(hist.p, 0, hist.bytes(), stream));
     SW_HIP(hipMemsetAsync(tickets.p, 0, tickets.bytes(), stream));
-    hipLaunchKernelGGL(k_rs_hist<BITS>, dim3((unsigned)((n + 32767) / 32768)), dim3(256), 0, stream, keys, n, begin_bit, end_bit,
-                       n_passes, hist.p);
+    if (perm_hi32 && begin_bit >= 32) {
+        hipLaunchKernelGGL(k_rs_perm_hist<BITS>, dim3(n_passes), dim3(RADIX), 0, stream, n, begin_bit, end_bit, hist.p);
+    } else {
+        SW_HIP(hipMemsetAsync(hist.p, 0, hist.bytes(), stream));
+        hipLaunchKernelGGL(k_rs_hist<BITS>, dim3((unsigned)((n + 32767) / 32768)), dim3(256), 0, stream, keys, n, begin_bit, end_bit,
+                           n_passes, hist.p);
+    }
     SW_HIP(hipGetLastError());
     for (unsigned p = 0; p < n_passes; ++p) {
         const unsigned sh = begin_bit + BITS * p, bits = std::min<unsigned>(BITS, end_bit - sh);
@@ -450,7 +471,7 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
 // sorted data and `alt` at the other buffer.  *d_fail (device word, zeroed by the caller) becomes non-zero if a pass gave
 // up waiting (the caller checks it at its next host synchronisation: check_sort_failed in index.hip).
 void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                       uint32_t *d_fail)
+                       uint32_t *d_fail, bool perm_hi32)
 {
     if (n == 0 || end_bit <= begin_bit) return;
     if (end_bit - begin_bit > 64) raise(SW_ERR_RUNTIME, "radix_sort_keys64: more than 64 key bits");
@@ -458,10 +479,10 @@ void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned beg
     const char *e = getenv("SEQWIN_AMD_RADIX_BITS");   // A/B: 8 or 9
     const bool nine = e ? atoi(e) == 9 : (bits + 8) / 9 < (bits + 7) / 8;   // 9-bit digits where they save a pass (54 bits: 6 for 7)
     const char *shape = getenv("SEQWIN_AMD_RADIX_SHAPE");   // A/B
-    if (shape && !strcmp(shape, "1024x8")) sort_passes<1024, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail);
-    else if (shape && !strcmp(shape, "512x9")) sort_passes<512, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail);
-    else if (nine) sort_passes<1024, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail);
-    else sort_passes<512, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail);
+    if (shape && !strcmp(shape, "1024x8")) sort_passes<1024, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32);
+    else if (shape && !strcmp(shape, "512x9")) sort_passes<512, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32);
+    else if (nine) sort_passes<1024, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32);
+    else sort_passes<512, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32);
 }
 
 }  // namespace sw
