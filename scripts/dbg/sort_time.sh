@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT
+cd $GRAFT_REPO_ROOT   # (the RADIX_DEBUG lines need a library built with -DSW_RADIX_ABLATION)
 python3 scripts/dbg/sort_time.py
 SEQWIN_AMD_RADIX_KERNEL=classic python3 scripts/dbg/sort_time.py
 SEQWIN_AMD_RADIX_DEBUG=1 python3 scripts/dbg/sort_time.py

@@ -122,8 +122,7 @@ constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
 template <int THREADS, int BITS>
 __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n,
                                                      unsigned shift, unsigned bits, const unsigned long long *__restrict__ digit_base,
-                                                     unsigned long long *__restrict__ state, uint32_t *__restrict__ fail,
-                                                     unsigned long long *__restrict__ next_hist, unsigned next_shift, unsigned next_bits)
+                                                     unsigned long long *__restrict__ state, uint32_t *__restrict__ fail)
 {
     constexpr uint32_t RADIX = 1u << BITS, WAVES = THREADS / 64, TILE = THREADS * RS_ITEMS;
     static_assert(RADIX <= (uint32_t)THREADS, "one thread per digit");
@@ -131,11 +130,9 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict_
     __shared__ uint16_t whist[WAVES][RADIX];         // per wave: running digit counts (<= 1024), then the wave's base inside the tile's digit
     __shared__ uint32_t lstart[RADIX];               // first local position of a digit in the tile
     __shared__ unsigned long long goff[RADIX];       // global position of local position 0 of a digit: out[goff[d] + local]
-    __shared__ uint32_t nh[RADIX];                   // the tile's histogram of the NEXT pass's digit (the keys are here anyway)
     __shared__ uint32_t wsum[RADIX / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     for (uint32_t i = tid; i < WAVES * RADIX; i += THREADS) (&whist[0][0])[i] = 0;
-    if (tid < RADIX) nh[tid] = 0;
     __syncthreads();
     const uint32_t tile = blockIdx.x;
     const uint64_t t0 = (uint64_t)tile * TILE;
@@ -148,12 +145,6 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict_
     for (int i = 0; i < RS_ITEMS; ++i) {
         const uint32_t li = wave * (64 * RS_ITEMS) + i * 64 + lane;
         key[i] = li < cnt_tile ? in[t0 + li] : ~0ull;
-    }
-    if (next_hist) {
-        const uint32_t nmask = (1u << next_bits) - 1u;
-#pragma unroll
-        for (int i = 0; i < RS_ITEMS; ++i)
-            if (wave * (64 * RS_ITEMS) + i * 64 + lane < cnt_tile) atomicAdd(&nh[(uint32_t)(key[i] >> next_shift) & nmask], 1u);
     }
 #pragma unroll
     for (int i = 0; i < RS_ITEMS; ++i) {
@@ -217,7 +208,6 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict_
             __hip_atomic_store(&st[d], RS_INC | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         goff[d] = digit_base[d] + excl - before;
-        if (next_hist && nh[d]) atomicAdd(&next_hist[d], (unsigned long long)nh[d]);
     }
     __syncthreads();
 #pragma unroll
@@ -252,8 +242,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                                                        uint32_t n_tiles, unsigned shift, unsigned bits,
                                                        const unsigned long long *__restrict__ digit_base,
                                                        unsigned long long *__restrict__ state, uint32_t *__restrict__ ticket,
-                                                       uint32_t *__restrict__ fail, unsigned long long *__restrict__ next_hist,
-                                                       unsigned next_shift, unsigned next_bits, uint32_t dbg)
+                                                       uint32_t *__restrict__ fail, uint32_t dbg)
 {
     constexpr uint32_t RADIX = 1u << BITS, WAVES = THREADS / 64, TILE = THREADS * RS_ITEMS;
     static_assert(RADIX <= (uint32_t)THREADS, "one thread per digit");
@@ -261,12 +250,10 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
     __shared__ uint16_t whist[WAVES][RADIX];
     __shared__ uint32_t lstart[RADIX];
     __shared__ unsigned long long goff[RADIX];
-    __shared__ uint32_t nh[RADIX];                   // histogram of the NEXT pass's digit over all tiles of this workgroup
     __shared__ uint32_t wsum[RADIX / 64];
     __shared__ uint32_t s_tile;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t dmask = (1u << bits) - 1u, nmask = (1u << next_bits) - 1u;
-    if (tid < RADIX) nh[tid] = 0;
+    const uint32_t dmask = (1u << bits) - 1u;
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
     uint32_t tile = s_tile;
@@ -290,11 +277,6 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
         __syncthreads();
         const uint64_t t0 = (uint64_t)tile * TILE;
         const uint32_t cnt_tile = (uint32_t)min((uint64_t)TILE, n - t0);
-        if (next_hist) {
-#pragma unroll
-            for (int i = 0; i < RS_ITEMS; ++i)
-                if (wave * (64 * RS_ITEMS) + i * 64 + lane < cnt_tile) atomicAdd(&nh[(uint32_t)(key[i] >> next_shift) & nmask], 1u);
-        }
 #pragma unroll
         for (int i = 0; i < RS_ITEMS; ++i) {
             const uint32_t li = wave * (64 * RS_ITEMS) + i * 64 + lane;
@@ -410,7 +392,6 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
         // (no barrier here: the next iteration touches sk / goff / s_tile only behind its own barriers)
         tile = ntile;
     }
-    if (next_hist && tid < RADIX && nh[tid]) atomicAdd(&next_hist[tid], (unsigned long long)nh[tid]);
 }
 
 template <int THREADS, int BITS>
@@ -422,9 +403,13 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
     const uint64_t n_tiles = (n + TILE - 1) / TILE;
     const char *kind = getenv("SEQWIN_AMD_RADIX_KERNEL");   // A/B: "classic" = one tile per workgroup
     const bool persistent = !(kind && !strcmp(kind, "classic"));
-    uint32_t dbg = 0;        // timing experiments only (scripts/dbg/sort_time.sh): 1 no look-back, 2 no stores, 4 no loads, 8 no ranking
+    uint32_t dbg = 0;
+#ifdef SW_RADIX_ABLATION     // timing experiments only (scripts/dbg/sort_time.sh; the output is NOT sorted): 1 no look-back, 2 no stores, 4 no loads, 8 no ranking
     if (const char *e = getenv("SEQWIN_AMD_RADIX_DEBUG")) dbg = (uint32_t)atoi(e);
-    static int grid_p = 0;   // (per template instance)   // resident workgroups of the persistent form on this device (any number would be correct)
+#endif
+    // resident workgroups of the persistent form (per template instance; taken from the first device that sorts -- any number
+    // is correct, tiles are handed out by tickets)
+    static int grid_p = 0;
     if (persistent && !grid_p) {
         int dev = 0, per_cu = 0;
         hipDeviceProp_t prop;
@@ -446,19 +431,15 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
     SW_HIP(hipGetLastError());
     for (unsigned p = 0; p < n_passes; ++p) {
         const unsigned sh = begin_bit + BITS * p, bits = std::min<unsigned>(BITS, end_bit - sh);
-        const bool more = p + 1 < n_passes;
-        const unsigned nsh = sh + BITS, nbits = more ? std::min<unsigned>(BITS, end_bit - nsh) : 0u;
         hipLaunchKernelGGL(k_rs_scan<BITS>, dim3(1), dim3(RADIX), 0, stream, hist.p + (size_t)p * RADIX);
         SW_HIP(hipMemsetAsync(state.p, 0, state.bytes(), stream));
-        unsigned long long *next = nullptr;   // (all histograms come from k_rs_hist; the in-pass count stays available: A/B)
-        (void)more;
         if (persistent)
             hipLaunchKernelGGL((k_rs_pass_p<THREADS, BITS>), dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)grid_p)), dim3(THREADS), 0,
                                stream, keys, alt, n, (uint32_t)n_tiles, sh, bits, hist.p + (size_t)p * RADIX, state.p, tickets.p + p, d_fail,
-                               next, nsh, nbits, dbg);
+                               dbg);
         else
             hipLaunchKernelGGL((k_rs_pass<THREADS, BITS>), dim3((unsigned)n_tiles), dim3(THREADS), 0, stream, keys, alt, n, sh, bits,
-                               hist.p + (size_t)p * RADIX, state.p, d_fail, next, nsh, nbits);
+                               hist.p + (size_t)p * RADIX, state.p, d_fail);
         SW_HIP(hipGetLastError());
         std::swap(keys, alt);
     }
