@@ -177,12 +177,15 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
 // `keys` points at the sorted data; *d_fail (device word, zeroed by the caller) becomes non-zero if a pass gave up
 // perm_hi32: the keys' upper halves are a permutation of 0 .. n-1 (the unsort's words): the digit histograms of a sort on
 // bits >= 32 then follow from n alone and the sweep that counts them is skipped
+// d_hist_given: digit counts the producer of the keys took while writing them (layout: radix_layout), scanned in place
 void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                       uint32_t *d_fail, bool perm_hi32 = false);
+                       uint32_t *d_fail, bool perm_hi32 = false, unsigned long long *d_hist_given = nullptr);
+void radix_layout(unsigned bits, unsigned *digit_bits, unsigned *n_passes);
 
 // index.hip: radix.hip or rocPRIM; d_fail: zeroed device word, to be read back and handed to check_sort_failed
 void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                 uint32_t *d_fail, bool perm_hi32 = false);
+                 uint32_t *d_fail, bool perm_hi32 = false, unsigned long long *d_hist_given = nullptr);
+bool sort_keys64_is_own(size_t n);   // radix.hip (digit counts may be handed in) or rocPRIM
 void check_sort_failed(uint32_t fail_word);
 
 // index.hip

@@ -58,15 +58,20 @@ void sort_pairs(K *&keys, K *&keys_alt, V *&vals, V *&vals_alt, size_t n, unsign
 // reads back at its next host synchronisation -- non-zero means a pass of radix.hip gave up waiting for a lower-numbered
 // workgroup (it relies on in-order dispatch, like rocPRIM's onesweep; never seen) and the result is not sorted:
 // check_sort_failed() then raises instead of the device hanging.
-void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                 uint32_t *d_fail, bool perm_hi32)
+bool sort_keys64_is_own(size_t n)
 {
     // measured per build: 745 M keys 211.1 against 214.5 ms with rocPRIM; 24 M keys 7.90 against 7.68 ms (the
     // per-pass state resets and launches weigh more on few tiles) -> the own passes from 2^26 keys on
     const char *e = getenv("SEQWIN_AMD_SORT");
     const bool own = e ? !strcmp(e, "own") : n >= (1ull << 26);
-    if (own && !(e && !strcmp(e, "rocprim"))) {
-        radix_sort_keys64(keys, keys_alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32);
+    return own && !(e && !strcmp(e, "rocprim"));
+}
+
+void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
+                 uint32_t *d_fail, bool perm_hi32, unsigned long long *d_hist_given)
+{
+    if (sort_keys64_is_own(n)) {
+        radix_sort_keys64(keys, keys_alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given);
         return;
     }
     rocprim::double_buffer<uint64_t> dk(keys, keys_alt);
@@ -810,13 +815,24 @@ struct RecOfKmer {   // record = top half of pos | record << 32 (exchange form)
     __device__ uint32_t at(uint64_t i) const { return (uint32_t)(kmer[i] >> 32); }
 };
 
+// With `hist` (radix.hip sorts the keys next: radix_layout): the workgroup takes `iters` consecutive blocks of 1024 records and
+// counts the digits of the keys it writes -- hist[pass][digit], hbits wide, key bits [0, end_bit) -- so that the sort needs
+// no counting sweep over the 6 GB of keys.
 template <class Rec>
 __global__ __launch_bounds__(256) void k_adj_pairs(const Rec rec, const uint32_t *__restrict__ rank,
                                                    const uint32_t *__restrict__ rec_asm, uint32_t asm_base, uint64_t n, unsigned nb,
                                                    uint64_t sentinel, uint64_t *__restrict__ key, uint64_t *__restrict__ cand_key,
-                                                   uint32_t *__restrict__ cand_asm, unsigned long long *__restrict__ n_cand)
+                                                   uint32_t *__restrict__ cand_asm, unsigned long long *__restrict__ n_cand,
+                                                   unsigned long long *__restrict__ hist, unsigned hbits, unsigned hpasses,
+                                                   unsigned end_bit, uint32_t iters)
 {
-    const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    __shared__ uint32_t sh_hist[8 * 512];
+    if (hist) {
+        for (uint32_t i = threadIdx.x; i < (hpasses << hbits); i += 256) sh_hist[i] = 0;
+        __syncthreads();
+    }
+    for (uint32_t it = 0; it < iters; ++it) {
+    const uint64_t i0 = (((uint64_t)blockIdx.x * iters + it) * blockDim.x + threadIdx.x) * 4;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t r[5], k[5];
     uint64_t out[4];
@@ -850,6 +866,15 @@ __global__ __launch_bounds__(256) void k_adj_pairs(const Rec rec, const uint32_t
             for (int j = 0; j < 4; ++j)
                 if (i0 + j + 1 < n) key[i0 + j] = out[j];
         }
+        if (hist) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j + 1 < n)
+                    for (unsigned p = 0; p < hpasses; ++p) {
+                        const unsigned shp = hbits * p, wd = min(hbits, end_bit - shp);
+                        atomicAdd(&sh_hist[(p << hbits) + ((uint32_t)(out[j] >> shp) & ((1u << wd) - 1u))], 1u);
+                    }
+        }
     }
     if (__any(cm != 0)) {   // rare: one atomic per wave that has candidates
         const uint32_t c = (uint32_t)__popc(cm);
@@ -869,6 +894,12 @@ __global__ __launch_bounds__(256) void k_adj_pairs(const Rec rec, const uint32_t
                 cand_asm[base] = asm_base + rec_asm[r[j]];
                 ++base;
             }
+    }
+    }   // (iters)
+    if (hist) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (hpasses << hbits); i += 256)
+            if (sh_hist[i]) atomicAdd(&hist[i], (unsigned long long)sh_hist[i]);
     }
 }
 
@@ -2344,13 +2375,14 @@ namespace {
 // (d_n_cand == nullptr: the caller knows the number of candidates, host_n_cand.)
 void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t sentinel, unsigned nb, unsigned ab,
                       uint64_t *ck, uint32_t *ca, const unsigned long long *d_n_cand, uint64_t host_n_cand,
-                      const uint64_t *rank_hash, hipStream_t stream, sw_index &ix, hipEvent_t rank_hash_ready = nullptr)
+                      const uint64_t *rank_hash, hipStream_t stream, sw_index &ix, hipEvent_t rank_hash_ready = nullptr,
+                      unsigned long long *d_hist = nullptr)
 {
     ix.n_edges = 0;
     if (m == 0) return;
     DevArray<uint32_t> sort_fail(1);
     SW_HIP(hipMemsetAsync(sort_fail.p, 0, 4, stream));
-    sort_keys64(keys, keys_alt, m, 0, 2 * nb, stream, sort_fail.p);
+    sort_keys64(keys, keys_alt, m, 0, 2 * nb, stream, sort_fail.p, false, d_hist);   // (d_hist: the digit counts k_adj_pairs took)
     DevArray<uint64_t> ukeys(m);
     DevArray<uint32_t> ucnt(m), ucount(1);
     unsigned long long n_cand = host_n_cand;
@@ -2537,11 +2569,21 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
             DevArray<uint32_t> ca(m);
             DevArray<unsigned long long> n_cand(1);
             SW_HIP(hipMemsetAsync(n_cand.p, 0, 8, stream));
-            hipLaunchKernelGGL(k_adj_pairs<RecArray>, dim3(adj_blocks), dim3(256), 0, stream, RecArray{occ.rec.p}, rank.p, d_rec_asm, 0u,
-                               n, nb, sentinel, k0.p, ck.p, ca.p, n_cand.p);
+            // when radix.hip sorts the keys, k_adj_pairs counts their digits on the way (no counting sweep over the keys)
+            DevArray<unsigned long long> ehist;
+            unsigned hbits = 0, hpasses = 0;
+            uint32_t iters = 1;
+            if (sort_keys64_is_own(m)) {
+                radix_layout(2 * nb, &hbits, &hpasses);
+                ehist.alloc((size_t)hpasses << hbits);
+                SW_HIP(hipMemsetAsync(ehist.p, 0, ehist.bytes(), stream));
+                iters = 32;
+            }
+            hipLaunchKernelGGL(k_adj_pairs<RecArray>, dim3((adj_blocks + iters - 1) / iters), dim3(256), 0, stream, RecArray{occ.rec.p},
+                               rank.p, d_rec_asm, 0u, n, nb, sentinel, k0.p, ck.p, ca.p, n_cand.p, ehist.p, hbits, hpasses, 2 * nb, iters);
             SW_HIP(hipGetLastError());
             edges_from_pairs(k0.p, k1.p, m, sentinel, nb, ab, ck.p, ca.p, n_cand.p, 0, node_hash.p, stream, ix,
-                             node_hash.p ? (hipEvent_t)ev[5] : (hipEvent_t) nullptr);
+                             node_hash.p ? (hipEvent_t)ev[5] : (hipEvent_t) nullptr, ehist.p);
         } else {
             DevArray<uint32_t> v0(m), v1(m);
             hipLaunchKernelGGL(k_adj_keys, dim3(adj_blocks), dim3(256), 0, stream, occ.rec.p, rank.p, d_rec_asm, n, nb,
@@ -2983,7 +3025,8 @@ void occ_adjacency_pairs(OrderedOcc &occ, const uint32_t *d_rec_asm, const uint3
                        TupleSrc{occ.hash.p, occ.kmer.p, occ.part->rec_off}, P, (uint32_t *)nullptr, occ.part->offs.p,
                        (uint64_t *)nullptr, (uint32_t *)nullptr, d_rank_by_row, rank.p);
     hipLaunchKernelGGL(k_adj_pairs<RecOfKmer>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, RecOfKmer{occ.kmer.p}, rank.p,
-                       d_rec_asm, (uint32_t)asm_base, n, nb, sentinel, keys.p, ck.p, ca.p, n_cand.p);
+                       d_rec_asm, (uint32_t)asm_base, n, nb, sentinel, keys.p, ck.p, ca.p, n_cand.p, (unsigned long long *)nullptr, 0u, 0u,
+                       2 * nb, 1u);
     SW_HIP(hipGetLastError());
     std::vector<uint64_t> kb(n_bounds);
     for (uint32_t j = 0; j < n_bounds; ++j) kb[j] = rank_bounds[j] << nb;   // key is monotone in rank_lo

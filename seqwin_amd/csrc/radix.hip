@@ -396,7 +396,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
 
 template <int THREADS, int BITS>
 void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream, uint32_t *d_fail,
-                 bool perm_hi32)
+                 bool perm_hi32, unsigned long long *d_hist_given)
 {
     constexpr uint32_t RADIX = 1u << BITS, TILE = THREADS * RS_ITEMS;
     const unsigned n_passes = (end_bit - begin_bit + BITS - 1) / BITS;
@@ -418,13 +418,16 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
         SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pass_p<THREADS, BITS>, THREADS, 0));
         grid_p = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
     }
-    DevArray<unsigned long long> hist((size_t)n_passes * RADIX), state((size_t)n_tiles * RADIX);
+    DevArray<unsigned long long> hist_own(d_hist_given ? 0 : (size_t)n_passes * RADIX), state((size_t)n_tiles * RADIX);
+    struct { unsigned long long *p; } hist{d_hist_given ? d_hist_given : hist_own.p};   // ([pass][digit] counts; scanned in place below)
     DevArray<uint32_t> tickets(n_passes);
     SW_HIP(hipMemsetAsync(tickets.p, 0, tickets.bytes(), stream));
-    if (perm_hi32 && begin_bit >= 32) {
+    if (d_hist_given) {
+        // (the producer of the keys counted the digits while it wrote them: radix_layout)
+    } else if (perm_hi32 && begin_bit >= 32) {
         hipLaunchKernelGGL(k_rs_perm_hist<BITS>, dim3(n_passes), dim3(RADIX), 0, stream, n, begin_bit, end_bit, hist.p);
     } else {
-        SW_HIP(hipMemsetAsync(hist.p, 0, hist.bytes(), stream));
+        SW_HIP(hipMemsetAsync(hist.p, 0, hist_own.bytes(), stream));
         hipLaunchKernelGGL(k_rs_hist<BITS>, dim3((unsigned)((n + 32767) / 32768)), dim3(256), 0, stream, keys, n, begin_bit, end_bit,
                            n_passes, hist.p);
     }
@@ -448,22 +451,41 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
 
 }  // namespace
 
+// which shape a sort of `bits` key bits takes: 0 = 512 threads x 8 bits, 1 = 1024 x 9, 2 = 1024 x 8, 3 = 512 x 9 (the last two: A/B)
+static int pick_shape(unsigned bits)
+{
+    const char *e = getenv("SEQWIN_AMD_RADIX_BITS");   // A/B: 8 or 9
+    const bool nine = e ? atoi(e) == 9 : (bits + 8) / 9 < (bits + 7) / 8;   // 9-bit digits where they save a pass (54 bits: 6 for 7)
+    const char *shape = getenv("SEQWIN_AMD_RADIX_SHAPE");   // A/B
+    if (shape && !strcmp(shape, "1024x8")) return 2;
+    if (shape && !strcmp(shape, "512x9")) return 3;
+    return nine ? 1 : 0;
+}
+
+// Digit width and number of passes of a sort on `bits` key bits -- for a producer that counts the digits of its keys while
+// it writes them (hist[pass][digit], 2^digit_bits counters per pass, pass p = key bits [begin + p * digit_bits, ...)) and
+// hands the counts to radix_sort_keys64 instead of the counting sweep.
+void radix_layout(unsigned bits, unsigned *digit_bits, unsigned *n_passes)
+{
+    const int sh = pick_shape(bits);
+    *digit_bits = (sh == 1 || sh == 3) ? 9u : 8u;
+    *n_passes = (bits + *digit_bits - 1) / *digit_bits;
+}
+
 // Stable sort of keys[0, n) by bits [begin_bit, end_bit); keys / alt are a double buffer, on return `keys` points at the
 // sorted data and `alt` at the other buffer.  *d_fail (device word, zeroed by the caller) becomes non-zero if a pass gave
 // up waiting (the caller checks it at its next host synchronisation: check_sort_failed in index.hip).
 void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                       uint32_t *d_fail, bool perm_hi32)
+                       uint32_t *d_fail, bool perm_hi32, unsigned long long *d_hist_given)
 {
     if (n == 0 || end_bit <= begin_bit) return;
     if (end_bit - begin_bit > 64) raise(SW_ERR_RUNTIME, "radix_sort_keys64: more than 64 key bits");
-    const unsigned bits = end_bit - begin_bit;
-    const char *e = getenv("SEQWIN_AMD_RADIX_BITS");   // A/B: 8 or 9
-    const bool nine = e ? atoi(e) == 9 : (bits + 8) / 9 < (bits + 7) / 8;   // 9-bit digits where they save a pass (54 bits: 6 for 7)
-    const char *shape = getenv("SEQWIN_AMD_RADIX_SHAPE");   // A/B
-    if (shape && !strcmp(shape, "1024x8")) sort_passes<1024, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32);
-    else if (shape && !strcmp(shape, "512x9")) sort_passes<512, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32);
-    else if (nine) sort_passes<1024, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32);
-    else sort_passes<512, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32);
+    switch (pick_shape(end_bit - begin_bit)) {
+    case 2: sort_passes<1024, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
+    case 3: sort_passes<512, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
+    case 1: sort_passes<1024, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
+    default: sort_passes<512, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
+    }
 }
 
 }  // namespace sw
