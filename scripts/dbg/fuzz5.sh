@@ -5,6 +5,6 @@ SEQWIN_AMD_SORT=own SEQWIN_AMD_UNSORT_DIRECT=4 SEQWIN_AMD_WINDOW_SPLIT=8,4 pytho
 SEQWIN_AMD_UNSORT_DIRECT=4 SEQWIN_AMD_SORT_KEYBITS=10 SEQWIN_AMD_NO_PACKED_EDGES=1 SEQWIN_AMD_CHECK_ORDER=1 python3 tests/tools/fuzz_gpu.py $T 23 > $O/fuzz_knobs.log 2>&1 &
 FUZZ_DIST=1 SEQWIN_AMD_SORT=own SEQWIN_AMD_RADIX_BITS=9 SEQWIN_AMD_UNSORT_DIRECT=6 python3 tests/tools/fuzz_gpu.py $T 24 > $O/fuzz_dist.log 2>&1 &
 FUZZ_LOWMEM=1 SEQWIN_AMD_LOWMEM_CHUNK_MBP=0 SEQWIN_AMD_RANKS=table python3 tests/tools/fuzz_gpu.py $T 25 > $O/fuzz_lowmem_table.log 2>&1 &
-for i in 1 2 3 4 5 6 7 8 9 10 11 12; do sleep 30; echo "t=$((i*30))s"; done
+for i in $(seq 1 40); do sleep 30; echo "t=$((i*30))s"; kill -0 $! 2>/dev/null || break; done
 wait
 tail -n 3 $O/fuzz_*.log
