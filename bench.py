@@ -150,8 +150,10 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_coll = os.environ.get("SEQWIN_DIST_FORCE_COLLECTIVES") == "1"   # every collective issued at world size 1 (RCCL on one GPU)
+    if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("SEQWIN_BENCH_BACKEND", "nccl")   # "gloo": smoke-test the N>1 path on one GPU
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -182,7 +184,7 @@ def main() -> None:
     bp_rank = (end - first) * rpg * rl
     total_bp = G_total * rpg * rl
 
-    use_dist = world > 1 or os.environ.get("SEQWIN_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: cost of the sharded path at N=1
+    use_dist = world > 1 or force_coll or os.environ.get("SEQWIN_BENCH_FORCE_DIST") == "1"   # FORCE_DIST: cost of the sharded path at N=1
     if use_dist:
         shard = swdist.Shard(batch, first_assembly=first, n_assemblies_total=G_total)
         engine = swdist.HipEngine("device" if world == 1 or dist.get_backend() == "nccl" else "host")

@@ -312,24 +312,35 @@ int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t 
 int sw_sort_keys64(void *keys_dev, void *alt_dev, uint64_t n, uint64_t begin_bit, uint64_t end_bit, void *stream, int *sorted_in_alt,
                    double *ms);
 
-/* ---- pairs form of the adjacency exchange (half the volume when pair + assembly do not fit one 64-bit key) ----------
+/* ---- pairs form of the adjacency exchange (what dist.py uses whenever every slice marked its ranks) ---------------------
  * The weight of an edge is the number of its adjacency records minus the records that repeat the pair inside one
  * assembly, and only records touching an occurrence whose node occurs more than once in its assembly can do that.  A slice
- * build with a record table and fewer than 2^31 nodes marks those occurrences in bit 31 of the ranks it returns
- * (sw_index_ranks_marked); when every slice did and the job has fewer than 2^31 nodes, the sources send ONE 64-bit pair key
- * per adjacency record plus the few candidate records with their assembly, and the owners count. */
+ * build with a record table and fewer than 2^31 nodes IN THE SLICE marks those occurrences in bit 31 of the slice-local
+ * ranks it returns (sw_index_ranks_marked); the sources then send ONE 64-bit key per adjacency record plus the few candidate
+ * records with their assembly, and the owners count.
+ * Ranks travel slice-LOCAL (32 bits); a source re-bases them itself: global rank = node_base[owner of the tuple] + local
+ * rank, which may need more than 32 bits (100 000 random genomes: 5e9 distinct minimizers; the reference indexes nodes with
+ * size_t, cpp/include/seqwin/graph.hpp:28-41, cpp/src/seqwin/build_internals.cpp:159-223).  An edge belongs to the owner of
+ * its rank_lo's range [lo_base, next lo_base) (rank_bounds), so its key is
+ *     (rank_lo - lo_base) << hi_bits | rank_hi,      hi_bits = bits of the total node count, lo_bits = bits of the widest range,
+ * lo_bits + hi_bits <= 64 (else SW_ERR_RUNTIME: more GPUs are needed). */
 int sw_index_ranks_marked(const sw_index *ix, int *marked);
-/* Source: keys_dev[<= n-1] (u64, DEVICE) = (rank_lo << n_bits) | rank_hi of every adjacency record, grouped by edge owner
- * (counts[n_bounds + 1]); the candidate records stay in the handle as rows {key, global assembly} grouped by owner
- * (cand_counts[n_bounds + 1]) until sw_occ_candidates copies them (sum of cand_counts rows of 2 u64) to a DEVICE buffer.
- * rank_by_row_dev: GLOBAL ranks with the repeat mark in bit 31. */
-int sw_occ_adjacency_pairs(const sw_occ *o, const void *rank_by_row_dev, uint64_t n_bits, uint64_t asm_base,
+/* Source: keys_dev[<= n-1] (u64, DEVICE) of every adjacency record, grouped by edge owner (counts[n_bounds + 1]); the candidate
+ * records stay in the handle as rows {key, global assembly} grouped by owner (cand_counts[n_bounds + 1]) until
+ * sw_occ_candidates copies them (sum of cand_counts rows of 2 u64) to a DEVICE buffer.
+ * rank_by_row_dev: slice-local ranks with the repeat mark, in the order of the rows sw_occ_partition wrote (what the reverse
+ * all-to-all delivers); node_base[n_owners + 1]: prefix of the node counts of the tuple partition's owners (HOST);
+ * rank_bounds[n_bounds]: ascending splitters of the GLOBAL rank space (HOST); key_bits[2] receives {lo_bits, hi_bits}. */
+int sw_occ_adjacency_pairs(const sw_occ *o, const void *rank_by_row_dev, const uint64_t *node_base, uint64_t n_owners, uint64_t asm_base,
                            const uint64_t *rank_bounds, uint64_t n_bounds, void *keys_dev, uint64_t *counts, uint64_t *cand_counts,
-                           void *stream);
+                           uint64_t *key_bits, void *stream);
 int sw_occ_candidates(const sw_occ *o, void *rows_dev, void *stream);
-/* Owner: edges of its rank range from the received pair keys and candidate rows (source-rank order). */
-int sw_slice_edges_pairs(sw_index *ix, const void *keys_dev, uint64_t m, const void *cand_rows_dev, uint64_t n_cand, uint64_t n_bits,
-                         uint64_t asm_bits, const void *rank_hash_dev, void *stream);
+/* Owner: edges of its rank range from the received keys and candidate rows (source-rank order).  lo_base: first global rank
+ * of this owner's range.  rank_hash_dev (DEVICE u64[n_owners * pad]): the job-wide rank -> hash table as
+ * all_gather_into_tensor leaves it -- slice owner o's node hashes (sw_index_node_hashes) at [o * pad, o * pad + its count). */
+int sw_slice_edges_pairs(sw_index *ix, const void *keys_dev, uint64_t m, const void *cand_rows_dev, uint64_t n_cand, uint64_t lo_bits,
+                         uint64_t hi_bits, uint64_t lo_base, uint64_t asm_bits, const void *rank_hash_dev, const uint64_t *node_base,
+                         uint64_t n_owners, uint64_t pad, void *stream);
 
 #ifdef __cplusplus
 }

@@ -943,15 +943,17 @@ int sw_index_ranks_marked(const sw_index *ix, int *marked)
     return guarded([&] { *marked = ix->ranks_marked ? 1 : 0; });
 }
 
-int sw_occ_adjacency_pairs(const sw_occ *o, const void *rank_by_row_dev, uint64_t n_bits, uint64_t asm_base,
+int sw_occ_adjacency_pairs(const sw_occ *o, const void *rank_by_row_dev, const uint64_t *node_base, uint64_t n_owners, uint64_t asm_base,
                            const uint64_t *rank_bounds, uint64_t n_bounds, void *keys_dev, uint64_t *counts, uint64_t *cand_counts,
-                           void *stream)
+                           uint64_t *key_bits, void *stream)
 {
     return guarded([&] {
-        if (n_bits < 1 || n_bits > 31) raise(SW_ERR_VALUE, "n_bits must be in [1, 31] (bit 31 of a rank word is the repeat mark)");
+        if (occ_partition_owners(*o->occ) == 0) raise(SW_ERR_VALUE, "sw_occ_adjacency_pairs needs the tuples partitioned by sw_occ_partition");
+        if (n_owners != occ_partition_owners(*o->occ))
+            raise(SW_ERR_VALUE, "node_base must hold one entry per owner of the tuple partition, plus the total");
         StreamScope scope((hipStream_t)stream);
-        occ_adjacency_pairs(*o->occ, o->batch->d_rec_asm.p, (const uint32_t *)rank_by_row_dev, (unsigned)n_bits, asm_base, rank_bounds,
-                            (uint32_t)n_bounds, (uint64_t *)keys_dev, counts, cand_counts, (hipStream_t)stream);
+        occ_adjacency_pairs(*o->occ, o->batch->d_rec_asm.p, (const uint32_t *)rank_by_row_dev, node_base, asm_base, rank_bounds,
+                            (uint32_t)n_bounds, (uint64_t *)keys_dev, counts, cand_counts, key_bits, (hipStream_t)stream);
     });
 }
 
@@ -963,15 +965,17 @@ int sw_occ_candidates(const sw_occ *o, void *rows_dev, void *stream)
     });
 }
 
-int sw_slice_edges_pairs(sw_index *ix, const void *keys_dev, uint64_t m, const void *cand_rows_dev, uint64_t n_cand, uint64_t n_bits,
-                         uint64_t asm_bits, const void *rank_hash_dev, void *stream)
+int sw_slice_edges_pairs(sw_index *ix, const void *keys_dev, uint64_t m, const void *cand_rows_dev, uint64_t n_cand, uint64_t lo_bits,
+                         uint64_t hi_bits, uint64_t lo_base, uint64_t asm_bits, const void *rank_hash_dev, const uint64_t *node_base,
+                         uint64_t n_owners, uint64_t pad, void *stream)
 {
     return guarded([&] {
         StreamScope scope((hipStream_t)stream);
         Event e0, e1;
         SW_HIP(hipEventRecord(e0, (hipStream_t)stream));
-        slice_edges_pairs(*ix, (const uint64_t *)keys_dev, m, (const uint64_t *)cand_rows_dev, n_cand, (unsigned)n_bits,
-                          (unsigned)asm_bits, (const uint64_t *)rank_hash_dev, (hipStream_t)stream);
+        slice_edges_pairs(*ix, (const uint64_t *)keys_dev, m, (const uint64_t *)cand_rows_dev, n_cand, (unsigned)lo_bits, (unsigned)hi_bits,
+                          lo_base, (unsigned)asm_bits, (const uint64_t *)rank_hash_dev, node_base, (uint32_t)n_owners, pad,
+                          (hipStream_t)stream);
         SW_HIP(hipEventRecord(e1, (hipStream_t)stream));
         SW_HIP(hipEventSynchronize(e1));
         float ms = 0.f;

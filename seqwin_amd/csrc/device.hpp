@@ -77,6 +77,18 @@ template <class T> struct DevArray {
     size_t bytes() const { return n * sizeof(T); }
 };
 
+// One tile of a fast class, as its workgroup reads it at start-up (32 B, one scalar load).  Written on the device by
+// k_plan_tiles (sketch.hip) from the per-record tables: the host never loops over tiles.
+struct alignas(32) TileDesc {
+    uint64_t bfirst;   // base index (batch-wide, in bases) of the tile's first element: rec_base + pos0 + E0
+    uint32_t ne;       // elements (k-mers) the tile holds: window ends + halo
+    uint32_t i0;       // idx of the tile's first window end (w - 1 for the first tile of a record)
+    uint32_t kpos;     // position in the record of the tile's first element (pos0 + E0)
+    uint32_t rec;      // record
+    uint32_t gid;      // global tile id (record-major, window order: the order pass follows it)
+    uint32_t flags;    // bit 0: the tile's reach crosses an invalid-base gap -> done by the generic kernel (gap_list)
+};
+
 // ---- per-(k, w) launch plan of a batch ---------------------------------------------------------
 // Valid k-mers of a record are numbered 0..n_valid-1 in increasing position ("idx space",
 // minimizer.cpp:69-70).  A segment is a maximal run of valid bases of length >= k; it contributes
@@ -98,12 +110,9 @@ struct Plan {
         uint32_t B = 0;                // threads per workgroup
         uint32_t TW = 0;               // window ends per tile (0 = class unavailable)
         uint32_t n_tiles = 0, n_gap = 0;
-        DevArray<uint32_t> tile_rec;   // [n_tiles] record of every tile (no search in the kernel)
-        DevArray<uint32_t> tile_i0;    // [n_tiles] idx of the tile's first window end (w - 1 for the first tile of a record)
-        DevArray<uint32_t> tile_gid;   // [n_tiles] global tile id (record-major, window order: the order pass follows it)
-        DevArray<uint32_t> tile_pos0;  // [n_tiles] position of idx 0 of the tile's segment (pos = pos0 + idx), or
-                                       // 0xFFFFFFFF: the tile's reach crosses an invalid-base gap -> generic kernel (gap_list)
-        DevArray<uint32_t> gap_list;   // [n_gap] class ids of those tiles
+        DevArray<uint32_t> rec_off;    // [R + 1] first tile of every record in this class
+        DevArray<TileDesc> desc;       // [n_tiles] one descriptor per tile: everything a workgroup needs (no search, ONE load)
+        DevArray<uint32_t> gap_list;   // [n_gap] class ids of the tiles whose reach crosses an invalid-base gap (-> generic kernel)
     } fc[2];
     uint64_t n_windows = 0;
     uint64_t n_valid = 0;
@@ -197,6 +206,7 @@ struct alignas(16) OccPay {
 };
 struct PartState;                       // index.hip: offsets of the last tuple partition (the way back walks them again)
 void part_state_delete(PartState *p);
+uint32_t occ_partition_owners(const struct OrderedOcc &occ);   // owners of the last tuple partition (0: none)
 struct OrderedOcc {
     // exchange form (multi-GPU tuple exchange, sw_sketch): the tuples themselves
     DevArray<uint64_t> hash;   // out_hash in (record_idx, pos) order
@@ -254,11 +264,12 @@ void occ_adjacency(const OrderedOcc &occ, const uint32_t *d_rec_asm, const uint3
                    uint64_t *d_rows_out, uint64_t *counts_host, hipStream_t stream);
 void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned nb, unsigned ab, const uint64_t *d_rank_hash,
                  hipStream_t stream);
-void occ_adjacency_pairs(OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_rank_by_row, unsigned nb, uint64_t asm_base,
-                         const uint64_t *rank_bounds, uint32_t n_bounds, uint64_t *d_keys_out, uint64_t *counts_host,
-                         uint64_t *cand_counts_host, hipStream_t stream);
-void slice_edges_pairs(sw_index &ix, const uint64_t *d_keys, uint64_t m, const uint64_t *d_cand_rows, uint64_t c, unsigned nb,
-                       unsigned ab, const uint64_t *d_rank_hash, hipStream_t stream);
+void occ_adjacency_pairs(OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_rank_by_row, const uint64_t *node_base,
+                         uint64_t asm_base, const uint64_t *rank_bounds, uint32_t n_bounds, uint64_t *d_keys_out,
+                         uint64_t *counts_host, uint64_t *cand_counts_host, uint64_t *key_bits_host, hipStream_t stream);
+void slice_edges_pairs(sw_index &ix, const uint64_t *d_keys, uint64_t m, const uint64_t *d_cand_rows, uint64_t c, unsigned lo_bits,
+                       unsigned hi_bits, uint64_t lo_base, unsigned ab, const uint64_t *d_rank_hash, const uint64_t *node_base,
+                       uint32_t n_owners, uint64_t pad, hipStream_t stream);
 void index_node_hashes(const sw_index &ix, uint64_t *d_out, hipStream_t stream);
 
 }  // namespace sw

@@ -246,6 +246,7 @@ __device__ __forceinline__ unsigned long long interleave32(uint32_t a, uint32_t 
 // order has the same node and assembly) -- only adjacencies touching such an occurrence can repeat a pair inside one
 // assembly (k_adj_pairs).  Needs rec_flag and fewer than 2^31 nodes.
 constexpr uint32_t RANK_REP = 0x80000000u;
+constexpr uint8_t OWNER_DROP = 0xFF;   // owner byte of a key that is no row (record boundary): lands behind the last owner
 template <bool BITS, bool REP>
 __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay, uint64_t n,
                                                uint64_t base, const uint32_t *__restrict__ rec_flag, sw_kmer *__restrict__ kmers,
@@ -901,6 +902,111 @@ __global__ __launch_bounds__(256) void k_adj_pairs(const Rec rec, const uint32_t
         for (uint32_t i = threadIdx.x; i < (hpasses << hbits); i += 256)
             if (sh_hist[i]) atomicAdd(&hist[i], (unsigned long long)sh_hist[i]);
     }
+}
+
+// ---- multi-GPU form: the ranks come back slice-LOCAL (with the repeat mark), together with the owner of every tuple ------
+// Global rank = node_base[owner] + local rank, up to 2^hi_bits - 1 -- more than 32 bits for the 5e9 distinct minimizers of
+// 100 000 random genomes (the reference indexes nodes with size_t, cpp/include/seqwin/graph.hpp:28-41).  An edge belongs to
+// the owner of its rank_lo's range (quantile splitters, dist.rank_bounds), so its key holds rank_lo RELATIVE to that range:
+//     key = (rank_lo - lo_base[owner]) << hi_bits | rank_hi          lo_bits + hi_bits <= 64
+// and the owner of every key travels next to it (one byte), because it no longer follows from the key's value.
+struct RankSpace {
+    uint64_t node_base[17];     // prefix of the node counts of the slice owners (n_owners + 1 entries)
+    uint64_t lo_base[17];       // first rank of every edge owner's range (n_edge_owners entries), then the total
+    uint32_t n_owners, n_edge_owners;
+    unsigned hi_bits;
+};
+
+template <class Rec>
+__global__ __launch_bounds__(256) void k_adj_pairs_dist(const Rec rec, const uint32_t *__restrict__ rank, const uint8_t *__restrict__ own,
+                                                        const uint32_t *__restrict__ rec_asm, uint32_t asm_base, uint64_t n,
+                                                        const RankSpace S, uint64_t *__restrict__ key, uint8_t *__restrict__ key_own,
+                                                        uint64_t *__restrict__ cand_key, uint32_t *__restrict__ cand_asm,
+                                                        uint8_t *__restrict__ cand_own, unsigned long long *__restrict__ n_cand)
+{
+    const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t r[5];
+    uint64_t g[5];            // global ranks
+    uint32_t mk = 0;          // bit j: occurrence i0 + j carries the repeat mark
+    uint64_t out[4];
+    uint8_t oo[4];
+    uint32_t cm = 0;
+    if (i0 + 1 < n) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const bool live = i0 + j < n;
+            r[j] = live ? rec.at(i0 + j) : 0xFFFFFFFFu;
+            const uint32_t k = live ? rank[i0 + j] : 0u;
+            g[j] = live ? S.node_base[own[i0 + j]] + (k & ~RANK_REP) : 0ull;
+            if (k & RANK_REP) mk |= 1u << j;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool pair = i0 + j + 1 < n && r[j] == r[j + 1];
+            uint64_t u = g[j], v = g[j + 1];
+            if (v < u) { const uint64_t t = u; u = v; v = t; }
+            uint32_t e = 0;
+            for (uint32_t q = 1; q < S.n_edge_owners; ++q) e += (S.lo_base[q] <= u) ? 1u : 0u;
+            out[j] = ((u - S.lo_base[e]) << S.hi_bits) | v;
+            oo[j] = pair ? (uint8_t)e : OWNER_DROP;
+            if (pair && ((mk >> j) & 3u)) cm |= 1u << j;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j + 1 < n) {
+                key[i0 + j] = out[j];
+                key_own[i0 + j] = oo[j];
+            }
+    }
+    if (__any(cm != 0)) {   // rare: one atomic per wave that has candidates
+        const uint32_t c = (uint32_t)__popc(cm);
+        uint32_t incl = c;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t total = __shfl(incl, 63, 64);
+        unsigned long long base = 0;
+        if (lane == 63) base = atomicAdd(n_cand, (unsigned long long)total);
+        base = __shfl(base, 63, 64) + (incl - c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((cm >> j) & 1u) {
+                cand_key[base] = out[j];
+                cand_asm[base] = asm_base + rec_asm[r[j]];
+                cand_own[base] = oo[j];
+                ++base;
+            }
+    }
+}
+
+// rank -> hash through the job-wide table as the all-gather leaves it: owner o's hashes at table[o * pad ...]
+struct RankHash {
+    const uint64_t *table;
+    uint64_t node_base[17];
+    uint64_t pad;
+    uint32_t n_owners;
+    __device__ uint64_t operator()(uint64_t rank) const
+    {
+        uint32_t o = 0;
+        for (uint32_t q = 1; q < n_owners; ++q) o += (node_base[q] <= rank) ? 1u : 0u;
+        return table[(uint64_t)o * pad + (rank - node_base[o])];
+    }
+};
+
+// one thread per run of equal wide keys (see k_edges_runs)
+__global__ void k_edges_runs_wide(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ usum, uint64_t n_edges,
+                                  unsigned hi_bits, uint64_t lo_base, const RankHash H, sw_edge *__restrict__ edges)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    const uint64_t key = ukeys[e];
+    const uint64_t u = (hi_bits >= 64 ? 0ull : (key >> hi_bits)) + lo_base;
+    const uint64_t v = hi_bits >= 64 ? key : (key & ((1ull << hi_bits) - 1ull));
+    edges[e].first = H(u);
+    edges[e].second = H(v);
+    edges[e].weight = usum[e];
 }
 
 struct RepeatFlag {   // 1 where a sorted candidate row repeats the (pair, assembly) of its predecessor
@@ -2373,16 +2479,22 @@ namespace {
 // the run lengths give the number of records of every pair; the candidates (records that may repeat their pair inside one
 // assembly: ck / ca, *d_n_cand of them, unordered) are sorted by (pair, assembly) and the repeats taken off.
 // (d_n_cand == nullptr: the caller knows the number of candidates, host_n_cand.)
+struct WideKeys {   // multi-GPU slices: key = (rank_lo - lo_base) << hi_bits | rank_hi, hashes through the per-owner table
+    unsigned lo_bits, hi_bits;
+    uint64_t lo_base;
+    RankHash hash;
+};
 void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t sentinel, unsigned nb, unsigned ab,
                       uint64_t *ck, uint32_t *ca, const unsigned long long *d_n_cand, uint64_t host_n_cand,
                       const uint64_t *rank_hash, hipStream_t stream, sw_index &ix, hipEvent_t rank_hash_ready = nullptr,
-                      unsigned long long *d_hist = nullptr)
+                      unsigned long long *d_hist = nullptr, const WideKeys *wide = nullptr)
 {
     ix.n_edges = 0;
     if (m == 0) return;
+    const unsigned key_bits = wide ? wide->lo_bits + wide->hi_bits : 2 * nb;
     DevArray<uint32_t> sort_fail(1);
     SW_HIP(hipMemsetAsync(sort_fail.p, 0, 4, stream));
-    sort_keys64(keys, keys_alt, m, 0, 2 * nb, stream, sort_fail.p, false, d_hist);   // (d_hist: the digit counts k_adj_pairs took)
+    sort_keys64(keys, keys_alt, m, 0, key_bits, stream, sort_fail.p, false, d_hist);   // (d_hist: the digit counts k_adj_pairs took)
     DevArray<uint64_t> ukeys(m);
     DevArray<uint32_t> ucnt(m), ucount(1);
     unsigned long long n_cand = host_n_cand;
@@ -2404,8 +2516,12 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
     if (ix.n_edges == 0) return;
     ix.edges.alloc(ix.n_edges);
     if (rank_hash_ready) SW_HIP(hipStreamWaitEvent(stream, rank_hash_ready, 0));   // (rank_hash is written on another stream)
-    hipLaunchKernelGGL(k_edges_runs, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, ucnt.p, 0u, ~0ull,
-                       (uint64_t)ix.n_edges, nb, ix.nodes.p, rank_hash, ix.edges.p);
+    if (wide)
+        hipLaunchKernelGGL(k_edges_runs_wide, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, ucnt.p, (uint64_t)ix.n_edges,
+                           wide->hi_bits, wide->lo_base, wide->hash, ix.edges.p);
+    else
+        hipLaunchKernelGGL(k_edges_runs, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, ucnt.p, 0u, ~0ull,
+                           (uint64_t)ix.n_edges, nb, ix.nodes.p, rank_hash, ix.edges.p);
     SW_HIP(hipGetLastError());
     if (n_cand) {
         const uint64_t c = n_cand;
@@ -2415,7 +2531,7 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
         uint32_t *a = ca, *a_alt = ca1.p;
         uint64_t *k = ck, *k_alt = ck1.p;
         sort_pairs(a, a_alt, k, k_alt, c, 0, ab, stream);
-        sort_pairs(k, k_alt, a, a_alt, c, 0, 2 * nb, stream);
+        sort_pairs(k, k_alt, a, a_alt, c, 0, key_bits, stream);
         DevArray<uint64_t> rkeys(c);
         DevArray<uint32_t> rdups(c), rcount(1);
         auto flags = rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), RepeatFlag{k, a});
@@ -2686,6 +2802,7 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
         SW_HIP(hipStreamSynchronize(stream));   // (the bitmaps are released here)
     } else {
         ix.nodes.alloc(0);
+        ix.ranks_marked = d_rec_asm && n_records;   // an empty slice returns no rank at all: it must not switch the job's pairs form off
     }
     if (slice) {
         ix.edges.alloc(0);
@@ -2762,21 +2879,23 @@ namespace {
 constexpr int PART_ROWS = 32;
 constexpr uint32_t PART_BUCKETS = 32;
 
+struct PartArgs;
+__device__ __forceinline__ uint32_t owner_of(const PartArgs &P, uint64_t kx);
 struct TupleSrc {   // rows from the ordered tuple stream
     const uint64_t *hash, *kmer;
     uint64_t rec_off;
-    __device__ uint64_t key(uint64_t i) const { return hash[i]; }
+    __device__ uint32_t owner(const PartArgs &P, uint64_t i) const { return owner_of(P, hash[i]); }
     __device__ void row(uint64_t i, uint64_t &r0, uint64_t &r1) const { r0 = hash[i]; r1 = kmer[i] + (rec_off << 32); }
 };
 struct RowSrc {     // rows[n][2], key = column 0
     const uint64_t *rows;
-    __device__ uint64_t key(uint64_t i) const { return rows[2 * i]; }
+    __device__ uint32_t owner(const PartArgs &P, uint64_t i) const { return owner_of(P, rows[2 * i]); }
     __device__ void row(uint64_t i, uint64_t &r0, uint64_t &r1) const { r0 = rows[2 * i]; r1 = rows[2 * i + 1]; }
 };
 
 struct KeySrc {     // rows[n] of packed keys (one column); the second output column is unused
     const uint64_t *rows;
-    __device__ uint64_t key(uint64_t i) const { return rows[i]; }
+    __device__ uint32_t owner(const PartArgs &P, uint64_t i) const { return owner_of(P, rows[i]); }
     __device__ void row(uint64_t i, uint64_t &r0, uint64_t &r1) const { r0 = rows[i]; r1 = 0; }
 };
 
@@ -2798,7 +2917,25 @@ struct PartState {   // what a tuple partition leaves behind for the way back (O
     bool valid = false;
 };
 void part_state_delete(PartState *p) { delete p; }
+uint32_t occ_partition_owners(const OrderedOcc &occ) { return occ.part && occ.part->valid ? occ.part->args.n_bounds + 1 : 0u; }
 namespace {
+
+// keys whose owner does not follow from their value (the edge keys of the multi-GPU adjacency hold rank_lo relative to their
+// owner's range): the producer wrote the owner of every key next to it (OWNER_DROP: not a row, lands behind the last owner)
+struct OwnedKeySrc {
+    const uint64_t *rows;
+    const uint8_t *own;
+    uint32_t n_owners;
+    __device__ uint32_t owner(const PartArgs &, uint64_t i) const { const uint8_t o = own[i]; return o == OWNER_DROP ? n_owners : o; }
+    __device__ void row(uint64_t i, uint64_t &r0, uint64_t &r1) const { r0 = rows[i]; r1 = 0; }
+};
+struct OwnedPairSrc {   // candidate rows {key, assembly} with their owner
+    const uint64_t *key_;
+    const uint32_t *asm_;
+    const uint8_t *own;
+    __device__ uint32_t owner(const PartArgs &, uint64_t i) const { return own[i]; }
+    __device__ void row(uint64_t i, uint64_t &r0, uint64_t &r1) const { r0 = key_[i]; r1 = asm_[i]; }
+};
 
 __device__ __forceinline__ uint32_t owner_of(const PartArgs &P, uint64_t kx)
 {
@@ -2826,7 +2963,7 @@ template <class Src, int MODE>
 __global__ __launch_bounds__(256) void k_partition(const Src src, const PartArgs P, uint32_t *__restrict__ hist,
                                                    const uint32_t *__restrict__ offsets, uint64_t *__restrict__ rows_out,
                                                    uint32_t *__restrict__ perm_out, const uint32_t *__restrict__ gather_in = nullptr,
-                                                   uint32_t *__restrict__ gather_out = nullptr)
+                                                   uint32_t *__restrict__ gather_out = nullptr, uint8_t *__restrict__ owner_out = nullptr)
 {
     constexpr bool WRITE = MODE != 0;
     __shared__ uint32_t cnt[4][PART_BUCKETS];
@@ -2842,13 +2979,14 @@ __global__ __launch_bounds__(256) void k_partition(const Src src, const PartArgs
         const uint64_t active = __ballot(live);
         if (!active) break;
         uint32_t o = 0;
-        if (live) o = owner_of(P, src.key(i));
+        if (live) o = src.owner(P, i);
         const uint64_t same = match5(o, active);
         if (live) {
             const uint32_t before = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
             const uint32_t start = cnt[wv][o];               // all lanes of a group read before the leader adds
             if (MODE == 2) {
                 gather_out[i] = gather_in[(uint64_t)start + before];
+                if (owner_out) owner_out[i] = (uint8_t)o;
             } else if (MODE == 1) {
                 const uint64_t dst = (uint64_t)start + before;
                 uint64_t r0, r1;
@@ -2886,16 +3024,23 @@ void stable_partition(const Src &src, uint64_t n, const uint64_t *bounds, uint32
 {
     if (n_bounds > 15) raise(SW_ERR_VALUE, "at most 16 owners are supported");
     for (uint32_t j = 0; j < n_bounds + 2; ++j) counts_host[j] = 0;
-    if (n == 0) return;
     if (n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 rows on one device");
     PartArgs P{};
     P.n = n;
     P.n_bounds = n_bounds;
-    for (uint32_t j = 0; j < n_bounds; ++j) P.bounds[j] = bounds[j];
+    for (uint32_t j = 0; j < n_bounds && bounds; ++j) P.bounds[j] = bounds[j];   // (null: the source knows its rows' owners itself)
     P.drop_key = drop_key;
     P.has_drop = has_drop ? 1u : 0u;
     P.cols = cols;
     P.n_waves = (uint32_t)((n + PART_ROWS * 64 - 1) / (PART_ROWS * 64));
+    if (n == 0) {
+        if (keep) {   // an empty shard is partitioned too: nothing to walk on the way back, but the owners are known
+            keep->args = P;
+            keep->offs.alloc(0);
+            keep->valid = true;
+        }
+        return;
+    }
     const uint64_t nh = (uint64_t)PART_BUCKETS * P.n_waves;
     DevArray<uint32_t> hist(nh), offs(nh);
     DevArray<unsigned long long> counts(PART_BUCKETS);
@@ -2997,59 +3142,98 @@ namespace {
 struct PairSrc {   // candidate rows as two arrays: key, assembly
     const uint64_t *key_;
     const uint32_t *asm_;
-    __device__ uint64_t key(uint64_t i) const { return key_[i]; }
+    __device__ uint32_t owner(const PartArgs &P, uint64_t i) const { return owner_of(P, key_[i]); }
     __device__ void row(uint64_t i, uint64_t &r0, uint64_t &r1) const { r0 = key_[i]; r1 = asm_[i]; }
 };
 }  // namespace
 
-// Pairs form of the adjacency exchange (ranks carry RANK_REP): d_keys_out[<= n - 1] = one pair key per adjacency record,
-// grouped by edge owner; the candidates (records that may repeat a pair inside one assembly) as {key, global assembly} rows,
-// grouped by owner, stay in occ.cand_rows.  counts_host / cand_counts_host [n_bounds + 1].
-void occ_adjacency_pairs(OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_rank_by_row, unsigned nb, uint64_t asm_base,
-                         const uint64_t *rank_bounds, uint32_t n_bounds, uint64_t *d_keys_out, uint64_t *counts_host,
-                         uint64_t *cand_counts_host, hipStream_t stream)
+// Pairs form of the adjacency exchange: d_keys_out[<= n - 1] = one key per adjacency record, grouped by edge owner; the
+// candidates (records that may repeat a pair inside one assembly) as {key, global assembly} rows, grouped by owner, stay
+// in occ.cand_rows.  d_rank_by_row: slice-LOCAL ranks with RANK_REP, in the order of the partitioned rows; node_base[n_owners
+// + 1]: prefix of the slice owners' node counts (n_owners = owners of the tuple partition).  counts_host / cand_counts_host
+// [n_bounds + 1]; key_bits_host[2] = {lo_bits, hi_bits} of the keys (see RankSpace).
+void occ_adjacency_pairs(OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_rank_by_row, const uint64_t *node_base,
+                         uint64_t asm_base, const uint64_t *rank_bounds, uint32_t n_bounds, uint64_t *d_keys_out,
+                         uint64_t *counts_host, uint64_t *cand_counts_host, uint64_t *key_bits_host, hipStream_t stream)
 {
     for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = cand_counts_host[j] = 0;
     occ.cand_rows.alloc(0);
+    if (!occ.part || !occ.part->valid) raise(SW_ERR_VALUE, "sw_occ_adjacency_pairs needs the tuples partitioned by sw_occ_partition");
+    const PartArgs &P = occ.part->args;
+    if (n_bounds > 15) raise(SW_ERR_VALUE, "at most 16 owners are supported");
+    RankSpace S{};
+    S.n_owners = P.n_bounds + 1;
+    S.n_edge_owners = n_bounds + 1;
+    for (uint32_t q = 0; q <= S.n_owners; ++q) S.node_base[q] = node_base[q];
+    const uint64_t total = node_base[S.n_owners];
+    uint64_t widest = 0;
+    for (uint32_t q = 0; q <= n_bounds; ++q) {
+        S.lo_base[q] = q ? rank_bounds[q - 1] : 0;
+        const uint64_t end = q < n_bounds ? rank_bounds[q] : total;
+        if (end < S.lo_base[q] || end > total) raise(SW_ERR_VALUE, "rank bounds must ascend and stay within the number of nodes");
+        widest = std::max(widest, end - S.lo_base[q]);
+    }
+    S.lo_base[n_bounds + 1] = total;
+    unsigned hi_bits = 1, lo_bits = 1;
+    while (hi_bits < 64 && (total >> hi_bits)) ++hi_bits;      // rank_hi < total < 2^hi_bits
+    while (lo_bits < 64 && (widest >> lo_bits)) ++lo_bits;
+    if (lo_bits + hi_bits > 64)
+        raise(SW_ERR_RUNTIME, "%llu nodes over %u edge owners do not fit 64-bit edge keys (%u + %u bits): use more GPUs",
+              (unsigned long long)total, n_bounds + 1, lo_bits, hi_bits);
+    S.hi_bits = hi_bits;
+    key_bits_host[0] = lo_bits;
+    key_bits_host[1] = hi_bits;
     const uint64_t n = occ.n;
     if (n < 2) return;
-    if (!occ.part || !occ.part->valid) raise(SW_ERR_VALUE, "sw_occ_adjacency_pairs needs the tuples partitioned by sw_occ_partition");
     const uint64_t m = n - 1;
-    const uint64_t sentinel = (nb == 32) ? ~0ull : ((1ull << (2 * nb)) - 1ull);
     DevArray<uint32_t> rank(n), ca(m);
+    DevArray<uint8_t> own(n), kown(m), cown(m);
     DevArray<uint64_t> keys(m), ck(m);
     DevArray<unsigned long long> n_cand(1);
     SW_HIP(hipMemsetAsync(n_cand.p, 0, 8, stream));
-    const PartArgs &P = occ.part->args;
+    // the ranks arrive in partitioned-row order; the partition was stable, so walking it again reads them back in stream
+    // order, together with the owner every tuple went to
     hipLaunchKernelGGL((k_partition<TupleSrc, 2>), dim3((P.n_waves + 3) / 4), dim3(256), 0, stream,
                        TupleSrc{occ.hash.p, occ.kmer.p, occ.part->rec_off}, P, (uint32_t *)nullptr, occ.part->offs.p,
-                       (uint64_t *)nullptr, (uint32_t *)nullptr, d_rank_by_row, rank.p);
-    hipLaunchKernelGGL(k_adj_pairs<RecOfKmer>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, RecOfKmer{occ.kmer.p}, rank.p,
-                       d_rec_asm, (uint32_t)asm_base, n, nb, sentinel, keys.p, ck.p, ca.p, n_cand.p, (unsigned long long *)nullptr, 0u, 0u,
-                       2 * nb, 1u);
+                       (uint64_t *)nullptr, (uint32_t *)nullptr, d_rank_by_row, rank.p, own.p);
+    hipLaunchKernelGGL(k_adj_pairs_dist<RecOfKmer>, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, stream, RecOfKmer{occ.kmer.p},
+                       rank.p, own.p, d_rec_asm, (uint32_t)asm_base, n, S, keys.p, kown.p, ck.p, ca.p, cown.p, n_cand.p);
     SW_HIP(hipGetLastError());
-    std::vector<uint64_t> kb(n_bounds);
-    for (uint32_t j = 0; j < n_bounds; ++j) kb[j] = rank_bounds[j] << nb;   // key is monotone in rank_lo
     uint64_t counts[18];
-    // dropped (sentinel) rows land after the last owner; the output buffer holds all m keys
-    stable_partition(KeySrc{keys.p}, m, kb.data(), n_bounds, true, sentinel, d_keys_out, (uint32_t *)nullptr, counts, stream, 1);
+    // dropped rows (record boundaries) land after the last owner; the output buffer holds all m keys
+    stable_partition(OwnedKeySrc{keys.p, kown.p, n_bounds + 1}, m, nullptr, n_bounds, true, 0, d_keys_out, (uint32_t *)nullptr, counts,
+                     stream, 1);
     for (uint32_t j = 0; j <= n_bounds; ++j) counts_host[j] = counts[j];
     unsigned long long c = 0;
     SW_HIP(hipMemcpyAsync(&c, n_cand.p, 8, hipMemcpyDeviceToHost, stream));
     SW_HIP(hipStreamSynchronize(stream));
     if (c) {
         occ.cand_rows.alloc(2 * c);
-        stable_partition(PairSrc{ck.p, ca.p}, c, kb.data(), n_bounds, false, 0, occ.cand_rows.p, (uint32_t *)nullptr, counts, stream);
+        stable_partition(OwnedPairSrc{ck.p, ca.p, cown.p}, c, nullptr, n_bounds, false, 0, occ.cand_rows.p, (uint32_t *)nullptr, counts,
+                         stream);
         for (uint32_t j = 0; j <= n_bounds; ++j) cand_counts_host[j] = counts[j];
     }
 }
 
-void slice_edges_pairs(sw_index &ix, const uint64_t *d_keys, uint64_t m, const uint64_t *d_cand_rows, uint64_t c, unsigned nb,
-                       unsigned ab, const uint64_t *d_rank_hash, hipStream_t stream)
+// Owner: edges of its rank range from the received keys and candidate rows.  rank_hash: the job-wide table, owner o's node
+// hashes at d_rank_hash[o * pad ...] (pad >= every owner's node count; what all_gather_into_tensor leaves).
+void slice_edges_pairs(sw_index &ix, const uint64_t *d_keys, uint64_t m, const uint64_t *d_cand_rows, uint64_t c, unsigned lo_bits,
+                       unsigned hi_bits, uint64_t lo_base, unsigned ab, const uint64_t *d_rank_hash, const uint64_t *node_base,
+                       uint32_t n_owners, uint64_t pad, hipStream_t stream)
 {
     ix.n_edges = 0;
     if (m >= 0xFFFFFFFFull || c >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 adjacency rows on one device");
+    if (n_owners == 0 || n_owners > 16) raise(SW_ERR_VALUE, "1 .. 16 owners are supported");
+    if (lo_bits + hi_bits > 64 || lo_bits == 0 || hi_bits == 0) raise(SW_ERR_VALUE, "edge keys: 1 <= lo_bits, hi_bits and lo_bits + hi_bits <= 64");
     if (m) {
+        WideKeys wk{};
+        wk.lo_bits = lo_bits;
+        wk.hi_bits = hi_bits;
+        wk.lo_base = lo_base;
+        wk.hash.table = d_rank_hash;
+        wk.hash.pad = pad;
+        wk.hash.n_owners = n_owners;
+        for (uint32_t q = 0; q <= n_owners; ++q) wk.hash.node_base[q] = node_base[q];
         DevArray<uint64_t> k0(m), k1(m), ck(c);
         DevArray<uint32_t> ca(c);
         SW_HIP(hipMemcpyAsync(k0.p, d_keys, m * 8, hipMemcpyDeviceToDevice, stream));
@@ -3057,7 +3241,7 @@ void slice_edges_pairs(sw_index &ix, const uint64_t *d_keys, uint64_t m, const u
             hipLaunchKernelGGL(k_split_rows2, dim3(blocks_for(c)), dim3(TPB), 0, stream, d_cand_rows, c, ck.p, ca.p);
             SW_HIP(hipGetLastError());
         }
-        edges_from_pairs(k0.p, k1.p, m, ~0ull, nb, ab, ck.p, ca.p, nullptr, c, d_rank_hash, stream, ix);   // rows carry no sentinels
+        edges_from_pairs(k0.p, k1.p, m, ~0ull, 0, ab, ck.p, ca.p, nullptr, c, nullptr, stream, ix, nullptr, nullptr, &wk);   // rows carry no sentinels
     }
     if (ix.n_edges == 0) ix.edges.alloc(0);
 }

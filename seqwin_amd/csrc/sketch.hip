@@ -32,6 +32,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "device.hpp"
 
@@ -81,16 +82,15 @@ struct SketchArgs {
     uint64_t cap;                 // total entries of the stage arrays (slots + overflow area)
     uint64_t ovf_base;            // first entry of the overflow area = n_tiles * slot_cap
     uint32_t slot_cap;            // entries of a tile's own slot at tile * slot_cap
-    const uint32_t *cls_tile_rec; // [class tiles] record of every tile of the class this launch covers
-    const uint32_t *cls_tile_i0;  // fast classes (and their list mode): idx of the tile's first window end; nullptr: (w - 1) + t * TW
-    const uint32_t *cls_tile_gid; // fast classes (and their list mode): global tile id; nullptr: rec_tile_off[rec] + t
-    const uint32_t *cls_tile_pos0; // fast class: [class tiles] pos of idx 0 of the tile's segment, 0xFFFFFFFF = gap tile (skipped)
+    const uint32_t *cls_tile_rec; // generic kernel, own class: [class tiles] record of every tile
+    const TileDesc *cls_desc;     // fast classes (and the generic kernel's list mode over them): [class tiles] descriptors
     uint32_t *tile_count;
     uint64_t *tile_offset;
     uint32_t *ovf_count;          // fast kernel: number of tiles handed over to the generic kernel
     uint32_t *ovf_list;           // fast kernel: their class tile ids; generic kernel in list mode reads it
     uint32_t rc_limit;            // fast kernel: records per run that may be consumed (RC; lower only for tests)
     const uint32_t *list;         // generic kernel: nullptr = own class, else class tile ids of the FAST class
+    unsigned long long *stamps;   // timing builds (-DSW_SK_STAMPS): [sampled tile][wave][16] shader-clock stamps, else nullptr
 };
 
 // 2-bit base reader over the packed stream (16 bases per 32-bit word).
@@ -210,12 +210,20 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
     // list mode: redo tiles of the fast class (same window ranges: TW = the fast class's TW <= NE - w)
     if (A.list && A.tile_base + blockIdx.x >= *A.ovf_count) return;   // list length is only known on the device
     const uint32_t ctile = A.list ? A.list[A.tile_base + blockIdx.x] : A.tile_base + blockIdx.x;
-    const uint32_t rec = A.cls_tile_rec[ctile];   // (one load instead of a 15-step search: the chain is pure latency)
-    // own class: tiles of a record are numbered t = 0, 1, ...; tiles of the fast classes carry their own descriptors
-    const uint32_t t = A.cls_tile_i0 ? 0u : ctile - A.cls_tile_off[rec];
-    const uint32_t tile = A.cls_tile_gid ? A.cls_tile_gid[ctile] : A.rec_tile_off[rec] + t;  // global tile id (order pass)
+    // own class: tiles of a record are numbered t = 0, 1, ...; tiles of the fast classes (list mode) carry descriptors
+    uint32_t rec, tile, I0;
+    if (A.cls_desc) {
+        const TileDesc d = A.cls_desc[ctile];
+        rec = d.rec;
+        tile = d.gid;                                         // global tile id (order pass)
+        I0 = d.i0;                                            // first window end (idx space)
+    } else {
+        rec = A.cls_tile_rec[ctile];   // (one load instead of a 15-step search: the chain is pure latency)
+        const uint32_t t = ctile - A.cls_tile_off[rec];
+        tile = A.rec_tile_off[rec] + t;
+        I0 = (w - 1) + t * A.TW;
+    }
     const uint32_t nvalid = A.rec_nvalid[rec];
-    const uint32_t I0 = A.cls_tile_i0 ? A.cls_tile_i0[ctile] : (w - 1) + t * A.TW;   // first window end (idx space)
     const bool first = I0 == w - 1;                           // first tile of its record
     const uint32_t I1 = (uint32_t)min((uint64_t)I0 + A.TW, (uint64_t)nvalid);   // no wrap near 2^32 k-mers               // one past the last window end
     const uint32_t E0 = first ? 0u : I0 - w;                  // first element held by this tile
@@ -441,6 +449,55 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
 // ================================================================================================
 constexpr uint32_t KF = 256;
 constexpr uint32_t RC = 12;   // published suffix records per run (12 x 8 B: the most that keeps 5 workgroups per CU)
+// A/B switches (timing builds: tests/tools/build_variant.sh <name> -DSW_SK_AB=bits; 0 = the shipped kernel)
+//   1 the suffix-record pass tests the slot address against the end of the lane's area (r02) instead of clamping it
+//   2 wave scans of the emit counts through ds_bpermute (__shfl_up, r02) instead of DPP row shifts
+//   4 whole-run minima of the window pass read in a counted loop (r02) instead of five loads in flight
+//   8 the winner of the window before the tile cleared in the bitmap by one thread between two barriers (r02)
+#ifndef SW_SK_AB
+#define SW_SK_AB 0
+#endif
+#ifndef SW_SK_SLEEP
+#define SW_SK_SLEEP 0      // experiment: every wave sleeps ~64 x this many cycles once per tile (is the kernel bound by wave latency?)
+#endif
+constexpr bool SK_CLAMP = !(SW_SK_AB & 1), SK_DPP_SCAN = !(SW_SK_AB & 2), SK_RUNMIN_UNROLLED = !(SW_SK_AB & 4),
+               SK_TWO_BARRIERS = (SW_SK_AB & 8) != 0;
+
+#ifdef SW_SK_STAMPS
+constexpr uint32_t STAMP_EVERY = 512, STAMP_SLOTS = 16;   // every 512th tile of a launch writes its waves' phase times
+#define SK_STAMP(i)                                                                                              \
+    do {                                                                                                         \
+        if (A.stamps && (ctile % STAMP_EVERY) == 0) {   /* (uniform) */                                          \
+            const uint32_t wv_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));              \
+            unsigned long long *p_ = A.stamps + ((size_t)(ctile / STAMP_EVERY) * (B / 64) + wv_) * STAMP_SLOTS + (i); \
+            const unsigned long long c_ = __builtin_readcyclecounter();                                          \
+            if ((threadIdx.x & 63u) == 0) __builtin_nontemporal_store(c_, p_);                                   \
+        }                                                                                                        \
+    } while (0)
+#else
+#define SK_STAMP(i) do { } while (0)
+#endif
+
+// inclusive prefix sum over the 64 lanes of a wave in DPP row shifts / broadcasts (six dependent VALU instructions, no trip
+// through the LDS crossbar: a __shfl_up scan is six dependent ds_bpermute round trips)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    if (SK_DPP_SCAN) {
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1 (zeros come in from below the row)
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8: inclusive within rows of 16
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+        return v;
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(v, d, 64);
+        if (lane >= d) v += up;
+    }
+    return v;
+}
 
 template <int L, int B> struct FastCfg {
     static constexpr int NE = B * L;
@@ -477,37 +534,63 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
     const uint32_t tid = threadIdx.x, w = A.w, k = A.k;
 
     const uint32_t ctile = A.tile_base + blockIdx.x;
-    const uint32_t rec = A.cls_tile_rec[ctile];
-    const uint32_t tile = A.cls_tile_gid[ctile];
-    const uint32_t nvalid = A.rec_nvalid[rec];
-    const uint32_t I0 = A.cls_tile_i0[ctile];
-    const bool first = I0 == w - 1;                    // first tile of its record
-    const uint32_t I1 = (uint32_t)min((uint64_t)I0 + A.TW, (uint64_t)nvalid);   // no wrap near 2^32 k-mers
-    const uint32_t E0 = first ? 0u : I0 - A.halo;      // halo >= w, a whole number of runs when w > L
-    const uint32_t ne = I1 - E0;
-    const uint32_t e_first = I0 - E0;
-    const uint32_t pos0 = A.cls_tile_pos0[ctile];   // the tile lies in ONE valid segment: idx g <-> pos0 + g
-    if (pos0 == 0xFFFFFFFFu) return;                // its reach crosses invalid bases: the generic kernel does it (gap list)
-    const uint64_t b_first = A.rec_base[rec] + pos0 + E0;
-    const uint32_t ph = (uint32_t)b_first & 15u;
-    const uint64_t word0 = b_first >> 4;
+    // ONE 32-byte scalar load tells the workgroup everything about its tile (r02: four per-tile words, then the record's base
+    // and length -- two dependent round trips before the first byte of the tile could be requested)
+    const TileDesc D = A.cls_desc[ctile];
+    const uint32_t rec = D.rec, tile = D.gid, ne = D.ne;
+    const bool first = D.i0 == w - 1;                  // first tile of its record
+    const uint32_t e_first = first ? w - 1 : A.halo;   // tile-local index of the first owned window end (halo >= w, whole runs when w > L)
+    const uint32_t ph = (uint32_t)D.bfirst & 15u;
+    const uint64_t word0 = D.bfirst >> 4;
+    SK_STAMP(0);
 
-    {   // stage the tile's packed words (coalesced), clear the emit bitmap, load the LUT
-        const uint32_t nw = (ph + ne + k + 14) / 16 + 2;
-        for (uint32_t i = tid; i < nw; i += B) {
-            const uint64_t gw = word0 + i;
-            STG[i] = (gw < A.packed_words) ? A.packed[gw] : 0u;
+    {   // stage the tile's packed words (coalesced), clear the emit bitmap, load the LUT and the warm-up table
+        // Everything the tile needs from global memory is REQUESTED first and stored to LDS afterwards: one round trip.  (r02:
+        // the word loop, the LUT and the table each waited for their own loads before the next were issued -- five round trips,
+        // 5 000 of a wave's 27 000 cycles, r03 stamps.)
+        const uint32_t nw = (ph + ne + k + 14) / 16 + 2;      // words the tile reads (<= NSTG)
+        const uint32_t nq = (nw + 3) / 4;                     // in groups of four: one 16-byte load per thread
+        struct __attribute__((packed, aligned(4))) Words4 { uint32_t x, y, z, w; };
+        static_assert(C::NSTG % 4 == 0 && (C::off_STG % 16) == 0, "16-byte stores into the staging area");
+        constexpr uint32_t QI = ((uint32_t)C::NSTG / 4 + B - 1) / B;    // groups per thread (1 for 256 threads, 3 for 64)
+        constexpr uint32_t TI = 256 / B;                                  // warm-up table rows per thread
+        Words4 pw[QI];
+#pragma unroll
+        for (uint32_t q = 0; q < QI; ++q) {
+            const uint32_t g = tid + q * B;
+            const uint64_t gw = word0 + 4ull * g;
+            pw[q] = Words4{0, 0, 0, 0};
+            if (g < nq) {
+                if (gw + 4 <= A.packed_words) {
+                    pw[q] = *reinterpret_cast<const Words4 *>(A.packed + gw);
+                } else {                                      // the batch's last words
+                    if (gw < A.packed_words) pw[q].x = A.packed[gw];
+                    if (gw + 1 < A.packed_words) pw[q].y = A.packed[gw + 1];
+                    if (gw + 2 < A.packed_words) pw[q].z = A.packed[gw + 2];
+                }
+            }
         }
+        const uint64_t lutv = (tid < 40) ? A.lut[tid] : 0ull;
+        ulonglong2 t4v[TI];
+#pragma unroll
+        for (uint32_t q = 0; q < TI; ++q) t4v[q] = reinterpret_cast<const ulonglong2 *>(A.t4)[tid + q * B];
+        // (tested only here, so that the whole descriptor is ONE scalar load and the tile's loads are on their way)
+        if (D.flags & 1u) return;                      // its reach crosses invalid bases: the generic kernel does it (gap list)
         for (uint32_t i = tid; i < (uint32_t)C::NEM; i += B) EM[i] = 0;
-        if (tid < 40) LUT[tid] = A.lut[tid];
         if (tid == 0) MISC[1] = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < QI; ++q) {
+            const uint32_t g = tid + q * B;
+            if (g < nq) *reinterpret_cast<uint4 *>(STG + 4 * g) = make_uint4(pw[q].x, pw[q].y, pw[q].z, pw[q].w);
+        }
+        if (tid < 40) LUT[tid] = lutv;
         // the 4 KiB warm-up table lives in LDS while the runs are hashed, in the space the suffix records take afterwards
         // (five dependent gathers per lane from global memory were ~4 % of the kernel's time, all of it latency)
-        for (uint32_t i = tid; i < 256u; i += B)
-            reinterpret_cast<ulonglong2 *>(REC)[i] = reinterpret_cast<const ulonglong2 *>(A.t4)[i];
+#pragma unroll
+        for (uint32_t q = 0; q < TI; ++q) reinterpret_cast<ulonglong2 *>(REC)[tid + q * B] = t4v[q];
     }
     __syncthreads();
-
+    SK_STAMP(1);
     const uint32_t e0 = tid * L;
     const uint32_t n = (e0 < ne) ? min((uint32_t)L, ne - e0) : 0u;
     uint64_t h[L];
@@ -612,6 +695,7 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
             return (sh >= 4 ? (m >> (sh - 4)) : (m << 4)) & 0xF0u;
         };
         const unsigned char *LUTb = reinterpret_cast<const unsigned char *>(LUT);
+        SK_STAMP(2);   // warm-up done
         uint64_t lf, lr;
         {
             const ulonglong2 e = *reinterpret_cast<const ulonglong2 *>(LUTb + lut_off(1));
@@ -641,7 +725,10 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
             }
         }
     }
+    SK_STAMP(3);   // roll loop done
     __syncthreads();   // every wave is done with the warm-up table: its space now takes the suffix records
+    SK_STAMP(4);
+    if (SW_SK_SLEEP) __builtin_amdgcn_s_sleep(SW_SK_SLEEP);
     if (n) {
         // ---- suffix records of the run, right to left (registers only) ---------------------------
         uint64_t cur = 0;
@@ -655,16 +742,33 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
             // are not written and the count is recovered from the address
             const uint32_t ra0 = (uint32_t)(C::off_REC + (size_t)tid * RC * 8), ra_end = ra0 + RC * 8;
             uint32_t ra = ra0 + 8;
+            if (SK_CLAMP) {
+                // the slot address stops at the lane's last slot: a 13th record overwrites the 12th, and such a run (more records
+                // than published, counted from the mask) sends its tile to the generic kernel anyway -- one v_min per record
+                // instead of a compare and an EXEC round trip (r03: 104.6 -> 103.4 ms at 15 000 genomes)
+                const uint32_t ra_last = ra_end - 8;
 #pragma unroll
-            for (int j = L - 2; j >= 0; --j) {
-                if (h[j] < cur) {                   // strictly smaller than everything to its right
-                    cur = h[j];
-                    mask |= 1u << j;
-                    if (ra < ra_end) *reinterpret_cast<uint64_t *>(smem + ra) = cur;
-                    ra += 8;
+                for (int j = L - 2; j >= 0; --j) {
+                    if (h[j] < cur) {               // strictly smaller than everything to its right
+                        cur = h[j];
+                        mask |= 1u << j;
+                        *reinterpret_cast<uint64_t *>(smem + ra) = cur;
+                        ra = min(ra + 8u, ra_last);
+                    }
                 }
+                cnt = (uint32_t)__popc(mask);
+            } else {
+#pragma unroll
+                for (int j = L - 2; j >= 0; --j) {
+                    if (h[j] < cur) {                   // strictly smaller than everything to its right
+                        cur = h[j];
+                        mask |= 1u << j;
+                        if (ra < ra_end) *reinterpret_cast<uint64_t *>(smem + ra) = cur;
+                        ra += 8;
+                    }
+                }
+                cnt = (ra - ra0) >> 3;
             }
-            cnt = (ra - ra0) >> 3;
         } else {
 #pragma unroll
             for (int j = L - 1; j >= 0; --j) {
@@ -683,6 +787,7 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
         RMp[tid] = (uint16_t)(e0 + off);
         if (cnt > A.rc_limit) MISC[1] = 1;                   // more records than published: redo this tile exactly
     }
+    SK_STAMP(5);   // suffix records published
     __syncthreads();
     if (MISC[1]) {                                   // uniform: hand the tile to the generic kernel (list mode)
         if (tid == 0) {
@@ -695,6 +800,7 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
     }
 
     // ---- phase 2: rightmost minimum of every window ending in this lane's run -------------------
+    SK_STAMP(6);
     if (n && e0 + n > w - 1) {
         const uint32_t j0 = (e0 >= w - 1) ? 0u : (w - 1 - e0);
         const uint32_t x0 = e0 + j0 - (w - 1);
@@ -703,17 +809,40 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
         uint64_t mA_h = ~0ull, mB_h = ~0ull;
         uint32_t mA_e = 0, mB_e = 0, maskA = 0, maskB = 0;
         if (rxA < tid) {
-            for (uint32_t r = tid; r-- > rxA + 2;) {
-                const uint64_t hh = RMh[r];
-                if (hh < mB_h) { mB_h = hh; mB_e = RMp[r]; }
-            }
-            mA_h = mB_h;
-            mA_e = mB_e;
-            maskA = MASK[rxA];
-            if (rxA + 1 < tid) {
-                const uint64_t hh = RMh[rxA + 1];
-                if (hh < mA_h) { mA_h = hh; mA_e = RMp[rxA + 1]; }
+            constexpr uint32_t WR = 6;   // whole runs read at once (w = 200, L = 32: five)
+            if (SK_RUNMIN_UNROLLED && __all(rxA + 1 < tid && tid - rxA - 2 <= WR)) {
+                // The kernel is bound by the latency of a wave's own instruction stream (r03: a sleep of 1 000 cycles per tile
+                // costs 3.5 %), and the counted loop below is one LDS round trip per run: here the minima of all runs, then the
+                // positions of the two winners, are requested together -- two round trips (r03 stamps: 1 144 -> ~300 cycles).
+                const uint32_t nw = tid - rxA - 2;       // runs every window of the lane holds whole: tid - 1 down to rxA + 2
+                uint64_t v[WR];
+#pragma unroll
+                for (uint32_t i = 0; i < WR; ++i) v[i] = RMh[max(tid - 1u - i, rxA + 1u)];   // (beyond nw: run rxA + 1, not looked at)
+                const uint64_t hA = RMh[rxA + 1];
+                maskA = MASK[rxA];
                 maskB = MASK[rxA + 1];
+                uint32_t br = rxA + 1;                   // run of the rightmost minimum (rxA + 1: none)
+#pragma unroll
+                for (uint32_t i = 0; i < WR; ++i)
+                    if (i < nw && v[i] < mB_h) { mB_h = v[i]; br = tid - 1u - i; }   // right to left, strictly smaller: the rightmost wins
+                const uint32_t eB = RMp[br], eA = RMp[rxA + 1];
+                mB_e = nw ? eB : 0u;
+                mA_h = mB_h;
+                mA_e = mB_e;
+                if (hA < mA_h) { mA_h = hA; mA_e = eA; }
+            } else {
+                for (uint32_t r = tid; r-- > rxA + 2;) {
+                    const uint64_t hh = RMh[r];
+                    if (hh < mB_h) { mB_h = hh; mB_e = RMp[r]; }
+                }
+                mA_h = mB_h;
+                mA_e = mB_e;
+                maskA = MASK[rxA];
+                if (rxA + 1 < tid) {
+                    const uint64_t hh = RMh[rxA + 1];
+                    if (hh < mA_h) { mA_h = hh; mA_e = RMp[rxA + 1]; }
+                    maskB = MASK[rxA + 1];
+                }
             }
         }
         // Window [x, e] = left region [x, e0) (earlier runs) + own prefix [e0, e].  The left region only
@@ -753,6 +882,7 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
         // the tile's first own one (its winner is cleared below: the previous tile emits it).
         const bool owner = e0 >= e_first, last_halo = e0 + (uint32_t)L == e_first;
         const bool wave_full = __all(n == (uint32_t)L && (owner || last_halo) && h[0] != ~0ull) && w > (uint32_t)L;
+        SK_STAMP(7);   // whole-run minima, masks
         if (wave_full) {
             if (last_halo) {
                 recompute(xb + (uint32_t)(L - 1), xb + (uint32_t)(L - 1) >= bnd);
@@ -823,12 +953,16 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
             }
         }
     }
+    SK_STAMP(8);   // window loop done
     __syncthreads();
-    if (tid == 0 && !first) {
-        const uint32_t sarg = MISC[0];
-        EM[sarg >> 5] &= ~(1u << (sarg & 31u));
+    if (SK_TWO_BARRIERS) {
+        if (tid == 0 && !first) {
+            const uint32_t sarg = MISC[0];
+            EM[sarg >> 5] &= ~(1u << (sarg & 31u));
+        }
+        __syncthreads();
     }
-    __syncthreads();
+    SK_STAMP(9);
 
     // ---- phase 3: compact the set bits in position order (hashes come from registers) -----------
     uint32_t bits = 0;
@@ -839,16 +973,19 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
             bits = (EM[tid >> 1] >> ((tid & 1u) * 16u)) & 0xFFFFu;
         }
         if (n < (uint32_t)L) bits &= (1u << n) - 1u;
+        if (!SK_TWO_BARRIERS && !first) {
+            // the winner of the window just before the tile belongs to the previous tile: its owner lane drops it from its
+            // own bits (r02: one thread cleared it in the bitmap between two barriers -- a barrier and a serial LDS round trip more)
+            const uint32_t sarg = MISC[0];
+            if ((sarg >> LSH) == tid) bits &= ~(1u << (sarg & LM));
+        }
     }
     const uint32_t cnt = (uint32_t)__popc(bits);
     const uint32_t lane = tid & 63u, wave = tid >> 6;
-    uint32_t incl = cnt;
-    for (uint32_t d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += up;
-    }
+    const uint32_t incl = wave_incl_scan(cnt);
     if (lane == 63) MISC[4 + wave] = incl;
     __syncthreads();
+    SK_STAMP(10);
     uint32_t wave_off = 0, total = 0;
     for (uint32_t i = 0; i < B / 64; ++i) {
         const uint32_t v = MISC[4 + i];
@@ -878,7 +1015,7 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
         uint64_t *const sh = A.stage_hash + make64(blo, bhi);
         uint64_t *const sk = A.stage_kmer + make64(blo, bhi);
         uint32_t ob = (wave_off + (incl - cnt)) * 8u;   // byte offset inside the tile's range (< 2^32: a range holds <= NE entries)
-        const uint32_t kpos = pos0 + E0 + e0;
+        const uint32_t kpos = D.kpos + e0;
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             if ((bits >> j) & 1u) {
@@ -890,6 +1027,7 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
             }
         }
     }
+    SK_STAMP(11);
 }
 
 // n_occ = sum of the per-tile counts (the tiles take no shared cursor any more): one atomic per workgroup of 4096 tiles.
@@ -900,6 +1038,74 @@ __global__ void k_sum_counts(const uint32_t *__restrict__ tile_count, uint32_t n
         v += tile_count[i];
     for (int d = 32; d; d >>= 1) v += __shfl_down(v, d, 64);
     if ((threadIdx.x & 63u) == 0 && v) atomicAdd(total, v);
+}
+
+// ---- the launch plan's per-tile tables, written on the device (r03) ---------------------------------------------------
+// The host decides per RECORD (how many tiles of which class); these kernels expand that into one descriptor per tile.
+// Before, a host loop over 750 k records / 10.2 M tiles and 160 MB of uploads took 110-120 ms per (batch, k, w) at 15 000
+// genomes -- 0.6 of a device build, paid by every first build.
+struct PlanTilesArgs {
+    const uint32_t *cls_off;        // [R + 1] first tile of every record in this class
+    const uint32_t *big_off;        // [R + 1] the same for the 256-thread class (a record's 64-thread tiles follow its big ones)
+    const uint32_t *rec_tile_off;   // [R + 1] global tile numbering
+    const uint32_t *rec_nvalid, *rec_seg_off, *seg_pos, *seg_idx;
+    const uint64_t *rec_base;
+    uint32_t n_records, n_tiles, cls, w, TW0, TW1, halo;
+    TileDesc *desc;
+    uint32_t *gap_list, *n_gap;
+};
+
+__device__ __forceinline__ uint32_t record_of_tile(const uint32_t *__restrict__ off, uint32_t n_records, uint32_t i)
+{
+    uint32_t lo = 0, hi = n_records;   // last record with off[r] <= i (records without tiles share their successor's offset)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_plan_tiles(const PlanTilesArgs P)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n_tiles) return;
+    const uint32_t r = record_of_tile(P.cls_off, P.n_records, i);
+    const uint32_t t = i - P.cls_off[r];
+    const uint32_t n_big = P.big_off[r + 1] - P.big_off[r];
+    const uint32_t nv = P.rec_nvalid[r];
+    const uint32_t TW = P.cls ? P.TW1 : P.TW0;
+    const uint64_t I0 = (uint64_t)(P.w - 1) + (P.cls ? (uint64_t)n_big * P.TW0 + (uint64_t)t * P.TW1 : (uint64_t)t * P.TW0);
+    const uint64_t I1 = min(I0 + TW, (uint64_t)nv);
+    const uint64_t E0 = (I0 == P.w - 1) ? 0 : I0 - P.halo;
+    // the segment that holds idx E0; the tile is a fast one if its reach [E0, I1) stays inside it
+    uint32_t a = P.rec_seg_off[r], b = P.rec_seg_off[r + 1];
+    const uint32_t s_end = b;
+    while (b - a > 1) {
+        const uint32_t mid = (a + b) >> 1;
+        if (P.seg_idx[mid] <= E0) a = mid; else b = mid;
+    }
+    const uint64_t seg_end = (a + 1 < s_end) ? P.seg_idx[a + 1] : nv;
+    TileDesc d;
+    d.ne = (uint32_t)(I1 - E0);
+    d.i0 = (uint32_t)I0;
+    d.rec = r;
+    d.gid = P.rec_tile_off[r] + (P.cls ? n_big : 0u) + t;
+    d.flags = 0;
+    const uint32_t pos0 = P.seg_pos[a] - P.seg_idx[a];   // idx g <-> pos0 + g inside the segment
+    d.kpos = pos0 + (uint32_t)E0;
+    d.bfirst = P.rec_base[r] + pos0 + E0;
+    if (I1 > seg_end) {
+        d.flags = 1;
+        P.gap_list[atomicAdd(P.n_gap, 1u)] = i;
+    }
+    P.desc[i] = d;
+}
+
+// record of every tile of the generic class
+__global__ void k_plan_gen_rec(const uint32_t *__restrict__ gen_off, uint32_t n_records, uint32_t n_tiles, uint32_t *__restrict__ tile_rec)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_tiles) tile_rec[i] = record_of_tile(gen_off, n_records, i);
 }
 
 size_t lds_bytes_for(uint32_t L)
@@ -970,16 +1176,19 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
 
     const HostBatch &h = b.host;
     const size_t R = h.rec_len.size();
-    std::vector<uint32_t> rec_seg_off(R + 1, 0), rec_nvalid(R, 0), rec_tile_off(R + 1, 0), gen_off(R + 1, 0), seg_pos, seg_idx,
-        gen_rec;
-    struct HostClass { std::vector<uint32_t> rec, pos0, i0, gid, gaps; uint64_t tiles = 0; } hc[2];
-    uint64_t tiles = 0, tiles_g = 0;
-    struct TileDesc { uint32_t cls, i0, pos0; };
-    std::vector<TileDesc> td;
+    // per RECORD: valid k-mers, segments, and how many tiles of which class; the per-tile tables follow on the device
+    std::vector<uint32_t> rec_seg_off(R + 1, 0), rec_nvalid(R, 0), rec_tile_off(R + 1, 0), gen_off(R + 1, 0), off0(R + 1, 0), off1(R + 1, 0),
+        seg_pos, seg_idx;
+    seg_pos.reserve(R);
+    seg_idx.reserve(R);
+    uint64_t tiles = 0, tiles_g = 0, tiles0 = 0, tiles1 = 0;
+    const bool tails = force && !strcmp(force, "tails");
     for (size_t r = 0; r < R; ++r) {
         rec_seg_off[r] = (uint32_t)seg_pos.size();
         rec_tile_off[r] = (uint32_t)tiles;
         gen_off[r] = (uint32_t)tiles_g;
+        off0[r] = (uint32_t)tiles0;
+        off1[r] = (uint32_t)tiles1;
         uint64_t nv = 0;
         for (uint32_t q = h.rec_run_off[r]; q < h.rec_run_off[r + 1]; ++q) {
             if (h.run_len[q] < k) continue;
@@ -1002,53 +1211,42 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
             // 256-thread tile leaves the VALU to its neighbours and costs well under a full one, so the model above does not
             // hold for tails; it stays behind SEQWIN_AMD_SKETCH=tails for experiments.
             bool fast = false;
-            td.clear();
+            uint64_t n_big = 0, n_small = 0;
             if (p.Lf) {
                 const uint64_t TW0 = p.fc[0].TW, TW1 = p.fc[1].TW;
                 const uint64_t nb = windows / TW0, rem = windows % TW0;
                 const uint64_t cost_a = (nb + (rem ? 1 : 0)) * 100;
-                const bool tails = force && !strcmp(force, "tails");
                 const uint64_t cost_b = (TW1 && tails) ? nb * 100 + (rem + TW1 - 1) / TW1 * 32 : ~0ull;
                 const uint64_t cost_c = TW1 ? (windows + TW1 - 1) / TW1 * 32 : ~0ull;
-                uint64_t n_big = nb + (rem ? 1 : 0), n_small = 0;                       // (a)
+                n_big = nb + (rem ? 1 : 0);                                                                  // (a)
                 if (cost_b < cost_a && cost_b <= cost_c) { n_big = nb; n_small = (rem + TW1 - 1) / TW1; }   // (b)
                 else if (cost_c < cost_a) { n_big = 0; n_small = (windows + TW1 - 1) / TW1; }               // (c)
-                for (uint64_t t = 0; t < n_big; ++t) td.push_back({0u, (uint32_t)((w - 1) + t * TW0), 0u});
-                for (uint64_t t = 0; t < n_small; ++t) td.push_back({1u, (uint32_t)((w - 1) + n_big * TW0 + t * TW1), 0u});
                 // a record with invalid bases is cut into the same tiles; those whose reach [E0, I1) crosses a gap are
-                // pre-listed for the generic kernel's list mode (the fast kernels skip them) -- unless most of its tiles
-                // would be, then the whole record goes to the generic class
+                // listed for the generic kernel's list mode (the fast kernels skip them) -- unless most of its tiles
+                // would be, then the whole record goes to the generic class.  Only such records are walked tile by tile here.
                 const uint32_t s0 = rec_seg_off[r], s1 = (uint32_t)seg_pos.size();
-                uint32_t sgm = s0;
-                uint64_t gap_free = 0;
-                for (TileDesc &d : td) {
-                    const uint64_t I0 = d.i0, I1 = std::min<uint64_t>(I0 + p.fc[d.cls].TW, nv);
-                    const uint64_t E0 = (I0 == w - 1) ? 0 : I0 - p.halo_f;
-                    while (sgm + 1 < s1 && seg_idx[sgm + 1] <= E0) ++sgm;          // segment holding idx E0
-                    const uint64_t seg_end = (sgm + 1 < s1) ? seg_idx[sgm + 1] : nv;
-                    if (I1 <= seg_end) {
-                        d.pos0 = seg_pos[sgm] - seg_idx[sgm];
-                        ++gap_free;
-                    } else {
-                        d.pos0 = 0xFFFFFFFFu;
+                if (s1 - s0 <= 1) {
+                    fast = true;
+                } else {
+                    uint32_t sgm = s0;
+                    uint64_t gap_free = 0;
+                    for (uint64_t t = 0; t < n_big + n_small; ++t) {
+                        const uint64_t I0 = (w - 1) + (t < n_big ? t * TW0 : n_big * TW0 + (t - n_big) * TW1);
+                        const uint64_t I1 = std::min<uint64_t>(I0 + (t < n_big ? TW0 : TW1), nv);
+                        const uint64_t E0 = (I0 == w - 1) ? 0 : I0 - p.halo_f;
+                        while (sgm + 1 < s1 && seg_idx[sgm + 1] <= E0) ++sgm;          // segment holding idx E0
+                        const uint64_t seg_end = (sgm + 1 < s1) ? seg_idx[sgm + 1] : nv;
+                        if (I1 <= seg_end) ++gap_free;
                     }
+                    fast = gap_free * 2 >= n_big + n_small;
                 }
-                fast = gap_free * 2 >= td.size();
             }
             if (fast) {
-                for (const TileDesc &d : td) {
-                    HostClass &c = hc[d.cls];
-                    if (d.pos0 == 0xFFFFFFFFu) c.gaps.push_back((uint32_t)c.tiles);
-                    c.rec.push_back((uint32_t)r);
-                    c.pos0.push_back(d.pos0);
-                    c.i0.push_back(d.i0);
-                    c.gid.push_back((uint32_t)tiles);
-                    ++c.tiles;
-                    ++tiles;
-                }
+                tiles0 += n_big;
+                tiles1 += n_small;
+                tiles += n_big + n_small;
             } else {
                 const uint64_t nt = (windows + p.TW - 1) / p.TW;
-                gen_rec.insert(gen_rec.end(), nt, (uint32_t)r);
                 tiles_g += nt;
                 tiles += nt;
             }
@@ -1058,12 +1256,69 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
     rec_seg_off[R] = (uint32_t)seg_pos.size();
     rec_tile_off[R] = (uint32_t)tiles;
     gen_off[R] = (uint32_t)tiles_g;
+    off0[R] = (uint32_t)tiles0;
+    off1[R] = (uint32_t)tiles1;
     p.n_tiles = (uint32_t)tiles;
     p.n_tiles_gen = (uint32_t)tiles_g;
     {   // a tile's own stage slot: 1.5 x the expected 2 / (w + 1) minimizers per window end, + 16
         const uint64_t tw = std::max<uint64_t>(p.TW, p.fc[0].TW);
         p.slot_cap = (uint32_t)std::min<uint64_t>(tw + w, (3 * tw / (w + 1) + 16 + 7) / 8 * 8);
         if (const char *e = getenv("SEQWIN_AMD_SLOT_CAP")) p.slot_cap = (uint32_t)std::max(1, atoi(e));   // test hook
+    }
+
+    auto up32 = [](DevArray<uint32_t> &d, const std::vector<uint32_t> &v) {
+        d.alloc(v.size());
+        if (!v.empty()) SW_HIP(hipMemcpy(d.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    };
+    up32(p.rec_seg_off, rec_seg_off);
+    up32(p.rec_nvalid, rec_nvalid);
+    up32(p.rec_tile_off, rec_tile_off);
+    up32(p.gen_tile_off, gen_off);
+    up32(p.seg_pos, seg_pos);
+    up32(p.seg_idx, seg_idx);
+    up32(p.fc[0].rec_off, off0);
+    up32(p.fc[1].rec_off, off1);
+    {   // the per-tile tables, on the device
+        DevArray<uint32_t> n_gap(2);
+        SW_HIP(hipMemset(n_gap.p, 0, 8));
+        const uint32_t nt[2] = {(uint32_t)tiles0, (uint32_t)tiles1};
+        for (int c = 0; c < 2; ++c) {
+            p.fc[c].n_tiles = nt[c];
+            p.fc[c].desc.alloc(nt[c]);
+            p.fc[c].gap_list.alloc(nt[c]);
+            if (!nt[c]) continue;
+            PlanTilesArgs a;
+            a.cls_off = p.fc[c].rec_off.p;
+            a.big_off = p.fc[0].rec_off.p;
+            a.rec_tile_off = p.rec_tile_off.p;
+            a.rec_nvalid = p.rec_nvalid.p;
+            a.rec_seg_off = p.rec_seg_off.p;
+            a.seg_pos = p.seg_pos.p;
+            a.seg_idx = p.seg_idx.p;
+            a.rec_base = b.d_rec_base.p;
+            a.n_records = (uint32_t)R;
+            a.n_tiles = nt[c];
+            a.cls = (uint32_t)c;
+            a.w = w;
+            a.TW0 = p.fc[0].TW;
+            a.TW1 = p.fc[1].TW;
+            a.halo = p.halo_f;
+            a.desc = p.fc[c].desc.p;
+            a.gap_list = p.fc[c].gap_list.p;
+            a.n_gap = n_gap.p + c;
+            hipLaunchKernelGGL(k_plan_tiles, dim3((nt[c] + 255) / 256), dim3(256), 0, 0, a);
+            SW_HIP(hipGetLastError());
+        }
+        p.gen_tile_rec.alloc(p.n_tiles_gen);
+        if (p.n_tiles_gen) {
+            hipLaunchKernelGGL(k_plan_gen_rec, dim3((p.n_tiles_gen + 255) / 256), dim3(256), 0, 0, p.gen_tile_off.p, (uint32_t)R,
+                               p.n_tiles_gen, p.gen_tile_rec.p);
+            SW_HIP(hipGetLastError());
+        }
+        uint32_t ng[2] = {0, 0};
+        SW_HIP(hipMemcpy(ng, n_gap.p, 8, hipMemcpyDeviceToHost));   // (synchronises: the tables are complete)
+        p.fc[0].n_gap = ng[0];
+        p.fc[1].n_gap = ng[1];
     }
 
     uint64_t lut[40];
@@ -1077,26 +1332,6 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
             lut[2 * idx + 1] = Sk[3 - in] ^ (out < 4 ? S[3 - out] : 0);  // reverse, before the sror
         }
 
-    auto up32 = [](DevArray<uint32_t> &d, const std::vector<uint32_t> &v) {
-        d.alloc(v.size());
-        if (!v.empty()) SW_HIP(hipMemcpy(d.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
-    };
-    up32(p.rec_seg_off, rec_seg_off);
-    up32(p.rec_nvalid, rec_nvalid);
-    up32(p.rec_tile_off, rec_tile_off);
-    for (int c = 0; c < 2; ++c) {
-        p.fc[c].n_tiles = (uint32_t)hc[c].tiles;
-        p.fc[c].n_gap = (uint32_t)hc[c].gaps.size();
-        up32(p.fc[c].tile_rec, hc[c].rec);
-        up32(p.fc[c].tile_i0, hc[c].i0);
-        up32(p.fc[c].tile_gid, hc[c].gid);
-        up32(p.fc[c].tile_pos0, hc[c].pos0);
-        up32(p.fc[c].gap_list, hc[c].gaps);
-    }
-    up32(p.gen_tile_off, gen_off);
-    up32(p.gen_tile_rec, gen_rec);
-    up32(p.seg_pos, seg_pos);
-    up32(p.seg_idx, seg_idx);
     p.lut.alloc(40);
     SW_HIP(hipMemcpy(p.lut.p, lut, sizeof lut, hipMemcpyHostToDevice));
     {   // 4-base warm-up table; byte b = c0 | c1 << 2 | c2 << 4 | c3 << 6 with c0 the earliest base
@@ -1163,6 +1398,14 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
     const uint64_t slots = (uint64_t)plan.n_tiles * plan.slot_cap;
     uint64_t ovf_cap = std::max<uint64_t>(4096, slots / 64);
     Event ev0, ev1, evj(false);
+#ifdef SW_SK_STAMPS
+    DevArray<unsigned long long> stamps;
+    const size_t n_stamp_waves = ((size_t)plan.fc[0].n_tiles / STAMP_EVERY + 1) * (BLOCK / 64);
+    if (getenv("SEQWIN_AMD_STAMPS")) {
+        stamps.alloc(n_stamp_waves * STAMP_SLOTS);
+        SW_HIP(hipMemsetAsync(stamps.p, 0, stamps.bytes(), stream));
+    }
+#endif
     for (;;) {
         const uint64_t cap = slots + ovf_cap;
         out.stage_hash.alloc(cap);
@@ -1192,10 +1435,9 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         a.tile_count = out.tile_count.p;
         a.tile_offset = out.tile_offset.p;
         a.list = nullptr;
-        a.cls_tile_pos0 = nullptr;
+        a.stamps = nullptr;
         a.cls_tile_rec = nullptr;
-        a.cls_tile_i0 = nullptr;
-        a.cls_tile_gid = nullptr;
+        a.cls_desc = nullptr;
         a.cls_tile_off = nullptr;
         a.ovf_count = nullptr;
         a.ovf_list = nullptr;
@@ -1220,10 +1462,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
             const Plan::FastClass &fc = plan.fc[c];
             if (!fc.n_tiles) continue;
             hipStream_t cs = (c == 1 && side) ? side : stream;
-            a.cls_tile_rec = fc.tile_rec.p;
-            a.cls_tile_pos0 = fc.tile_pos0.p;
-            a.cls_tile_i0 = fc.tile_i0.p;
-            a.cls_tile_gid = fc.tile_gid.p;
+            a.cls_desc = fc.desc.p;
             a.ovf_count = ovf_count.p + c;
             a.ovf_list = ovf_list[c];
             a.L = plan.Lf;
@@ -1232,6 +1471,9 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
             for (uint32_t tb = 0; tb < fc.n_tiles; tb += MAX_TILES_PER_LAUNCH) {
                 const uint32_t nt = std::min(fc.n_tiles - tb, MAX_TILES_PER_LAUNCH);
                 a.tile_base = tb;
+#ifdef SW_SK_STAMPS
+                a.stamps = (c == 0 && tb == 0) ? stamps.p : nullptr;
+#endif
                 if (plan.Lf == 32 && c == 0) hipLaunchKernelGGL((sketch_fast_kernel<32, BLOCK>), dim3(nt), dim3(BLOCK), 0, cs, a);
                 else if (plan.Lf == 32) hipLaunchKernelGGL((sketch_fast_kernel<32, 64>), dim3(nt), dim3(64), 0, cs, a);
                 else if (c == 0) hipLaunchKernelGGL((sketch_fast_kernel<16, BLOCK>), dim3(nt), dim3(BLOCK), 0, cs, a);
@@ -1247,8 +1489,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         if (plan.n_tiles_gen) {
             a.cls_tile_off = plan.gen_tile_off.p;
             a.cls_tile_rec = plan.gen_tile_rec.p;
-            a.cls_tile_i0 = nullptr;      // own class: tile t of its record, (w - 1) + t * TW
-            a.cls_tile_gid = nullptr;
+            a.cls_desc = nullptr;         // own class: tile t of its record, (w - 1) + t * TW
             a.L = plan.L;
             a.TW = plan.TW;
             a.n_tiles = plan.n_tiles_gen;
@@ -1267,9 +1508,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         for (int c = 0; c < 2; ++c) {
             const Plan::FastClass &fc = plan.fc[c];
             if (!fc.n_tiles) continue;
-            al[c].cls_tile_rec = fc.tile_rec.p;
-            al[c].cls_tile_i0 = fc.tile_i0.p;
-            al[c].cls_tile_gid = fc.tile_gid.p;
+            al[c].cls_desc = fc.desc.p;
             al[c].ovf_count = ovf_count.p + c;
             al[c].L = plan.Lg_list;
             al[c].TW = fc.TW;
@@ -1316,6 +1555,33 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         }
         if (total[0] <= ovf_cap) {
             out.n_occ = total[1];
+#ifdef SW_SK_STAMPS
+            if (stamps.p) {   // mean shader clocks between the stamps of a wave, over the sampled tiles
+                std::vector<unsigned long long> hs(n_stamp_waves * STAMP_SLOTS);
+                SW_HIP(hipMemcpy(hs.data(), stamps.p, stamps.bytes(), hipMemcpyDeviceToHost));
+                double acc[STAMP_SLOTS] = {0}, tile_life = 0;
+                size_t nw = 0, nt = 0;
+                for (size_t t = 0; t + (BLOCK / 64) <= n_stamp_waves; t += BLOCK / 64) {
+                    unsigned long long t_first = ~0ull, t_last = 0;
+                    bool ok = true;
+                    for (size_t wv = 0; wv < BLOCK / 64; ++wv) {
+                        const unsigned long long *st = &hs[(t + wv) * STAMP_SLOTS];
+                        if (!st[0] || !st[11]) { ok = false; continue; }
+                        for (int i = 1; i <= 11; ++i) acc[i] += st[i] && st[i - 1] ? (double)(st[i] - st[i - 1]) : 0.0;
+                        ++nw;
+                        t_first = std::min(t_first, st[0]);
+                        t_last = std::max(t_last, st[11]);
+                    }
+                    if (ok) { tile_life += (double)(t_last - t_first); ++nt; }
+                }
+                fprintf(stderr, "[stamps] %zu waves of %zu tiles; mean clocks per phase:", nw, nt);
+                static const char *nm[] = {"", "stage+barrier", "warmup", "roll", "barrier", "suffix", "barrier+ovf", "runmins", "windows",
+                                           "barrier x2", "scan+barrier", "emit"};
+                double sum = 0;
+                for (int i = 1; i <= 11; ++i) { fprintf(stderr, " %s=%.0f", nm[i], nw ? acc[i] / nw : 0.0); sum += nw ? acc[i] / nw : 0.0; }
+                fprintf(stderr, " | wave total %.0f, tile first-to-last %.0f\n", sum, nt ? tile_life / nt : 0.0);
+            }
+#endif
             break;
         }
         ovf_cap = total[0];  // exact size is now known

@@ -229,7 +229,9 @@ class HipEngine:
         check(lib.sw_index_ranks_marked(ix._h, ctypes.byref(m)))
         return bool(m.value)
 
-    def adjacency_pairs(self, occ, ranks_by_row, n_bits: int, asm_base: int, rank_bounds):
+    def adjacency_pairs(self, occ, ranks_by_row, node_base, asm_base: int, rank_bounds):
+        """ranks_by_row: slice-LOCAL ranks (uint32 patterns, repeat mark in bit 31) in partitioned-row order; node_base: prefix
+        of the node counts of the tuple owners.  -> (keys by edge owner, counts, candidate rows, candidate counts, (lo_bits, hi_bits))"""
         from ._lib import c_u64, c_vp, check, lib
         t = self.torch
         ranks_by_row = ranks_by_row.to(self.gpu).contiguous()
@@ -237,22 +239,33 @@ class HipEngine:
         keys = t.empty((m,), dtype=t.int64, device=self.gpu)
         nb = len(rank_bounds)
         b = (c_u64 * max(nb, 1))(*rank_bounds)
-        cnt, ccnt = (c_u64 * (nb + 1))(), (c_u64 * (nb + 1))()
-        check(lib.sw_occ_adjacency_pairs(occ._h, c_vp(ranks_by_row.data_ptr()), c_u64(n_bits), c_u64(asm_base), b, c_u64(nb),
-                                         c_vp(keys.data_ptr()), cnt, ccnt, c_vp(self._stream())))
+        base = (c_u64 * len(node_base))(*node_base)
+        cnt, ccnt, bits = (c_u64 * (nb + 1))(), (c_u64 * (nb + 1))(), (c_u64 * 2)()
+        check(lib.sw_occ_adjacency_pairs(occ._h, c_vp(ranks_by_row.data_ptr()), base, c_u64(len(node_base) - 1), c_u64(asm_base), b,
+                                         c_u64(nb), c_vp(keys.data_ptr()), cnt, ccnt, bits, c_vp(self._stream())))
         counts, cand_counts = [int(x) for x in cnt], [int(x) for x in ccnt]
         cand = t.empty((sum(cand_counts), 2), dtype=t.int64, device=self.gpu)
         check(lib.sw_occ_candidates(occ._h, c_vp(cand.data_ptr()), c_vp(self._stream())))
-        return keys[:sum(counts)].to(self.device), counts, cand.to(self.device), cand_counts
+        return keys[:sum(counts)].to(self.device), counts, cand.to(self.device), cand_counts, (int(bits[0]), int(bits[1]))
 
-    def slice_edges_pairs(self, ix, keys, cand, n_bits: int, asm_bits: int, rank_hash) -> None:
+    def slice_edges_pairs(self, ix, keys, cand, key_bits, lo_base: int, asm_bits: int, rank_hash, node_base, pad: int) -> None:
+        """rank_hash: the job-wide table, owner o's node hashes at [o * pad, o * pad + its count)."""
         from ._lib import c_u64, c_vp, check, lib
         keys = keys.to(self.gpu).contiguous()
         cand = cand.to(self.gpu).contiguous()
         rank_hash = rank_hash.to(self.gpu).contiguous()
+        base = (c_u64 * len(node_base))(*node_base)
         check(lib.sw_slice_edges_pairs(ix._h, c_vp(keys.data_ptr()), c_u64(keys.shape[0]), c_vp(cand.data_ptr()),
-                                       c_u64(cand.shape[0]), c_u64(n_bits), c_u64(asm_bits), c_vp(rank_hash.data_ptr()),
-                                       c_vp(self._stream())))
+                                       c_u64(cand.shape[0]), c_u64(key_bits[0]), c_u64(key_bits[1]), c_u64(lo_base), c_u64(asm_bits),
+                                       c_vp(rank_hash.data_ptr()), base, c_u64(len(node_base) - 1), c_u64(pad), c_vp(self._stream())))
+
+    def node_hash_part(self, ix, pad: int):
+        """This slice's share of the job-wide rank -> hash table: its node hashes at the front of `pad` words (the rest
+        is never read: sw_slice_edges_pairs goes through node_base)."""
+        from ._lib import c_vp, check, lib
+        out = self.torch.empty((pad,), dtype=self.torch.int64, device=self.gpu)
+        check(lib.sw_index_node_hashes(ix._h, c_vp(out.data_ptr()), c_vp(self._stream())))
+        return out.to(self.device)
 
     def free_occ(self, occ) -> None:
         occ.close()
@@ -322,9 +335,12 @@ class ShardedIndex:
         mine = np.array(self.engine.checksums(self.merged, *bases), np.uint64)
         if len(sizes) == 1:
             return tuple(int(v) for v in mine)
-        t = torch.from_numpy(mine.view(np.int64).copy()).to(self.engine.device)   # int64 addition wraps = sum modulo 2^64
+        # sum modulo 2^64 without relying on signed overflow in the backend: 32-bit halves, each sum below 2^63
+        halves = np.stack([mine & np.uint64(0xFFFFFFFF), mine >> np.uint64(32)]).astype(np.int64)
+        t = torch.from_numpy(halves).to(self.engine.device)
         dist.all_reduce(t, group=self.group)
-        return tuple(int(v) for v in t.cpu().numpy().view(np.uint64))
+        lo, hi = t.cpu().numpy().astype(np.uint64)
+        return tuple(int(v) for v in (lo + (hi << np.uint64(32))))
 
     def gather(self, dst: int = 0, group=None):
         """Concatenate all slices on rank ``dst`` -> (kmers, nodes, edges, record_offsets) or None elsewhere.
@@ -349,7 +365,8 @@ class ShardedIndex:
             buf[:len(raw)] = torch.from_numpy(raw.copy())
             buf = buf.to(self.engine.device)
             parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-            dist.gather(buf, parts, dst=dst, group=group)
+            # (dst is a rank of `group`; dist.gather addresses processes by their global rank)
+            dist.gather(buf, parts, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
             if rank == dst:
                 out.append(np.concatenate([p.cpu().numpy()[:sizes[r][j] * dt.itemsize].view(dt) for r, p in enumerate(parts)]))
         if rank != dst:
@@ -428,6 +445,17 @@ def rank_bounds(n_parts: int, total_nodes: int) -> list[int]:
     return [total_nodes - math.isqrt(((n_parts - j) * total_nodes * total_nodes) // n_parts) for j in range(1, n_parts)]
 
 
+def node_bases(node_counts) -> list[int]:
+    """Prefix of the slice owners' node counts: global rank = node_bases[owner] + slice-local rank.
+    SEQWIN_DIST_NODE_SPACING=K (tests) leaves K unused ranks behind every owner's nodes, so that a small job walks through the
+    rank widths of BASELINE configs[4] (5e9 distinct minimizers: 33-bit ranks) -- every consumer goes through the bases."""
+    spacing = int(os.environ.get("SEQWIN_DIST_NODE_SPACING", "0"))
+    out = [0]
+    for c in node_counts:
+        out.append(out[-1] + int(c) + spacing)
+    return out
+
+
 def adjacency_asm_bits(n_bits: int, n_assemblies_total: int) -> int:
     """Width of the assembly field of a packed adjacency key ((rank_lo << n_bits | rank_hi) << asm_bits | assembly),
     or 0 when the key does not fit 64 bits and rows travel as {key, assembly} pairs."""
@@ -445,13 +473,31 @@ def _exchange_rows(rows, counts, dev, group):
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     send = torch.tensor([int(c) for c in counts], dtype=torch.int64, device=dev)
-    parts = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(parts, send, group=group)
-    matrix = torch.stack(parts).tolist()                      # matrix[src][dst]
+    parts = torch.empty((world, world), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(parts.view(-1), send, group=group)
+    matrix = parts.tolist()                                   # matrix[src][dst]
     recv_l = [int(matrix[src][rank]) for src in range(world)]
     out = torch.empty((sum(recv_l),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
     dist.all_to_all_single(out, rows.contiguous(), recv_l, [int(c) for c in counts], group=group)
     return out, recv_l, matrix
+
+
+def _exchange_rows_pair(rows_a, counts_a, rows_b, counts_b, dev, group):
+    """Two row exchanges (adjacency keys and candidate rows) whose split sizes travel in ONE all_gather."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    send = torch.tensor([int(c) for c in counts_a] + [int(c) for c in counts_b], dtype=torch.int64, device=dev)
+    parts = torch.empty((world, 2 * world), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(parts.view(-1), send, group=group)
+    matrix = parts.tolist()                                   # matrix[src] = counts_a by destination, then counts_b
+    outs = []
+    for rows, counts, off in ((rows_a, counts_a, 0), (rows_b, counts_b, world)):
+        recv_l = [int(matrix[src][off + rank]) for src in range(world)]
+        out = torch.empty((sum(recv_l),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
+        dist.all_to_all_single(out, rows.contiguous(), recv_l, [int(c) for c in counts], group=group)
+        outs.append(out)
+    return outs
 
 
 def _gather_ints(values, dev, group) -> list[int]:
@@ -459,9 +505,9 @@ def _gather_ints(values, dev, group) -> list[int]:
     import torch
     import torch.distributed as dist
     t = torch.tensor([int(v) for v in (values if isinstance(values, (list, tuple)) else [values])], dtype=torch.int64, device=dev)
-    parts = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
-    dist.all_gather(parts, t, group=group)
-    return [int(x) for x in torch.cat(parts).tolist()]   # one device-to-host copy
+    out = torch.empty((dist.get_world_size(group) * t.numel(),), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return [int(x) for x in out.tolist()]   # one device-to-host copy
 
 
 def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, group=None) -> ShardedIndex:
@@ -520,60 +566,60 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     t3 = time.perf_counter()
 
     # C2: node ranks back to the sources; C3: rank -> hash table everywhere
-    # A slice build may have marked, in bit 31 of the ranks, the occurrences whose node recurs in their assembly: if every
-    # slice did and the job has fewer than 2^31 nodes, the adjacency travels in its pairs form (one 64-bit key per record
-    # plus the few records that can repeat a pair inside an assembly) instead of {pair, assembly} rows.
+    # A slice build marks, in bit 31 of the slice-local ranks it returns, the occurrences whose node recurs in their assembly:
+    # if every slice did, the adjacency travels in its pairs form -- one 64-bit key per record plus the few records that can
+    # repeat a pair inside an assembly.  The ranks go back as they are (32 bits, slice-local); the sources re-base them inside
+    # the library (global rank = node_base[owner] + local rank, possibly more than 32 bits) -- no arithmetic on them here.
     marked = bool(getattr(engine, "ranks_marked", lambda ix: False)(ix))
-    REP = 0x80000000
     if multi:
         info = _gather_ints([n_nodes, 1 if marked else 0], dev, group)          # [n_nodes, marked] of every rank
         node_cnt, all_marked = info[0::2], all(info[1::2])
-        node_base, total_nodes = sum(node_cnt[:rank]), sum(node_cnt)
-        if total_nodes >= 0xFFFFFFFF:
-            raise RuntimeError("more than 2^32-2 nodes")
-        pairs = all_marked and total_nodes < REP and not os.environ.get("SEQWIN_AMD_NO_PACKED_EDGES")
-        # slice-local ranks are uint32 bit patterns held in int32: widen UNSIGNED, add the base below the mark
-        rr = r_ranks.to(torch.int64) & 0xFFFFFFFF
-        if marked:
-            rr = ((rr & (REP - 1)) + node_base) | ((rr & REP) if pairs else 0)
-        else:
-            rr = rr + node_base
-        r_ranks = rr.to(torch.int32)
-        ranks_by_row = torch.empty((occ.n,), dtype=torch.int32, device=dev)
-        dist.all_to_all_single(ranks_by_row, r_ranks.contiguous(), [int(c) for c in cnt], recv_cnt, group=group)
-        hashes = engine.node_hashes(ix)
-        pad = max(node_cnt)
-        mine = torch.zeros((pad,), dtype=torch.int64, device=dev)
-        mine[:n_nodes] = hashes
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        hash_work = dist.all_gather(parts, mine, group=group, async_op=True)   # overlaps the adjacency build below
-        rank_hash = None
     else:
-        total_nodes, rank_hash, hash_work = n_nodes, engine.node_hashes(ix), None
-        pairs = marked and total_nodes < REP and not os.environ.get("SEQWIN_AMD_NO_PACKED_EDGES")
-        ranks_by_row = r_ranks if (pairs or not marked) else (r_ranks.to(torch.int64) & (REP - 1)).to(torch.int32)
-    n_bits = max(1, (total_nodes).bit_length())     # total_nodes <= 2^n_bits - 1
+        node_cnt, all_marked = [n_nodes], marked
+    node_base = node_bases(node_cnt)
+    total_nodes = node_base[-1]
+    pairs = all_marked and not os.environ.get("SEQWIN_AMD_NO_PACKED_EDGES")
+    rb = rank_bounds(world, total_nodes)
     if pairs:
         asm_bits = max(1, int(shard.n_assemblies_total).bit_length())
-        adj, acnt, cand, ccnt = engine.adjacency_pairs(occ, ranks_by_row, n_bits, shard.first_assembly,
-                                                       rank_bounds(world, total_nodes))
         if multi:
-            r_adj, _, _ = _exchange_rows(adj, acnt, dev, group)
-            r_cand, _, _ = _exchange_rows(cand, ccnt, dev, group)
+            ranks_by_row = torch.empty((occ.n,), dtype=torch.int32, device=dev)
+            dist.all_to_all_single(ranks_by_row, r_ranks.contiguous(), [int(c) for c in cnt], recv_cnt, group=group)
+            pad = max(1, max(node_cnt))
+            mine = engine.node_hash_part(ix, pad)                               # this slice's hashes at the front of `pad` words
+            table = torch.empty((world * pad,), dtype=torch.int64, device=dev)
+            hash_work = dist.all_gather_into_tensor(table, mine, group=group, async_op=True)   # overlaps the adjacency build below
+        else:
+            ranks_by_row, pad, hash_work = r_ranks, max(1, n_nodes), None
+            table = engine.node_hash_part(ix, pad)
+        adj, acnt, cand, ccnt, key_bits = engine.adjacency_pairs(occ, ranks_by_row, node_base, shard.first_assembly, rb)
+        if multi:
+            r_adj, r_cand = _exchange_rows_pair(adj, acnt, cand, ccnt, dev, group)
+            hash_work.wait()
         else:
             r_adj, r_cand = adj, cand
+        t4 = time.perf_counter()
+        engine.slice_edges_pairs(ix, r_adj, r_cand, key_bits, rb[rank - 1] if rank else 0, asm_bits, table, node_base, pad)
     else:
+        # {pair, assembly} rows or packed (pair, assembly) keys on GLOBAL 32-bit ranks (test knob; slices without marks)
+        REP = 0x80000000
+        if total_nodes >= 0xFFFFFFFF:
+            raise RuntimeError("more than 2^32-2 nodes need the pairs form of the adjacency (every slice must mark its ranks)")
+        rr = r_ranks.to(torch.int64) & 0xFFFFFFFF                               # uint32 patterns held in int32: widen UNSIGNED
+        rr = ((rr & (REP - 1)) if marked else rr) + node_base[rank]
+        if multi:
+            ranks_by_row = torch.empty((occ.n,), dtype=torch.int32, device=dev)
+            dist.all_to_all_single(ranks_by_row, rr.to(torch.int32).contiguous(), [int(c) for c in cnt], recv_cnt, group=group)
+            parts = [torch.empty((max(1, max(node_cnt)),), dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(parts, engine.node_hash_part(ix, max(1, max(node_cnt))), group=group)
+            rank_hash = torch.cat([p[:c] for p, c in zip(parts, node_cnt)])
+        else:
+            ranks_by_row, rank_hash = rr.to(torch.int32), engine.node_hashes(ix)
+        n_bits = max(1, (total_nodes).bit_length())     # total_nodes <= 2^n_bits - 1
         asm_bits = adjacency_asm_bits(n_bits, shard.n_assemblies_total)
-        adj, acnt = engine.adjacency(occ, perm, ranks_by_row, n_bits, asm_bits, shard.first_assembly,
-                                     rank_bounds(world, total_nodes))
+        adj, acnt = engine.adjacency(occ, perm, ranks_by_row, n_bits, asm_bits, shard.first_assembly, rb)
         r_adj = _exchange_rows(adj, acnt, dev, group)[0] if multi else adj
-    if multi:
-        hash_work.wait()
-        rank_hash = torch.cat([p[:c] for p, c in zip(parts, node_cnt)])
-    t4 = time.perf_counter()
-    if pairs:
-        engine.slice_edges_pairs(ix, r_adj, r_cand, n_bits, asm_bits, rank_hash)
-    else:
+        t4 = time.perf_counter()
         engine.slice_edges(ix, r_adj, n_bits, asm_bits, rank_hash)
     tm.update(engine.timings(ix))
     t5 = time.perf_counter()

@@ -35,6 +35,9 @@ SMOKE = [HERE / "smoke/targets/target-1.fasta", HERE / "smoke/targets/target-2.f
          HERE / "smoke/non-targets/non-target-1.fasta", HERE / "smoke/non-targets/non-target-2.fasta"]
 SMOKE_KW = [(17, 10), (21, 200), (7, 10), (15, 50), (31, 50)]
 HASH_K = [3, 4, 15, 16, 17, 18, 19, 21, 31, 32, 33, 34, 47, 64]
+# round 3: the k and w the GPU tests use against the oracle beyond the fast kernel's k <= 256 / the tiles' w <= 4096
+HASH_K_WIDE = [100, 255, 256, 257, 300]
+LONG_KW = [(64, 1000), (100, 4097), (255, 200), (256, 1000), (257, 20000), (300, 1000)]
 
 
 def synth_sets(rng: np.random.Generator) -> dict[str, list[Path]]:
@@ -75,11 +78,34 @@ def synth_sets(rng: np.random.Generator) -> dict[str, list[Path]]:
     e1.write_text(">empty\n>short\nACGTACGTAC\n\n>dupA\r\n" + wrap(d, 80, "\r\n") + "  \n>dupB extra words\n" + wrap(d, 50) +
                   ">tandem\n" + wrap("ACGTTGCA" * 120, 64) + ">polyA\n" + wrap("A" * 600, 100))
     e2 = out / "edge_2.fa.gz"  # gzip member, leading N's, trailing N's
-    with gzip.open(e2, "wt") as f:
-        f.write(">gz1\n" + wrap("NNNNNNNN" + rand(800) + "NNNN", 61) + ">gz2\n" + wrap(mutate(d, 0.02), 70))
+    e2_text = ">gz1\n" + wrap("NNNNNNNN" + rand(800) + "NNNN", 61) + ">gz2\n" + wrap(mutate(d, 0.02), 70)
+    if not e2.exists() or gzip.open(e2, "rt").read() != e2_text:   # (a gzip member carries its time stamp: not rewritten when unchanged)
+        with gzip.open(e2, "wt") as f:
+            f.write(e2_text)
     e3 = out / "edge_3.fa"  # no records at all
     e3.write_text("")
     sets["edge"] = [e0, e1, e2, e3]
+
+    # long: contigs long enough for windows of thousands of k-mers (own generator: the sets above stay as they are)
+    rl = np.random.default_rng(20261004)
+
+    def randl(n):
+        return "".join(B[rl.integers(0, 4, n)])
+
+    base = randl(52_000)
+    paths = []
+    for a in range(3):
+        sq = list(base)
+        idx = rl.random(len(sq)) < 0.01
+        for i in np.nonzero(idx)[0]:
+            sq[i] = B[rl.integers(0, 4)]
+        sq = "".join(sq)
+        if a == 1:   # N runs: one long, two closer than k = 300 to each other
+            sq = sq[:9000] + "N" * 700 + sq[9000:30000] + "N" + sq[30000:30200] + "NN" + sq[30200:]
+        p = out / f"long_{a}.fa"
+        p.write_text(f">long{a}_c0\n" + wrap(sq, 80) + f">long{a}_c1 short\n" + wrap(randl(1500), 80))
+        paths.append(p)
+    sets["long"] = paths
     return sets
 
 
@@ -105,7 +131,12 @@ def main() -> None:
             ref._get_penalty_native(arrays["kmers"], scored, arrays["record_offsets"],
                                     np.asarray(is_targets, np.bool_), 1)
             arrays["nodes_scored"] = scored
-        np.savez_compressed(out / f"{name}.npz", **arrays)
+        f = out / f"{name}.npz"
+        if f.exists():   # (an existing vector is checked, not rewritten: the archives are not byte-reproducible)
+            old = np.load(f)
+            assert sorted(old.files) == sorted(arrays) and all(np.array_equal(old[k_], arrays[k_]) for k_ in arrays), name
+        else:
+            np.savez_compressed(f, **arrays)
         manifest["cases"].append(dict(name=name, paths=[str(p.relative_to(HERE)) for p in paths], k=k, w=w,
                                       is_targets=is_targets, ids=ids,
                                       n_kmers=int(len(arrays["kmers"])), n_nodes=int(len(arrays["nodes"])),
@@ -117,8 +148,10 @@ def main() -> None:
         add(f"pan_k{k}_w{w}", sets["pan"], k, w, [True, True, True, False, False, False])
     for k, w in [(21, 200), (11, 5), (17, 10), (5, 1), (33, 40)]:
         add(f"edge_k{k}_w{w}", sets["edge"], k, w, [True, False, True, False])
-    for k in HASH_K:  # w = 1: every valid k-mer is its own minimizer
+    for k in HASH_K + HASH_K_WIDE:  # w = 1: every valid k-mer is its own minimizer
         add(f"hash_k{k}", [sets["edge"][0], SMOKE[0]], k, 1)
+    for k, w in LONG_KW:
+        add(f"long_k{k}_w{w}", sets["long"], k, w, [True, False, True])
 
     # (iv) operator-level known answers, inputs as in the reference's test_graph.py
     K, N = oracle.KMER_DTYPE, oracle.NODE_DTYPE

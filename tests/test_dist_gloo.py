@@ -112,7 +112,7 @@ class NumpyEngine:
         perm = np.argsort(owner, kind="stable")
         rows = np.stack([occ.hash[perm], occ.kmer[perm] + (U64(rec_offset) << U64(32))], axis=1)
         counts = np.bincount(owner, minlength=len(bounds) + 1).tolist()
-        occ.perm = perm   # (the HIP engine's handle remembers its partition the same way)
+        occ.perm, occ.counts = perm, counts   # (the HIP engine's handle remembers its partition the same way)
         return torch.from_numpy(rows.view(np.int64).copy()), torch.from_numpy(perm.astype(np.int32)), counts
 
     def slice_build(self, rows, kmer_base, record_offsets, is_targets):
@@ -133,28 +133,44 @@ class NumpyEngine:
     def ranks_marked(self, ix):
         return ix.get("marked", False)
 
-    def adjacency_pairs(self, occ, ranks_by_row, n_bits, asm_base, rank_bounds):
+    def adjacency_pairs(self, occ, ranks_by_row, node_base, asm_base, rank_bounds):
+        # slice-local ranks (+ repeat mark) come back in partitioned-row order; the owner of row j follows from the partition
         w = np.zeros(occ.n, U64)
         w[occ.perm] = ranks_by_row.numpy().view(np.uint32).astype(U64)
-        rank, rep = w & U64(0x7FFFFFFF), (w >> U64(31)).astype(bool)
+        own = np.zeros(occ.n, np.int64)
+        own[occ.perm] = np.repeat(np.arange(len(occ.counts)), occ.counts)
+        rank = (w & U64(0x7FFFFFFF)) + np.asarray(node_base, U64)[own]
+        rep = (w >> U64(31)).astype(bool)
+        total = int(node_base[-1])
+        lo_base = np.array([0] + [int(b) for b in rank_bounds], dtype=U64)
+        ends = [int(b) for b in rank_bounds] + [total]
+        widest = max(e - int(b) for e, b in zip(ends, lo_base))
+        hi_bits, lo_bits = max(1, total.bit_length()), max(1, int(widest).bit_length())
+        assert lo_bits + hi_bits <= 64
         rec = (occ.kmer >> U64(32)).astype(np.int64)
         ok = rec[1:] == rec[:-1] if occ.n > 1 else np.zeros(0, bool)
-        u, v = rank[:-1][ok], rank[1:][ok]
-        key = (np.minimum(u, v) << U64(n_bits)) | np.maximum(u, v)
+        u, v = np.minimum(rank[:-1], rank[1:])[ok], np.maximum(rank[:-1], rank[1:])[ok]
+        owner = np.searchsorted(np.array(rank_bounds, dtype=U64), u, side="right")
+        key = ((u - lo_base[owner]) << U64(hi_bits)) | v
         asm = (occ.rec_asm[rec[:-1][ok]] + asm_base).astype(U64)
         cand = (rep[:-1] | rep[1:])[ok] if occ.n > 1 else np.zeros(0, bool)
-        kb = np.array([b << n_bits for b in rank_bounds], dtype=U64)
-        owner = np.searchsorted(kb, key, side="right")
         p = np.argsort(owner, kind="stable")
         co = owner[cand]
         cp = np.argsort(co, kind="stable")
         crows = np.stack([key[cand][cp], asm[cand][cp]], axis=1) if cand.any() else np.zeros((0, 2), U64)
         return (torch.from_numpy(key[p].view(np.int64).copy()), np.bincount(owner, minlength=len(rank_bounds) + 1).tolist(),
-                torch.from_numpy(crows.view(np.int64).copy()), np.bincount(co, minlength=len(rank_bounds) + 1).tolist())
+                torch.from_numpy(crows.view(np.int64).copy()), np.bincount(co, minlength=len(rank_bounds) + 1).tolist(),
+                (lo_bits, hi_bits))
 
-    def slice_edges_pairs(self, ix, keys, cand, n_bits, asm_bits, rank_hash):
+    def slice_edges_pairs(self, ix, keys, cand, key_bits, lo_base, asm_bits, rank_hash, node_base, pad):
         k = keys.numpy().view(U64)
         table = rank_hash.numpy().view(U64)
+        base = np.asarray(node_base, U64)
+
+        def hash_of(rank):   # owner o's hashes sit at table[o * pad ...]
+            o = np.searchsorted(base[1:-1], rank, side="right")
+            return table[(o.astype(U64) * U64(pad) + (rank - base[o])).astype(np.int64)]
+
         edges = np.zeros(0, oracle.EDGE_DTYPE)
         if len(k):
             uk, cnt = np.unique(k, return_counts=True)
@@ -163,11 +179,17 @@ class NumpyEngine:
             if len(c):   # records that repeat their (pair, assembly) do not count
                 rows, rc = np.unique(c, axis=0, return_counts=True)
                 np.subtract.at(w, np.searchsorted(uk, rows[:, 0]), rc - 1)
+            hi_bits = key_bits[1]
             edges = np.zeros(len(uk), oracle.EDGE_DTYPE)
-            edges["first"] = table[(uk >> U64(n_bits)).astype(np.int64)]
-            edges["second"] = table[(uk & U64((1 << n_bits) - 1)).astype(np.int64)]
+            edges["first"] = hash_of((uk >> U64(hi_bits)) + U64(lo_base))
+            edges["second"] = hash_of(uk & U64((1 << hi_bits) - 1))
             edges["weight"] = w.astype(np.uint64)
         ix["edges"] = edges
+
+    def node_hash_part(self, ix, pad):
+        out = np.zeros(pad, U64)
+        out[:len(ix["nodes"])] = ix["nodes"]["hash"]
+        return torch.from_numpy(out.view(np.int64).copy())
 
     def node_hashes(self, ix):
         return torch.from_numpy(ix["nodes"]["hash"].view(np.int64).copy())

@@ -155,13 +155,17 @@ def test_rccl_collectives_world1(tmp_path):
     assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
 
 
-def routed_tuple_exchange(paths, world, k, w, tar, packed=True, pairs=None):
+def routed_tuple_exchange(paths, world, k, w, tar, packed=True, pairs=None, shards=None, sums_only=False):
     """The tuple-exchange form with the all-to-all steps done by hand on ONE GPU (P shards, one after another).
     pairs (default: whenever the slices marked their ranks, as dist.py decides): adjacency as pair keys + candidate rows;
-    else packed keys (when they fit) or {pair, assembly} rows."""
+    else packed keys (when they fit) or {pair, assembly} rows.
+    shards: ready-made Shard objects instead of FASTA paths; sums_only: return (sizes, checksums) of the concatenated
+    result -- every slice's share at its offsets, added modulo 2^64 -- instead of the arrays (full-size runs)."""
     eng = swdist.HipEngine()
-    parts = swdist.partition_assemblies(len(paths), world)
-    shards = [swdist.Shard(Batch.from_fasta(paths[a:b], n_cpu=2), a, len(paths)) for a, b in parts]
+    if shards is None:
+        parts = swdist.partition_assemblies(len(paths), world)
+        shards = [swdist.Shard(Batch.from_fasta(paths[a:b], n_cpu=2), a, len(paths)) for a, b in parts]
+    assert len(shards) == world
     occs = [eng.sketch(s, k, w) for s in shards]
     offs = [s.batch.record_offsets() for s in shards]
     rec_base, glob, total = [], [np.zeros(1, np.uint32)], 0
@@ -180,36 +184,39 @@ def routed_tuple_exchange(paths, world, k, w, tar, packed=True, pairs=None):
         slices.append((ix, r_ranks))
         kbase += r_rows.shape[0]
     node_cnt = [s[0].sizes()[1] for s in slices]
-    total_nodes = sum(node_cnt)
+    node_base = swdist.node_bases(node_cnt)
+    total_nodes = node_base[-1]
     REP = 0x80000000
     marked = [eng.ranks_marked(s[0]) for s in slices]
     if pairs is None:
-        pairs = all(marked) and total_nodes < REP
-    assert not pairs or (all(marked) and total_nodes < REP)
+        pairs = all(marked)
+    assert not pairs or all(marked)
     for owner in range(world):
         ix, r_ranks = slices[owner]
-        rr = r_ranks.to(torch.int64) & 0xFFFFFFFF
-        if marked[owner]:   # the mark in bit 31 stays above the re-based rank (pairs form) or is dropped
-            rr = ((rr & (REP - 1)) + sum(node_cnt[:owner])) | ((rr & REP) if pairs else 0)
+        if pairs:
+            g = r_ranks                              # slice-local, repeat mark in bit 31: the sources re-base them in the library
         else:
-            rr = rr + sum(node_cnt[:owner])
-        g = rr.to(torch.int32)
+            rr = r_ranks.to(torch.int64) & 0xFFFFFFFF
+            g = (((rr & (REP - 1)) if marked[owner] else rr) + node_base[owner]).to(torch.int32)
         o = 0
         for r in range(world):
             c = int(cnts[r][owner])
             ranks_back[r][owner] = g[o:o + c]
             o += c
-    rank_hash = torch.cat([eng.node_hashes(s[0]) for s in slices])
-    n_bits = max(1, total_nodes.bit_length())
+    pad = max(1, max(node_cnt))
     rb = swdist.rank_bounds(world, total_nodes)
-    asm_bits = swdist.adjacency_asm_bits(n_bits, shards[0].n_assemblies_total) if packed else 0
     if pairs:
+        table = torch.cat([eng.node_hash_part(s[0], pad) for s in slices])          # what all_gather_into_tensor leaves
         asm_bits = max(1, int(shards[0].n_assemblies_total).bit_length())
+    else:
+        rank_hash = torch.cat([eng.node_hashes(s[0]) for s in slices])
+        n_bits = max(1, total_nodes.bit_length())
+        asm_bits = swdist.adjacency_asm_bits(n_bits, shards[0].n_assemblies_total) if packed else 0
     adj = []
     for r in range(world):
         by_row = torch.cat(ranks_back[r]) if occs[r].n else torch.zeros(0, dtype=torch.int32, device=eng.gpu)
         if pairs:
-            adj.append(eng.adjacency_pairs(occs[r], by_row, n_bits, shards[r].first_assembly, rb))
+            adj.append(eng.adjacency_pairs(occs[r], by_row, node_base, shards[r].first_assembly, rb))
         else:
             adj.append(eng.adjacency(occs[r], perms[r], by_row, n_bits, asm_bits, shards[r].first_assembly, rb))
     kmers, nodes, edges = [], [], []
@@ -223,11 +230,22 @@ def routed_tuple_exchange(paths, world, k, w, tar, packed=True, pairs=None):
                 cc = np.concatenate([[0], np.cumsum(adj[r][3])])
                 cpieces.append(adj[r][2][cc[owner]:cc[owner + 1]])
         if pairs:
-            eng.slice_edges_pairs(slices[owner][0], torch.cat(pieces), torch.cat(cpieces), n_bits, asm_bits, rank_hash)
+            assert all(a[4] == adj[0][4] for a in adj)        # every source derives the same key layout
+            eng.slice_edges_pairs(slices[owner][0], torch.cat(pieces), torch.cat(cpieces), adj[0][4], rb[owner - 1] if owner else 0,
+                                  asm_bits, table, node_base, pad)
         else:
             eng.slice_edges(slices[owner][0], torch.cat(pieces), n_bits, asm_bits, rank_hash)
-        K, N, E = slices[owner][0].export()
-        kmers.append(K); nodes.append(N); edges.append(E)
+        if not sums_only:
+            K, N, E = slices[owner][0].export()
+            kmers.append(K); nodes.append(N); edges.append(E)
+    if sums_only:
+        sizes, sums = [0, 0, 0], [0, 0, 0]
+        for ix, _ in slices:
+            share = ix.checksums(*sizes)
+            sums = [(a + b) % 2**64 for a, b in zip(sums, share)]
+            sizes = [a + b for a, b in zip(sizes, ix.sizes())]
+            ix.close()
+        return tuple(sizes), tuple(sums)
     return np.concatenate(kmers), np.concatenate(nodes), np.concatenate(edges), record_offsets
 
 
@@ -243,6 +261,34 @@ def test_routed_tuple_exchange_equals_single_batch(world):
             got = routed_tuple_exchange(paths, world, k, w, tar, packed, pairs)
             assert np.array_equal(got[0], ek) and np.array_equal(got[1], en), (world, k, w, packed, pairs)
             assert np.array_equal(got[2], ee) and np.array_equal(got[3], eo), (world, k, w, packed, pairs)
+
+
+def test_routed_tuple_exchange_with_33_bit_ranks(monkeypatch):
+    """BASELINE configs[4] at k >= 19 has ~5e9 distinct minimizers over 8 GPUs: global node ranks need 33 bits and an edge key
+    holds rank_lo relative to its owner's range (31 bits at most) next to a 33-bit rank_hi.  SEQWIN_DIST_NODE_SPACING leaves
+    625 M unused ranks behind every owner's nodes, so this small set walks through exactly those widths."""
+    monkeypatch.setenv("SEQWIN_DIST_NODE_SPACING", str(625_000_000))
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa")) + sorted((GOLDEN / "synth").glob("edge_*"))]
+    tar = [i % 3 != 0 for i in range(len(paths))]
+    for k, w in [(15, 20), (21, 200)]:
+        ek, en, ee, eo, _ = oracle.build(paths, k, w)
+        oracle.get_penalty(ek, en, eo, tar)
+        got = routed_tuple_exchange(paths, 8, k, w, tar)
+        assert np.array_equal(got[0], ek) and np.array_equal(got[1], en) and np.array_equal(got[2], ee) and np.array_equal(got[3], eo)
+    # the key layout such a job gets: 33-bit rank_hi, rank_lo within 31 bits
+    eng = swdist.HipEngine()
+    shard = swdist.Shard(Batch.from_fasta(paths[:2], n_cpu=2), 0, len(paths))
+    occ = eng.sketch(shard, 15, 20)
+    rows, _, cnt = eng.partition(occ, swdist.hash_bounds(8)[0], 0)
+    base = swdist.node_bases([1000] * 8)
+    assert base[-1] > 2**32
+    out = eng.adjacency_pairs(occ, torch.zeros(occ.n, dtype=torch.int32, device=eng.gpu), base, 0, swdist.rank_bounds(8, base[-1]))
+    assert out[4] == (31, 33)
+    # two owners cannot hold that many ranks in a 64-bit key: refused, not wrapped
+    rows2, _, _ = eng.partition(occ, swdist.hash_bounds(2)[0], 0)
+    with pytest.raises(RuntimeError, match="64-bit edge keys"):
+        eng.adjacency_pairs(occ, torch.zeros(occ.n, dtype=torch.int32, device=eng.gpu), [0, 2**32, 2**33], 0,
+                            swdist.rank_bounds(2, 2**33))
 
 
 @pytest.mark.parametrize("case", ["few_tops_random_lows", "pairs_sharing_top", "ascending_lows", "random", "one_top_long_runs",

@@ -132,6 +132,18 @@ def test_config2_full_size_properties(tmp_path):
     gold = json.loads((GOLDEN / "bench_checksums.json").read_text())["bacteria15k/k21/w200"]
     assert gold["counts"] == {"kmers": nk, "nodes": nn, "edges": ne}
     assert [f"{s:016x}" for s in ix.checksums()] == gold["checksums"]
+    # The full-size arrays themselves against the compiled reference, through a restriction: the occurrences of the first
+    # 256 genomes (record_idx < 256 * 50), grouped by node, keep their order in the 15 000-genome result (hash order, then
+    # (record, pos) inside a node) -- they must be exactly the reference's `kmers` of those 256 genomes, node for node.
+    n_sub = 256
+    K, N, _ = ix.export()
+    sel = np.flatnonzero(K["record_idx"] < n_sub * rpg)
+    sub_k = K[sel]
+    node_of = np.searchsorted(N["start"], sel, side="right") - 1
+    del K
+    sub_nodes, sub_start, sub_cnt = np.unique(node_of, return_index=True, return_counts=True)
+    sub_hash = N["hash"][sub_nodes]
+    del N, sel, node_of
     # idempotence at full size
     ix.close()
     ix2 = b.build_index(k, w, tar)
@@ -147,7 +159,84 @@ def test_config2_full_size_properties(tmp_path):
     six = sub.build_index(k, w, tar[:n])
     K, N, E = six.export()
     assert np.array_equal(K, ek) and np.array_equal(N, en) and np.array_equal(E, ee), kind
+    # ... and the restriction of the 75 Gbp build taken above
+    assert n == n_sub and np.array_equal(sub_k, ek), kind
+    assert np.array_equal(sub_hash, en["hash"]) and np.array_equal(sub_start.astype(np.uint64), en["start"]), kind
+    assert np.array_equal((sub_start + sub_cnt).astype(np.uint64), en["stop"]), kind
     # a shard of the job holds the same genomes as the unsharded batch (bench.py --gpus N, strong scaling)
     sh = Batch.synthetic(3, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED, first_genome=100)
     offs, ids = sh.records()
     assert ids[0][0] == "g100_c0" and sh.record(0) == sub.record(100 * rpg) and sh.record(3 * rpg - 1) == sub.record(103 * rpg - 1)
+
+
+def _bench_line(extra_args, env_extra):
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline"] + extra_args, capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_config3_sharded_full_size():
+    """BASELINE configs[3] -- the 15 000-genome set through the SHARDED path -- at full size on this one GPU, twice:
+    (1) seqwin_amd.dist.build_sharded_index with every collective issued for real over RCCL at world size 1
+        (bench.py, SEQWIN_DIST_FORCE_COLLECTIVES=1): the line's checksums must be the committed N = 1 ones;
+    (2) routed by hand for P = 8: the eight shards a node's GPUs would hold (Batch.synthetic(first_genome=...), the
+        reference's worker partition build.cpp:350-356) are sketched one after another, their tuples, ranks and adjacency
+        keys are routed exactly as the all-to-all steps route them, and the eight slices' checksum shares
+        (sw_index_checksums_at) must add up to the same committed checksums -- shard-count invariance
+        (reference tests/smoke/test_graph.py:67-127) on the 75 Gbp set."""
+    from test_gpu_dist import routed_tuple_exchange
+
+    from seqwin_amd import dist as swdist
+    gold = json.loads((GOLDEN / "bench_checksums.json").read_text())["bacteria15k/k21/w200"]
+    line = _bench_line(["--steps", "1", "--warmup", "1"], {"SEQWIN_DIST_FORCE_COLLECTIVES": "1", "SEQWIN_BENCH_FORCE_DIST": "1"})
+    assert line["parity"]["n1_checksums_equal"] is True and line["counts"] == gold["counts"]
+    assert line["checksums"] == gold["checksums"]
+
+    G, rpg, rl, anc, snp, _ = WORKLOADS["bacteria15k"]
+    world, k, w = 8, 21, 200
+    tar = np.arange(G) % 2 == 0
+    shards = []
+    for first, end in swdist.partition_assemblies(G, world):
+        shards.append(swdist.Shard(Batch.synthetic(end - first, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED, first_genome=first),
+                                   first, G))
+    sizes, sums = routed_tuple_exchange(None, world, k, w, tar, shards=shards, sums_only=True)
+    assert dict(zip(("kmers", "nodes", "edges"), sizes)) == gold["counts"]
+    assert [f"{v:016x}" for v in sums] == gold["checksums"]
+
+
+@pytest.mark.parametrize("k", [15, 19, 31])
+def test_config4_slice(tmp_path, k):
+    """BASELINE configs[4] (100 000 x 5 Mbp iid-random genomes over 8 GPUs, k in {15, 19, 31}): one GPU's share,
+    12 500 genomes = 62.5 Gbp, every minimizer nearly its own node at k >= 19 (622 M nodes, 60-bit edge keys).
+    Device-side structural self-check, the committed checksums, and the first 64 genomes of the same generator against
+    the compiled reference."""
+    G, rpg, rl, anc, snp, _ = WORKLOADS["random100k"]
+    w = 200
+    b = Batch.synthetic(G, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED)
+    tar = np.arange(G) % 2 == 0
+    ix = b.build_index(k, w, tar)
+    nk, nn, ne = ix.sizes()
+    t = ix.timings()
+    assert t["total_bp"] == G * rpg * rl == 62_500_000_000
+    assert 0.0097 < nk / t["total_bp"] < 0.0102
+    v = ix.verify(G)
+    assert all(v[key] == 0 for key in list(v)[:8]), v
+    assert nn <= nk and ne <= nk - G * rpg and ne <= v["weight_sum"] <= nk - G * rpg
+    gold = json.loads((GOLDEN / "bench_checksums.json").read_text())[f"random100k/k{k}/w{w}"]
+    assert gold["counts"] == {"kmers": nk, "nodes": nn, "edges": ne}
+    assert [f"{s:016x}" for s in ix.checksums()] == gold["checksums"]
+    ix.close()
+    n = 64
+    sub = Batch.synthetic(n, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED)
+    assert sub.record(0) == b.record(0) and sub.record(n - 1) == b.record(n - 1)
+    b.close()
+    paths, _ = write_fasta_sample(sub, n, str(tmp_path))
+    ek, en, ee, eo, kind = _reference_arrays(paths, k, w, tar[:n])
+    six = sub.build_index(k, w, tar[:n])
+    K, N, E = six.export()
+    assert np.array_equal(K, ek) and np.array_equal(N, en) and np.array_equal(E, ee), kind
