@@ -92,6 +92,22 @@ def cpu_baseline_and_parity(batch, k, w, n_genomes_sample, is_targets):
         oracle.get_penalty(kmers, nodes, ro, tar)
         runs.append((time.perf_counter() - t0, 1))
     dt, used = min(runs)
+    # T_e2e: the same files through the drop-in boundary -- FASTA on local disk -> numpy arrays + get_penalty (sw_build /
+    # sw_get_penalty: host ingest, upload, device build, download).  Reported beside the baseline; never `value`.
+    from seqwin_amd import _core
+    e2e_runs = []
+    _core._build_native(paths[:2], k, w, 2, False)   # (library warm-up: allocator, module load)
+    for n_cpu in sorted({min(8, cores), cores}):
+        t0 = time.perf_counter()
+        gk, gn, ge, go, _ = _core._build_native(paths, k, w, n_cpu, False)
+        _core._get_penalty_native(gk, gn, go, tar, n_cpu)
+        e2e_runs.append((time.perf_counter() - t0, n_cpu))
+        e2e_equal = bool(np.array_equal(gk, kmers) and np.array_equal(gn, nodes) and np.array_equal(ge, edges))
+        del gk, gn, ge
+    e2e_dt, e2e_cpu = min(e2e_runs)
+    e2e = {"value": round(bp / e2e_dt / 1e9, 3), "unit": "Gbp/s", "n_cpu": e2e_cpu, "equal_to_cpu_baseline": e2e_equal,
+           "sample": f"the same {n} FASTA files through sw_build + sw_get_penalty (ingest + PCIe + device + download); wall "
+                     + ", ".join(f"{t:.3f} s at n_cpu={c}" for t, c in e2e_runs)}
     # the HIP path on the same files, through the same ingest as sw_build
     sb = Batch.from_fasta(paths, n_cpu=min(16, cores))
     six = sb.build_index(k, w, tar)
@@ -110,7 +126,7 @@ def cpu_baseline_and_parity(batch, k, w, n_genomes_sample, is_targets):
             "n_kmers": int(len(kmers)), "n_nodes": int(len(nodes)), "n_edges": int(len(edges))}
     parity = {"vs": kind, "sample_genomes": n, "equal": equal,
               "compared": "kmers, nodes (hash, start, stop, n_tar, n_neg, penalty bit-for-bit), edges, record_offsets"}
-    return base, parity
+    return base, parity, e2e
 
 
 def golden_checksums(workload, k, w):
@@ -206,10 +222,19 @@ def main() -> None:
         if ix is not None:
             (ix.merged if hasattr(ix, "merged") else ix).close()
 
-    ix = None
-    for _ in range(args.warmup):
+    # what a one-shot sw_build pays on the device side: launch plan (host + device, cached in the batch afterwards), first
+    # hipMalloc of every pool block, and the build itself
+    # (the first of the W warm-up steps; with --warmup 0 it is part of the timed region and not reported separately)
+    ix, first_build_ms, first_plan_ms = None, None, None
+    fence()
+    for i in range(args.warmup):
         release(ix)
+        t_first = time.perf_counter()
         ix = step()
+        if i == 0:
+            fence()
+            first_build_ms = (time.perf_counter() - t_first) * 1e3
+            first_plan_ms = ix.timings().get("plan_ms", 0.0)
     fence()
     stage = {}
     t0 = time.perf_counter()
@@ -240,11 +265,22 @@ def main() -> None:
         ms_per_step = dt / args.steps * 1e3
         value = total_bp / (dt / args.steps) / 1e9
         stage = {key: v / args.steps for key, v in stage.items()}
-        # dominant kernel = sketch_fast_kernel (one launch per step per GPU).  Algorithmic bytes per launch
-        # (DESIGN.md section 3.3): read the 2-bit input once + write one 16 B tuple per minimizer.
-        sk_bytes = 0.25 * bp_rank + 16.0 * n_occ_local
-        sk_ms = stage["sketch_ms"]
+        # Dominant kernel: the fused sketch kernel (one launch per step per GPU) wherever the sketch stage is the longest
+        # (w = 200); at small windows the index stages take over and the line says so.  Algorithmic bytes per launch
+        # (DESIGN.md section 3.3): sketch = read the 2-bit input once + write one 16 B tuple per minimizer; nodes stage =
+        # read the tuple + write the kmers entry + the nodes; edges stage = write + read one adjacency record + the edges.
+        tot0 = counts.tolist()
+        stage_bytes = {"sketch_ms": 0.25 * bp_rank + 16.0 * n_occ_local,
+                       "nodes_ms": (24.0 * tot0[0] + 40.0 * tot0[1]) / world,
+                       "edges_ms": (40.0 * tot0[0] + 24.0 * tot0[2]) / world}
+        dominant = max(stage_bytes, key=lambda key: stage.get(key, 0.0))
+        sk_bytes = stage_bytes[dominant]
+        sk_ms = stage[dominant]
         achieved = sk_bytes / (sk_ms * 1e-3) / 1e9
+        plan_L = 32 if w >= 32 else 16
+        dom_kernel = {"sketch_ms": f"sketch_fast_kernel<{plan_L}, 256>" if (k <= 256 and w >= 16) else "sketch_generic_kernel",
+                      "nodes_ms": "nodes stage: rocprim onesweep pair passes + k_nodes + unsort (no single dominant kernel)",
+                      "edges_ms": "edges stage: k_rs_pass_p radix passes + run lengths (no single dominant kernel)"}[dominant]
         # whole path, SURVEY 8d: 0.25 N_bp + 40 N_occ + 40 N_adj + 40 N_node + 24 N_edge  (N_adj ~= N_occ)
         tot = counts.tolist()
         path_bytes = 0.25 * total_bp + 80.0 * tot[0] + 40.0 * tot[1] + 24.0 * tot[2]
@@ -253,7 +289,8 @@ def main() -> None:
         traffic, traffic_src, valu_insts = None, None, None
         try:
             tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-            if (tj.get("workload"), tj.get("k"), tj.get("w")) == (args.workload, k, w) and world == 1:
+            if (tj.get("workload"), tj.get("k"), tj.get("w")) == (args.workload, k, w) and world == 1 and dominant == "sketch_ms" \
+                    and not args.genomes:
                 traffic, traffic_src = int(tj["hbm_bytes_per_launch"]), tj.get("source")
                 valu_insts = tj.get("valu_wave_insts_per_launch")
         except Exception:
@@ -266,17 +303,21 @@ def main() -> None:
                                    f"{snp / 1e4:g}% substitutions), on-device generator, seed {SEED}",
                        "genomes": G_total, "genomes_per_gpu": end - first, "mean_bp": rpg * rl, "k": k, "w": w,
                        "parallelism": f"assembly-sharded x{world} ({scaling} scaling)" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "kernel": "sketch_fast_kernel<32, 256>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(sk_bytes), "avg_launch_ms": round(sk_ms, 4),
-                         "note": "integer-VALU issue bound at w=200 (DESIGN.md section 3.1); measured HBM traffic is in profiles/",
+                         "dominant_stage": dominant,
+                         "note": ("bound by the latency of a wave's own instruction stream and by integer VALU issue at w=200 "
+                                  "(DESIGN.md section 3.1); measured HBM traffic is in profiles/") if dominant == "sketch_ms"
+                                 else "the index stages (HBM-bound radix sorts) take over at small windows; `achieved` is the stage's algorithmic bytes over its time",
                          "path_algorithmic_bytes": int(path_bytes),
                          "path_achieved_GBs": round(path_bytes / world / (dt / args.steps) / 1e9, 2),
                          "path_frac": round(path_bytes / world / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 5),
-                         "sketch_Gbp_per_s_per_gpu": round(bp_rank / (sk_ms * 1e-3) / 1e9, 2)},
+                         "sketch_Gbp_per_s_per_gpu": round(bp_rank / (stage["sketch_ms"] * 1e-3) / 1e9, 2)},
             "stages_ms": {key: round(v, 4) for key, v in stage.items()},
-            "plan_ms": round(tm.get("plan_ms", 0.0), 3),
+            "plan_ms": round(first_plan_ms if first_plan_ms is not None else tm.get("plan_ms", 0.0), 3),
+            "first_build_ms": round(first_build_ms, 3) if first_build_ms is not None else None,
             "counts": {"kmers": tot[0], "nodes": tot[1], "edges": tot[2]},
             "checksums": [f"{s:016x}" for s in sums],
         }
@@ -284,8 +325,8 @@ def main() -> None:
             # explanatory (not the mandated roofline): integer VALU issue, 256 CU x 4 SIMD x 32 lanes x 2.4 GHz peak
             lane_ops = valu_insts * 64.0
             out["roofline"]["valu"] = {"lane_ops_per_bp": round(lane_ops / bp_rank, 1),
-                                       "achieved_Tlaneops_per_s": round(lane_ops / (sk_ms * 1e-3) / 1e12, 2),
-                                       "peak_Tlaneops_per_s": 78.64, "frac": round(lane_ops / (sk_ms * 1e-3) / 78.64e12, 3),
+                                       "achieved_Tlaneops_per_s": round(lane_ops / (stage["sketch_ms"] * 1e-3) / 1e12, 2),
+                                       "peak_Tlaneops_per_s": 78.64, "frac": round(lane_ops / (stage["sketch_ms"] * 1e-3) / 78.64e12, 3),
                                        "source": "SQ_INSTS_VALU of the committed PMC profile (profiles/*_pmc_sketch.txt)",
                                        "note": "peak = 32 lanes/clk/SIMD (2 cycles per wave64 VOP2); three-operand VOP3, v_cndmask, "
                                                "v_cmp and 64-bit moves measure 4.2-4.9 cycles (scripts/micro/valu_kinds.hip), "
@@ -300,7 +341,7 @@ def main() -> None:
             # shard-count invariance at full size: same checksums whatever the number of GPUs (and as in earlier rounds)
             parity["n1_checksums_equal"] = gold["checksums"] == out["checksums"] and gold["counts"] == out["counts"]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"], ref_par = cpu_baseline_and_parity(batch, k, w, args.cpu_sample_genomes, my_targets)
+            out["cpu_baseline"], ref_par, out["e2e"] = cpu_baseline_and_parity(batch, k, w, args.cpu_sample_genomes, my_targets)
             parity.update(ref_par)
         if parity:
             out["parity"] = parity

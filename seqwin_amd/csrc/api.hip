@@ -96,6 +96,7 @@ void alloc_join(hipStream_t side)
     v.erase(std::remove(v.begin(), v.end(), side), v.end());
 }
 
+void release_resident_if_idle();   // (below: drops the parked index of the last sw_build unless a call is using it)
 void *dev_alloc(size_t bytes)
 {
     Pool &p = pool();
@@ -134,6 +135,12 @@ void *dev_alloc(size_t bytes)
     if (e != hipSuccess) {
         (void)hipGetLastError();
         dev_pool_trim();  // give cached blocks back and retry once
+        e = hipMalloc(&ptr, sz);
+    }
+    if (e != hipSuccess) {   // the index a finished sw_build left resident is a convenience, not a claim on HBM
+        (void)hipGetLastError();
+        release_resident_if_idle();
+        dev_pool_trim();
         e = hipMalloc(&ptr, sz);
     }
     if (e != hipSuccess) {
@@ -442,6 +449,14 @@ Resident &resident()
 }
 
 // the sums of k_identity (index.hip) over host arrays, on n_threads threads
+}  // namespace
+void release_resident_if_idle()
+{
+    Resident &r = resident();
+    std::unique_lock<std::mutex> lock(r.mu, std::try_to_lock);   // (held: a get_penalty / filter_kmers call is working on it)
+    if (lock.owns_lock()) r.ix.reset();
+}
+namespace {
 void host_identity(const sw_kmer *kmers, uint64_t nk, const sw_node *nodes, uint64_t nn, unsigned n_threads, uint64_t *sums2)
 {
     const uint64_t G = 0x9E3779B97F4A7C15ULL;
@@ -1298,11 +1313,27 @@ void sw_graph_free(sw_graph *g)
         Resident &r = resident();
         std::lock_guard<std::mutex> lock(r.mu);
         r.ix = std::move(g->g.ixp);
+        if (r.ix) {   // get_penalty / filter_kmers read kmers and nodes only: the edges go back to the pool at once
+            r.ix->edges.release();
+            r.ix->n_edges = 0;
+        }
         r.kmer_sum = g->g.identity[0];
         r.node_sum = g->g.identity[1];
     }
     delete g;
 }
+
+namespace {
+struct FilterStash {
+    const void *kmers = nullptr, *nodes = nullptr;
+    uint64_t n_kmers = 0, n_nodes = 0, n_used = 0, used_sum = 0, nk = 0, nn = 0;
+    uint64_t id[2] = {0, 0};   // position-dependent checksums of the caller's kmers / nodes (host_identity) at the size phase
+    DevArray<sw_kmer> kout;
+    DevArray<sw_node> nout;
+    bool valid = false;
+};
+thread_local FilterStash g_filter_stash;
+}  // namespace
 
 void sw_resident_stats(uint64_t *out)
 {
@@ -1318,6 +1349,7 @@ void sw_release_resident(void)
     Resident &r = resident();
     std::lock_guard<std::mutex> lock(r.mu);
     r.ix.reset();
+    g_filter_stash = FilterStash();   // (this thread's pending sw_filter_kmers result as well)
 }
 
 int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint64_t n_nodes, const uint32_t *record_offsets,
@@ -1387,16 +1419,7 @@ int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint6
 // sw_filter_kmers is called twice per logical call (sizes, then data): the size phase leaves its device result here and
 // the data phase only copies it out when it is called with the same arguments (same host pointers and sizes, same
 // used_hashes content) on the same thread -- one upload and one compute per logical call.
-namespace {
-struct FilterStash {
-    const void *kmers = nullptr, *nodes = nullptr;
-    uint64_t n_kmers = 0, n_nodes = 0, n_used = 0, used_sum = 0, nk = 0, nn = 0;
-    DevArray<sw_kmer> kout;
-    DevArray<sw_node> nout;
-    bool valid = false;
-};
-thread_local FilterStash g_filter_stash;
-}  // namespace
+
 
 int sw_filter_kmers(const sw_kmer *kmers, uint64_t n_kmers, const sw_node *nodes, uint64_t n_nodes,
                     const uint64_t *used_hashes, uint64_t n_used, sw_kmer *kmers_out, sw_node *nodes_out,
@@ -1408,8 +1431,12 @@ int sw_filter_kmers(const sw_kmer *kmers, uint64_t n_kmers, const sw_node *nodes
         for (uint64_t i = 0; i < n_used; ++i) used_sum += mix64(used_hashes[i]);   // order-independent, as the hash set is
         FilterStash &st = g_filter_stash;
         const bool data_phase = kmers_out || nodes_out;
+        const unsigned id_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        uint64_t id_now[2] = {0, 0};
+        if ((data_phase && st.valid) || !data_phase) host_identity(kmers, n_kmers, nodes, n_nodes, id_threads, id_now);
+        // (the contents count, not only the addresses: a caller may have rewritten its arrays in place between the two phases)
         if (data_phase && st.valid && st.kmers == kmers && st.nodes == nodes && st.n_kmers == n_kmers && st.n_nodes == n_nodes &&
-            st.n_used == n_used && st.used_sum == used_sum) {
+            st.n_used == n_used && st.used_sum == used_sum && st.id[0] == id_now[0] && st.id[1] == id_now[1]) {
             *n_kmers_out = st.nk;
             *n_nodes_out = st.nn;
             if (kmers_out && st.nk) SW_HIP(hipMemcpy(kmers_out, st.kout.p, st.nk * sizeof(sw_kmer), hipMemcpyDeviceToHost));
@@ -1429,8 +1456,8 @@ int sw_filter_kmers(const sw_kmer *kmers, uint64_t n_kmers, const sw_node *nodes
         SW_HIP(hipGetDevice(&dev));
         bool use_resident = false;
         if (res.ix && res.ix->device == dev && res.ix->n_kmers == n_kmers && n_kmers) {
-            uint64_t id[2];
-            host_identity(kmers, n_kmers, nullptr, 0, 16, id);
+            uint64_t id[2] = {id_now[0], 0};
+            if (data_phase && !st.valid) host_identity(kmers, n_kmers, nullptr, 0, id_threads, id);
             use_resident = id[0] == res.kmer_sum;
         }
         DevArray<sw_kmer> d_kmers, d_kout;
@@ -1461,6 +1488,8 @@ int sw_filter_kmers(const sw_kmer *kmers, uint64_t n_kmers, const sw_node *nodes
             st.n_nodes = n_nodes;
             st.n_used = n_used;
             st.used_sum = used_sum;
+            st.id[0] = id_now[0];
+            st.id[1] = id_now[1];
             st.nk = nk;
             st.nn = nn;
             st.kout = std::move(d_kout);

@@ -2064,6 +2064,13 @@ void concat_occ(std::vector<OrderedOcc> &chunks, const std::vector<uint64_t> &re
         at += ch.n;
         ch = OrderedOcc();   // (released blocks are reused in stream order)
     }
+    // The chunk-sized blocks are too small for the full-size sort buffers that follow (the pool hands out blocks within 25 %
+    // of the request): back to the device with them now, instead of peaking 24 B per minimizer above the one-shot build until
+    // a failed hipMalloc trims the pool.
+    if (chunks.size() > 1) {
+        SW_HIP(hipStreamSynchronize(stream));
+        dev_pool_trim();
+    }
 }
 
 namespace {

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include "device.hpp"
 
@@ -409,14 +411,22 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
 #endif
     // resident workgroups of the persistent form (per template instance; taken from the first device that sorts -- any number
     // is correct, tiles are handed out by tickets)
-    static int grid_p = 0;
-    if (persistent && !grid_p) {
-        int dev = 0, per_cu = 0;
-        hipDeviceProp_t prop;
+    int grid_p = 0;
+    if (persistent) {
+        static std::mutex &mu = *new std::mutex;                          // leaked on purpose (see api.hip: pool())
+        static std::map<int, int> &grids = *new std::map<int, int>;       // per device (and per template instance)
+        int dev = 0;
         SW_HIP(hipGetDevice(&dev));
-        SW_HIP(hipGetDeviceProperties(&prop, dev));
-        SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pass_p<THREADS, BITS>, THREADS, 0));
-        grid_p = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+        std::lock_guard<std::mutex> lock(mu);
+        int &g = grids[dev];
+        if (!g) {
+            int per_cu = 0;
+            hipDeviceProp_t prop;
+            SW_HIP(hipGetDeviceProperties(&prop, dev));
+            SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pass_p<THREADS, BITS>, THREADS, 0));
+            g = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+        }
+        grid_p = g;
     }
     DevArray<unsigned long long> hist_own(d_hist_given ? 0 : (size_t)n_passes * RADIX), state((size_t)n_tiles * RADIX);
     struct { unsigned long long *p; } hist{d_hist_given ? d_hist_given : hist_own.p};   // ([pass][digit] counts; scanned in place below)

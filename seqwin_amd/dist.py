@@ -465,6 +465,56 @@ def adjacency_asm_bits(n_bits: int, n_assemblies_total: int) -> int:
     return ab if 2 * n_bits + ab <= 64 else 0
 
 
+# RCCL 2.26 (ROCm 7.0, this image) delivers only the first 568.5 MiB of a peer's message in all_to_all_single -- measured at
+# world size 1 with 1.19 GB messages, tests/tools/rccl_self_check.py: everything behind byte 596 115 456 of the output is left
+# untouched, no error.  Messages therefore travel in rounds of at most SEQWIN_DIST_MSG_LIMIT_MB (default 256) per peer.
+_MSG_LIMIT = int(os.environ.get("SEQWIN_DIST_MSG_LIMIT_MB", "256")) << 20
+
+
+def _all_to_all_rows(out, rows, recv_counts, send_counts, group) -> None:
+    """all_to_all_single(out, rows, recv_counts, send_counts) in rounds that keep every per-peer message below _MSG_LIMIT."""
+    import torch
+    import torch.distributed as dist
+    row_bytes = rows.element_size() * (rows[0].numel() if rows.dim() > 1 and rows.shape[0] else 1)
+    cap = max(1, _MSG_LIMIT // max(1, row_bytes))
+    send_counts, recv_counts = [int(c) for c in send_counts], [int(c) for c in recv_counts]
+    if max(send_counts + recv_counts + [0]) <= cap:
+        dist.all_to_all_single(out, rows.contiguous(), recv_counts, send_counts, group=group)
+        return
+    world = len(send_counts)
+    s_off = [sum(send_counts[:p]) for p in range(world)]
+    r_off = [sum(recv_counts[:p]) for p in range(world)]
+    done = 0
+    while done < max(send_counts + recv_counts):
+        s_n = [min(cap, max(0, c - done)) for c in send_counts]
+        r_n = [min(cap, max(0, c - done)) for c in recv_counts]
+        piece = torch.cat([rows[s_off[p] + done:s_off[p] + done + s_n[p]] for p in range(world)])
+        got = torch.empty((sum(r_n),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        dist.all_to_all_single(got, piece, r_n, s_n, group=group)
+        at = 0
+        for p in range(world):
+            out[r_off[p] + done:r_off[p] + done + r_n[p]] = got[at:at + r_n[p]]
+            at += r_n[p]
+        done += cap
+
+
+def _all_gather_parts(table, mine, pad: int, group, async_op: bool = False):
+    """all_gather_into_tensor(table[world * pad], mine[pad]); in rounds through a staging buffer when a part exceeds _MSG_LIMIT."""
+    import torch
+    import torch.distributed as dist
+    if pad * mine.element_size() <= _MSG_LIMIT:
+        return dist.all_gather_into_tensor(table, mine, group=group, async_op=async_op)
+    world = table.numel() // pad
+    cap = _MSG_LIMIT // mine.element_size()
+    view = table.view(world, pad)
+    for at in range(0, pad, cap):
+        n = min(cap, pad - at)
+        got = torch.empty((world, n), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(got.view(-1), mine[at:at + n].contiguous(), group=group)
+        view[:, at:at + n] = got
+    return None
+
+
 def _exchange_rows(rows, counts, dev, group):
     """all_to_all_single of rows grouped by destination.  One all_gather makes the whole (source x destination) count
     matrix known everywhere (instead of a count all_to_all plus further gathers of totals); returns
@@ -478,7 +528,7 @@ def _exchange_rows(rows, counts, dev, group):
     matrix = parts.tolist()                                   # matrix[src][dst]
     recv_l = [int(matrix[src][rank]) for src in range(world)]
     out = torch.empty((sum(recv_l),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
-    dist.all_to_all_single(out, rows.contiguous(), recv_l, [int(c) for c in counts], group=group)
+    _all_to_all_rows(out, rows, recv_l, counts, group)
     return out, recv_l, matrix
 
 
@@ -495,7 +545,7 @@ def _exchange_rows_pair(rows_a, counts_a, rows_b, counts_b, dev, group):
     for rows, counts, off in ((rows_a, counts_a, 0), (rows_b, counts_b, world)):
         recv_l = [int(matrix[src][off + rank]) for src in range(world)]
         out = torch.empty((sum(recv_l),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
-        dist.all_to_all_single(out, rows.contiguous(), recv_l, [int(c) for c in counts], group=group)
+        _all_to_all_rows(out, rows, recv_l, counts, group)
         outs.append(out)
     return outs
 
@@ -584,18 +634,25 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
         asm_bits = max(1, int(shard.n_assemblies_total).bit_length())
         if multi:
             ranks_by_row = torch.empty((occ.n,), dtype=torch.int32, device=dev)
-            dist.all_to_all_single(ranks_by_row, r_ranks.contiguous(), [int(c) for c in cnt], recv_cnt, group=group)
+            _all_to_all_rows(ranks_by_row, r_ranks, cnt, recv_cnt, group)
             pad = max(1, max(node_cnt))
             mine = engine.node_hash_part(ix, pad)                               # this slice's hashes at the front of `pad` words
             table = torch.empty((world * pad,), dtype=torch.int64, device=dev)
-            hash_work = dist.all_gather_into_tensor(table, mine, group=group, async_op=True)   # overlaps the adjacency build below
+            hash_work = _all_gather_parts(table, mine, pad, group, async_op=True)   # overlaps the adjacency build below
         else:
             ranks_by_row, pad, hash_work = r_ranks, max(1, n_nodes), None
             table = engine.node_hash_part(ix, pad)
         adj, acnt, cand, ccnt, key_bits = engine.adjacency_pairs(occ, ranks_by_row, node_base, shard.first_assembly, rb)
         if multi:
+            # (waited for BEFORE the next collective: torch runs synchronous collectives on the current stream and this one on
+            #  its own -- two kernels of one communicator at once corrupt each other's data, seen at world size 1, r03)
+            if hash_work is not None:
+                hash_work.wait()
             r_adj, r_cand = _exchange_rows_pair(adj, acnt, cand, ccnt, dev, group)
-            hash_work.wait()
+            if world == 1 and os.environ.get("SEQWIN_DIST_DEBUG"):   # what went through the collectives must come back unchanged
+                print("[dist debug] ranks", torch.equal(ranks_by_row, r_ranks), "adj", torch.equal(r_adj, adj), tuple(r_adj.shape),
+                      tuple(adj.shape), "cand", torch.equal(r_cand, cand), tuple(cand.shape), "table",
+                      torch.equal(table[:n_nodes], engine.node_hash_part(ix, pad)[:n_nodes]), "counts", acnt, ccnt, flush=True)
         else:
             r_adj, r_cand = adj, cand
         t4 = time.perf_counter()
@@ -609,7 +666,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
         rr = ((rr & (REP - 1)) if marked else rr) + node_base[rank]
         if multi:
             ranks_by_row = torch.empty((occ.n,), dtype=torch.int32, device=dev)
-            dist.all_to_all_single(ranks_by_row, rr.to(torch.int32).contiguous(), [int(c) for c in cnt], recv_cnt, group=group)
+            _all_to_all_rows(ranks_by_row, rr.to(torch.int32), cnt, recv_cnt, group)
             parts = [torch.empty((max(1, max(node_cnt)),), dtype=torch.int64, device=dev) for _ in range(world)]
             dist.all_gather(parts, engine.node_hash_part(ix, max(1, max(node_cnt))), group=group)
             rank_hash = torch.cat([p[:c] for p, c in zip(parts, node_cnt)])

@@ -230,8 +230,16 @@ def test_config4_slice(tmp_path, k):
     gold = json.loads((GOLDEN / "bench_checksums.json").read_text())[f"random100k/k{k}/w{w}"]
     assert gold["counts"] == {"kmers": nk, "nodes": nn, "edges": ne}
     assert [f"{s:016x}" for s in ix.checksums()] == gold["checksums"]
-    ix.close()
     n = 64
+    restricted = None
+    if k == 19:   # (one k: 5 GB of kmers to the host) the 62.5 Gbp arrays themselves, restricted to the first 64 genomes
+        K, N, _ = ix.export()
+        sel = np.flatnonzero(K["record_idx"] < n * rpg)
+        node_of = np.searchsorted(N["start"], sel, side="right") - 1
+        un, ustart, ucnt = np.unique(node_of, return_index=True, return_counts=True)
+        restricted = (K[sel], N["hash"][un], ustart.astype(np.uint64), (ustart + ucnt).astype(np.uint64))
+        del K, N, sel, node_of
+    ix.close()
     sub = Batch.synthetic(n, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED)
     assert sub.record(0) == b.record(0) and sub.record(n - 1) == b.record(n - 1)
     b.close()
@@ -240,3 +248,6 @@ def test_config4_slice(tmp_path, k):
     six = sub.build_index(k, w, tar[:n])
     K, N, E = six.export()
     assert np.array_equal(K, ek) and np.array_equal(N, en) and np.array_equal(E, ee), kind
+    if restricted is not None:
+        assert np.array_equal(restricted[0], ek) and np.array_equal(restricted[1], en["hash"]), kind
+        assert np.array_equal(restricted[2], en["start"]) and np.array_equal(restricted[3], en["stop"]), kind
