@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <map>
 #include <mutex>
 
@@ -20,6 +21,15 @@ namespace sw {
 namespace {
 
 constexpr int RS_ITEMS = 16;
+#ifdef SW_RS_STAMPS   // timing builds: every 64th tile of a pass writes the shader clock at its phase boundaries (thread 0)
+__device__ unsigned long long *g_rs_stamps = nullptr;
+#define RS_STAMP(i)                                                                                        \
+    do {                                                                                                   \
+        if (g_rs_stamps && (tile & 63u) == 0 && threadIdx.x == 0) g_rs_stamps[(size_t)(tile >> 6) * 16 + (i)] = clock64(); \
+    } while (0)
+#else
+#define RS_STAMP(i) do { } while (0)
+#endif
 #ifndef RS_LOOK
 #define RS_LOOK 4   // predecessors read per look-back step (independent loads; 8: more registers and state traffic, 29.0 against 25.1 ms)
 #endif
@@ -273,6 +283,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
         uint32_t tid = tid0;
         asm volatile("" : "+v"(tid));
         const uint32_t lane = tid & 63u, wave = tid >> 6;
+        RS_STAMP(0);
         uint32_t fut = 0;
         if (tid == 0) fut = atomicAdd(ticket, 1u);      // the next tile (the atomic's latency hides behind the ranking)
         for (uint32_t i = tid; i < WAVES * RADIX / 2; i += THREADS) (reinterpret_cast<uint32_t *>(&whist[0][0]))[i] = 0;
@@ -294,7 +305,9 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
             if (live && below == 0) whist[wave][d] = (uint16_t)(prior + (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi));
             __builtin_amdgcn_wave_barrier();
         }
+        RS_STAMP(1);   // this wave's keys ranked
         __syncthreads();
+        RS_STAMP(2);
         uint32_t total = 0, incl = 0;
         unsigned long long pre[RS_LOOK];
         unsigned long long *st = state + (size_t)tile * RADIX;
@@ -319,6 +332,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
             }
             if (lane == 63) wsum[wave] = incl;
         }
+        RS_STAMP(3);   // digit totals published, scan
         __syncthreads();
         uint32_t before = 0;
         if (tid < RADIX) {
@@ -336,6 +350,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                 sk[lstart[d] + whist[wave][d] + rank[i]] = key[i];
             }
         }
+        RS_STAMP(4);   // keys in LDS in digit order
         const uint32_t ntile = s_tile;
 #pragma unroll
         for (int i = 0; i < RS_ITEMS; ++i) {            // the next tile's keys are on their way during the look-back and the write-out
@@ -382,7 +397,9 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
             }
             goff[d] = digit_base[d] + excl - before;
         }
+        RS_STAMP(5);   // digit 0's look-back done
         __syncthreads();
+        RS_STAMP(6);   // every digit's
 #pragma unroll
         for (int j = 0; j < RS_ITEMS; ++j) {
             const uint32_t t = j * THREADS + tid;
@@ -391,6 +408,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                 if (!(dbg & 2u)) out[goff[(uint32_t)(k >> shift) & dmask] + t] = k;
             }
         }
+        RS_STAMP(7);   // stores issued
         // (no barrier here: the next iteration touches sk / goff / s_tile only behind its own barriers)
         tile = ntile;
     }
@@ -442,8 +460,20 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
                            n_passes, hist.p);
     }
     SW_HIP(hipGetLastError());
+#ifdef SW_RS_STAMPS
+    DevArray<unsigned long long> stamps;
+    const size_t n_st = (size_t)(n_tiles / 64 + 1) * 16;
+    if (getenv("SEQWIN_AMD_STAMPS") && persistent) stamps.alloc(n_st);
+#endif
     for (unsigned p = 0; p < n_passes; ++p) {
         const unsigned sh = begin_bit + BITS * p, bits = std::min<unsigned>(BITS, end_bit - sh);
+#ifdef SW_RS_STAMPS
+        if (stamps.p) {
+            SW_HIP(hipMemsetAsync(stamps.p, 0, stamps.bytes(), stream));
+            unsigned long long *ptr = stamps.p;
+            SW_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rs_stamps), &ptr, sizeof ptr, 0, hipMemcpyHostToDevice, stream));
+        }
+#endif
         hipLaunchKernelGGL(k_rs_scan<BITS>, dim3(1), dim3(RADIX), 0, stream, hist.p + (size_t)p * RADIX);
         SW_HIP(hipMemsetAsync(state.p, 0, state.bytes(), stream));
         if (persistent)
@@ -454,6 +484,25 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
             hipLaunchKernelGGL((k_rs_pass<THREADS, BITS>), dim3((unsigned)n_tiles), dim3(THREADS), 0, stream, keys, alt, n, sh, bits,
                                hist.p + (size_t)p * RADIX, state.p, d_fail);
         SW_HIP(hipGetLastError());
+#ifdef SW_RS_STAMPS
+        if (stamps.p) {
+            std::vector<unsigned long long> hs(n_st);
+            SW_HIP(hipStreamSynchronize(stream));
+            SW_HIP(hipMemcpy(hs.data(), stamps.p, stamps.bytes(), hipMemcpyDeviceToHost));
+            double acc[8] = {0};
+            size_t cnt = 0;
+            for (size_t t = 0; t + 16 <= n_st; t += 16) {
+                if (!hs[t] || !hs[t + 7]) continue;
+                for (int i = 1; i <= 7; ++i) acc[i] += (double)(hs[t + i] - hs[t + i - 1]);
+                ++cnt;
+            }
+            static const char *nm[] = {"", "rank", "barrier", "totals+scan", "barrier+scatter", "lookback(d0)", "barrier", "write-out"};
+            fprintf(stderr, "[rs stamps] %d x %d bits, pass %u, %zu tiles sampled; mean clocks:", THREADS, BITS, p, cnt);
+            double sum = 0;
+            for (int i = 1; i <= 7; ++i) { fprintf(stderr, " %s=%.0f", nm[i], cnt ? acc[i] / cnt : 0.0); sum += cnt ? acc[i] / cnt : 0.0; }
+            fprintf(stderr, " | tile %.0f\n", sum);
+        }
+#endif
         std::swap(keys, alt);
     }
     // (hist / state go back to the pool here; their next user is ordered after these kernels on this stream)
@@ -461,7 +510,7 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
 
 }  // namespace
 
-// which shape a sort of `bits` key bits takes: 0 = 512 threads x 8 bits, 1 = 1024 x 9, 2 = 1024 x 8, 3 = 512 x 9 (the last two: A/B)
+// which shape a sort of `bits` key bits takes: 0 = 512 threads x 8 bits, 1 = 1024 x 9, 2 = 1024 x 8, 3 = 512 x 9, 4 = 256 x 8 (the last three: A/B)
 static int pick_shape(unsigned bits)
 {
     const char *e = getenv("SEQWIN_AMD_RADIX_BITS");   // A/B: 8 or 9
@@ -469,6 +518,7 @@ static int pick_shape(unsigned bits)
     const char *shape = getenv("SEQWIN_AMD_RADIX_SHAPE");   // A/B
     if (shape && !strcmp(shape, "1024x8")) return 2;
     if (shape && !strcmp(shape, "512x9")) return 3;
+    if (shape && !strcmp(shape, "256x8")) return 4;
     return nine ? 1 : 0;
 }
 
@@ -494,6 +544,7 @@ void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned beg
     case 2: sort_passes<1024, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
     case 3: sort_passes<512, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
     case 1: sort_passes<1024, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
+    case 4: sort_passes<256, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
     default: sort_passes<512, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
     }
 }
