@@ -5,8 +5,8 @@
 // on the device.  A pass follows the onesweep scheme -- the first digit's histogram in one sweep (every pass counts the next
 // digit of the keys it holds anyway), then per pass one kernel that ranks a tile's keys, learns the tile's global digit
 // offsets by decoupled look-back and writes the keys out through LDS in digit order -- with a ballot-based rank (no LDS
-// atomics in the ranking, so the order inside a digit is the input order: stable).  745 M 54-bit keys: 26.3 ms against 31.2
-// for rocPRIM's onesweep (scripts/dbg/sort_time.py); with loads, stores and look-back switched off a pass still takes 70 % of
+// atomics in the ranking, so the order inside a digit is the input order: stable).  745 M 54-bit keys: 25.0 ms against 29.9 (r03: tests/tools/sort_time.py; r02: 26.3 against 31.2)
+// for rocPRIM's onesweep (tests/tools/sort_time.py); with loads, stores and look-back switched off a pass still takes 70 % of
 // its time (ranking, LDS traffic, five barriers per tile with one 150 KiB workgroup per CU): the passes are bound on chip.
 #include <algorithm>
 #include <cstdlib>
@@ -424,7 +424,7 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
     const char *kind = getenv("SEQWIN_AMD_RADIX_KERNEL");   // A/B: "classic" = one tile per workgroup
     const bool persistent = !(kind && !strcmp(kind, "classic"));
     uint32_t dbg = 0;
-#ifdef SW_RADIX_ABLATION     // timing experiments only (scripts/dbg/sort_time.sh; the output is NOT sorted): 1 no look-back, 2 no stores, 4 no loads, 8 no ranking
+#ifdef SW_RADIX_ABLATION     // timing experiments only (tests/tools/sort_time.py with SEQWIN_AMD_RADIX_DEBUG; the output is NOT sorted): 1 no look-back, 2 no stores, 4 no loads, 8 no ranking
     if (const char *e = getenv("SEQWIN_AMD_RADIX_DEBUG")) dbg = (uint32_t)atoi(e);
 #endif
     // resident workgroups of the persistent form (per template instance; taken from the first device that sorts -- any number

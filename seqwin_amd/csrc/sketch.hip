@@ -1123,7 +1123,7 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
     // the halo eats the tile (window ends per 8192-element tile: 7168 at w = 1024, 4096 at w = 4096).  The minimizers of w
     // are a subset of those of any smaller window w' (the rightmost minimum of a window is the rightmost minimum of every
     // sub-window that contains it), so for w > SW_WINDOW_SPLIT the tile kernels run with w' = 1024 and order_tuples
-    // (index.hip) picks the minimizers of w out of that sparse set.  Measured on 2.46 Gbp (scripts/dbg/lw_check.py),
+    // (index.hip) picks the minimizers of w out of that sparse set.  Measured on 2.46 Gbp (tests/tools/lw_check.py),
     // whole build, direct / two-step: w = 1500 5.6 / 6.0 ms, 2048 7.1 / 5.9, 3000 7.3 / 5.8, 4096 10.0 / 5.7.
     // SEQWIN_AMD_WINDOW_SPLIT="T,B" (tests, A/B): windows above T <= SW_MAX_WINDOW go through base B <= T.
     uint32_t split_at = SW_WINDOW_SPLIT, split_base = 1024;
