@@ -454,6 +454,8 @@ constexpr uint32_t RC = 12;   // published suffix records per run (12 x 8 B: the
 //   2 wave scans of the emit counts through ds_bpermute (__shfl_up, r02) instead of DPP row shifts
 //   4 whole-run minima of the window pass read in a counted loop (r02) instead of five loads in flight
 //   8 the winner of the window before the tile cleared in the bitmap by one thread between two barriers (r02)
+//  16 the masked moves of the window pass behind v_cmp + s_and_saveexec (r02) instead of v_cmpx (EXEC written by the compare)
+//  32 the suffix-record pass as the compiler lays it out (compare, EXEC round trip, branch) instead of v_cmpx statements
 #ifndef SW_SK_AB
 #define SW_SK_AB 0
 #endif
@@ -461,7 +463,8 @@ constexpr uint32_t RC = 12;   // published suffix records per run (12 x 8 B: the
 #define SW_SK_SLEEP 0      // experiment: every wave sleeps ~64 x this many cycles once per tile (is the kernel bound by wave latency?)
 #endif
 constexpr bool SK_CLAMP = !(SW_SK_AB & 1), SK_DPP_SCAN = !(SW_SK_AB & 2), SK_RUNMIN_UNROLLED = !(SW_SK_AB & 4),
-               SK_TWO_BARRIERS = (SW_SK_AB & 8) != 0;
+               SK_TWO_BARRIERS = (SW_SK_AB & 8) != 0, SK_CMPX = !(SW_SK_AB & 16),
+               SK_SUFFIX_ASM = !(SW_SK_AB & 32);
 
 #ifdef SW_SK_STAMPS
 constexpr uint32_t STAMP_EVERY = 512, STAMP_SLOTS = 16;   // every 512th tile of a launch writes its waves' phase times
@@ -742,7 +745,30 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
             // are not written and the count is recovered from the address
             const uint32_t ra0 = (uint32_t)(C::off_REC + (size_t)tid * RC * 8), ra_end = ra0 + RC * 8;
             uint32_t ra = ra0 + 8;
-            if (SK_CLAMP) {
+            if (SK_CLAMP && SK_SUFFIX_ASM) {
+                // (r03) one statement per element: the compare writes EXEC (v_cmpx), the record is taken under it -- hash to the
+                // lane's next slot, position bit, slot address advanced and clamped to the last slot -- and EXEC is restored from a
+                // loop-invariant copy: seven instructions, one of them scalar, no branch (the compiler's form: nine, with an EXEC
+                // round trip that waits for the compare and a branch around the body, at every element)
+                using lds_ptr = __attribute__((address_space(3))) unsigned char *;
+                const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr)smem;            // LDS address of the kernel's static area
+                uint32_t wa = lds0 + ra;                                             // absolute LDS address of the next slot
+                const uint32_t wa_last = lds0 + ra_end - 8;
+                const unsigned long long ex_all = __builtin_amdgcn_read_exec();
+#pragma unroll
+                for (int j = L - 2; j >= 0; --j)
+                    asm volatile("v_cmpx_lt_u64_e32 vcc, %[hj], %[cur]\n\t"
+                                 "v_mov_b64_e32 %[cur], %[hj]\n\t"
+                                 "v_or_b32_e32 %[mask], %[bit], %[mask]\n\t"
+                                 "ds_write_b64 %[wa], %[hj]\n\t"
+                                 "v_add_u32_e32 %[wa], 8, %[wa]\n\t"
+                                 "v_min_u32_e32 %[wa], %[wa], %[last]\n\t"
+                                 "s_mov_b64 exec, %[ex]"
+                                 : [cur] "+v"(cur), [mask] "+v"(mask), [wa] "+v"(wa)
+                                 : [hj] "v"(h[j]), [bit] "n"(1u << j), [last] "v"(wa_last), [ex] "s"(ex_all)
+                                 : "vcc", "memory");
+                cnt = (uint32_t)__popc(mask);
+            } else if (SK_CLAMP) {
                 // the slot address stops at the lane's last slot: a 13th record overwrites the 12th, and such a run (more records
                 // than published, counted from the mask) sends its tile to the generic kernel anyway -- one v_min per record
                 // instead of a compare and an EXEC round trip (r03: 104.6 -> 103.4 ms at 15 000 genomes)
@@ -895,13 +921,25 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
                 // the own prefix minimum only falls while it stays current, so it wins some window iff it wins
                 // the first one.  No per-step LDS atomic, no "did the winner change" test (marks are idempotent).
                 uint32_t own = 0, pre_bit = 0;
+                const unsigned long long ex_owner = __builtin_amdgcn_read_exec();   // the owner lanes: EXEC of every statement of the loop
                 const uint32_t jb = ((w - 1u) & LM) ? ((w - 1u) & LM) : (uint32_t)L;   // wave-uniform (kernel argument)
 #pragma unroll
                 for (int j = 0; j < L; ++j) {
                     // prefix minimum, '<=' for the newcomer (rightmost wins): lanes with pre_h >= h[j] take h[j] and bit j.
                     // Written with EXEC masking (restored inside the statement): v_cndmask issues at ~4.2 cycles per
                     // wave on gfx950, a masked v_mov / v_or at ~2.5 (scripts/micro/valu_kinds.hip).
+                    // (r03) v_cmpx writes EXEC itself: one scalar instruction per masked statement (the restore from a loop-invariant
+                    // copy) instead of two, and no scalar instruction that waits for the compare's result
                     unsigned long long sv;
+                    if (SK_CMPX)
+                        asm volatile("v_cmpx_ge_u64_e32 vcc, %[pre], %[hj]\n\t"
+                                     "v_mov_b64_e32 %[pre], %[hj]\n\t"
+                                     "v_mov_b32_e32 %[pb], %[bit]\n\t"
+                                     "s_mov_b64 exec, %[ex]"
+                                     : [pre] "+v"(pre_h), [pb] "+v"(pre_bit)
+                                     : [hj] "v"(h[j]), [bit] "n"(1u << j), [ex] "s"(ex_owner)
+                                     : "vcc");
+                    else
                     asm volatile("v_cmp_ge_u64_e32 vcc, %[pre], %[hj]\n\t"
                                  "s_and_saveexec_b64 %[sv], vcc\n\t"
                                  "v_mov_b64_e32 %[pre], %[hj]\n\t"
@@ -918,6 +956,14 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
                         if (lc_h < pre_h) atomicOr(&EM[lc_e >> 5], 1u << (lc_e & 31u));
                     }
                     // the own prefix minimum wins this window unless the left region holds a strictly smaller hash
+                    if (SK_CMPX)
+                        asm volatile("v_cmpx_ge_u64_e32 vcc, %[lc], %[pre]\n\t"
+                                     "v_or_b32_e32 %[own], %[own], %[pb]\n\t"
+                                     "s_mov_b64 exec, %[ex]"
+                                     : [own] "+v"(own)
+                                     : [lc] "v"(lc_h), [pre] "v"(pre_h), [pb] "v"(pre_bit), [ex] "s"(ex_owner)
+                                     : "vcc");
+                    else
                     asm volatile("v_cmp_ge_u64_e32 vcc, %[lc], %[pre]\n\t"
                                  "s_and_saveexec_b64 %[sv], vcc\n\t"
                                  "v_or_b32_e32 %[own], %[own], %[pb]\n\t"
