@@ -335,10 +335,10 @@ int sw_occ_adjacency_pairs(const sw_occ *o, const void *rank_by_row_dev, const u
                            const uint64_t *rank_bounds, uint64_t n_bounds, void *keys_dev, uint64_t *counts, uint64_t *cand_counts,
                            uint64_t *key_bits, void *stream);
 int sw_occ_candidates(const sw_occ *o, void *rows_dev, void *stream);
-/* Owner: edges of its rank range from the received keys and candidate rows (source-rank order).  lo_base: first global rank
- * of this owner's range.  rank_hash_dev (DEVICE u64[n_owners * pad]): the job-wide rank -> hash table as
+/* Owner: edges of its rank range from the received keys and candidate rows (source-rank order).  keys_dev is sorted in place
+ * (its contents are not preserved).  lo_base: first global rank of this owner's range.  rank_hash_dev (DEVICE u64[n_owners * pad]): the job-wide rank -> hash table as
  * all_gather_into_tensor leaves it -- slice owner o's node hashes (sw_index_node_hashes) at [o * pad, o * pad + its count). */
-int sw_slice_edges_pairs(sw_index *ix, const void *keys_dev, uint64_t m, const void *cand_rows_dev, uint64_t n_cand, uint64_t lo_bits,
+int sw_slice_edges_pairs(sw_index *ix, void *keys_dev, uint64_t m, const void *cand_rows_dev, uint64_t n_cand, uint64_t lo_bits,
                          uint64_t hi_bits, uint64_t lo_base, uint64_t asm_bits, const void *rank_hash_dev, const uint64_t *node_base,
                          uint64_t n_owners, uint64_t pad, void *stream);
 

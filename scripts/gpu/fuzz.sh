@@ -2,7 +2,7 @@
 # usage (through gpurun): bash scripts/gpu/fuzz.sh <tag> [seconds]
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O; cd $R; T=${2:-240}
 python3 tests/tools/fuzz_gpu.py $T 21 > $O/fuzz_default.log 2>&1 &
-SEQWIN_AMD_SORT=own SEQWIN_AMD_UNSORT_DIRECT=4 SEQWIN_AMD_WINDOW_SPLIT=8,4 python3 tests/tools/fuzz_gpu.py $T 22 > $O/fuzz_unsort_winsplit.log 2>&1 &
+SEQWIN_AMD_SORT=own SEQWIN_AMD_EDGE_SKIP_PASSES=2 SEQWIN_AMD_UNSORT_DIRECT=4 SEQWIN_AMD_WINDOW_SPLIT=8,4 python3 tests/tools/fuzz_gpu.py $T 22 > $O/fuzz_unsort_winsplit.log 2>&1 &
 SEQWIN_AMD_UNSORT_DIRECT=4 SEQWIN_AMD_SORT_KEYBITS=10 SEQWIN_AMD_NO_PACKED_EDGES=1 SEQWIN_AMD_CHECK_ORDER=1 python3 tests/tools/fuzz_gpu.py $T 23 > $O/fuzz_knobs.log 2>&1 &
 FUZZ_DIST=1 SEQWIN_AMD_SORT=own SEQWIN_AMD_RADIX_BITS=9 SEQWIN_AMD_UNSORT_DIRECT=6 python3 tests/tools/fuzz_gpu.py $T 24 > $O/fuzz_dist.log 2>&1 &
 FUZZ_LOWMEM=1 SEQWIN_AMD_LOWMEM_CHUNK_MBP=0 SEQWIN_AMD_RANKS=table SEQWIN_AMD_RC=3 python3 tests/tools/fuzz_gpu.py $T 25 > $O/fuzz_lowmem_table_rc3.log 2>&1 &

@@ -980,7 +980,7 @@ int sw_occ_candidates(const sw_occ *o, void *rows_dev, void *stream)
     });
 }
 
-int sw_slice_edges_pairs(sw_index *ix, const void *keys_dev, uint64_t m, const void *cand_rows_dev, uint64_t n_cand, uint64_t lo_bits,
+int sw_slice_edges_pairs(sw_index *ix, void *keys_dev, uint64_t m, const void *cand_rows_dev, uint64_t n_cand, uint64_t lo_bits,
                          uint64_t hi_bits, uint64_t lo_base, uint64_t asm_bits, const void *rank_hash_dev, const uint64_t *node_base,
                          uint64_t n_owners, uint64_t pad, void *stream)
 {
@@ -988,7 +988,7 @@ int sw_slice_edges_pairs(sw_index *ix, const void *keys_dev, uint64_t m, const v
         StreamScope scope((hipStream_t)stream);
         Event e0, e1;
         SW_HIP(hipEventRecord(e0, (hipStream_t)stream));
-        slice_edges_pairs(*ix, (const uint64_t *)keys_dev, m, (const uint64_t *)cand_rows_dev, n_cand, (unsigned)lo_bits, (unsigned)hi_bits,
+        slice_edges_pairs(*ix, (uint64_t *)keys_dev, m, (const uint64_t *)cand_rows_dev, n_cand, (unsigned)lo_bits, (unsigned)hi_bits,
                           lo_base, (unsigned)asm_bits, (const uint64_t *)rank_hash_dev, node_base, (uint32_t)n_owners, pad,
                           (hipStream_t)stream);
         SW_HIP(hipEventRecord(e1, (hipStream_t)stream));

@@ -188,12 +188,12 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
 // bits >= 32 then follow from n alone and the sweep that counts them is skipped
 // d_hist_given: digit counts the producer of the keys took while writing them (layout: radix_layout), scanned in place
 void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                       uint32_t *d_fail, bool perm_hi32 = false, unsigned long long *d_hist_given = nullptr);
+                       uint32_t *d_fail, bool perm_hi32 = false, unsigned long long *d_hist_given = nullptr, unsigned layout_bits = 0);
 void radix_layout(unsigned bits, unsigned *digit_bits, unsigned *n_passes);
 
 // index.hip: radix.hip or rocPRIM; d_fail: zeroed device word, to be read back and handed to check_sort_failed
 void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                 uint32_t *d_fail, bool perm_hi32 = false, unsigned long long *d_hist_given = nullptr);
+                 uint32_t *d_fail, bool perm_hi32 = false, unsigned long long *d_hist_given = nullptr, unsigned layout_bits = 0);
 bool sort_keys64_is_own(size_t n);   // radix.hip (digit counts may be handed in) or rocPRIM
 void check_sort_failed(uint32_t fail_word);
 
@@ -267,7 +267,7 @@ void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned 
 void occ_adjacency_pairs(OrderedOcc &occ, const uint32_t *d_rec_asm, const uint32_t *d_rank_by_row, const uint64_t *node_base,
                          uint64_t asm_base, const uint64_t *rank_bounds, uint32_t n_bounds, uint64_t *d_keys_out,
                          uint64_t *counts_host, uint64_t *cand_counts_host, uint64_t *key_bits_host, hipStream_t stream);
-void slice_edges_pairs(sw_index &ix, const uint64_t *d_keys, uint64_t m, const uint64_t *d_cand_rows, uint64_t c, unsigned lo_bits,
+void slice_edges_pairs(sw_index &ix, uint64_t *d_keys, uint64_t m, const uint64_t *d_cand_rows, uint64_t c, unsigned lo_bits,
                        unsigned hi_bits, uint64_t lo_base, unsigned ab, const uint64_t *d_rank_hash, const uint64_t *node_base,
                        uint32_t n_owners, uint64_t pad, hipStream_t stream);
 void index_node_hashes(const sw_index &ix, uint64_t *d_out, hipStream_t stream);

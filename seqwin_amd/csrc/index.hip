@@ -68,10 +68,10 @@ bool sort_keys64_is_own(size_t n)
 }
 
 void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                 uint32_t *d_fail, bool perm_hi32, unsigned long long *d_hist_given)
+                 uint32_t *d_fail, bool perm_hi32, unsigned long long *d_hist_given, unsigned layout_bits)
 {
     if (sort_keys64_is_own(n)) {
-        radix_sort_keys64(keys, keys_alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given);
+        radix_sort_keys64(keys, keys_alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given, layout_bits);
         return;
     }
     rocprim::double_buffer<uint64_t> dk(keys, keys_alt);
@@ -1369,9 +1369,10 @@ __global__ void k_rot_keys(uint32_t *__restrict__ key32, uint64_t n, unsigned le
 // in ascending position, so the key list comes out sorted.
 constexpr uint32_t DESC_BLOCK = 1024;   // positions per workgroup (256 threads x 4 consecutive positions)
 
-// The two-phase sort works on a "view" of n elements ordered by (key, low): key(q) is the 32-bit phase-1 key, low(q)
-// what orders elements of equal key, load / store move a whole element.
+// The two-phase sort works on a "view" of n elements ordered by (key, low): key(q) is the phase-1 key (View::Key: 32 bits for
+// the occurrences, 64 for the edge keys), low(q) what orders elements of equal key, load / store move a whole element.
 struct PayView {   // key32[q] = top half of the hash, pay[q].low = its low half
+    using Key = uint32_t;
     using Elem = OccPay;
     uint32_t *key32;
     OccPay *pay;
@@ -1381,20 +1382,31 @@ struct PayView {   // key32[q] = top half of the hash, pay[q].low = its low half
     __device__ void load(uint64_t q, uint32_t &k, OccPay &v) const { k = key32[q]; v = pay[q]; }
     __device__ void store(uint64_t q, uint32_t k, const OccPay &v) const { key32[q] = k; pay[q] = v; }
 };
+struct EdgeKeyView {   // 64-bit adjacency keys sorted on bits [low_bits, 64) only: phase-1 key = those bits, the whole key orders the rest
+    using Key = uint64_t;
+    using Elem = uint64_t;
+    uint64_t *keys;
+    unsigned low_bits;
+    __device__ uint64_t key(uint64_t q) const { return keys[q] >> low_bits; }
+    __device__ uint64_t low(uint64_t q) const { return keys[q]; }
+    __device__ static uint64_t low_of(const uint64_t &v) { return v; }
+    __device__ void load(uint64_t q, uint64_t &k, uint64_t &v) const { v = keys[q]; k = v >> low_bits; }
+    __device__ void store(uint64_t q, uint64_t, const uint64_t &v) const { keys[q] = v; }
+};
 
 template <class View>
-__device__ __forceinline__ uint32_t descents_of_thread(const View &V, uint32_t kmask, uint64_t n, uint64_t q0, uint32_t *heads = nullptr)
+__device__ __forceinline__ uint32_t descents_of_thread(const View &V, typename View::Key kmask, uint64_t n, uint64_t q0, uint32_t *heads = nullptr)
 {
     uint32_t m = 0, hm = 0;   // bit i: position q0 + i is a descent / differs from its predecessor (a run head of this order)
     if (heads) *heads = 0;
     if (q0 >= n) return 0;
-    uint32_t kp = q0 ? V.key(q0 - 1) : 0;
+    typename View::Key kp = q0 ? V.key(q0 - 1) : 0;
     uint64_t lp = q0 ? V.low(q0 - 1) : 0;
 #pragma unroll
     for (uint32_t i = 0; i < 4; ++i) {
         const uint64_t q = q0 + i;
         if (q >= n) break;
-        const uint32_t kq = V.key(q);
+        const typename View::Key kq = V.key(q);
         const uint64_t lq = V.low(q);
         if (q && (kq & kmask) == (kp & kmask) && (kq < kp || (kq == kp && lq < lp))) m |= 1u << i;
         if (q == 0 || kq != kp || lq != lp) hm |= 1u << i;
@@ -1446,7 +1458,7 @@ __device__ __forceinline__ uint32_t descents_of_thread(const PayView &V, uint32_
 // its slot, so that the listing pass need not read the block's 20 KB again.)
 constexpr uint32_t DESC_SLOT = 4;
 template <class View>
-__global__ __launch_bounds__(256) void k_count_descents(const View V, uint32_t kmask, uint64_t n, unsigned long long *__restrict__ cnt,
+__global__ __launch_bounds__(256) void k_count_descents(const View V, typename View::Key kmask, uint64_t n, unsigned long long *__restrict__ cnt,
                                                         uint32_t *__restrict__ slot_q, uint32_t *__restrict__ slot_k)
 {
     const uint64_t q0 = (uint64_t)blockIdx.x * DESC_BLOCK + threadIdx.x * 4u;
@@ -1473,7 +1485,7 @@ __global__ __launch_bounds__(256) void k_count_descents(const View V, uint32_t k
         mm &= mm - 1;
         const uint32_t at = atomicAdd(&s_n, 1u);
         s_q[at] = (uint32_t)(q0 + i);
-        s_kk[at] = V.key(q0 + i) & kmask;
+        s_kk[at] = (uint32_t)(V.key(q0 + i) & kmask);   // (only read by a general repair: 32-bit keys)
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1493,7 +1505,7 @@ __global__ __launch_bounds__(256) void k_count_descents(const View V, uint32_t k
 }
 
 template <class View>
-__global__ __launch_bounds__(256) void k_list_descents(const View V, uint32_t kmask, uint64_t n,
+__global__ __launch_bounds__(256) void k_list_descents(const View V, typename View::Key kmask, uint64_t n,
                                                        const unsigned long long *__restrict__ cnt,
                                                        const unsigned long long *__restrict__ off, uint32_t n_blocks,
                                                        uint32_t *__restrict__ bad, uint32_t cap, uint32_t *__restrict__ bad_q,
@@ -1535,7 +1547,7 @@ __global__ __launch_bounds__(256) void k_list_descents(const View V, uint32_t km
     while (mm) {
         const uint32_t i = (uint32_t)__builtin_ctz(mm);
         mm &= mm - 1;
-        if (base < cap) bad[base] = V.key(q0 + i) & kmask;
+        if (base < cap) bad[base] = (uint32_t)(V.key(q0 + i) & kmask);
         if (base < cap_q) bad_q[base] = (uint32_t)(q0 + i);
         ++base;
     }
@@ -1561,8 +1573,11 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t lane)   // `
     return ((uint64_t)hi << 32) | lo;
 }
 
+__device__ __forceinline__ uint32_t readlane_key(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ uint64_t readlane_key(uint64_t v, uint32_t lane) { return readlane64(v, lane); }
+
 template <class View>
-__global__ __launch_bounds__(256) void k_repair_wave(const View V, uint32_t kmask, uint64_t n, const uint32_t *__restrict__ bad_q,
+__global__ __launch_bounds__(256) void k_repair_wave(const View V, typename View::Key kmask, uint64_t n, const uint32_t *__restrict__ bad_q,
                                                      const unsigned long long *__restrict__ n_desc, uint32_t *__restrict__ big,
                                                      uint32_t *__restrict__ n_big, uint32_t *__restrict__ status)
 {
@@ -1575,7 +1590,7 @@ __global__ __launch_bounds__(256) void k_repair_wave(const View V, uint32_t kmas
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     for (uint32_t b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < D; b += n_waves) {   // (wave-uniform)
         const uint32_t q = bad_q[b];
-        const uint32_t k = V.key(q) & kmask;
+        const typename View::Key k = V.key(q) & kmask;
         if (b && (V.key(bad_q[b - 1]) & kmask) == k) continue;   // an earlier descent of the same run owns it
         uint64_t a = q, e = (uint64_t)q + 1;                     // [a, e) belongs to the run
         bool too_long = false;
@@ -1612,7 +1627,7 @@ __global__ __launch_bounds__(256) void k_repair_wave(const View V, uint32_t kmas
             }
             continue;
         }
-        uint32_t ki = 0;
+        typename View::Key ki = 0;
         typename View::Elem vi;
         uint64_t li = 0;
         const bool have = lane < len;
@@ -1622,7 +1637,7 @@ __global__ __launch_bounds__(256) void k_repair_wave(const View V, uint32_t kmas
         }
         uint32_t rank = 0;
         for (uint32_t j = 0; j < len; ++j) {
-            const uint32_t kj = (uint32_t)__builtin_amdgcn_readlane((int)ki, (int)j);
+            const typename View::Key kj = readlane_key(ki, j);
             const uint64_t lj = readlane64(li, j);
             rank += (kj < ki || (kj == ki && (lj < li || (lj == li && j < lane)))) ? 1u : 0u;
         }
@@ -1640,9 +1655,10 @@ template <class View>
 __global__ __launch_bounds__(256) void k_repair_sort(const View V, const uint32_t *__restrict__ n_big, const uint32_t *__restrict__ big)
 {
     __shared__ typename View::Elem sv[REPAIR_MAX_RUN];
-    __shared__ uint32_t sk[REPAIR_MAX_RUN];
+    __shared__ typename View::Key sk[REPAIR_MAX_RUN];
     __shared__ uint16_t srank[REPAIR_MAX_RUN];
-    __shared__ uint32_t w_k[4], w_cnt[4];
+    __shared__ typename View::Key w_k[4];
+    __shared__ uint32_t w_cnt[4];
     __shared__ uint64_t w_l[4];
     const uint32_t B = *n_big;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -1652,16 +1668,17 @@ __global__ __launch_bounds__(256) void k_repair_sort(const View V, const uint32_
         for (uint32_t i = tid; i < len; i += blockDim.x) V.load(a + i, sk[i], sv[i]);
         __syncthreads();
         const uint32_t per = (len + 255u) / 256u, i0 = min(len, tid * per), i1 = min(len, i0 + per);   // this thread's chunk
-        uint32_t placed = 0, last_k = 0;
+        uint32_t placed = 0;
+        typename View::Key last_k = 0;
         uint64_t last_l = 0;
         bool have_last = false;
         for (uint32_t it = 0; it < REPAIR_MAX_VALUES && placed < len; ++it) {
             // the smallest (key, low) above the last one placed
-            uint32_t mk = ~0u;
+            typename View::Key mk = ~(typename View::Key)0;
             uint64_t ml = ~0ull;
             bool any = false;
             for (uint32_t i = i0; i < i1; ++i) {
-                const uint32_t k = sk[i];
+                const typename View::Key k = sk[i];
                 const uint64_t l = View::low_of(sv[i]);
                 if (have_last && !(k > last_k || (k == last_k && l > last_l))) continue;
                 if (!any || k < mk || (k == mk && l < ml)) {
@@ -1671,7 +1688,7 @@ __global__ __launch_bounds__(256) void k_repair_sort(const View V, const uint32_
                 }
             }
             for (int d = 32; d; d >>= 1) {
-                const uint32_t ok = __shfl_xor(mk, d, 64);
+                const typename View::Key ok = __shfl_xor(mk, d, 64);
                 const uint64_t ol = __shfl_xor(ml, d, 64);
                 const bool oany = __shfl_xor((int)any, d, 64) != 0;
                 if (oany && (!any || ok < mk || (ok == mk && ol < ml))) {
@@ -1722,12 +1739,12 @@ __global__ __launch_bounds__(256) void k_repair_sort(const View V, const uint32_
             for (uint32_t i = tid; i < len; i += blockDim.x) V.store(a + srank[i], sk[i], sv[i]);
         } else {
             for (uint32_t i = tid; i < len; i += blockDim.x) {
-                const uint32_t ki = sk[i];
+                const typename View::Key ki = sk[i];
                 const typename View::Elem vi = sv[i];
                 const uint64_t li = View::low_of(vi);
                 uint32_t rank = 0;
                 for (uint32_t j = 0; j < len; ++j) {
-                    const uint32_t kj = sk[j];
+                    const typename View::Key kj = sk[j];
                     const uint64_t lj = View::low_of(sv[j]);
                     rank += (kj < ki || (kj == ki && (lj < li || (lj == li && j < i)))) ? 1u : 0u;
                 }
@@ -1748,7 +1765,7 @@ struct RepairState {
 // enqueue: list the descents of the phase-1 order, repair short runs in place.  `bad` (may be null) also receives the
 // masked keys of the descents, ascending, for a general repair.
 template <class View>
-void enqueue_repair(const View &V, uint32_t kmask, uint64_t n, uint32_t *bad, uint32_t cap, RepairState &r, hipStream_t stream)
+void enqueue_repair(const View &V, typename View::Key kmask, uint64_t n, uint32_t *bad, uint32_t cap, RepairState &r, hipStream_t stream)
 {
     const uint32_t n_blocks = (uint32_t)((n + DESC_BLOCK - 1) / DESC_BLOCK);
     const uint32_t max_desc = (uint32_t)std::min<uint64_t>(REPAIR_MAX_DESC, std::max<uint64_t>(n, 1));
@@ -2501,24 +2518,55 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
     const unsigned key_bits = wide ? wide->lo_bits + wide->hi_bits : 2 * nb;
     DevArray<uint32_t> sort_fail(1);
     SW_HIP(hipMemsetAsync(sort_fail.p, 0, 4, stream));
-    sort_keys64(keys, keys_alt, m, 0, key_bits, stream, sort_fail.p, false, d_hist);   // (d_hist: the digit counts k_adj_pairs took)
+    // Two phases, like the node sort: the radix passes leave out the lowest digit of rank_hi, and the few runs of equal upper
+    // bits that hold two different pairs out of order are repaired in place (one sweep over the keys instead of a pass: 15k
+    // genomes, 745 M keys: 18 334 descents with 9 bits left out, edges 34.9 -> 32.5 ms; with 18 bits 8.4 M descents -- more
+    // than the repair takes).  Anything the in-place repair leaves (more than 2^22 descents, two pairs of one run with more
+    // than 2048 records) makes the whole sort run again on all bits.
+    unsigned low_bits = 0, skip = 0, digit_bits = 0, n_passes = 0;
+    if (sort_keys64_is_own(m)) {
+        radix_layout(key_bits, &digit_bits, &n_passes);
+        const unsigned hb = wide ? wide->hi_bits : nb;
+        skip = hb >= digit_bits + 8 ? 1 : 0;
+        if (const char *e = getenv("SEQWIN_AMD_EDGE_SKIP_PASSES")) skip = (unsigned)atoi(e);   // A/B, tests (0: all bits by radix passes)
+        skip = std::min(skip, n_passes - 1);
+        low_bits = skip * digit_bits;
+    }
+    sort_keys64(keys, keys_alt, m, low_bits, key_bits, stream, sort_fail.p, false,
+                d_hist ? d_hist + ((size_t)skip << digit_bits) : nullptr, key_bits);   // (d_hist: the digit counts k_adj_pairs took)
+    RepairState rep;
+    if (low_bits) enqueue_repair(EdgeKeyView{keys, low_bits}, ~0ull, m, nullptr, 0, rep, stream);
     DevArray<uint64_t> ukeys(m);
     DevArray<uint32_t> ucnt(m), ucount(1);
     unsigned long long n_cand = host_n_cand;
-    {
+    for (int attempt = 0;; ++attempt) {
         size_t tmp_bytes = 0;
         SW_HIP(rocprim::run_length_encode(nullptr, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
         DevArray<unsigned char> tmp(tmp_bytes);
         SW_HIP(rocprim::run_length_encode(tmp.p, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
         hipLaunchKernelGGL(k_drop_sentinel_run, dim3(1), dim3(1), 0, stream, ukeys.p, sentinel, ucount.p);
         SW_HIP(hipGetLastError());
-        uint32_t n_edges = 0, failed = 0;
+        uint32_t n_edges = 0, failed = 0, left = 0;
         SW_HIP(hipMemcpyAsync(&n_edges, ucount.p, 4, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipMemcpyAsync(&failed, sort_fail.p, 4, hipMemcpyDeviceToHost, stream));
+        if (low_bits && attempt == 0) SW_HIP(hipMemcpyAsync(&left, rep.status.p, 4, hipMemcpyDeviceToHost, stream));
         if (d_n_cand) SW_HIP(hipMemcpyAsync(&n_cand, d_n_cand, 8, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipStreamSynchronize(stream));   // (tmp is released here, after the pass has finished)
         check_sort_failed(failed);
+        if (low_bits && attempt == 0 && getenv("SEQWIN_AMD_DEBUG_EDGE_REPAIR")) {
+            unsigned long long nd[2] = {0, 0};
+            uint32_t st[2] = {0, 0};
+            SW_HIP(hipMemcpy(nd, rep.n_desc.p, 16, hipMemcpyDeviceToHost));
+            SW_HIP(hipMemcpy(st, rep.status.p, 8, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[edge repair] %llu keys, %u low bits: %llu descents, %u long runs, leftovers %u\n", (unsigned long long)m, low_bits,
+                    nd[0], st[1], st[0]);
+        }
+        if (left) {   // the in-place repair left runs unsorted: the keys are still the same multiset, sort them on all bits
+            sort_keys64(keys, keys_alt, m, 0, key_bits, stream, sort_fail.p);
+            continue;
+        }
         ix.n_edges = n_edges;
+        break;
     }
     if (ix.n_edges == 0) return;
     ix.edges.alloc(ix.n_edges);
@@ -3224,7 +3272,7 @@ void occ_adjacency_pairs(OrderedOcc &occ, const uint32_t *d_rec_asm, const uint3
 
 // Owner: edges of its rank range from the received keys and candidate rows.  rank_hash: the job-wide table, owner o's node
 // hashes at d_rank_hash[o * pad ...] (pad >= every owner's node count; what all_gather_into_tensor leaves).
-void slice_edges_pairs(sw_index &ix, const uint64_t *d_keys, uint64_t m, const uint64_t *d_cand_rows, uint64_t c, unsigned lo_bits,
+void slice_edges_pairs(sw_index &ix, uint64_t *d_keys, uint64_t m, const uint64_t *d_cand_rows, uint64_t c, unsigned lo_bits,
                        unsigned hi_bits, uint64_t lo_base, unsigned ab, const uint64_t *d_rank_hash, const uint64_t *node_base,
                        uint32_t n_owners, uint64_t pad, hipStream_t stream)
 {
@@ -3241,14 +3289,14 @@ void slice_edges_pairs(sw_index &ix, const uint64_t *d_keys, uint64_t m, const u
         wk.hash.pad = pad;
         wk.hash.n_owners = n_owners;
         for (uint32_t q = 0; q <= n_owners; ++q) wk.hash.node_base[q] = node_base[q];
-        DevArray<uint64_t> k0(m), k1(m), ck(c);
+        // the received keys are sorted where they lie (the caller's buffer is one half of the double buffer: it is clobbered)
+        DevArray<uint64_t> k1(m), ck(c);
         DevArray<uint32_t> ca(c);
-        SW_HIP(hipMemcpyAsync(k0.p, d_keys, m * 8, hipMemcpyDeviceToDevice, stream));
         if (c) {
             hipLaunchKernelGGL(k_split_rows2, dim3(blocks_for(c)), dim3(TPB), 0, stream, d_cand_rows, c, ck.p, ca.p);
             SW_HIP(hipGetLastError());
         }
-        edges_from_pairs(k0.p, k1.p, m, ~0ull, 0, ab, ck.p, ca.p, nullptr, c, nullptr, stream, ix, nullptr, nullptr, &wk);   // rows carry no sentinels
+        edges_from_pairs(d_keys, k1.p, m, ~0ull, 0, ab, ck.p, ca.p, nullptr, c, nullptr, stream, ix, nullptr, nullptr, &wk);   // rows carry no sentinels
     }
     if (ix.n_edges == 0) ix.edges.alloc(0);
 }

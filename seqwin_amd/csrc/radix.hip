@@ -536,11 +536,12 @@ void radix_layout(unsigned bits, unsigned *digit_bits, unsigned *n_passes)
 // sorted data and `alt` at the other buffer.  *d_fail (device word, zeroed by the caller) becomes non-zero if a pass gave
 // up waiting (the caller checks it at its next host synchronisation: check_sort_failed in index.hip).
 void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
-                       uint32_t *d_fail, bool perm_hi32, unsigned long long *d_hist_given)
+                       uint32_t *d_fail, bool perm_hi32, unsigned long long *d_hist_given, unsigned layout_bits)
 {
     if (n == 0 || end_bit <= begin_bit) return;
     if (end_bit - begin_bit > 64) raise(SW_ERR_RUNTIME, "radix_sort_keys64: more than 64 key bits");
-    switch (pick_shape(end_bit - begin_bit)) {
+    // (layout_bits: the upper passes of a radix_layout(layout_bits) sort -- same digit width, begin_bit on a digit boundary)
+    switch (pick_shape(layout_bits ? layout_bits : end_bit - begin_bit)) {
     case 2: sort_passes<1024, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
     case 3: sort_passes<512, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
     case 1: sort_passes<1024, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;

@@ -72,6 +72,10 @@ KNOBS = [
     {"SEQWIN_AMD_RANKS": "table"},                                         # ... or through the open-addressing hash table (A/B path)
     {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_UNSORT_DIRECT": "4"},           # csrc/radix.hip for the keys-only sorts (default from 2^26 keys on)
     {"SEQWIN_AMD_SORT": "rocprim"},
+    {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_EDGE_SKIP_PASSES": "1"},        # edge sort in two phases: radix passes on the upper digits, in-place repair
+    {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_EDGE_SKIP_PASSES": "2"},        # ... all of rank_hi left to the repair (wave and workgroup forms)
+    {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_EDGE_SKIP_PASSES": "3"},        # ... runs too long for it: the sort runs again on all bits
+    {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_EDGE_SKIP_PASSES": "0"},        # ... off
     {"SEQWIN_AMD_WINDOW_SPLIT": "8,4"},                                    # windows above 8 as if above SW_MAX_WINDOW: sketch with w' = 4, select
     {"SEQWIN_AMD_WINDOW_SPLIT": "100,64", "SEQWIN_AMD_RANKS": "table"},
 ]
