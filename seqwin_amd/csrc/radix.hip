@@ -83,7 +83,8 @@ __global__ void k_rs_perm_hist(uint64_t n, unsigned begin_bit, unsigned end_bit,
 }
 
 // exclusive scan of a pass's digit counts (one workgroup of RADIX threads)
-template <int BITS> __global__ void k_rs_scan(unsigned long long *__restrict__ h)
+constexpr uint32_t RS_CURSOR_STRIDE = 32;   // an unstable pass's digit cursors lie 256 B apart (atomics spread over the L2 channels)
+template <int BITS> __global__ void k_rs_scan(unsigned long long *__restrict__ h, unsigned long long *__restrict__ cursor)
 {
     constexpr uint32_t RADIX = 1u << BITS;
     __shared__ unsigned long long s[RADIX];
@@ -97,6 +98,7 @@ template <int BITS> __global__ void k_rs_scan(unsigned long long *__restrict__ h
         __syncthreads();
     }
     h[threadIdx.x] = s[threadIdx.x] - v;
+    if (cursor) cursor[(size_t)threadIdx.x * RS_CURSOR_STRIDE] = s[threadIdx.x] - v;
 }
 
 constexpr unsigned long long RS_AGG = 1ull << 62, RS_INC = 2ull << 62, RS_VAL = (1ull << 62) - 1ull;
@@ -254,7 +256,8 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                                                        uint32_t n_tiles, unsigned shift, unsigned bits,
                                                        const unsigned long long *__restrict__ digit_base,
                                                        unsigned long long *__restrict__ state, uint32_t *__restrict__ ticket,
-                                                       uint32_t *__restrict__ fail, uint32_t dbg)
+                                                       uint32_t *__restrict__ fail, uint32_t dbg,
+                                                       unsigned long long *__restrict__ cursor)
 {
     constexpr uint32_t RADIX = 1u << BITS, WAVES = THREADS / 64, TILE = THREADS * RS_ITEMS;
     static_assert(RADIX <= (uint32_t)THREADS, "one thread per digit");
@@ -319,12 +322,18 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                 whist[w][d] = (uint16_t)total;
                 total += c;
             }
-            __hip_atomic_store(&st[d], (tile == 0 ? RS_INC : RS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cursor) {
+                // UNSTABLE pass (the order inside a digit's range is free: the unsort): the tile claims its places in every
+                // digit's range with one atomic add -- no states, no look-back; the answer is due after the keys sit in LDS
+                pre[0] = total ? atomicAdd(&cursor[(size_t)d * RS_CURSOR_STRIDE], (unsigned long long)total) : 0ull;
+            } else {
+                __hip_atomic_store(&st[d], (tile == 0 ? RS_INC : RS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int j = 0; j < RS_LOOK; ++j)   // the first look-back step: requested now, examined after the keys are placed in LDS
-                pre[j] = (int64_t)tile - 1 - j >= 0
-                             ? __hip_atomic_load(&state[(size_t)(tile - 1 - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                             : RS_INC;
+                for (int j = 0; j < RS_LOOK; ++j)   // the first look-back step: requested now, examined after the keys are placed in LDS
+                    pre[j] = (int64_t)tile - 1 - j >= 0
+                                 ? __hip_atomic_load(&state[(size_t)(tile - 1 - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : RS_INC;
+            }
             incl = total;
             for (uint32_t dd = 1; dd < 64; dd <<= 1) {
                 const uint32_t up = __shfl_up(incl, dd, 64);
@@ -357,7 +366,9 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
             const uint64_t g = (uint64_t)ntile * TILE + wave * (64 * RS_ITEMS) + i * 64 + lane;
             key[i] = (ntile < n_tiles && g < n && !(dbg & 4u)) ? in[g] : (dbg & 4u ? g * 0x9E3779B97F4A7C15ull : ~0ull);
         }
-        if (tid < RADIX) {                              // look-back, four predecessors per step
+        if (tid < RADIX && cursor) {
+            goff[tid] = pre[0] - before;                // (cursor[d] started at digit_base[d])
+        } else if (tid < RADIX) {                       // look-back, four predecessors per step
             const uint32_t d = tid;
             unsigned long long excl = 0;
             if (tile) {
@@ -448,6 +459,8 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
     }
     DevArray<unsigned long long> hist_own(d_hist_given ? 0 : (size_t)n_passes * RADIX), state((size_t)n_tiles * RADIX);
     struct { unsigned long long *p; } hist{d_hist_given ? d_hist_given : hist_own.p};   // ([pass][digit] counts; scanned in place below)
+    const bool unstable = perm_hi32 && persistent && !getenv("SEQWIN_AMD_RADIX_STABLE_UNSORT");   // (A/B: the look-back form)
+    DevArray<unsigned long long> cursor(unstable ? (size_t)RADIX * RS_CURSOR_STRIDE : 0);
     DevArray<uint32_t> tickets(n_passes);
     SW_HIP(hipMemsetAsync(tickets.p, 0, tickets.bytes(), stream));
     if (d_hist_given) {
@@ -474,12 +487,14 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
             SW_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_rs_stamps), &ptr, sizeof ptr, 0, hipMemcpyHostToDevice, stream));
         }
 #endif
-        hipLaunchKernelGGL(k_rs_scan<BITS>, dim3(1), dim3(RADIX), 0, stream, hist.p + (size_t)p * RADIX);
-        SW_HIP(hipMemsetAsync(state.p, 0, state.bytes(), stream));
+        // (only the FIRST pass may be unstable: the later ones must keep the order the earlier ones made)
+        unsigned long long *cur = unstable && p == 0 ? cursor.p : nullptr;
+        hipLaunchKernelGGL(k_rs_scan<BITS>, dim3(1), dim3(RADIX), 0, stream, hist.p + (size_t)p * RADIX, cur);
+        if (!cur) SW_HIP(hipMemsetAsync(state.p, 0, state.bytes(), stream));
         if (persistent)
             hipLaunchKernelGGL((k_rs_pass_p<THREADS, BITS>), dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)grid_p)), dim3(THREADS), 0,
                                stream, keys, alt, n, (uint32_t)n_tiles, sh, bits, hist.p + (size_t)p * RADIX, state.p, tickets.p + p, d_fail,
-                               dbg);
+                               dbg, cur);
         else
             hipLaunchKernelGGL((k_rs_pass<THREADS, BITS>), dim3((unsigned)n_tiles), dim3(THREADS), 0, stream, keys, alt, n, sh, bits,
                                hist.p + (size_t)p * RADIX, state.p, d_fail);
