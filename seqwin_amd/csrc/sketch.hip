@@ -464,7 +464,7 @@ constexpr uint32_t RC = 12;   // published suffix records per run (12 x 8 B: the
 #endif
 constexpr bool SK_CLAMP = !(SW_SK_AB & 1), SK_DPP_SCAN = !(SW_SK_AB & 2), SK_RUNMIN_UNROLLED = !(SW_SK_AB & 4),
                SK_TWO_BARRIERS = (SW_SK_AB & 8) != 0, SK_CMPX = !(SW_SK_AB & 16),
-               SK_SUFFIX_ASM = !(SW_SK_AB & 32);
+               SK_SUFFIX_ASM = !(SW_SK_AB & 32), SK_SUFFIX_MIN = (SW_SK_AB & 64) != 0;
 
 #ifdef SW_SK_STAMPS
 constexpr uint32_t STAMP_EVERY = 512, STAMP_SLOTS = 16;   // every 512th tile of a launch writes its waves' phase times
@@ -755,18 +755,37 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
                 uint32_t wa = lds0 + ra;                                             // absolute LDS address of the next slot
                 const uint32_t wa_last = lds0 + ra_end - 8;
                 const unsigned long long ex_all = __builtin_amdgcn_read_exec();
+                if (SK_SUFFIX_MIN) {
 #pragma unroll
-                for (int j = L - 2; j >= 0; --j)
-                    asm volatile("v_cmpx_lt_u64_e32 vcc, %[hj], %[cur]\n\t"
-                                 "v_mov_b64_e32 %[cur], %[hj]\n\t"
-                                 "v_or_b32_e32 %[mask], %[bit], %[mask]\n\t"
-                                 "ds_write_b64 %[wa], %[hj]\n\t"
-                                 "v_add_u32_e32 %[wa], 8, %[wa]\n\t"
-                                 "v_min_u32_e32 %[wa], %[wa], %[last]\n\t"
-                                 "s_mov_b64 exec, %[ex]"
-                                 : [cur] "+v"(cur), [mask] "+v"(mask), [wa] "+v"(wa)
-                                 : [hj] "v"(h[j]), [bit] "n"(1u << j), [last] "v"(wa_last), [ex] "s"(ex_all)
-                                 : "vcc", "memory");
+                    for (int j = L - 2; j >= 0; --j)
+                        asm volatile("v_cmpx_lt_u64_e32 vcc, %[hj], %[cur]\n\t"
+                                     "v_mov_b64_e32 %[cur], %[hj]\n\t"
+                                     "v_or_b32_e32 %[mask], %[bit], %[mask]\n\t"
+                                     "ds_write_b64 %[wa], %[hj]\n\t"
+                                     "v_add_u32_e32 %[wa], 8, %[wa]\n\t"
+                                     "v_min_u32_e32 %[wa], %[wa], %[last]\n\t"
+                                     "s_mov_b64 exec, %[ex]"
+                                     : [cur] "+v"(cur), [mask] "+v"(mask), [wa] "+v"(wa)
+                                     : [hj] "v"(h[j]), [bit] "n"(1u << j), [last] "v"(wa_last), [ex] "s"(ex_all)
+                                     : "vcc", "memory");
+                } else {
+                    // (r03) no clamp either: a lane with more than RC records writes on into the slots of the lanes behind it (the
+                    // last lane: into at most (L - RC) * 8 bytes of RMh, which follows REC) -- but such a lane has cnt > rc_limit
+                    // and sends the whole tile to the generic kernel below, so nothing of what it overwrote is ever read
+                    static_assert(C::off_RMh == C::off_REC + (size_t)B * RC * 8 && (size_t)B * 8 >= (size_t)L * 8,
+                                  "the records of the last lane may run on into RMh, and nowhere else");
+#pragma unroll
+                    for (int j = L - 2; j >= 0; --j)
+                        asm volatile("v_cmpx_lt_u64_e32 vcc, %[hj], %[cur]\n\t"
+                                     "v_mov_b64_e32 %[cur], %[hj]\n\t"
+                                     "v_or_b32_e32 %[mask], %[bit], %[mask]\n\t"
+                                     "ds_write_b64 %[wa], %[hj]\n\t"
+                                     "v_add_u32_e32 %[wa], 8, %[wa]\n\t"
+                                     "s_mov_b64 exec, %[ex]"
+                                     : [cur] "+v"(cur), [mask] "+v"(mask), [wa] "+v"(wa)
+                                     : [hj] "v"(h[j]), [bit] "n"(1u << j), [ex] "s"(ex_all)
+                                     : "vcc", "memory");
+                }
                 cnt = (uint32_t)__popc(mask);
             } else if (SK_CLAMP) {
                 // the slot address stops at the lane's last slot: a 13th record overwrites the 12th, and such a run (more records
