@@ -367,6 +367,10 @@ struct DeviceSink : ChunkSink {
 // FASTA files -> device-resident batch
 void ingest_to_device(const char *const *paths, size_t n_paths, uint64_t n_cpu, sw_batch &b)
 {
+    if (device_gz_ingest(paths, n_paths, n_cpu, b)) {   // many .gz files: inflate + parse + pack on the device (ingest_dev.hip)
+        upload_tables(b);
+        return;
+    }
     if (n_paths >= 2 && !getenv("SEQWIN_AMD_NO_STREAM_UPLOAD")) {
         const auto t0 = std::chrono::steady_clock::now();
         DeviceSink sink(b, pinned_ring(b.device));

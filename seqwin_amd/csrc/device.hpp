@@ -146,6 +146,10 @@ struct sw_batch {
 };
 
 namespace sw { struct OrderedOcc; }
+namespace sw {
+// ingest_dev.hip: many .gz files -> batch, inflated / parsed / packed on the device (false: take the host route)
+bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, sw_batch &b);
+}
 
 struct sw_occ {   // ordered tuple stream of one shard (tuple-exchange form of the multi-GPU build)
     const sw_batch *batch = nullptr;

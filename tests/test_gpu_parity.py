@@ -732,3 +732,95 @@ def test_sort_keys64_is_a_stable_radix_sort(impl, monkeypatch):
         out = b if flag.value else a
         field = (keys >> begin) & ((1 << (end - begin)) - 1) if end - begin < 64 else keys
         assert torch.equal(out, keys[torch.sort(field, stable=True).indices]), (n, begin, end)
+
+
+def _device_gz_batches() -> int:
+    import ctypes
+    from seqwin_amd._lib import lib
+    lib.sw_device_gz_batches.restype = ctypes.c_uint64
+    return int(lib.sw_device_gz_batches())
+
+
+def test_device_gz_ingest_matches_host_route(tmp_path, monkeypatch):
+    """.gz inputs inflated, parsed and packed ON THE DEVICE (csrc/ingest_dev.hip: the gzip branch of fasta_reader.cpp:109-203
+    and the parse of :41-95, one file per lane) give the batch the host route gives: records, ids, graph -- and the oracle's
+    graph.  Stored / fixed / dynamic blocks (compresslevel 0 / 1 / 9 and a hand-made fixed-code stream), header fields (FNAME,
+    FEXTRA, FCOMMENT, FHCRC), CRLF, blank and whitespace-only lines, lower case, IUPAC, N runs, an id that ends the file,
+    records without sequence, long matches (repeats) and incompressible text."""
+    import zlib
+    rng = random.Random(5)
+    texts = []
+    for a in range(70):                      # more files than one wave has lanes
+        txt = "" if a % 9 else "\n  \n"
+        for r in range(rng.randrange(0, 5)):
+            n = rng.choice([0, 1, 31, 32, 33, 64, 100, 1000, 5000, 40000, 130000])
+            s = _randseq(rng, n)
+            if a % 7 == 3 and n > 1000:
+                s = (s[:500] * (n // 500 + 1))[:n]                  # repeats: matches of the maximum length, distances up to 500
+            txt += f">rec{r}_{a}" + rng.choice([" some description", "\tx", "", " "]) + rng.choice(["\n", "\r\n"])
+            width = rng.choice([60, 70, 80, 7, 1000, 10**6])
+            for i in range(0, len(s), width):
+                txt += s[i:i + width] + rng.choice(["\n", "\r\n", " \n", "\n\n"])
+        if a % 11 == 5:
+            txt += ">last_id_without_newline"
+        if a % 13 == 6:
+            txt = txt.rstrip("\n")
+        texts.append(txt.encode())
+    texts.append(b"")                                                # an empty file
+    texts.append(b">only_header\n")
+    texts.append(bytes(rng.getrandbits(8) | 0x40 for _ in range(50000)).replace(b">", b"A"))   # no header: ...
+    texts[-1] = b">noise\n" + texts[-1]                              # ... under one (incompressible: stored blocks at level 9 too)
+    paths = []
+    for i, t in enumerate(texts):
+        p = tmp_path / f"a{i}.fa.gz"
+        level = [0, 1, 6, 9][i % 4]
+        if i % 5 == 0:                                               # hand-made member: FEXTRA + FNAME + FCOMMENT + FHCRC, fixed-code stream
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, zlib.Z_FIXED if i % 10 == 0 else zlib.Z_DEFAULT_STRATEGY)
+            body = co.compress(t) + co.flush()
+            head = bytes([0x1F, 0x8B, 8, 2 | 4 | 8 | 16, 0, 0, 0, 0, 0, 255]) + (5).to_bytes(2, "little") + b"extra" + b"name.fa\0" + b"a comment\0"
+            head += (zlib.crc32(head) & 0xFFFF).to_bytes(2, "little")
+            p.write_bytes(head + body + zlib.crc32(t).to_bytes(4, "little") + (len(t) & 0xFFFFFFFF).to_bytes(4, "little"))
+        else:
+            with gzip.GzipFile(p, "wb", compresslevel=level) as f:
+                f.write(t)
+        paths.append(p)
+    k, w = 15, 20
+    monkeypatch.setenv("SEQWIN_AMD_DEVICE_INFLATE", "0")
+    host = KmerGraph(paths, kmerlen=k, windowsize=w, n_cpu=3)
+    monkeypatch.setenv("SEQWIN_AMD_DEVICE_INFLATE", "1")
+    n0 = _device_gz_batches()
+    dev = KmerGraph(paths, kmerlen=k, windowsize=w, n_cpu=3)
+    assert _device_gz_batches() == n0 + 1                            # the device route was taken, not declined
+    assert np.array_equal(dev.record_offsets, host.record_offsets) and [list(x) for x in dev.record_ids] == [list(x) for x in host.record_ids]
+    assert np.array_equal(dev.kmers, host.kmers) and np.array_equal(dev.nodes, host.nodes) and np.array_equal(dev.edges, host.edges)
+    exp = oracle.build(paths, k, w)
+    assert_graph_equal((dev.kmers, dev.nodes, dev.edges, dev.record_offsets, dev.record_ids),
+                       dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])), [list(t) for t in exp[4]])
+    b_dev = Batch.from_fasta(paths, n_cpu=2)
+    assert _device_gz_batches() == n0 + 2
+    monkeypatch.setenv("SEQWIN_AMD_DEVICE_INFLATE", "0")
+    b_host = Batch.from_fasta(paths, n_cpu=2)
+    i_dev, i_host = b_dev.info(), b_host.info()
+    assert all(i_dev[key] == i_host[key] for key in ("n_assemblies", "n_records", "total_bp"))   # (device_bytes: the host route over-allocates)
+    ix_dev, ix_host = b_dev.build_index(k, w), b_host.build_index(k, w)
+    assert ix_dev.checksums() == ix_host.checksums()
+
+    # what the device route declines goes through the host route, with the host route's outcome
+    monkeypatch.setenv("SEQWIN_AMD_DEVICE_INFLATE", "1")
+    two = tmp_path / "two_members.fa.gz"                              # concatenated members: gzread reads them as one file
+    two.write_bytes(gzip.compress(b">m1\nACGTACGTACGTACGTACGTAAAC\n") + gzip.compress(b">m2\nTTGACCAGTACGGGATACCAGT\n"))
+    g = KmerGraph([paths[1], two], kmerlen=5, windowsize=3, n_cpu=1)
+    assert _device_gz_batches() == n0 + 2 and [len(x) for x in g.record_ids][1] == 2
+    exp = oracle.build([paths[1], two], 5, 3)
+    assert np.array_equal(g.kmers, exp[0])
+    bad = tmp_path / "bad_crc.fa.gz"
+    raw = bytearray(gzip.compress(b">c\n" + b"ACGTTGCA" * 400 + b"\n", compresslevel=0))
+    raw[40] ^= 0x02                                                   # a stored byte changed: same length, CRC-32 differs
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(RuntimeError, match="gzip read error"):
+        KmerGraph([paths[1], bad], kmerlen=5, windowsize=3, n_cpu=1)
+    ctl = tmp_path / "ctl.fa.gz"
+    ctl.write_bytes(gzip.compress(b">c\nACGT\x03ACGT\n"))
+    with pytest.raises(ValueError, match="control byte"):
+        KmerGraph([ctl], kmerlen=3, windowsize=1, n_cpu=1)
+    assert _device_gz_batches() == n0 + 2
