@@ -155,7 +155,7 @@ void sw_hostbatch_free(sw_hostbatch *hb);
 /* Host ingest: read + pack FASTA files (fasta_reader.cpp:207-213 semantics) on n_cpu host threads and upload them
  * as one device-resident batch (assembly i of the batch = assembly_paths[i]). */
 int sw_batch_from_fasta(const char *const *assembly_paths, size_t n_assemblies, uint64_t n_cpu, sw_batch **out);
-/* Inputs that are all single-member .gz files and number 512 or more (SEQWIN_AMD_DEVICE_INFLATE=1: any number, =0: never)
+/* Inputs that are all single-member .gz files and number 320 per host thread or more (SEQWIN_AMD_DEVICE_INFLATE=1: any number, =0: never)
  * are inflated, parsed and packed ON THE DEVICE (the gzip branch of fasta_reader.cpp:109-203 and the parse of :41-95, one
  * file per lane; csrc/ingest_dev.hip) -- same batch, bit for bit; anything irregular in a file sends the whole call through
  * the host route, which reports errors the way the reference does.  Number of batches this process built that way: */
