@@ -161,7 +161,8 @@ def _byte_soup_files(tmp_path, seed=7, n_files=12):
             elif style < 0.8:
                 seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
                 k = max(1, n // 200)
-                seq[rng.integers(0, max(n, 1), k) % max(n, 1)] = rng.choice(any_byte, k) if n else []
+                if n:
+                    seq[rng.integers(0, n, k) % n] = rng.choice(any_byte, k)
             else:
                 seq = rng.choice(any_byte, n)
             width = int(rng.choice([1, 7, 31, 32, 33, 60, 64, 80, 100, 100000]))
@@ -231,6 +232,116 @@ def test_host_ingest_under_sanitizers(tmp_path):
     for bad in (ctl, nohdr, notgz, tmp_path / "missing.fa"):
         out = subprocess.run([str(exe), "2", str(tmp_path / "x.bin"), str(files[0]), str(bad)], capture_output=True, text=True, env=env)
         assert out.returncode == 3 and "refused" in out.stderr and "Sanitizer" not in out.stderr, (bad.name, out.returncode, out.stderr[-2000:])
+
+
+def test_device_gz_decoder_and_parser_under_sanitizers(tmp_path):
+    """The device gzip ingest's DEFLATE decoder and FASTA parser / packer (seqwin_amd/csrc/gz_dev.hpp -- the code the kernels
+    of ingest_dev.hip run one file per lane) compiled for the HOST with AddressSanitizer + UBSan
+    (`make -C seqwin_amd/csrc gzsan`), on buffers laid out and sized as in HBM: byte soup at every compression level and
+    strategy, multi-block streams with flush points, all gzip header fields -> the records, ids and bases of the host reader
+    (replaces the gzip branch of fasta_reader.cpp:109-203 and the parse of :41-95); truncated, bit-flipped, padded and
+    mis-sized streams, several members, control bytes, sequence before a header -> declined (the library then takes the
+    host route), never a sanitizer report, never an accepted stream whose text differs from zlib's.  CPU only."""
+    import subprocess
+    import zlib
+    if subprocess.run(["make", "-C", str(ROOT / "seqwin_amd" / "csrc"), "gzsan"], capture_output=True).returncode != 0:
+        pytest.skip("no sanitizer runtime for g++ here")
+    exe = ROOT / "seqwin_amd" / "csrc" / "build" / "gz_dev_san"
+    env = dict(__import__("os").environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    rng = __import__("random").Random(23)
+
+    def member(text: bytes, i: int) -> bytes:
+        level, strat = rng.choice(range(10)), rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED])
+        co = zlib.compressobj(level, zlib.DEFLATED, -rng.choice([9, 12, 15]), rng.choice([1, 8, 9]), strat)
+        body, at = b"", 0
+        while at < len(text):                      # several blocks, empty stored blocks at the flush points
+            step = rng.choice([1, 100, 5000, 10**6])
+            body += co.compress(text[at:at + step])
+            at += step
+            if rng.random() < 0.3:
+                body += co.flush(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+        body += co.flush()
+        flg = [0, 8, 2 | 4 | 8 | 16][i % 3]
+        head = bytes([0x1F, 0x8B, 8, flg, 0, 0, 0, 0, 0, 255])
+        if flg & 4:
+            head += (5).to_bytes(2, "little") + b"extra"
+        if flg & 8:
+            head += b"name.fa\0"
+        if flg & 16:
+            head += b"a comment\0"
+        if flg & 2:
+            head += (zlib.crc32(head) & 0xFFFF).to_bytes(2, "little")
+        return head + body + zlib.crc32(text).to_bytes(4, "little") + (len(text) & 0xFFFFFFFF).to_bytes(4, "little")
+
+    plain = _byte_soup_files(tmp_path, seed=29, n_files=20)
+    extra = [b"", b">only_header", b">a\n>b\r\n>c", b"\n\n   \n", b">r\n" + b"ACGT" * 70000 + b"\n", b">hp\n" + b"A" * 100000 + b"\n>at\n" + b"AT" * 30000,
+             b">x desc\r\n" + bytes(rng.choice(b"ACGTN") for _ in range(3000)) * 40 + b"\r\n"]
+    for j, t in enumerate(extra):
+        q = tmp_path / f"extra{j}.fa"
+        q.write_bytes(t)
+        plain.append(q)
+    gz = []
+    for i, q in enumerate(plain):
+        g = tmp_path / (q.name + ".gz")
+        g.write_bytes(member(q.read_bytes(), i))
+        assert gzip.decompress(g.read_bytes()) == q.read_bytes()
+        gz.append(g)
+    dump = tmp_path / "dump.bin"
+    out = subprocess.run([str(exe), str(dump)] + [str(g) for g in gz], capture_output=True, text=True, env=env)
+    assert out.returncode == 0 and "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
+    offs, ids, seqs, bp = _host_ingest(plain, 2)
+    blob = b"".join(i.encode() + b"\0" for i in ids)
+    lens = np.array([len(x) for x in seqs], np.uint32)
+    assert dump.read_bytes() == offs.astype(np.uint32).tobytes() + blob + lens.tobytes() + b"".join(seqs)
+    assert f"{len(gz)} assemblies {len(seqs)} records {bp} bp" in out.stdout
+
+    # what must be declined (exit code 4) without a report
+    good = gz[0].read_bytes()
+    declined = {
+        "two_members": gzip.compress(b">m1\nACGT\n") + gzip.compress(b">m2\nAC\n"),
+        "control": member(b">r\nACGT\x01ACGT\n", 0),
+        "nohdr": member(b"ACGT\n>r\nAC\n", 0),
+        "notgz": b"\x1f\x8b\x08\x00" + bytes(range(200)),
+        "reserved_flag": bytes([0x1F, 0x8B, 8, 0x20]) + good[4:],
+        "bad_crc": good[:-8] + bytes([good[-8] ^ 1]) + good[-7:],
+        "isize_short": good[:-4] + (max(1, int.from_bytes(good[-4:], "little")) - 1).to_bytes(4, "little"),
+        "isize_long": good[:-4] + (int.from_bytes(good[-4:], "little") + 3).to_bytes(4, "little"),
+    }
+    for name, raw in declined.items():
+        q = tmp_path / f"{name}.fa.gz"
+        q.write_bytes(raw)
+        out = subprocess.run([str(exe), str(tmp_path / "x.bin"), str(gz[1]), str(q)], capture_output=True, text=True, env=env)
+        assert out.returncode == 4 and "declined" in out.stderr and "Sanitizer" not in out.stderr and "runtime error" not in out.stderr, \
+            (name, out.returncode, out.stderr[-2000:])
+    # mutated streams: declined, or accepted with exactly the text zlib gives for them
+    bases = [g.read_bytes() for g in gz if g.stat().st_size > 40][:10]
+    for it in range(250):
+        raw = bytearray(rng.choice(bases))
+        hl, kind = 10, rng.randrange(3)             # (mutations stay behind the fixed part of the header)
+        if kind == 0:
+            for _ in range(rng.randrange(1, 4)):
+                raw[rng.randrange(hl, len(raw) - 8)] ^= 1 << rng.randrange(8)
+        elif kind == 1:
+            cut = rng.randrange(hl, len(raw) - 8)
+            raw = raw[:cut] + raw[-8:]
+        else:
+            at = rng.randrange(hl, len(raw) - 8)
+            raw[at:at] = bytes(rng.getrandbits(8) for _ in range(rng.randrange(1, 20)))
+        q = tmp_path / "mut.fa.gz"
+        q.write_bytes(bytes(raw))
+        out = subprocess.run([str(exe), str(tmp_path / "m.bin"), str(q)], capture_output=True, text=True, env=env)
+        assert out.returncode in (0, 4) and "Sanitizer" not in out.stderr and "runtime error" not in out.stderr, (it, out.returncode, out.stderr[-2000:])
+        if out.returncode == 0:                     # (the CRC-32 matched: the mutation hit bytes that do not reach the text)
+            try:
+                text = gzip.decompress(bytes(raw))
+            except Exception:
+                text = None
+            assert text is not None, it
+            ref = tmp_path / "mut_ref.fa"
+            ref.write_bytes(text)
+            o2, i2, s2, _ = _host_ingest([ref], 1)
+            b2 = b"".join(i.encode() + b"\0" for i in i2)
+            assert (tmp_path / "m.bin").read_bytes() == o2.astype(np.uint32).tobytes() + b2 + np.array([len(x) for x in s2], np.uint32).tobytes() + b"".join(s2)
 
 
 def test_half_word_rotate_formulas(tmp_path):
