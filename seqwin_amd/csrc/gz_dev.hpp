@@ -199,7 +199,7 @@ SW_GZ_FN uint32_t inflate_one(LaneTables &t, LaneScratch &g, const uint8_t *comp
         if (n - fl >= 64) flush64();
     };
     const bool prof = prof_out != nullptr;
-    unsigned long long p_build = 0, p_dec = 0, p_blocks = 0, p_look = 0, p_match = 0, p_t0 = 0;
+    unsigned long long p_build = 0, p_dec = 0, p_blocks = 0, p_look = 0, p_match = 0, p_t0 = 0, p_load = 0, p_nload = 0;
     while (!last && st == ST_OK) {
         if (prof) { p_t0 = SW_GZ_CLOCK(); ++p_blocks; }
         if (!br.need(3)) { st = ST_TRUNCATED; break; }
@@ -366,8 +366,14 @@ SW_GZ_FN uint32_t inflate_one(LaneTables &t, LaneScratch &g, const uint8_t *comp
                     if (sp + 8 <= fl) {
                         const uint64_t a = text_off + sp;
                         const uint32_t off = (uint32_t)(a & 7u);
+                        unsigned long long c0 = 0;
+                        if (prof) c0 = SW_GZ_CLOCK();
                         const uint64_t w0 = ow[a >> 3], w1 = ow[(a >> 3) + 1];
                         v = off ? (w0 >> (8u * off)) | (w1 << (64u - 8u * off)) : w0;
+                        if (prof) {                                  // (the stamp waits for the words: v feeds it)
+                            p_load += SW_GZ_CLOCK() - c0 + (v & 0ull);
+                            ++p_nload;
+                        }
                     } else {                                         // (then sp >= n - 128: fl >= n - 71)
                         v = 0;
 #pragma unroll
@@ -388,7 +394,7 @@ SW_GZ_FN uint32_t inflate_one(LaneTables &t, LaneScratch &g, const uint8_t *comp
     }
     for (; fl < n; ++fl) out[fl] = t.ring[fl & 127u];   // the tail
     if (prof) {
-        prof_out[0] = p_build; prof_out[1] = p_dec; prof_out[2] = p_blocks; prof_out[3] = p_look; prof_out[4] = p_match; prof_out[5] = n;
+        prof_out[0] = p_build; prof_out[1] = p_dec; prof_out[2] = p_blocks; prof_out[3] = p_look; prof_out[4] = p_match; prof_out[5] = n; prof_out[6] = p_load; prof_out[7] = p_nload;
     }
     if (st == ST_OK) {
         const uint64_t used = br.pos - (br.cnt >> 3);     // whole bytes still in the bit buffer were not consumed

@@ -248,8 +248,8 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     if (timing) {
         unsigned long long hp[8];
         SW_HIP(hipMemcpy(hp, d_prof.p, 64, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[seqwin_amd] inflate, file 0: %llu bytes, %llu blocks, %llu lookups, %llu matches; clocks: table set-up %llu, decoding %llu\n",
-                hp[5], hp[2], hp[3], hp[4], hp[0], hp[1]);
+        fprintf(stderr, "[seqwin_amd] inflate, file 0: %llu bytes, %llu blocks, %llu lookups, %llu matches; clocks: table set-up %llu, decoding %llu, "
+                        "of which %llu in %llu window loads from HBM\n", hp[5], hp[2], hp[3], hp[4], hp[0], hp[1], hp[6], hp[7]);
     }
     std::vector<uint32_t> status;
     to_host(status, d_status, nf);
