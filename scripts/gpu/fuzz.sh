@@ -1,11 +1,16 @@
 # differential fuzz campaign on the GPU box: five processes share the card (six make four of them crawl).
-# usage (through gpurun): bash scripts/gpu/fuzz.sh <tag> [seconds]
+# usage (through gpurun): bash scripts/gpu/fuzz.sh <tag> [seconds] [gz]      gz: the two device-gzip-ingest campaigns instead
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O; cd $R; T=${2:-240}
+if [ "$3" = "gz" ]; then
+FUZZ_GZ=1 SEQWIN_AMD_DEVICE_INFLATE=1 python3 tests/tools/fuzz_gpu.py $T 26 > $O/fuzz_device_gz.log 2>&1 &
+FUZZ_GZ=1 SEQWIN_AMD_DEVICE_INFLATE=1 SEQWIN_AMD_RC=3 SEQWIN_AMD_SLOT_CAP=3 python3 tests/tools/fuzz_gpu.py $T 27 > $O/fuzz_device_gz_rc3.log 2>&1 &
+else
 python3 tests/tools/fuzz_gpu.py $T 21 > $O/fuzz_default.log 2>&1 &
 SEQWIN_AMD_SORT=own SEQWIN_AMD_EDGE_SKIP_PASSES=2 SEQWIN_AMD_UNSORT_DIRECT=4 SEQWIN_AMD_WINDOW_SPLIT=8,4 python3 tests/tools/fuzz_gpu.py $T 22 > $O/fuzz_unsort_winsplit.log 2>&1 &
 SEQWIN_AMD_UNSORT_DIRECT=4 SEQWIN_AMD_SORT_KEYBITS=10 SEQWIN_AMD_NO_PACKED_EDGES=1 SEQWIN_AMD_CHECK_ORDER=1 python3 tests/tools/fuzz_gpu.py $T 23 > $O/fuzz_knobs.log 2>&1 &
 FUZZ_DIST=1 SEQWIN_AMD_SORT=own SEQWIN_AMD_RADIX_BITS=9 SEQWIN_AMD_UNSORT_DIRECT=6 python3 tests/tools/fuzz_gpu.py $T 24 > $O/fuzz_dist.log 2>&1 &
 FUZZ_LOWMEM=1 SEQWIN_AMD_LOWMEM_CHUNK_MBP=0 SEQWIN_AMD_RANKS=table SEQWIN_AMD_RC=3 python3 tests/tools/fuzz_gpu.py $T 25 > $O/fuzz_lowmem_table_rc3.log 2>&1 &
+fi
 for i in $(seq 1 40); do sleep 30; echo "t=$((i*30))s"; kill -0 $! 2>/dev/null || break; done
 wait
 tail -n 1 $O/fuzz_*.log

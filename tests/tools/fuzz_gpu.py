@@ -13,6 +13,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 replay = [int(x) for x in sys.argv[3:]]
 LOWMEM = os.environ.get("FUZZ_LOWMEM") == "1"      # sw_build's chunked low-memory route (set SEQWIN_AMD_LOWMEM_CHUNK_MBP=0: one assembly per chunk)
 DIST = os.environ.get("FUZZ_DIST") == "1"          # also push every case through the routed multi-GPU forms (P shards on one GPU)
+GZ_ALL = os.environ.get("FUZZ_GZ") == "1"          # every file gzipped (levels 0-9): with SEQWIN_AMD_DEVICE_INFLATE=1 the device ingest route
 if DIST:
     sys.path.insert(0, str(ROOT / "tests"))
     from test_gpu_dist import _route_and_merge, routed_tuple_exchange          # optional: replay these exact case seeds and print the first differences
@@ -51,11 +52,11 @@ while time.time() < t_end and (not replay or it < len(replay)):
             width = rng.choice([60, 80, 7, 100000])
             for i in range(0, len(s), width):
                 txt.append(s[i:i + width] + rng.choice(["\n", "\r\n", " \n"]))
-        gz = rng.random() < 0.2
+        gz = rng.random() < 0.2 or GZ_ALL
         p = os.path.join(tmp, f"{it}_{a}.fa" + (".gz" if gz else ""))
         data = "".join(txt)
         if gz:
-            with gzip.open(p, "wt") as f:
+            with gzip.open(p, "wt", compresslevel=(seed + a) % 10 if GZ_ALL else 9) as f:
                 f.write(data)
         else:
             with open(p, "w") as f:
