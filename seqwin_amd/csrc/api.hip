@@ -764,6 +764,7 @@ int sw_index_build(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, con
 {
     return guarded([&] {
         std::unique_ptr<sw_index> ix(new sw_index);
+        ix->last_stream = (hipStream_t)stream;
         do_index_build(*const_cast<sw_batch *>(b), kmerlen, windowsize, is_targets, n_assemblies, (hipStream_t)stream, *ix);
         *out = ix.release();
     });
@@ -822,7 +823,12 @@ int sw_index_verify(const sw_index *ix, uint64_t n_assemblies, int scored, uint6
     });
 }
 
-void sw_index_free(sw_index *ix) { delete ix; }
+void sw_index_free(sw_index *ix)
+{
+    if (!ix) return;
+    StreamScope scope(ix->last_stream);   // the blocks go back tagged with the stream that used them last (not the null stream)
+    delete ix;
+}
 
 int sw_index_threshold_sums(const sw_index *ix, uint64_t *sums)
 {
@@ -871,6 +877,7 @@ int sw_occ_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void
         StreamScope scope((hipStream_t)stream);
         Plan &plan = get_plan(bb, kmerlen, windowsize);
         std::unique_ptr<sw_occ> o(new sw_occ);
+        o->last_stream = (hipStream_t)stream;
         o->batch = b;
         o->occ = new OrderedOcc;
         SketchOut sk;
@@ -888,13 +895,19 @@ int sw_occ_size(const sw_occ *o, uint64_t *n, double *sketch_ms)
     });
 }
 
-void sw_occ_free(sw_occ *o) { delete o; }
+void sw_occ_free(sw_occ *o)
+{
+    if (!o) return;
+    StreamScope scope(o->last_stream);
+    delete o;
+}
 
 int sw_occ_partition(const sw_occ *o, const uint64_t *bounds, uint64_t n_bounds, uint64_t rec_offset, void *rows_dev,
                      void *perm_dev, uint64_t *counts, void *stream)
 {
     return guarded([&] {
         StreamScope scope((hipStream_t)stream);
+        const_cast<sw_occ *>(o)->last_stream = (hipStream_t)stream;
         occ_partition(*o->occ, bounds, (uint32_t)n_bounds, rec_offset, (uint64_t *)rows_dev, (uint32_t *)perm_dev, counts,
                       (hipStream_t)stream);
     });
@@ -908,6 +921,7 @@ int sw_occ_adjacency(const sw_occ *o, const void *perm_dev, const void *rank_by_
         if (n_bits < 1 || n_bits > 32) raise(SW_ERR_VALUE, "n_bits must be in [1, 32]");
         if (asm_bits && 2 * n_bits + asm_bits > 64) raise(SW_ERR_VALUE, "packed adjacency keys need 2 n_bits + asm_bits <= 64");
         StreamScope scope((hipStream_t)stream);
+        const_cast<sw_occ *>(o)->last_stream = (hipStream_t)stream;
         occ_adjacency(*o->occ, o->batch->d_rec_asm.p, (const uint32_t *)perm_dev, (const uint32_t *)rank_by_row_dev,
                       (unsigned)n_bits, (unsigned)asm_bits, asm_base, rank_bounds, (uint32_t)n_bounds, (uint64_t *)rows_dev,
                       counts, (hipStream_t)stream);
@@ -919,6 +933,7 @@ int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t 
 {
     return guarded([&] {
         StreamScope scope((hipStream_t)stream);
+        const_cast<sw_index *>(ix)->last_stream = (hipStream_t)stream;
         Event e0, e1;
         SW_HIP(hipEventRecord(e0, (hipStream_t)stream));
         slice_edges(*ix, (const uint64_t *)adj_rows_dev, m, (unsigned)n_bits, (unsigned)asm_bits,
@@ -971,6 +986,7 @@ int sw_occ_adjacency_pairs(const sw_occ *o, const void *rank_by_row_dev, const u
         if (n_owners != occ_partition_owners(*o->occ))
             raise(SW_ERR_VALUE, "node_base must hold one entry per owner of the tuple partition, plus the total");
         StreamScope scope((hipStream_t)stream);
+        const_cast<sw_occ *>(o)->last_stream = (hipStream_t)stream;
         occ_adjacency_pairs(*o->occ, o->batch->d_rec_asm.p, (const uint32_t *)rank_by_row_dev, node_base, asm_base, rank_bounds,
                             (uint32_t)n_bounds, (uint64_t *)keys_dev, counts, cand_counts, key_bits, (hipStream_t)stream);
     });
@@ -979,6 +995,7 @@ int sw_occ_adjacency_pairs(const sw_occ *o, const void *rank_by_row_dev, const u
 int sw_occ_candidates(const sw_occ *o, void *rows_dev, void *stream)
 {
     return guarded([&] {
+        const_cast<sw_occ *>(o)->last_stream = (hipStream_t)stream;
         if (o->occ->cand_rows.n)
             SW_HIP(hipMemcpyAsync(rows_dev, o->occ->cand_rows.p, o->occ->cand_rows.n * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     });
@@ -990,6 +1007,7 @@ int sw_slice_edges_pairs(sw_index *ix, void *keys_dev, uint64_t m, const void *c
 {
     return guarded([&] {
         StreamScope scope((hipStream_t)stream);
+        const_cast<sw_index *>(ix)->last_stream = (hipStream_t)stream;
         Event e0, e1;
         SW_HIP(hipEventRecord(e0, (hipStream_t)stream));
         slice_edges_pairs(*ix, (uint64_t *)keys_dev, m, (const uint64_t *)cand_rows_dev, n_cand, (unsigned)lo_bits, (unsigned)hi_bits,
@@ -1007,6 +1025,7 @@ int sw_index_node_hashes(const sw_index *ix, void *dst_dev, void *stream)
 {
     return guarded([&] {
         StreamScope scope((hipStream_t)stream);
+        const_cast<sw_index *>(ix)->last_stream = (hipStream_t)stream;
         index_node_hashes(*ix, (uint64_t *)dst_dev, (hipStream_t)stream);
     });
 }
@@ -1024,6 +1043,7 @@ int sw_index_occ_rows(const sw_index *ix, uint64_t rec_offset, void *rows_dev, v
 {
     return guarded([&] {
         StreamScope scope((hipStream_t)stream);
+        const_cast<sw_index *>(ix)->last_stream = (hipStream_t)stream;
         index_occ_rows(*ix, rec_offset, (uint64_t *)rows_dev, (hipStream_t)stream);
     });
 }
@@ -1042,6 +1062,7 @@ int sw_index_splits(const sw_index *ix, const uint64_t *node_bounds, const uint6
 {
     return guarded([&] {
         StreamScope scope((hipStream_t)stream);
+        const_cast<sw_index *>(ix)->last_stream = (hipStream_t)stream;
         index_splits(*ix, node_bounds, edge_bounds, (uint32_t)n_bounds, occ_split, edge_split, (hipStream_t)stream);
     });
 }
@@ -1078,6 +1099,7 @@ static void merge_like(const void *occ_rows_dev, uint64_t n_occ, const void *edg
         hipStream_t st = (hipStream_t)stream;
         StreamScope scope(st);
         std::unique_ptr<sw_index> ix(new sw_index);
+        ix->last_stream = st;
         SW_HIP(hipGetDevice(&ix->device));
         uint64_t n_tar = 0, n_neg = 0;
         DevArray<uint8_t> d_tar;

@@ -155,6 +155,7 @@ struct sw_occ {   // ordered tuple stream of one shard (tuple-exchange form of t
     const sw_batch *batch = nullptr;
     sw::OrderedOcc *occ = nullptr;
     float sketch_ms = 0.f;
+    hipStream_t last_stream = nullptr;   // the stream its arrays were last used on: sw_occ_free releases them under it
     ~sw_occ();
 };
 
@@ -166,6 +167,7 @@ struct sw_index {
     sw::DevArray<sw_edge> edges;
     sw_timings timings{};
     bool ranks_marked = false;   // slice build: the returned ranks carry "node recurs in its assembly" in bit 31
+    hipStream_t last_stream = nullptr;   // the stream its arrays were last used on: sw_index_free releases them under it
 };
 
 namespace sw {
