@@ -249,7 +249,8 @@ class HipEngine:
         return keys[:sum(counts)].to(self.device), counts, cand.to(self.device), cand_counts, (int(bits[0]), int(bits[1]))
 
     def slice_edges_pairs(self, ix, keys, cand, key_bits, lo_base: int, asm_bits: int, rank_hash, node_base, pad: int) -> None:
-        """rank_hash: the job-wide table, owner o's node hashes at [o * pad, o * pad + its count)."""
+        """rank_hash: the job-wide table, owner o's node hashes at [o * pad, o * pad + its count).
+        ``keys`` is sorted where it lies (one half of the sort's double buffer): its contents are not preserved."""
         from ._lib import c_u64, c_vp, check, lib
         keys = keys.to(self.gpu).contiguous()
         cand = cand.to(self.gpu).contiguous()
