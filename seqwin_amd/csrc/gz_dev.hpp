@@ -1,5 +1,5 @@
 // gz_dev.hpp -- DEFLATE decoder and FASTA parser / 2-bit packer of the device gzip ingest (ingest_dev.hip), one stream per
-// caller.  Plain C++ over pointers: the kernels of ingest_dev.hip run it one file per lane (tables in LDS, scratch in HBM);
+// caller.  Plain C++ over pointers: the kernels of ingest_dev.hip run it one file per lane (all decoder state in LDS);
 // tests/tools/gz_dev_san_driver.cpp compiles THE SAME code for the host with AddressSanitizer + UBSan and feeds it
 // well-formed and broken streams (tests/test_abi_cpu.py) -- GPU sanitizers do not exist on the target.
 #pragma once
@@ -30,29 +30,26 @@ SW_GZ_FN uint32_t brev32(uint32_t v)
     return (v >> 16) | (v << 16);
 }
 
-constexpr int LIT_BITS = 9, DIST_BITS = 7;
+constexpr int LIT_BITS = 8, DIST_BITS = 7;
 constexpr uint32_t ST_OK = 0, ST_BAD_BLOCK = 1, ST_BAD_CODE = 2, ST_TRUNCATED = 3, ST_OVERFLOW = 4, ST_BAD_DIST = 5, ST_BAD_LENS = 6,
                    ST_TRAILING = 7, ST_SHORT = 8;
 
-struct LaneTables {            // per lane, in LDS
+struct LaneTables {            // per lane, in LDS: everything a stream's decoder touches except its input and output
     // literal / length table over LIT_BITS bits: [3:0] bits to drop (0: a longer code, or none -- bit by bit), [5:4] n;
     // n = 1..3: that many LITERALS in bytes 1..3 (DNA text is ~2 bits per base: one lookup takes up to three bases);
     // n = 0: one symbol (>= 256: end of block or a length code) in [24:8]
     uint32_t lit[1 << LIT_BITS];
     uint16_t dist[1 << DIST_BITS];  // distance table: symbol << 4 | code length (0: longer than DIST_BITS bits, or no code)
+    uint16_t lsym[288];             // symbols in (length, symbol) order: canonical decoding of the long codes
+    uint16_t dsym[32];
     uint16_t lcount[16], dcount[16], offs[16];
+    uint8_t lens[320];              // code lengths of a block's two alphabets (table set-up)
     // the last 128 bytes of output.  Text goes to HBM 64 bytes at a time: a lane's loads wait for ALL its earlier stores (one
     // vmcnt for both on gfx9), so storing every byte at once made every match -- three of four symbols in level-6 DNA --
-    // pay a store's round trip before its own (~4 us per match; r03).  Matches that reach into the unwritten tail read it here.
+    // pay a store's round trip before its own (r03).  Matches that reach into the unwritten tail read it here.
     alignas(8) uint8_t ring[128];
 };
 static_assert(sizeof(LaneTables) * 64 <= 160 * 1024, "one wave's tables must fit the CU's LDS");
-struct LaneScratch {           // per lane, in HBM: what only a block's table set-up and the rare long codes touch
-    uint16_t lsym[288];             // symbols in (length, symbol) order: canonical decoding of the long codes
-    uint16_t dsym[32];
-    uint16_t single[1 << LIT_BITS]; // one-symbol literal / length table the multi-literal one is made from
-    uint8_t lens[320];
-};
 
 SW_GZ_CONST uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
 SW_GZ_CONST uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -112,7 +109,8 @@ struct BitReader {
 };
 
 // canonical Huffman tables from code lengths (RFC 1951 3.2.2).  Returns 0: complete code, > 0: incomplete, < 0: over-subscribed.
-SW_GZ_FN int build_tables(const uint8_t *lens, uint32_t n, uint16_t *count, uint16_t *symbols, uint16_t *primary, int pbits, uint16_t *offs)
+template <class P>
+SW_GZ_FN int build_tables(const uint8_t *lens, uint32_t n, uint16_t *count, uint16_t *symbols, P *primary, int pbits, uint16_t *offs)
 {
     for (int l = 0; l < 16; ++l) count[l] = 0;
     for (uint32_t s = 0; s < n; ++s) ++count[lens[s]];
@@ -133,7 +131,7 @@ SW_GZ_FN int build_tables(const uint8_t *lens, uint32_t n, uint16_t *count, uint
         for (uint32_t j = 0; j < count[l]; ++j) {
             const uint32_t sym = symbols[idx++];
             const uint32_t r = brev32(code) >> (32 - l);   // the stream carries a code's bits most significant first
-            for (uint32_t k = r; k < (1u << pbits); k += 1u << l) primary[k] = (uint16_t)((sym << 4) | (uint32_t)l);
+            for (uint32_t k = r; k < (1u << pbits); k += 1u << l) primary[k] = (P)((sym << 4) | (uint32_t)l);
             ++code;
         }
         code <<= 1;
@@ -176,7 +174,7 @@ SW_GZ_FN int decode_symbol(BitReader &br, const uint16_t *primary, int pbits, co
 // One deflate stream comp[start, end) -> arena[text_off, text_off + cap) (arena: 8-byte aligned, text_off a multiple of 16,
 // 16 readable bytes behind every region).  Returns ST_OK only if the stream ends exactly at `end` after exactly cap bytes.
 // prof_out (may be null): clocks in table set-up / decoding, blocks, lookups, matches, bytes.
-SW_GZ_FN uint32_t inflate_one(LaneTables &t, LaneScratch &g, const uint8_t *comp, uint64_t start, uint64_t end, uint8_t *arena,
+SW_GZ_FN uint32_t inflate_one(LaneTables &t, const uint8_t *comp, uint64_t start, uint64_t end, uint8_t *arena,
                               uint64_t text_off, uint64_t cap, unsigned long long *prof_out)
 {
     BitReader br;
@@ -224,11 +222,11 @@ SW_GZ_FN uint32_t inflate_one(LaneTables &t, LaneScratch &g, const uint8_t *comp
         if (type == 3) { st = ST_BAD_BLOCK; break; }
         uint32_t nlen, ndist;
         if (type == 1) {                        // fixed code (3.2.6)
-            for (int s = 0; s < 144; ++s) g.lens[s] = 8;
-            for (int s = 144; s < 256; ++s) g.lens[s] = 9;
-            for (int s = 256; s < 280; ++s) g.lens[s] = 7;
-            for (int s = 280; s < 288; ++s) g.lens[s] = 8;
-            for (int s = 288; s < 318; ++s) g.lens[s] = 5;
+            for (int s = 0; s < 144; ++s) t.lens[s] = 8;
+            for (int s = 144; s < 256; ++s) t.lens[s] = 9;
+            for (int s = 256; s < 280; ++s) t.lens[s] = 7;
+            for (int s = 280; s < 288; ++s) t.lens[s] = 8;
+            for (int s = 288; s < 318; ++s) t.lens[s] = 5;
             nlen = 288;
             ndist = 30;
         } else {                                // dynamic code (3.2.7)
@@ -240,19 +238,19 @@ SW_GZ_FN uint32_t inflate_one(LaneTables &t, LaneScratch &g, const uint8_t *comp
             const uint32_t ncode = br.peek(4) + 4;
             br.drop(4);
             if (nlen > 286 || ndist > 30) { st = ST_BAD_LENS; break; }
-            for (int i = 0; i < 19; ++i) g.lens[i] = 0;
+            for (int i = 0; i < 19; ++i) t.lens[i] = 0;
             for (uint32_t i = 0; i < ncode; ++i) {
                 if (!br.need(3)) { st = ST_TRUNCATED; break; }
-                g.lens[kClOrder[i]] = (uint8_t)br.peek(3);
+                t.lens[kClOrder[i]] = (uint8_t)br.peek(3);
                 br.drop(3);
             }
             if (st != ST_OK) break;
             // the code-length code: its tables live in the distance tables' space until the lengths are read
-            if (build_tables(g.lens, 19, t.dcount, g.dsym, t.dist, DIST_BITS, t.offs) != 0) { st = ST_BAD_LENS; break; }
+            if (build_tables(t.lens, 19, t.dcount, t.dsym, t.dist, DIST_BITS, t.offs) != 0) { st = ST_BAD_LENS; break; }
             uint32_t idx = 0;
-            uint8_t *ll = g.lens;                // (the 19 lengths above have been consumed)
+            uint8_t *ll = t.lens;                // (the 19 lengths above have been consumed)
             while (idx < nlen + ndist) {
-                const int sym = decode_symbol(br, t.dist, DIST_BITS, t.dcount, g.dsym);
+                const int sym = decode_symbol(br, t.dist, DIST_BITS, t.dcount, t.dsym);
                 if (sym < 0) { st = ST_BAD_CODE; break; }
                 if (sym < 16) {
                     ll[idx++] = (uint8_t)sym;
@@ -281,14 +279,16 @@ SW_GZ_FN uint32_t inflate_one(LaneTables &t, LaneScratch &g, const uint8_t *comp
             if (ll[256] == 0) { st = ST_BAD_LENS; break; }     // no end-of-block code
         }
         {
-            const int e1 = build_tables(g.lens, nlen, t.lcount, g.lsym, g.single, LIT_BITS, t.offs);
+            const int e1 = build_tables(t.lens, nlen, t.lcount, t.lsym, t.lit, LIT_BITS, t.offs);
             // (the fixed distance code is incomplete by definition: 30 of 32 five-bit codes)
             if (type == 2 && e1 && (e1 < 0 || nlen != (uint32_t)t.lcount[0] + t.lcount[1])) { st = ST_BAD_LENS; break; }   // incomplete: one code only
-            const int e2 = build_tables(g.lens + nlen, ndist, t.dcount, g.dsym, t.dist, DIST_BITS, t.offs);
+            const int e2 = build_tables(t.lens + nlen, ndist, t.dcount, t.dsym, t.dist, DIST_BITS, t.offs);
             if (type == 2 && e2 && (e2 < 0 || ndist != (uint32_t)t.dcount[0] + t.dcount[1])) { st = ST_BAD_LENS; break; }
         }
-        for (uint32_t i = 0; i < (1u << LIT_BITS); ++i) {    // up to three literals per entry
-            const uint32_t a = g.single[i], la = a & 15u;
+        // t.lit holds one symbol per entry (symbol << 4 | length); up to three literals per entry are packed IN PLACE, from the
+        // last entry down: entry i looks at entries i >> (bits taken) < i only, which are still in their one-symbol form
+        for (uint32_t i = (1u << LIT_BITS); i-- > 0;) {
+            const uint32_t a = t.lit[i], la = a & 15u;
             uint32_t e = 0;
             if (la) {
                 if ((a >> 4) >= 256u) {
@@ -297,7 +297,7 @@ SW_GZ_FN uint32_t inflate_one(LaneTables &t, LaneScratch &g, const uint8_t *comp
                     uint32_t total = la, cnt = 1, lits = a >> 4;
                     for (int more = 0; more < 2; ++more) {
                         // the bits behind the codes taken so far; a code found there counts if all its bits lie inside the window
-                        const uint32_t b = g.single[i >> total], lb = b & 15u;
+                        const uint32_t b = t.lit[i >> total], lb = b & 15u;     // (i == 0: its own entry, not yet rewritten)
                         if (!lb || total + lb > (uint32_t)LIT_BITS || (b >> 4) >= 256u) break;
                         lits |= (b >> 4) << (8 * cnt);
                         total += lb;
@@ -332,7 +332,7 @@ SW_GZ_FN uint32_t inflate_one(LaneTables &t, LaneScratch &g, const uint8_t *comp
                     br.drop(tl);
                     sym = (int)(e >> 8);
                 } else {
-                    sym = decode_long(br, t.lcount, g.lsym);
+                    sym = decode_long(br, t.lcount, t.lsym);
                     if (sym < 0) { st = br.cnt == 0 && br.pos >= br.end ? ST_TRUNCATED : ST_BAD_CODE; break; }
                     if (sym < 256) {
                         if (n >= cap) { st = ST_OVERFLOW; break; }
@@ -348,7 +348,7 @@ SW_GZ_FN uint32_t inflate_one(LaneTables &t, LaneScratch &g, const uint8_t *comp
             if (!br.need(kLenExtra[li])) { st = ST_TRUNCATED; break; }
             const uint32_t len = kLenBase[li] + br.peek(kLenExtra[li]);
             br.drop(kLenExtra[li]);
-            const int ds = decode_symbol(br, t.dist, DIST_BITS, t.dcount, g.dsym);
+            const int ds = decode_symbol(br, t.dist, DIST_BITS, t.dcount, t.dsym);
             if (ds < 0 || ds > 29) { st = ST_BAD_CODE; break; }
             if (!br.need(kDistExtra[ds])) { st = ST_TRUNCATED; break; }
             const uint64_t dist = (uint64_t)kDistBase[ds] + br.peek(kDistExtra[ds]);

@@ -43,7 +43,6 @@ struct InflateArgs {
     const uint32_t *isize;
     uint32_t n_files;
     uint32_t *status;
-    LaneScratch *scratch;                    // [n_files]
     unsigned long long *prof;                // (SEQWIN_AMD_DEBUG_TIMING) file 0: clocks in table set-up / decoding, blocks, lookups, matches
 };
 
@@ -52,7 +51,7 @@ __global__ __launch_bounds__(64) void k_inflate(const InflateArgs A)
     __shared__ LaneTables T[64];
     const uint32_t f = blockIdx.x * 64 + threadIdx.x;
     if (f >= A.n_files) return;
-    A.status[f] = inflate_one(T[threadIdx.x], A.scratch[f], A.comp, A.data_start[f], A.data_end[f], A.text, A.text_off[f], A.isize[f],
+    A.status[f] = inflate_one(T[threadIdx.x], A.comp, A.data_start[f], A.data_end[f], A.text, A.text_off[f], A.isize[f],
                               A.prof && f == 0 ? A.prof : nullptr);
 }
 
@@ -239,10 +238,9 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     SW_HIP(hipMemcpy(d_toff.p, toff.data(), (nf + 1) * 8ull, hipMemcpyHostToDevice));
     SW_HIP(hipMemcpy(d_isize.p, isize.data(), nf * 4ull, hipMemcpyHostToDevice));
     const unsigned blocks = (nf + 63) / 64;
-    DevArray<LaneScratch> d_scratch(nf);
     DevArray<unsigned long long> d_prof(8);
     SW_HIP(hipMemset(d_prof.p, 0, 64));
-    InflateArgs ia{d_comp.p, d_dstart.p, d_dend.p, d_text.p, d_toff.p, d_isize.p, nf, d_status.p, d_scratch.p, timing ? d_prof.p : nullptr};
+    InflateArgs ia{d_comp.p, d_dstart.p, d_dend.p, d_text.p, d_toff.p, d_isize.p, nf, d_status.p, timing ? d_prof.p : nullptr};
     hipLaunchKernelGGL(k_inflate, dim3(blocks), dim3(64), 0, nullptr, ia);
     SW_HIP(hipGetLastError());
     if (timing) {

@@ -53,9 +53,8 @@ int main(int argc, char **argv)
     memset(text, 0x5A, toff[nf] + 16);
 
     static LaneTables tables;
-    static LaneScratch scratch;
     for (size_t i = 0; i < nf; ++i) {
-        const uint32_t st = inflate_one(tables, scratch, comp, dstart[i], dend[i], text, toff[i], isize[i], nullptr);
+        const uint32_t st = inflate_one(tables, comp, dstart[i], dend[i], text, toff[i], isize[i], nullptr);
         if (st != ST_OK) return decline("inflate status", argv[i + 2], st);
     }
     static uint8_t cls[256];
