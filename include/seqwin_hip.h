@@ -346,6 +346,19 @@ int sw_occ_candidates(const sw_occ *o, void *rows_dev, void *stream);
 int sw_slice_edges_pairs(sw_index *ix, void *keys_dev, uint64_t m, const void *cand_rows_dev, uint64_t n_cand, uint64_t lo_bits,
                          uint64_t hi_bits, uint64_t lo_base, uint64_t asm_bits, const void *rank_hash_dev, const uint64_t *node_base,
                          uint64_t n_owners, uint64_t pad, void *stream);
+/* The same without the job-wide table (rank_hash_dev == NULL above: 8 B per node of the WHOLE job on every GPU -- 40 GB at
+ * 5e9 nodes): the edges then hold global ranks and their hashes are asked from the node owners, 12 B per distinct endpoint.
+ *   1. edge owner: sw_index_edge_hash_requests -> *n_requests distinct endpoint ranks, as owner-LOCAL ranks (u32) in ascending
+ *      global order, counts[n_owners] of them for each node owner; sw_index_edge_hash_request_rows copies them out (DEVICE);
+ *   2. the requests travel to the node owners (all-to-all by counts); a node owner answers the ranks it received with
+ *      sw_index_node_hash_lookup: hashes_dev[i] = hash of its node local_ranks_dev[i];
+ *   3. the replies travel back in request order; sw_index_edge_hash_attach(ix, replies_dev, *n_requests) writes them into the
+ *      edges.  Until then sw_index_export / _checksums of this index see ranks in edges.first / .second. */
+int sw_index_edge_hash_requests(sw_index *ix, const uint64_t *node_base, uint64_t n_owners, uint64_t *counts, uint64_t *n_requests,
+                                void *stream);
+int sw_index_edge_hash_request_rows(const sw_index *ix, void *local_ranks_dev, void *stream);
+int sw_index_node_hash_lookup(const sw_index *ix, const void *local_ranks_dev, uint64_t n, void *hashes_dev, void *stream);
+int sw_index_edge_hash_attach(sw_index *ix, const void *replies_dev, uint64_t n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1021,6 +1021,39 @@ int sw_slice_edges_pairs(sw_index *ix, void *keys_dev, uint64_t m, const void *c
     });
 }
 
+int sw_index_edge_hash_requests(sw_index *ix, const uint64_t *node_base, uint64_t n_owners, uint64_t *counts, uint64_t *n_requests,
+                                void *stream)
+{
+    return guarded([&] {
+        StreamScope scope((hipStream_t)stream);
+        ix->last_stream = (hipStream_t)stream;
+        *n_requests = edge_hash_requests(*ix, node_base, (uint32_t)n_owners, counts, (hipStream_t)stream);
+    });
+}
+
+int sw_index_edge_hash_request_rows(const sw_index *ix, void *local_ranks_dev, void *stream)
+{
+    return guarded([&] { edge_hash_request_rows(*ix, (uint32_t *)local_ranks_dev, (hipStream_t)stream); });
+}
+
+int sw_index_node_hash_lookup(const sw_index *ix, const void *local_ranks_dev, uint64_t n, void *hashes_dev, void *stream)
+{
+    return guarded([&] {
+        StreamScope scope((hipStream_t)stream);
+        const_cast<sw_index *>(ix)->last_stream = (hipStream_t)stream;
+        node_hash_lookup(*ix, (const uint32_t *)local_ranks_dev, n, (uint64_t *)hashes_dev, (hipStream_t)stream);
+    });
+}
+
+int sw_index_edge_hash_attach(sw_index *ix, const void *replies_dev, uint64_t n, void *stream)
+{
+    return guarded([&] {
+        StreamScope scope((hipStream_t)stream);
+        ix->last_stream = (hipStream_t)stream;
+        edge_hash_attach(*ix, (const uint64_t *)replies_dev, n, (hipStream_t)stream);
+    });
+}
+
 int sw_index_node_hashes(const sw_index *ix, void *dst_dev, void *stream)
 {
     return guarded([&] {

@@ -159,6 +159,7 @@ struct sw_occ {   // ordered tuple stream of one shard (tuple-exchange form of t
     ~sw_occ();
 };
 
+namespace sw { struct EdgeHashJob; }
 struct sw_index {
     int device = 0;
     uint64_t n_kmers = 0, n_nodes = 0, n_edges = 0;
@@ -168,6 +169,14 @@ struct sw_index {
     sw_timings timings{};
     bool ranks_marked = false;   // slice build: the returned ranks carry "node recurs in its assembly" in bit 31
     hipStream_t last_stream = nullptr;   // the stream its arrays were last used on: sw_index_free releases them under it
+    // multi-GPU slices built without the job-wide rank -> hash table: edges hold global RANKS until the hashes have been
+    // asked from the node owners (index.hip: edge_hash_requests / edge_hash_attach)
+    bool edges_hold_ranks = false;
+    sw::EdgeHashJob *hash_job = nullptr;
+    sw_index() = default;
+    sw_index(const sw_index &) = delete;
+    sw_index &operator=(const sw_index &) = delete;
+    ~sw_index();
 };
 
 namespace sw {
@@ -277,5 +286,12 @@ void slice_edges_pairs(sw_index &ix, uint64_t *d_keys, uint64_t m, const uint64_
                        unsigned hi_bits, uint64_t lo_base, unsigned ab, const uint64_t *d_rank_hash, const uint64_t *node_base,
                        uint32_t n_owners, uint64_t pad, hipStream_t stream);
 void index_node_hashes(const sw_index &ix, uint64_t *d_out, hipStream_t stream);
+// rank -> hash by request instead of the job-wide table (slices whose edges hold ranks): the distinct endpoint ranks of the
+// slice's edges as owner-local ranks grouped by node owner (counts_host[n_owners]); lookups at the node owner; the replies,
+// in the order of the requests, put into the edges
+uint64_t edge_hash_requests(sw_index &ix, const uint64_t *node_base, uint32_t n_owners, uint64_t *counts_host, hipStream_t stream);
+void edge_hash_request_rows(const sw_index &ix, uint32_t *d_out, hipStream_t stream);
+void node_hash_lookup(const sw_index &ix, const uint32_t *d_local_ranks, uint64_t n, uint64_t *d_out, hipStream_t stream);
+void edge_hash_attach(sw_index &ix, const uint64_t *d_replies, uint64_t n, hipStream_t stream);
 
 }  // namespace sw

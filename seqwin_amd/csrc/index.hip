@@ -989,6 +989,7 @@ struct RankHash {
     uint32_t n_owners;
     __device__ uint64_t operator()(uint64_t rank) const
     {
+        if (!table) return rank;                 // no table: the edges keep global ranks (edge_hash_requests / _attach)
         uint32_t o = 0;
         for (uint32_t q = 1; q < n_owners; ++q) o += (node_base[q] <= rank) ? 1u : 0u;
         return table[(uint64_t)o * pad + (rank - node_base[o])];
@@ -3277,6 +3278,7 @@ void slice_edges_pairs(sw_index &ix, uint64_t *d_keys, uint64_t m, const uint64_
                        uint32_t n_owners, uint64_t pad, hipStream_t stream)
 {
     ix.n_edges = 0;
+    ix.edges_hold_ranks = d_rank_hash == nullptr;   // (null table: first / second stay global ranks for now)
     if (m >= 0xFFFFFFFFull || c >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 adjacency rows on one device");
     if (n_owners == 0 || n_owners > 16) raise(SW_ERR_VALUE, "1 .. 16 owners are supported");
     if (lo_bits + hi_bits > 64 || lo_bits == 0 || hi_bits == 0) raise(SW_ERR_VALUE, "edge keys: 1 <= lo_bits, hi_bits and lo_bits + hi_bits <= 64");
@@ -3306,6 +3308,176 @@ void index_node_hashes(const sw_index &ix, uint64_t *d_out, hipStream_t stream)
     if (ix.n_nodes == 0) return;
     hipLaunchKernelGGL(k_node_hashes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, d_out);
     SW_HIP(hipGetLastError());
+}
+
+// ---- rank -> hash by request (multi-GPU slices built without the job-wide table) ---------------------------------
+// The edges of a slice name up to 2 E distinct nodes by global rank.  Sorted by rank (a pair sort: rank, slot = edge * 2 +
+// side) the distinct ones are the requests: owner-local ranks, ascending, so the requests to one node owner are one
+// contiguous piece and that owner reads its hashes in order.  The replies come back in request order and go into the edges
+// through the same sorted list.  Volume: 12 B per distinct endpoint instead of 8 B per node of the whole job per GPU.
+struct EdgeHashJob {
+    DevArray<uint32_t> slot, uniq;   // [2 E], in rank order: where the hash goes / which request answers it
+    DevArray<uint32_t> req;          // [n_unique]
+    uint64_t n_unique = 0, n_slots = 0;
+};
+}  // namespace sw
+sw_index::~sw_index() { delete hash_job; }
+namespace sw {
+namespace {
+__global__ void k_edge_ranks(const sw_edge *__restrict__ edges, uint64_t n_edges, uint64_t *__restrict__ rank, uint32_t *__restrict__ slot)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_edges) return;
+    rank[2 * e] = edges[e].first;
+    rank[2 * e + 1] = edges[e].second;
+    slot[2 * e] = (uint32_t)(2 * e);
+    slot[2 * e + 1] = (uint32_t)(2 * e + 1);
+}
+struct RankHeadFlag {   // 1 where a sorted rank differs from its predecessor
+    const uint64_t *rank;
+    __host__ __device__ uint32_t operator()(uint64_t j) const { return (j == 0 || rank[j] != rank[j - 1]) ? 1u : 0u; }
+};
+struct OwnerBases {
+    uint64_t base[18];
+    uint32_t n_owners;
+};
+// cum[j] = number of distinct ranks up to and including sorted position j; the head of every distinct rank writes its request
+__global__ void k_edge_requests(const uint64_t *__restrict__ rank, const uint32_t *__restrict__ cum, uint64_t n, const OwnerBases B,
+                                uint32_t *__restrict__ uniq, uint32_t *__restrict__ req, uint32_t *__restrict__ bad)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t u = cum[j] - 1u;
+    uniq[j] = u;
+    if (j == 0 || rank[j] != rank[j - 1]) {
+        const uint64_t r = rank[j];
+        uint32_t o = 0;
+        for (uint32_t q = 1; q < B.n_owners; ++q) o += (B.base[q] <= r) ? 1u : 0u;
+        if (r >= B.base[B.n_owners] || r - B.base[o] > 0xFFFFFFFFull) atomicOr(bad, 1u);
+        req[u] = (uint32_t)(r - B.base[o]);
+    }
+}
+// cnt[o] = distinct ranks below base[o] (o = 0 .. n_owners): one thread each, a binary search in the sorted ranks
+__global__ void k_owner_cuts(const uint64_t *__restrict__ rank, const uint32_t *__restrict__ cum, uint64_t n, const OwnerBases B,
+                             unsigned long long *__restrict__ below)
+{
+    const uint32_t o = threadIdx.x;
+    if (o > B.n_owners) return;
+    uint64_t lo = 0, hi = n;        // first j with rank[j] >= base[o]
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (rank[mid] < B.base[o]) lo = mid + 1; else hi = mid;
+    }
+    below[o] = lo ? cum[lo - 1] : 0u;
+}
+__global__ void k_lookup_hashes(const sw_node *__restrict__ nodes, uint64_t n_nodes, const uint32_t *__restrict__ local, uint64_t n,
+                                uint64_t *__restrict__ out, uint32_t *__restrict__ bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = local[i];
+    if (r >= n_nodes) {
+        atomicOr(bad, 1u);
+        out[i] = 0;
+        return;
+    }
+    out[i] = nodes[r].hash;
+}
+__global__ void k_attach_hashes(sw_edge *__restrict__ edges, const uint32_t *__restrict__ slot, const uint32_t *__restrict__ uniq,
+                                const uint64_t *__restrict__ replies, uint64_t n)
+{
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t s = slot[j];
+    uint64_t *e = reinterpret_cast<uint64_t *>(edges + (s >> 1));
+    e[s & 1u] = replies[uniq[j]];
+}
+}  // namespace
+
+uint64_t edge_hash_requests(sw_index &ix, const uint64_t *node_base, uint32_t n_owners, uint64_t *counts_host, hipStream_t stream)
+{
+    if (!ix.edges_hold_ranks) raise(SW_ERR_VALUE, "the edges of this index hold hashes already (it was built with the rank -> hash table)");
+    if (n_owners == 0 || n_owners > 16) raise(SW_ERR_VALUE, "1 to 16 node owners are supported");
+    for (uint32_t o = 0; o < n_owners; ++o) counts_host[o] = 0;
+    delete ix.hash_job;
+    ix.hash_job = new EdgeHashJob;
+    EdgeHashJob &J = *ix.hash_job;
+    const uint64_t n = 2 * ix.n_edges;
+    if (n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^31-1 edges on one device");
+    J.n_slots = n;
+    if (n == 0) return 0;
+    OwnerBases B{};
+    B.n_owners = n_owners;
+    for (uint32_t o = 0; o <= n_owners; ++o) B.base[o] = node_base[o];
+    unsigned bits = 1;
+    while (bits < 64 && (node_base[n_owners] >> bits)) ++bits;
+    DevArray<uint64_t> r0(n), r1(n);
+    DevArray<uint32_t> s0(n), s1(n), cum(n), bad(1);
+    DevArray<unsigned long long> below(n_owners + 1);
+    SW_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
+    hipLaunchKernelGGL(k_edge_ranks, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ix.edges.p, (uint64_t)ix.n_edges, r0.p, s0.p);
+    SW_HIP(hipGetLastError());
+    uint64_t *rk = r0.p, *rk_alt = r1.p;
+    uint32_t *sl = s0.p, *sl_alt = s1.p;
+    sort_pairs(rk, rk_alt, sl, sl_alt, n, 0, bits, stream);
+    inclusive_sum(rocprim::make_transform_iterator(rocprim::make_counting_iterator<uint64_t>(0), RankHeadFlag{rk}), cum.p, n, (uint32_t)0,
+                  stream);
+    uint32_t n_unique = 0;
+    SW_HIP(hipMemcpyAsync(&n_unique, cum.p + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    J.n_unique = n_unique;
+    J.uniq.alloc(n);
+    J.req.alloc(n_unique);
+    hipLaunchKernelGGL(k_edge_requests, dim3(blocks_for(n)), dim3(TPB), 0, stream, rk, cum.p, n, B, J.uniq.p, J.req.p, bad.p);
+    hipLaunchKernelGGL(k_owner_cuts, dim3(1), dim3(32), 0, stream, rk, cum.p, n, B, below.p);
+    SW_HIP(hipGetLastError());
+    unsigned long long h[18];
+    uint32_t hb = 0;
+    SW_HIP(hipMemcpyAsync(h, below.p, (n_owners + 1) * 8, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipMemcpyAsync(&hb, bad.p, 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    if (hb) raise(SW_ERR_VALUE, "an edge names a rank outside the node bases");
+    for (uint32_t o = 0; o < n_owners; ++o) counts_host[o] = h[o + 1] - h[o];
+    // the slots in rank order are kept (the sort's current buffer)
+    if (sl == s0.p) J.slot = std::move(s0); else J.slot = std::move(s1);
+    return n_unique;
+}
+
+void edge_hash_request_rows(const sw_index &ix, uint32_t *d_out, hipStream_t stream)
+{
+    if (!ix.hash_job) raise(SW_ERR_VALUE, "sw_index_edge_hash_requests has not been called on this index");
+    if (ix.hash_job->n_unique)
+        SW_HIP(hipMemcpyAsync(d_out, ix.hash_job->req.p, ix.hash_job->n_unique * 4, hipMemcpyDeviceToDevice, stream));
+}
+
+void node_hash_lookup(const sw_index &ix, const uint32_t *d_local_ranks, uint64_t n, uint64_t *d_out, hipStream_t stream)
+{
+    if (n == 0) return;
+    DevArray<uint32_t> bad(1);
+    SW_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
+    hipLaunchKernelGGL(k_lookup_hashes, dim3(blocks_for(n)), dim3(TPB), 0, stream, ix.nodes.p, (uint64_t)ix.n_nodes, d_local_ranks, n, d_out,
+                       bad.p);
+    SW_HIP(hipGetLastError());
+    uint32_t hb = 0;
+    SW_HIP(hipMemcpyAsync(&hb, bad.p, 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));
+    if (hb) raise(SW_ERR_VALUE, "a requested rank is not a node of this slice");
+}
+
+void edge_hash_attach(sw_index &ix, const uint64_t *d_replies, uint64_t n, hipStream_t stream)
+{
+    if (!ix.hash_job) raise(SW_ERR_VALUE, "sw_index_edge_hash_requests has not been called on this index");
+    EdgeHashJob &J = *ix.hash_job;
+    if (n != J.n_unique) raise(SW_ERR_VALUE, "%llu replies for %llu requests", (unsigned long long)n, (unsigned long long)J.n_unique);
+    if (J.n_slots) {
+        hipLaunchKernelGGL(k_attach_hashes, dim3(blocks_for(J.n_slots)), dim3(TPB), 0, stream, ix.edges.p, J.slot.p, J.uniq.p, d_replies,
+                           J.n_slots);
+        SW_HIP(hipGetLastError());
+        SW_HIP(hipStreamSynchronize(stream));   // (the job's arrays go back to the pool below)
+    }
+    delete ix.hash_job;
+    ix.hash_job = nullptr;
+    ix.edges_hold_ranks = false;
 }
 
 void index_threshold_sums(const sw_index &ix, hipStream_t stream, uint64_t *sums3)

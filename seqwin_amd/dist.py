@@ -27,6 +27,7 @@ drives the same choreography over gloo with a numpy engine defined in tests/.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 import time
@@ -254,11 +255,42 @@ class HipEngine:
         from ._lib import c_u64, c_vp, check, lib
         keys = keys.to(self.gpu).contiguous()
         cand = cand.to(self.gpu).contiguous()
-        rank_hash = rank_hash.to(self.gpu).contiguous()
+        table = c_vp(0)                                  # None: the edges keep global ranks (edge_hash_requests / _attach follow)
+        if rank_hash is not None:
+            rank_hash = rank_hash.to(self.gpu).contiguous()
+            table = c_vp(rank_hash.data_ptr())
         base = (c_u64 * len(node_base))(*node_base)
         check(lib.sw_slice_edges_pairs(ix._h, c_vp(keys.data_ptr()), c_u64(keys.shape[0]), c_vp(cand.data_ptr()),
                                        c_u64(cand.shape[0]), c_u64(key_bits[0]), c_u64(key_bits[1]), c_u64(lo_base), c_u64(asm_bits),
-                                       c_vp(rank_hash.data_ptr()), base, c_u64(len(node_base) - 1), c_u64(pad), c_vp(self._stream())))
+                                       table, base, c_u64(len(node_base) - 1), c_u64(pad), c_vp(self._stream())))
+
+    # rank -> hash by request (no job-wide table): see sw_index_edge_hash_requests in include/seqwin_hip.h
+    def edge_hash_requests(self, ix, node_base):
+        """-> (owner-local ranks of the distinct endpoints of ix's edges, u32-in-int32 tensor in ascending global order;
+        how many of them go to each node owner)"""
+        import torch
+        from ._lib import c_u64, c_vp, check, lib
+        n_owners = len(node_base) - 1
+        base = (c_u64 * len(node_base))(*node_base)
+        cnt = (c_u64 * n_owners)()
+        n = c_u64()
+        check(lib.sw_index_edge_hash_requests(ix._h, base, c_u64(n_owners), cnt, ctypes.byref(n), c_vp(self._stream())))
+        req = torch.empty((n.value,), dtype=torch.int32, device=self.gpu)
+        check(lib.sw_index_edge_hash_request_rows(ix._h, c_vp(req.data_ptr()), c_vp(self._stream())))
+        return req.to(self.device), [int(c) for c in cnt]
+
+    def node_hash_lookup(self, ix, local_ranks):
+        import torch
+        from ._lib import c_u64, c_vp, check, lib
+        r = local_ranks.to(self.gpu).contiguous()
+        out = torch.empty((r.shape[0],), dtype=torch.int64, device=self.gpu)
+        check(lib.sw_index_node_hash_lookup(ix._h, c_vp(r.data_ptr()), c_u64(r.shape[0]), c_vp(out.data_ptr()), c_vp(self._stream())))
+        return out.to(self.device)
+
+    def edge_hash_attach(self, ix, replies) -> None:
+        from ._lib import c_u64, c_vp, check, lib
+        r = replies.to(self.gpu).contiguous()
+        check(lib.sw_index_edge_hash_attach(ix._h, c_vp(r.data_ptr()), c_u64(r.shape[0]), c_vp(self._stream())))
 
     def node_hash_part(self, ix, pad: int):
         """This slice's share of the job-wide rank -> hash table: its node hashes at the front of `pad` words (the rest
@@ -457,6 +489,17 @@ def node_bases(node_counts) -> list[int]:
     return out
 
 
+def hash_route(total_nodes: int) -> str:
+    """"table": every GPU gets the whole rank -> hash table (all-gather, 8 B per node of the job); "requests": the edge owners
+    ask the node owners for the hashes of their edges' distinct endpoints (12 B per endpoint, no table in HBM).
+    SEQWIN_DIST_HASH_ROUTE forces one; else the table up to SEQWIN_DIST_TABLE_LIMIT_MB (default 4096)."""
+    forced = os.environ.get("SEQWIN_DIST_HASH_ROUTE")
+    if forced in ("table", "requests"):
+        return forced
+    limit = int(os.environ.get("SEQWIN_DIST_TABLE_LIMIT_MB", "4096")) << 20
+    return "requests" if int(total_nodes) * 8 > limit else "table"
+
+
 def adjacency_asm_bits(n_bits: int, n_assemblies_total: int) -> int:
     """Width of the assembly field of a packed adjacency key ((rank_lo << n_bits | rank_hi) << asm_bits | assembly),
     or 0 when the key does not fit 64 bits and rows travel as {key, assembly} pairs."""
@@ -633,16 +676,22 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     rb = rank_bounds(world, total_nodes)
     if pairs:
         asm_bits = max(1, int(shard.n_assemblies_total).bit_length())
+        # How the edge owners get the hashes of their edges' endpoints: the whole rank -> hash table on every GPU (8 B per node
+        # of the job: 0.64 GB at 15 000 genomes, 40 GB at configs[4] with k >= 19), or -- above SEQWIN_DIST_TABLE_LIMIT_MB,
+        # default 4096 -- by asking the node owners for the distinct endpoints only (hash_route "requests", below).
+        by_request = hash_route(total_nodes) == "requests"
+        table, pad, hash_work = None, max(1, max(node_cnt)), None
         if multi:
             ranks_by_row = torch.empty((occ.n,), dtype=torch.int32, device=dev)
             _all_to_all_rows(ranks_by_row, r_ranks, cnt, recv_cnt, group)
-            pad = max(1, max(node_cnt))
-            mine = engine.node_hash_part(ix, pad)                               # this slice's hashes at the front of `pad` words
-            table = torch.empty((world * pad,), dtype=torch.int64, device=dev)
-            hash_work = _all_gather_parts(table, mine, pad, group, async_op=True)   # overlaps the adjacency build below
+            if not by_request:
+                mine = engine.node_hash_part(ix, pad)                           # this slice's hashes at the front of `pad` words
+                table = torch.empty((world * pad,), dtype=torch.int64, device=dev)
+                hash_work = _all_gather_parts(table, mine, pad, group, async_op=True)   # overlaps the adjacency build below
         else:
-            ranks_by_row, pad, hash_work = r_ranks, max(1, n_nodes), None
-            table = engine.node_hash_part(ix, pad)
+            ranks_by_row = r_ranks
+            if not by_request:
+                table = engine.node_hash_part(ix, pad)
         adj, acnt, cand, ccnt, key_bits = engine.adjacency_pairs(occ, ranks_by_row, node_base, shard.first_assembly, rb)
         if multi:
             # (waited for BEFORE the next collective: torch runs synchronous collectives on the current stream and this one on
@@ -653,11 +702,24 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
             if world == 1 and os.environ.get("SEQWIN_DIST_DEBUG"):   # what went through the collectives must come back unchanged
                 print("[dist debug] ranks", torch.equal(ranks_by_row, r_ranks), "adj", torch.equal(r_adj, adj), tuple(r_adj.shape),
                       tuple(adj.shape), "cand", torch.equal(r_cand, cand), tuple(cand.shape), "table",
-                      torch.equal(table[:n_nodes], engine.node_hash_part(ix, pad)[:n_nodes]), "counts", acnt, ccnt, flush=True)
+                      table is None or torch.equal(table[:n_nodes], engine.node_hash_part(ix, pad)[:n_nodes]), "counts", acnt, ccnt,
+                      flush=True)
         else:
             r_adj, r_cand = adj, cand
         t4 = time.perf_counter()
         engine.slice_edges_pairs(ix, r_adj, r_cand, key_bits, rb[rank - 1] if rank else 0, asm_bits, table, node_base, pad)
+        if by_request:
+            # the edges hold global ranks: their distinct endpoints, as owner-local ranks grouped by node owner, go to the
+            # node owners; the hashes come back in the same order
+            req, req_cnt = engine.edge_hash_requests(ix, node_base)
+            if multi:
+                got, got_cnt, _ = _exchange_rows(req, req_cnt, dev, group)
+                answers = engine.node_hash_lookup(ix, got)
+                replies = torch.empty((int(req.shape[0]),), dtype=torch.int64, device=dev)
+                _all_to_all_rows(replies, answers, req_cnt, got_cnt, group)
+            else:
+                replies = engine.node_hash_lookup(ix, req)
+            engine.edge_hash_attach(ix, replies)
     else:
         # {pair, assembly} rows or packed (pair, assembly) keys on GLOBAL 32-bit ranks (test knob; slices without marks)
         REP = 0x80000000

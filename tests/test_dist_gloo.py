@@ -164,12 +164,17 @@ class NumpyEngine:
 
     def slice_edges_pairs(self, ix, keys, cand, key_bits, lo_base, asm_bits, rank_hash, node_base, pad):
         k = keys.numpy().view(U64)
-        table = rank_hash.numpy().view(U64)
         base = np.asarray(node_base, U64)
+        ix["edges_hold_ranks"] = rank_hash is None
+        if rank_hash is None:
+            def hash_of(rank):   # no table: the edges keep global ranks until edge_hash_attach
+                return rank
+        else:
+            table = rank_hash.numpy().view(U64)
 
-        def hash_of(rank):   # owner o's hashes sit at table[o * pad ...]
-            o = np.searchsorted(base[1:-1], rank, side="right")
-            return table[(o.astype(U64) * U64(pad) + (rank - base[o])).astype(np.int64)]
+            def hash_of(rank):   # owner o's hashes sit at table[o * pad ...]
+                o = np.searchsorted(base[1:-1], rank, side="right")
+                return table[(o.astype(U64) * U64(pad) + (rank - base[o])).astype(np.int64)]
 
         edges = np.zeros(0, oracle.EDGE_DTYPE)
         if len(k):
@@ -185,6 +190,26 @@ class NumpyEngine:
             edges["second"] = hash_of(uk & U64((1 << hi_bits) - 1))
             edges["weight"] = w.astype(np.uint64)
         ix["edges"] = edges
+
+    def edge_hash_requests(self, ix, node_base):
+        assert ix["edges_hold_ranks"]
+        base = np.asarray(node_base, U64)
+        e = ix["edges"]
+        ranks = np.stack([e["first"], e["second"]], axis=1).ravel()          # slot = edge * 2 + side
+        uniq, inv = np.unique(ranks, return_inverse=True)
+        owner = np.searchsorted(base[1:-1], uniq, side="right")
+        ix["hash_job"] = inv.ravel()
+        local = (uniq - base[owner]).astype(np.uint32)
+        return torch.from_numpy(local.view(np.int32).copy()), np.bincount(owner, minlength=len(node_base) - 1).tolist()
+
+    def node_hash_lookup(self, ix, local_ranks):
+        r = local_ranks.numpy().view(np.uint32).astype(np.int64)
+        return torch.from_numpy(ix["nodes"]["hash"][r].view(np.int64).copy())
+
+    def edge_hash_attach(self, ix, replies):
+        h = replies.numpy().view(U64)[ix.pop("hash_job")].reshape(-1, 2)
+        ix["edges"]["first"], ix["edges"]["second"] = h[:, 0], h[:, 1]
+        ix["edges_hold_ranks"] = False
 
     def node_hash_part(self, ix, pad):
         out = np.zeros(pad, U64)
@@ -249,6 +274,8 @@ def _worker(rank, world, port, paths, k, w, tar, out_path, mode):
         start, end = swdist.partition_assemblies(len(paths), world)[rank]
         eng = NumpyEngine()
         eng.mark_repeats = mode != "tuples_rows"   # "tuples": adjacency in its pairs form; "tuples_rows": {pair, assembly} rows
+        if mode == "tuples_requests":              # ... and the edge owners ask the node owners for hashes (no job-wide table)
+            os.environ["SEQWIN_DIST_HASH_ROUTE"] = "requests"
         mine = paths[start:end]
         eng._offs = oracle.build(mine, k, w)[3]
         build = swdist.build_sharded_index if mode.startswith("tuples") else swdist.build_sharded_index_merge
@@ -265,7 +292,7 @@ def _worker(rank, world, port, paths, k, w, tar, out_path, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["tuples", "tuples_rows", "merge"])
+@pytest.mark.parametrize("mode", ["tuples", "tuples_requests", "tuples_rows", "merge"])
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("case", ["smoke", "pan", "edge"])
 def test_sharded_build_equals_single(tmp_path, world, case, mode):
@@ -320,6 +347,14 @@ def test_single_process_tuple_form_equals_oracle():
     oracle.get_penalty(ek, en, eo, tar)
     k, n, e = sharded.export()
     assert np.array_equal(k, ek) and np.array_equal(n, en) and np.array_equal(e, ee)
+    os.environ["SEQWIN_DIST_HASH_ROUTE"] = "requests"      # hashes asked for instead of looked up in the table
+    try:
+        sharded = swdist.build_sharded_index(swdist.Shard(paths, 0, len(paths)), 15, 20, tar, engine=eng)
+    finally:
+        del os.environ["SEQWIN_DIST_HASH_ROUTE"]
+    k, n, e = sharded.export()
+    assert np.array_equal(k, ek) and np.array_equal(n, en) and np.array_equal(e, ee)
+    assert swdist.hash_route(10**6) == "table" and swdist.hash_route(5 * 10**9) == "requests"     # 8 MB / 40 GB of table
 
 
 def test_rank_bounds():

@@ -2,6 +2,8 @@
 sw_index_merge) on ONE GPU: P shard batches are built one after another, their rows are routed by
 hand exactly as all_to_all_single would route them, every owner's slice is merged, and the
 concatenation must equal the single-batch index bit for bit (shard-count invariance)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -67,6 +69,13 @@ def test_world1_sharded_index_matches_direct():
         for x, y in zip(direct.export(), sharded.export()):
             assert np.array_equal(x, y)
         assert sharded.timings()["n_occ_local"] == direct.sizes()[0]
+    os.environ["SEQWIN_DIST_HASH_ROUTE"] = "requests"
+    try:
+        sharded = swdist.build_sharded_index(swdist.Shard(b, 0, 24), 21, 200, tar)
+    finally:
+        del os.environ["SEQWIN_DIST_HASH_ROUTE"]
+    for x, y in zip(direct.export(), sharded.export()):
+        assert np.array_equal(x, y)
 
 
 def _gloo_worker(rank, world, port, paths, k, w, tar, out_path, mode):
@@ -81,7 +90,9 @@ def _gloo_worker(rank, world, port, paths, k, w, tar, out_path, mode):
         set_device(0)
         start, end = swdist.partition_assemblies(len(paths), world)[rank]
         shard = swdist.Shard(Batch.from_fasta(paths[start:end], n_cpu=2), start, len(paths))
-        build = swdist.build_sharded_index if mode == "tuples" else swdist.build_sharded_index_merge
+        if mode == "tuples_requests":
+            os.environ["SEQWIN_DIST_HASH_ROUTE"] = "requests"
+        build = swdist.build_sharded_index if mode.startswith("tuples") else swdist.build_sharded_index_merge
         sharded = build(shard, k, w, tar, engine=swdist.HipEngine("host"))
         full = sharded.gather(0)
         if rank == 0:
@@ -90,7 +101,7 @@ def _gloo_worker(rank, world, port, paths, k, w, tar, out_path, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["tuples", "merge"])
+@pytest.mark.parametrize("mode", ["tuples", "tuples_requests", "merge"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_two_processes_one_gpu_real_collectives(tmp_path, world, mode):
     """The full multi-process path -- HIP engine in every process, real all_to_all_single / all_gather
@@ -155,12 +166,14 @@ def test_rccl_collectives_world1(tmp_path):
     assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
 
 
-def routed_tuple_exchange(paths, world, k, w, tar, packed=True, pairs=None, shards=None, sums_only=False):
+def routed_tuple_exchange(paths, world, k, w, tar, packed=True, pairs=None, shards=None, sums_only=False, requests=False):
     """The tuple-exchange form with the all-to-all steps done by hand on ONE GPU (P shards, one after another).
     pairs (default: whenever the slices marked their ranks, as dist.py decides): adjacency as pair keys + candidate rows;
     else packed keys (when they fit) or {pair, assembly} rows.
     shards: ready-made Shard objects instead of FASTA paths; sums_only: return (sizes, checksums) of the concatenated
-    result -- every slice's share at its offsets, added modulo 2^64 -- instead of the arrays (full-size runs)."""
+    result -- every slice's share at its offsets, added modulo 2^64 -- instead of the arrays (full-size runs).
+    requests (pairs form): no job-wide rank -> hash table; the edge owners ask the node owners for the hashes of their edges'
+    distinct endpoints (dist.hash_route "requests")."""
     eng = swdist.HipEngine()
     if shards is None:
         parts = swdist.partition_assemblies(len(paths), world)
@@ -232,9 +245,25 @@ def routed_tuple_exchange(paths, world, k, w, tar, packed=True, pairs=None, shar
         if pairs:
             assert all(a[4] == adj[0][4] for a in adj)        # every source derives the same key layout
             eng.slice_edges_pairs(slices[owner][0], torch.cat(pieces), torch.cat(cpieces), adj[0][4], rb[owner - 1] if owner else 0,
-                                  asm_bits, table, node_base, pad)
+                                  asm_bits, None if requests else table, node_base, pad)
         else:
             eng.slice_edges(slices[owner][0], torch.cat(pieces), n_bits, asm_bits, rank_hash)
+    if pairs and requests:
+        # requests to node owner o: the pieces of all edge owners, in edge-owner order; the answers go back the same way
+        asked = [eng.edge_hash_requests(slices[q][0], node_base) for q in range(world)]
+        cuts_q = [np.concatenate([[0], np.cumsum(c)]) for _, c in asked]
+        answers = [[None] * world for _ in range(world)]
+        for o in range(world):
+            got = torch.cat([asked[q][0][cuts_q[q][o]:cuts_q[q][o + 1]] for q in range(world)])
+            ans = eng.node_hash_lookup(slices[o][0], got)
+            at = 0
+            for q in range(world):
+                c = int(asked[q][1][o])
+                answers[q][o] = ans[at:at + c]
+                at += c
+        for q in range(world):
+            eng.edge_hash_attach(slices[q][0], torch.cat(answers[q]))
+    for owner in range(world):
         if not sums_only:
             K, N, E = slices[owner][0].export()
             kmers.append(K); nodes.append(N); edges.append(E)
@@ -261,6 +290,8 @@ def test_routed_tuple_exchange_equals_single_batch(world):
             got = routed_tuple_exchange(paths, world, k, w, tar, packed, pairs)
             assert np.array_equal(got[0], ek) and np.array_equal(got[1], en), (world, k, w, packed, pairs)
             assert np.array_equal(got[2], ee) and np.array_equal(got[3], eo), (world, k, w, packed, pairs)
+        got = routed_tuple_exchange(paths, world, k, w, tar, requests=True)       # hashes asked for, no job-wide table
+        assert all(np.array_equal(a, b) for a, b in zip(got, (ek, en, ee, eo))), (world, k, w, "requests")
 
 
 def test_routed_tuple_exchange_with_33_bit_ranks(monkeypatch):
@@ -273,8 +304,9 @@ def test_routed_tuple_exchange_with_33_bit_ranks(monkeypatch):
     for k, w in [(15, 20), (21, 200)]:
         ek, en, ee, eo, _ = oracle.build(paths, k, w)
         oracle.get_penalty(ek, en, eo, tar)
-        got = routed_tuple_exchange(paths, 8, k, w, tar)
-        assert np.array_equal(got[0], ek) and np.array_equal(got[1], en) and np.array_equal(got[2], ee) and np.array_equal(got[3], eo)
+        for requests in (False, True):
+            got = routed_tuple_exchange(paths, 8, k, w, tar, requests=requests)
+            assert np.array_equal(got[0], ek) and np.array_equal(got[1], en) and np.array_equal(got[2], ee) and np.array_equal(got[3], eo)
     # the key layout such a job gets: 33-bit rank_hi, rank_lo within 31 bits
     eng = swdist.HipEngine()
     shard = swdist.Shard(Batch.from_fasta(paths[:2], n_cpu=2), 0, len(paths))

@@ -192,14 +192,17 @@ def test_config3_sharded_full_size():
         reference's worker partition build.cpp:350-356) are sketched one after another, their tuples, ranks and adjacency
         keys are routed exactly as the all-to-all steps route them, and the eight slices' checksum shares
         (sw_index_checksums_at) must add up to the same committed checksums -- shard-count invariance
-        (reference tests/smoke/test_graph.py:67-127) on the 75 Gbp set."""
+        (reference tests/smoke/test_graph.py:67-127) on the 75 Gbp set.  (1) runs with both ways of bringing node hashes to
+        the edge owners, (2) with the request route (the table route at P = 8 is covered on the small sets)."""
     from test_gpu_dist import routed_tuple_exchange
 
     from seqwin_amd import dist as swdist
     gold = json.loads((GOLDEN / "bench_checksums.json").read_text())["bacteria15k/k21/w200"]
-    line = _bench_line(["--steps", "1", "--warmup", "1"], {"SEQWIN_DIST_FORCE_COLLECTIVES": "1", "SEQWIN_BENCH_FORCE_DIST": "1"})
-    assert line["parity"]["n1_checksums_equal"] is True and line["counts"] == gold["counts"]
-    assert line["checksums"] == gold["checksums"]
+    for route in ("table", "requests"):      # rank -> hash from the all-gathered table / asked from the node owners (dist.hash_route)
+        line = _bench_line(["--steps", "1", "--warmup", "1"], {"SEQWIN_DIST_FORCE_COLLECTIVES": "1", "SEQWIN_BENCH_FORCE_DIST": "1",
+                                                               "SEQWIN_DIST_HASH_ROUTE": route})
+        assert line["parity"]["n1_checksums_equal"] is True and line["counts"] == gold["counts"], route
+        assert line["checksums"] == gold["checksums"], route
 
     G, rpg, rl, anc, snp, _ = WORKLOADS["bacteria15k"]
     world, k, w = 8, 21, 200
@@ -208,7 +211,7 @@ def test_config3_sharded_full_size():
     for first, end in swdist.partition_assemblies(G, world):
         shards.append(swdist.Shard(Batch.synthetic(end - first, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED, first_genome=first),
                                    first, G))
-    sizes, sums = routed_tuple_exchange(None, world, k, w, tar, shards=shards, sums_only=True)
+    sizes, sums = routed_tuple_exchange(None, world, k, w, tar, shards=shards, sums_only=True, requests=True)
     assert dict(zip(("kmers", "nodes", "edges"), sizes)) == gold["counts"]
     assert [f"{v:016x}" for v in sums] == gold["checksums"]
 
