@@ -82,13 +82,14 @@ while time.time() < t_end and (not replay or it < len(replay)):
             tar = [i % 2 == 0 for i in range(len(ps))]
             P = rng.choice([2, 3, 4, 8])
             for fn in (routed_tuple_exchange, _route_and_merge):
-                d = fn(ps, P, k, w, tar)
+                kw = {"requests": seed % 2 == 1} if fn is routed_tuple_exchange else {}   # hashes by request on every other case
+                d = fn(ps, P, k, w, tar, **kw)
                 ok = ok and np.array_equal(d[0], exp[0]) and np.array_equal(d[1], exp[1]) and np.array_equal(d[2], exp[2]) \
                     and np.array_equal(d[3], exp[3])
                 if not ok:
                     print("  dist form", fn.__name__, "P =", P)
                     if True:
-                        d2 = fn(ps, P, k, w, tar)
+                        d2 = fn(ps, P, k, w, tar, **kw)
                         print("    retry equal to expected:", all(np.array_equal(a, b) for a, b in zip(d2[:4], exp[:4])),
                               " retry equal to first:", all(np.array_equal(a, b) for a, b in zip(d2[:4], d[:4])))
                         for name, x, y in zip(("kmers", "nodes", "edges", "offsets"), d[:4], exp[:4]):
