@@ -51,10 +51,19 @@ struct LaneTables {            // per lane, in LDS: everything a stream's decode
 };
 static_assert(sizeof(LaneTables) * 64 <= 160 * 1024, "one wave's tables must fit the CU's LDS");
 
-SW_GZ_CONST uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-SW_GZ_CONST uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-SW_GZ_CONST uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-SW_GZ_CONST uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+// RFC 1951 3.2.5: base value and extra bits of length code 257 + li and of distance code ds, as arithmetic (a table in
+// memory would be a per-lane global load -- a memory round trip -- four times per match)
+SW_GZ_FN void length_code(uint32_t li, uint32_t &base, uint32_t &extra)
+{
+    extra = li < 4u ? 0u : (li - 4u) >> 2;
+    base = li < 8u ? 3u + li : ((4u + (li & 3u)) << extra) + 3u;
+    if (li == 28u) { base = 258u; extra = 0u; }
+}
+SW_GZ_FN void distance_code(uint32_t ds, uint32_t &base, uint32_t &extra)
+{
+    extra = ds < 2u ? 0u : (ds >> 1) - 1u;
+    base = ds < 2u ? 1u + ds : ((2u + (ds & 1u)) << extra) + 1u;
+}
 SW_GZ_CONST uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct BitReader {
@@ -345,14 +354,18 @@ SW_GZ_FN uint32_t inflate_one(LaneTables &t, const uint8_t *comp, uint64_t start
             if (prof) ++p_match;
             if (sym > 285) { st = ST_BAD_CODE; break; }
             const uint32_t li = (uint32_t)sym - 257u;
-            if (!br.need(kLenExtra[li])) { st = ST_TRUNCATED; break; }
-            const uint32_t len = kLenBase[li] + br.peek(kLenExtra[li]);
-            br.drop(kLenExtra[li]);
+            uint32_t lbase, lextra;
+            length_code(li, lbase, lextra);
+            if (!br.need(lextra)) { st = ST_TRUNCATED; break; }
+            const uint32_t len = lbase + br.peek(lextra);
+            br.drop(lextra);
             const int ds = decode_symbol(br, t.dist, DIST_BITS, t.dcount, t.dsym);
             if (ds < 0 || ds > 29) { st = ST_BAD_CODE; break; }
-            if (!br.need(kDistExtra[ds])) { st = ST_TRUNCATED; break; }
-            const uint64_t dist = (uint64_t)kDistBase[ds] + br.peek(kDistExtra[ds]);
-            br.drop(kDistExtra[ds]);
+            uint32_t dbase, dextra;
+            distance_code((uint32_t)ds, dbase, dextra);
+            if (!br.need(dextra)) { st = ST_TRUNCATED; break; }
+            const uint64_t dist = (uint64_t)dbase + br.peek(dextra);
+            br.drop(dextra);
             if (dist > n) { st = ST_BAD_DIST; break; }
             if (n + len > cap) { st = ST_OVERFLOW; break; }
             if (dist >= 8) {
