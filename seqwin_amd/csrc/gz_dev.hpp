@@ -189,7 +189,6 @@ SW_GZ_FN uint32_t inflate_one(LaneTables &t, const uint8_t *comp, uint64_t start
     BitReader br;
     br.init(comp, start, end);
     uint8_t *out = arena + text_off;
-    
     uint64_t n = 0, fl = 0;                   // bytes produced / bytes in HBM (a multiple of 64 until the end)
     uint32_t st = ST_OK;
     bool last = false;

@@ -139,9 +139,9 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     const char *mode = getenv("SEQWIN_AMD_DEVICE_INFLATE");
     if (mode && !strcmp(mode, "0")) return false;
     const bool forced = mode && !strcmp(mode, "1");
-    // A lane inflates ~1.6 MB of text per second whatever the number of files (every match is a memory round trip of the
-    // lane's own: 3.3 us per symbol, r03), a host thread ~370 MB/s: the device wins from ~320 files per host thread on
-    // (measured: 8 192 files of 1 Mbp, 16 threads: 843 ms against 1 387 ms; 1 024 files: 802 against 181 ms).
+    // A lane inflates ~1.7 MB of text per second whatever the number of files (64 independent decoders run in lockstep, one wave per
+    // CU: ~7 500 clocks per symbol, r03), a host thread ~370 MB/s: the device wins from ~320 files per host thread on
+    // (measured: 8 192 files of 1 Mbp, 16 threads: 817 ms against 1 404 ms; 1 024 files: 760 against 178 ms).
     const uint64_t host_threads = std::min<uint64_t>(std::max<uint64_t>(1, n_cpu), 64);
     if (n_paths == 0 || n_paths >= 0xFFFFFFFFull || (!forced && n_paths < 320 * host_threads)) return false;
     for (size_t i = 0; i < n_paths; ++i)
