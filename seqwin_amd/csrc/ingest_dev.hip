@@ -108,19 +108,18 @@ struct Pinned {   // one pinned staging buffer per worker, kept for the life of 
     char *p = nullptr;
     hipStream_t st = nullptr;
 };
-Pinned &pinned_slot(size_t i)
+Pinned &pinned_slot(int device, size_t i)   // (the calling thread has made `device` current: the stream belongs to it)
 {
     static std::mutex mu;
-    static std::vector<Pinned *> *slots = new std::vector<Pinned *>;   // leaked on purpose
+    static std::map<std::pair<int, size_t>, Pinned *> *slots = new std::map<std::pair<int, size_t>, Pinned *>;   // leaked on purpose
     std::lock_guard<std::mutex> lock(mu);
-    while (slots->size() <= i) slots->push_back(nullptr);
-    if (!(*slots)[i]) {
-        Pinned *s = new Pinned;
+    Pinned *&s = (*slots)[{device, i}];
+    if (!s) {
+        s = new Pinned;
         SW_HIP(hipHostMalloc((void **)&s->p, Pinned::BYTES, hipHostMallocDefault));
         SW_HIP(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-        (*slots)[i] = s;
     }
-    return *(*slots)[i];
+    return *s;
 }
 
 template <class T> void to_host(std::vector<T> &dst, const DevArray<T> &src, size_t n)
@@ -173,7 +172,8 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     const size_t n_workers = std::max<size_t>(1, std::min<size_t>({(size_t)std::max<uint64_t>(1, n_cpu), n_paths, 32}));
     auto reader = [&](size_t w) {
         try {
-            Pinned &pin = pinned_slot(w);
+            SW_HIP(hipSetDevice(b.device));            // (a new thread starts on device 0)
+            Pinned &pin = pinned_slot(b.device, w);
             for (;;) {
                 const size_t i = next.fetch_add(1);
                 if (i >= n_paths || !ok.load()) break;
