@@ -581,6 +581,31 @@ SW_GZ_FN void parse_one(const uint8_t *cls, const uint32_t (*crc_tab)[256], cons
             if (ch + 1 < n_chunks) nx = tv[ch + 1];
             const uint32_t wv[4] = {cu.x, cu.y, cu.z, cu.w};
             const uint64_t left = n - ch * 16;
+            if (mode == 3 && have && left >= 16) {
+                // a whole chunk inside a sequence line (four of the five chunks of an 80-column line): sixteen look-ups in
+                // flight, and if all are bases they go into the accumulator together (Packer::push_block, all valid)
+                uint32_t any = 0;
+                uint64_t codes = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t k = cls[(wv[j >> 2] >> (8 * (j & 3))) & 0xFFu];
+                    any |= k;
+                    codes |= (uint64_t)k << (2 * j);
+                }
+                if (any < 4u) {
+                    if (run_start < 0) run_start = (int64_t)len;
+                    acc |= codes << (2 * nacc);
+                    len += 16;
+                    nacc += 16;
+                    if (nacc >= 32) {
+                        if (WRITE) D.words[wb + n_words] = acc;
+                        ++n_words;
+                        nacc -= 32;
+                        acc = nacc ? codes >> (32 - 2 * nacc) : 0;    // the bases that did not fit the word
+                    }
+                    continue;
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t v = wv[q];
