@@ -231,12 +231,22 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     if (toff[n_paths] + toff[n_paths] / 2 > free_b) return decline("not enough free HBM for the text", 0, toff[n_paths]);
     const uint32_t nf = (uint32_t)n_paths;
     DevArray<uint8_t> d_text(toff[n_paths] + 16);
+    // Lane j of the kernels takes file perm[j], the files in descending size: a wave lasts as long as its largest file, so
+    // files of like size share a wave (genomes of one job differ by a few x in size)
+    std::vector<uint32_t> perm(nf);
+    for (uint32_t i = 0; i < nf; ++i) perm[i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t c) { return isize[a] > isize[c]; });
+    auto permuted = [&](const auto &v) {
+        typename std::decay<decltype(v)>::type out(nf);
+        for (uint32_t j = 0; j < nf; ++j) out[j] = v[perm[j]];
+        return out;
+    };
     DevArray<uint64_t> d_dstart(nf), d_dend(nf), d_toff(nf + 1);
     DevArray<uint32_t> d_isize(nf), d_status(nf);
-    SW_HIP(hipMemcpy(d_dstart.p, dstart.data(), nf * 8ull, hipMemcpyHostToDevice));
-    SW_HIP(hipMemcpy(d_dend.p, dend.data(), nf * 8ull, hipMemcpyHostToDevice));
-    SW_HIP(hipMemcpy(d_toff.p, toff.data(), (nf + 1) * 8ull, hipMemcpyHostToDevice));
-    SW_HIP(hipMemcpy(d_isize.p, isize.data(), nf * 4ull, hipMemcpyHostToDevice));
+    SW_HIP(hipMemcpy(d_dstart.p, permuted(dstart).data(), nf * 8ull, hipMemcpyHostToDevice));
+    SW_HIP(hipMemcpy(d_dend.p, permuted(dend).data(), nf * 8ull, hipMemcpyHostToDevice));
+    SW_HIP(hipMemcpy(d_toff.p, permuted(toff).data(), nf * 8ull, hipMemcpyHostToDevice));      // (the kernels read text_off[f] only)
+    SW_HIP(hipMemcpy(d_isize.p, permuted(isize).data(), nf * 4ull, hipMemcpyHostToDevice));
     const unsigned blocks = (nf + 63) / 64;
     DevArray<unsigned long long> d_prof(8);
     SW_HIP(hipMemset(d_prof.p, 0, 64));
@@ -251,8 +261,8 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     }
     std::vector<uint32_t> status;
     to_host(status, d_status, nf);
-    for (uint32_t i = 0; i < nf; ++i)
-        if (status[i] != ST_OK) return decline("inflate status", i, status[i]);   // corrupt, or more than one member: the host route decides
+    for (uint32_t j = 0; j < nf; ++j)
+        if (status[j] != ST_OK) return decline("inflate status", perm[j], status[j]);   // corrupt, or more than one member: the host route decides
     d_comp.release();
     const auto t2 = std::chrono::steady_clock::now();
 
@@ -266,8 +276,9 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     pa.counts = d_counts.p;
     hipLaunchKernelGGL(k_parse<false>, dim3(blocks), dim3(64), 0, nullptr, pa);
     SW_HIP(hipGetLastError());
-    std::vector<ParseCounts> counts;
-    to_host(counts, d_counts, nf);
+    std::vector<ParseCounts> counts_by_lane, counts(nf);
+    to_host(counts_by_lane, d_counts, nf);
+    for (uint32_t j = 0; j < nf; ++j) counts[perm[j]] = counts_by_lane[j];
     std::vector<uint64_t> word_base(nf + 1, 0), id_base(nf + 1, 0);
     std::vector<uint32_t> rec_idx(nf + 1, 0), run_base(nf + 1, 0);
     uint64_t total_bp = 0;
@@ -287,10 +298,10 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     DevArray<uint64_t> d_wb(nf), d_ib(nf), d_rec_base(n_rec);
     DevArray<uint32_t> d_ri(nf), d_ub(nf), d_rec_len(n_rec), d_rec_run_off(n_rec), d_run_pos(n_runs), d_run_len(n_runs);
     DevArray<char> d_ids(n_id);
-    SW_HIP(hipMemcpy(d_wb.p, word_base.data(), nf * 8ull, hipMemcpyHostToDevice));
-    SW_HIP(hipMemcpy(d_ib.p, id_base.data(), nf * 8ull, hipMemcpyHostToDevice));
-    SW_HIP(hipMemcpy(d_ri.p, rec_idx.data(), nf * 4ull, hipMemcpyHostToDevice));
-    SW_HIP(hipMemcpy(d_ub.p, run_base.data(), nf * 4ull, hipMemcpyHostToDevice));
+    SW_HIP(hipMemcpy(d_wb.p, permuted(word_base).data(), nf * 8ull, hipMemcpyHostToDevice));
+    SW_HIP(hipMemcpy(d_ib.p, permuted(id_base).data(), nf * 8ull, hipMemcpyHostToDevice));
+    SW_HIP(hipMemcpy(d_ri.p, permuted(rec_idx).data(), nf * 4ull, hipMemcpyHostToDevice));
+    SW_HIP(hipMemcpy(d_ub.p, permuted(run_base).data(), nf * 4ull, hipMemcpyHostToDevice));
     SW_HIP(hipMemsetAsync(d_packed.p + 2 * n_words, 0, 8 * 4, nullptr));   // the read slack
     pa.word_base = d_wb.p;
     pa.id_base = d_ib.p;
