@@ -456,6 +456,8 @@ constexpr uint32_t RC = 12;   // published suffix records per run (12 x 8 B: the
 //   8 the winner of the window before the tile cleared in the bitmap by one thread between two barriers (r02)
 //  16 the masked moves of the window pass behind v_cmp + s_and_saveexec (r02) instead of v_cmpx (EXEC written by the compare)
 //  32 the suffix-record pass as the compiler lays it out (compare, EXEC round trip, branch) instead of v_cmpx statements
+//  64 the suffix-record pass clamps its slot address (v_min per element, r03a) instead of writing on into the neighbours' slots
+// 128 the emit loop tests every position in every lane instead of skipping, by a scalar test, those no lane of the wave emits
 #ifndef SW_SK_AB
 #define SW_SK_AB 0
 #endif
@@ -464,7 +466,7 @@ constexpr uint32_t RC = 12;   // published suffix records per run (12 x 8 B: the
 #endif
 constexpr bool SK_CLAMP = !(SW_SK_AB & 1), SK_DPP_SCAN = !(SW_SK_AB & 2), SK_RUNMIN_UNROLLED = !(SW_SK_AB & 4),
                SK_TWO_BARRIERS = (SW_SK_AB & 8) != 0, SK_CMPX = !(SW_SK_AB & 16),
-               SK_SUFFIX_ASM = !(SW_SK_AB & 32), SK_SUFFIX_MIN = (SW_SK_AB & 64) != 0;
+               SK_SUFFIX_ASM = !(SW_SK_AB & 32), SK_SUFFIX_MIN = (SW_SK_AB & 64) != 0, SK_EMIT_GUARD = !(SW_SK_AB & 128);
 
 #ifdef SW_SK_STAMPS
 constexpr uint32_t STAMP_EVERY = 512, STAMP_SLOTS = 16;   // every 512th tile of a launch writes its waves' phase times
@@ -500,6 +502,18 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
         if (lane >= d) v += up;
     }
     return v;
+}
+
+// OR over the 64 lanes of a wave (DPP row shifts / broadcasts as in wave_incl_scan; the result is read from lane 63): wave-uniform
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 template <int L, int B> struct FastCfg {
@@ -1047,6 +1061,7 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
     }
     const uint32_t cnt = (uint32_t)__popc(bits);
     const uint32_t lane = tid & 63u, wave = tid >> 6;
+    const uint32_t wave_bits = SK_EMIT_GUARD ? wave_or(bits) : 0u;   // positions some lane of this wave emits (scalar)
     const uint32_t incl = wave_incl_scan(cnt);
     if (lane == 63) MISC[4 + wave] = incl;
     __syncthreads();
@@ -1081,16 +1096,30 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
         uint64_t *const sk = A.stage_kmer + make64(blo, bhi);
         uint32_t ob = (wave_off + (incl - cnt)) * 8u;   // byte offset inside the tile's range (< 2^32: a range holds <= NE entries)
         const uint32_t kpos = D.kpos + e0;
+        // the canonical hash is staged; out_hash = extend_hashes(h) (hashing_internals.hpp:89-103: one 64-bit multiply +
+        // xor-shift) is applied by k_order, which touches every tuple anyway and is HBM-bound
+#define SK_EMIT(J)                                                                                                            \
+    if ((J) < L && ((bits >> ((J) & 31)) & 1u)) {                                                                             \
+        *reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(sh) + ob) = h[(J) < L ? (J) : 0];                     \
+        *reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(sk) + ob) = make64(kpos + (uint32_t)(J), rec);        \
+        ob += 8u;                                                                                                             \
+    }
+        if (SK_EMIT_GUARD) {
+            // (r03) a scalar test in front of every position: the 53 % of positions no lane of the wave emits at cost two scalar
+            // instructions instead of a lane test (v_and + v_cmp + EXEC round trip).  The wave-wide OR is six DPP steps; through
+            // LDS (r03, first try) the same guard lost 0.5 %, as a scalar jump into the bodies (a while / switch over the set
+            // bits) it costs six more VGPRs -- four waves per SIMD, 116.9 ms
 #pragma unroll
-        for (int j = 0; j < L; ++j) {
-            if ((bits >> j) & 1u) {
-                // the canonical hash is staged; out_hash = extend_hashes(h) (hashing_internals.hpp:89-103: one 64-bit
-                // multiply + xor-shift) is applied by k_order, which touches every tuple anyway and is HBM-bound
-                *reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(sh) + ob) = h[j];
-                *reinterpret_cast<uint64_t *>(reinterpret_cast<unsigned char *>(sk) + ob) = make64(kpos + (uint32_t)j, rec);
-                ob += 8u;
-            }
+            for (int j = 0; j < L; ++j)
+                if (wave_bits & (1u << j)) {
+                    asm volatile("" ::: "memory");      // (keeps the scalar test apart from the lane test)
+                    SK_EMIT(j)
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < L; ++j) { SK_EMIT(j) }
         }
+#undef SK_EMIT
     }
     SK_STAMP(11);
 }
