@@ -205,6 +205,8 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
 void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
                        uint32_t *d_fail, bool perm_hi32 = false, unsigned long long *d_hist_given = nullptr, unsigned layout_bits = 0);
 void radix_layout(unsigned bits, unsigned *digit_bits, unsigned *n_passes);
+// keys[i] >> 32 a permutation of 0 .. n-1: grouped by the index bits [low_bits, nbit) in two unstable passes (false: not taken)
+bool radix_unsort_perm(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned low_bits, unsigned nbit, hipStream_t stream, uint32_t *d_fail);
 
 // index.hip: radix.hip or rocPRIM; d_fail: zeroed device word, to be read back and handed to check_sort_failed
 void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream,

@@ -2007,7 +2007,8 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
         if (nbit > UNSORT_BITS) {   // buckets of 2^14 consecutive indices: sort on the index's bits above those
             // (begin_bit > 0 of rocPRIM's radix sort is checked on this stack by scripts/micro/sort_beginbit.hip)
             uint64_t *v_alt = uv1.p;
-            sort_keys64(v, v_alt, n, 32 + UNSORT_BITS, 32 + nbit, stream, words.p + 2, true);   // (the indices are a permutation)
+            if (!(sort_keys64_is_own(n) && radix_unsort_perm(v, v_alt, n, UNSORT_BITS, nbit, stream, words.p + 2)))
+                sort_keys64(v, v_alt, n, 32 + UNSORT_BITS, 32 + nbit, stream, words.p + 2, true);   // (the indices are a permutation)
         }
         hipLaunchKernelGGL(k_unsort_bucket, dim3((unsigned)((n + UNSORT_RANGE - 1) / UNSORT_RANGE)), dim3(1024), 0, stream, v, n,
                            rank_out);

@@ -257,7 +257,8 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                                                        const unsigned long long *__restrict__ digit_base,
                                                        unsigned long long *__restrict__ state, uint32_t *__restrict__ ticket,
                                                        uint32_t *__restrict__ fail, uint32_t dbg,
-                                                       unsigned long long *__restrict__ cursor)
+                                                       unsigned long long *__restrict__ cursor, uint32_t cursor_stride,
+                                                       uint32_t group_shift)
 {
     constexpr uint32_t RADIX = 1u << BITS, WAVES = THREADS / 64, TILE = THREADS * RS_ITEMS;
     static_assert(RADIX <= (uint32_t)THREADS, "one thread per digit");
@@ -325,7 +326,10 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
             if (cursor) {
                 // UNSTABLE pass (the order inside a digit's range is free: the unsort): the tile claims its places in every
                 // digit's range with one atomic add -- no states, no look-back; the answer is due after the keys sit in LDS
-                pre[0] = total ? atomicAdd(&cursor[(size_t)d * RS_CURSOR_STRIDE], (unsigned long long)total) : 0ull;
+                // (group_shift < 64: the cursors of the range of 2^group_shift positions the tile lies in -- a pass inside the buckets
+                //  an earlier pass made, see radix_unsort_perm)
+                const uint64_t group = group_shift < 64u ? (((uint64_t)tile * TILE) >> group_shift) : 0ull;
+                pre[0] = total ? atomicAdd(&cursor[(group * RADIX + d) * cursor_stride], (unsigned long long)total) : 0ull;
             } else {
                 __hip_atomic_store(&st[d], (tile == 0 ? RS_INC : RS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
@@ -494,7 +498,7 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
         if (persistent)
             hipLaunchKernelGGL((k_rs_pass_p<THREADS, BITS>), dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)grid_p)), dim3(THREADS), 0,
                                stream, keys, alt, n, (uint32_t)n_tiles, sh, bits, hist.p + (size_t)p * RADIX, state.p, tickets.p + p, d_fail,
-                               dbg, cur);
+                               dbg, cur, RS_CURSOR_STRIDE, 64u);
         else
             hipLaunchKernelGGL((k_rs_pass<THREADS, BITS>), dim3((unsigned)n_tiles), dim3(THREADS), 0, stream, keys, alt, n, sh, bits,
                                hist.p + (size_t)p * RADIX, state.p, d_fail);
@@ -524,6 +528,60 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
 }
 
 }  // namespace
+
+namespace {
+// cursor[(g * RADIX + d) * stride] = first position of digit d inside group g of a permutation sorted so far on the bits above
+// this digit: (g << group_bits) + (d << digit_shift)   (one group: group_bits = 64)
+__global__ void k_rs_perm_cursors(unsigned long long *__restrict__ cursor, uint32_t n_groups, uint32_t radix, uint32_t stride,
+                                  unsigned group_bits, unsigned digit_shift)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_groups * radix) return;
+    const uint64_t g = i / radix, d = i % radix;
+    cursor[(size_t)i * stride] = (group_bits < 64 ? g << group_bits : 0ull) + (d << digit_shift);
+}
+}  // namespace
+
+// The unsort's partial sort as TWO unstable passes, most significant digit first: keys[i] >> 32 are a permutation of 0 .. n-1
+// and only their grouping by the index bits [low_bits, nbit) matters (the order inside a group is free).  So every bucket's
+// place is known in advance -- digit d of the first pass owns positions [d << (low_bits + 8), ...), and inside it digit e of
+// the second pass owns [.. + (e << low_bits), ...) -- and a tile claims its places with one atomic add per digit: no counting,
+// no scan, no look-back in either pass (an LSD pair of passes needs its second one stable).  Takes two digits of up to 8
+// bits (8 < nbit - low_bits <= 16, tiles of 8192 keys inside one first-pass bucket); returns false otherwise.
+bool radix_unsort_perm(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned low_bits, unsigned nbit, hipStream_t stream, uint32_t *d_fail)
+{
+    constexpr int THREADS = 512, BITS = 8;
+    constexpr uint32_t RADIX = 1u << BITS, TILE = THREADS * RS_ITEMS;
+    if (n == 0 || nbit <= low_bits + 8 || nbit > low_bits + 16 || getenv("SEQWIN_AMD_RADIX_STABLE_UNSORT")) return false;
+    if ((1ull << (low_bits + 8)) % TILE) return false;
+    const char *kind = getenv("SEQWIN_AMD_RADIX_KERNEL");
+    if (kind && !strcmp(kind, "classic")) return false;
+    const unsigned hi_bits = nbit - low_bits - 8;                         // 1 .. 8
+    const uint32_t n_groups = (uint32_t)((n + (1ull << (low_bits + 8)) - 1) >> (low_bits + 8));
+    const uint64_t n_tiles = (n + TILE - 1) / TILE;
+    int dev = 0, per_cu = 0;
+    SW_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    SW_HIP(hipGetDeviceProperties(&prop, dev));
+    SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pass_p<THREADS, BITS>, THREADS, 0));
+    const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)std::max(1, per_cu) * std::max(1, prop.multiProcessorCount));
+    DevArray<unsigned long long> cur_a((size_t)RADIX * RS_CURSOR_STRIDE), cur_b((size_t)n_groups * RADIX);
+    DevArray<uint32_t> tickets(2);
+    SW_HIP(hipMemsetAsync(tickets.p, 0, 8, stream));
+    hipLaunchKernelGGL(k_rs_perm_cursors, dim3(1), dim3(RADIX), 0, stream, cur_a.p, 1u, RADIX, RS_CURSOR_STRIDE, 64u, low_bits + 8);
+    hipLaunchKernelGGL(k_rs_perm_cursors, dim3((n_groups * RADIX + 255) / 256), dim3(256), 0, stream, cur_b.p, n_groups, RADIX, 1u,
+                       low_bits + 8, low_bits);
+    hipLaunchKernelGGL((k_rs_pass_p<THREADS, BITS>), dim3(grid), dim3(THREADS), 0, stream, keys, alt, n, (uint32_t)n_tiles,
+                       32u + low_bits + 8, hi_bits, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, tickets.p, d_fail,
+                       0u, cur_a.p, RS_CURSOR_STRIDE, 64u);
+    std::swap(keys, alt);
+    hipLaunchKernelGGL((k_rs_pass_p<THREADS, BITS>), dim3(grid), dim3(THREADS), 0, stream, keys, alt, n, (uint32_t)n_tiles, 32u + low_bits,
+                       8u, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, tickets.p + 1, d_fail, 0u, cur_b.p, 1u,
+                       low_bits + 8);
+    std::swap(keys, alt);
+    SW_HIP(hipGetLastError());
+    return true;
+}
 
 // which shape a sort of `bits` key bits takes: 0 = 512 threads x 8 bits, 1 = 1024 x 9, 2 = 1024 x 8, 3 = 512 x 9, 4 = 256 x 8 (the last three: A/B)
 static int pick_shape(unsigned bits)
