@@ -324,6 +324,25 @@ def test_sharded_build_equals_single(tmp_path, world, case, mode):
         assert np.array_equal(np.load(str(out) + f".sums{r}.npy"), exp_sums)
 
 
+@pytest.mark.parametrize("mode", ["tuples", "tuples_requests"])
+def test_eight_ranks_with_empty_shards(tmp_path, mode):
+    """World size 8 -- what `bench.py --gpus 8` runs -- on six assemblies: two ranks hold no assembly at all, some hash ranges
+    and some edge ranges own nothing; every collective still has to line up (split sizes of zero, empty requests)."""
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa"))]
+    assert len(paths) == 6
+    k, w = 15, 20
+    tar = [i % 2 == 0 for i in range(len(paths))]
+    out = tmp_path / "merged.npz"
+    mp.spawn(_worker, nprocs=8, args=(8, _free_port(), paths, k, w, tar, str(out), mode), join=True)
+    got = np.load(out)
+    ek, en, ee, eo, _ = oracle.build(paths, k, w)
+    oracle.get_penalty(ek, en, eo, tar)
+    assert np.array_equal(got["kmers"], ek) and np.array_equal(got["nodes"], en)
+    assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
+    from seqwin_amd.device import host_checksums
+    assert np.array_equal(got["sums"], np.array(host_checksums(ek, en, ee), np.uint64))
+
+
 def test_partition_formula():
     # cpp/src/seqwin/build.cpp:350-356
     assert swdist.partition_assemblies(10, 3) == [(0, 4), (4, 7), (7, 10)]

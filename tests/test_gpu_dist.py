@@ -123,6 +123,27 @@ def test_two_processes_one_gpu_real_collectives(tmp_path, world, mode):
     assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
 
 
+@pytest.mark.parametrize("mode", ["tuples", "tuples_requests"])
+def test_four_processes_with_an_empty_shard(tmp_path, mode):
+    """Four ranks on three assemblies: the last rank holds no assembly (an empty batch, empty tuple stream, nothing to send)
+    while it still owns a hash range and an edge range -- HIP engine in every process, real collectives over gloo."""
+    import socket
+
+    import torch.multiprocessing as mp
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa"))[:3]]
+    tar = [True, False, True]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "merged.npz"
+    mp.spawn(_gloo_worker, nprocs=4, args=(4, port, paths, 15, 20, tar, str(out), mode), join=True)
+    got = np.load(out)
+    ek, en, ee, eo, _ = oracle.build(paths, 15, 20)
+    oracle.get_penalty(ek, en, eo, tar)
+    assert np.array_equal(got["kmers"], ek) and np.array_equal(got["nodes"], en)
+    assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
+
+
 def _rccl_worker(rank, port, paths, k, w, tar, out_path):
     import os
     os.environ["SEQWIN_DIST_FORCE_COLLECTIVES"] = "1"
