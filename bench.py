@@ -289,8 +289,11 @@ def main() -> None:
         traffic, traffic_src, valu_insts = None, None, None
         try:
             tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+            import hashlib
+            same_kernel = tj.get("sketch_hip_sha256") == hashlib.sha256(
+                (ROOT / "seqwin_amd" / "csrc" / "sketch.hip").read_bytes()).hexdigest()   # stale profile -> traffic null
             if (tj.get("workload"), tj.get("k"), tj.get("w")) == (args.workload, k, w) and world == 1 and dominant == "sketch_ms" \
-                    and not args.genomes:
+                    and not args.genomes and same_kernel:
                 traffic, traffic_src = int(tj["hbm_bytes_per_launch"]), tj.get("source")
                 valu_insts = tj.get("valu_wave_insts_per_launch")
         except Exception:

@@ -17,6 +17,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 
 
@@ -149,6 +150,10 @@ def main():
         if fast and traffic and fast[0].get("SQ_INSTS_VALU"):
             traffic["valu_wave_insts_per_launch"] = sum(fast[0]["SQ_INSTS_VALU"]) / len(fast[0]["SQ_INSTS_VALU"])
         if traffic:
+            # stamp with the kernel's source: bench.py reports `traffic` only while sketch.hip still is what was profiled
+            import hashlib
+            src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "seqwin_amd", "csrc", "sketch.hip")
+            traffic["sketch_hip_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
             json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
         print(open(a.out_prefix + "_hbm_traffic.txt").read())
         print(traffic)

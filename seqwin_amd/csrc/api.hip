@@ -454,11 +454,24 @@ Resident &resident()
 
 // the sums of k_identity (index.hip) over host arrays, on n_threads threads
 }  // namespace
+// set while THIS thread holds Resident::mu (sw_get_penalty / sw_filter_kmers allocate while they work on the resident
+// arrays): try_lock on a mutex the calling thread owns is undefined, so the owner is told apart before the mutex is touched
+thread_local bool t_resident_held = false;
+struct ResidentLock {
+    std::unique_lock<std::mutex> lk;
+    explicit ResidentLock(std::mutex &m) : lk(m) { t_resident_held = true; }
+    void unlock() { if (lk.owns_lock()) { lk.unlock(); t_resident_held = false; } }
+    ~ResidentLock() { if (lk.owns_lock()) t_resident_held = false; }
+};
 void release_resident_if_idle()
 {
+    if (t_resident_held) return;                                 // this very call is working on it
     Resident &r = resident();
-    std::unique_lock<std::mutex> lock(r.mu, std::try_to_lock);   // (held: a get_penalty / filter_kmers call is working on it)
-    if (lock.owns_lock()) r.ix.reset();
+    std::unique_lock<std::mutex> lock(r.mu, std::try_to_lock);   // (held by another thread: a call is working on it)
+    if (!lock.owns_lock() || !r.ix) return;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || r.ix->device != dev) return;   // HBM of another device does not help this hipMalloc
+    r.ix.reset();
 }
 namespace {
 void host_identity(const sw_kmer *kmers, uint64_t nk, const sw_node *nodes, uint64_t nn, unsigned n_threads, uint64_t *sums2)
@@ -1438,7 +1451,7 @@ int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint6
         SW_HIP(hipMemcpy(d_tar.p, is_targets, n_assemblies, hipMemcpyHostToDevice));
         // the arrays of the last sw_build are usually still in HBM (Resident): use them when the caller's are the same
         Resident &res = resident();
-        std::unique_lock<std::mutex> rlock(res.mu);
+        ResidentLock rlock(res.mu);
         int dev = -1;
         SW_HIP(hipGetDevice(&dev));
         bool use_resident = false;
@@ -1510,7 +1523,7 @@ int sw_filter_kmers(const sw_kmer *kmers, uint64_t n_kmers, const sw_node *nodes
         std::sort(used.begin(), used.end());  // filter.cpp:145
         // kmers: the resident copy of the last sw_build when the caller's array is that one (Resident)
         Resident &res = resident();
-        std::unique_lock<std::mutex> rlock(res.mu);
+        ResidentLock rlock(res.mu);
         int dev = -1;
         SW_HIP(hipGetDevice(&dev));
         bool use_resident = false;

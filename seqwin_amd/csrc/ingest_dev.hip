@@ -21,6 +21,8 @@
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
+#include <exception>
+#include <mutex>
 #include <thread>
 
 #include <fcntl.h>
@@ -170,6 +172,12 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     std::atomic<bool> ok{true};
     std::atomic<size_t> bad_file{0};
     const size_t n_workers = std::max<size_t>(1, std::min<size_t>({(size_t)std::max<uint64_t>(1, n_cpu), n_paths, 32}));
+    std::mutex err_mu;
+    std::exception_ptr device_error;                   // a HIP failure in a reader is an error of the call, not a reason to decline
+    struct Fd {                                        // closes on every way out of the loop body
+        int fd;
+        ~Fd() { if (fd >= 0) close(fd); }
+    };
     auto reader = [&](size_t w) {
         try {
             SW_HIP(hipSetDevice(b.device));            // (a new thread starts on device 0)
@@ -177,7 +185,8 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
             for (;;) {
                 const size_t i = next.fetch_add(1);
                 if (i >= n_paths || !ok.load()) break;
-                const int fd = open(paths[i], O_RDONLY);
+                const Fd file{open(paths[i], O_RDONLY)};
+                const int fd = file.fd;
                 if (fd < 0) { bad_file.store(i); ok.store(false); break; }
                 uint64_t done = 0;
                 bool first = true, bad = false;
@@ -204,7 +213,6 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
                     SW_HIP(hipMemcpyAsync(d_comp.p + coff[i] + done, pin.p, got, hipMemcpyHostToDevice, pin.st));
                     done += got;
                 }
-                close(fd);
                 if (bad || dstart[i] + 8 > fsize[i]) { bad_file.store(i); ok.store(false); break; }
                 crc_want[i] = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
                 isize[i] = (uint32_t)tail[4] | ((uint32_t)tail[5] << 8) | ((uint32_t)tail[6] << 16) | ((uint32_t)tail[7] << 24);
@@ -212,7 +220,9 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
                 dstart[i] += coff[i];
             }
             SW_HIP(hipStreamSynchronize(pin.st));
-        } catch (...) {
+        } catch (...) {                                // SW_HIP raised: hipHostMalloc / hipMemcpyAsync / a device fault
+            std::lock_guard<std::mutex> g(err_mu);
+            if (!device_error) device_error = std::current_exception();
             ok.store(false);
         }
     };
@@ -221,10 +231,13 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
         for (size_t w = 0; w < n_workers; ++w) th.emplace_back(reader, w);
         for (auto &t : th) t.join();
     }
+    if (device_error) std::rethrow_exception(device_error);
     if (!ok.load()) return decline("unreadable, or not a plain gzip header", bad_file.load(), 0);
     const auto t1 = std::chrono::steady_clock::now();
 
     // -- inflate -------------------------------------------------------------------------------------------------------
+    // (The three kernels, the memsets and the synchronous copies below run on the NULL stream: the batch is not handed out before
+    //  the hipDeviceSynchronize at the end, and every DevArray released on the way is fenced by the pool on its next owner's stream.)
     std::vector<uint64_t> toff(n_paths + 1, 0);
     for (size_t i = 0; i < n_paths; ++i) toff[i + 1] = toff[i] + (((uint64_t)isize[i] + 15) & ~15ull);
     SW_HIP(hipMemGetInfo(&free_b, &total_b));

@@ -489,15 +489,17 @@ def node_bases(node_counts) -> list[int]:
     return out
 
 
-def hash_route(total_nodes: int) -> str:
+def hash_route(table_words: int) -> str:
     """"table": every GPU gets the whole rank -> hash table (all-gather, 8 B per node of the job); "requests": the edge owners
     ask the node owners for the hashes of their edges' distinct endpoints (12 B per endpoint, no table in HBM).
+    ``table_words`` is the size of the table as it would be allocated: world * max(node count of a slice), i.e. padded to the
+    largest slice (skewed owners or SEQWIN_DIST_NODE_SPACING make that more than the node total).
     SEQWIN_DIST_HASH_ROUTE forces one; else the table up to SEQWIN_DIST_TABLE_LIMIT_MB (default 4096)."""
     forced = os.environ.get("SEQWIN_DIST_HASH_ROUTE")
     if forced in ("table", "requests"):
         return forced
     limit = int(os.environ.get("SEQWIN_DIST_TABLE_LIMIT_MB", "4096")) << 20
-    return "requests" if int(total_nodes) * 8 > limit else "table"
+    return "requests" if int(table_words) * 8 > limit else "table"
 
 
 def adjacency_asm_bits(n_bits: int, n_assemblies_total: int) -> int:
@@ -515,21 +517,27 @@ def adjacency_asm_bits(n_bits: int, n_assemblies_total: int) -> int:
 _MSG_LIMIT = int(os.environ.get("SEQWIN_DIST_MSG_LIMIT_MB", "256")) << 20
 
 
-def _all_to_all_rows(out, rows, recv_counts, send_counts, group) -> None:
-    """all_to_all_single(out, rows, recv_counts, send_counts) in rounds that keep every per-peer message below _MSG_LIMIT."""
+def _all_to_all_rows(out, rows, recv_counts, send_counts, group, global_max: int) -> None:
+    """all_to_all_single(out, rows, recv_counts, send_counts) in rounds that keep every per-peer message below _MSG_LIMIT.
+
+    ``global_max`` is the largest entry of the job-wide (source x destination) count matrix of this exchange: the number of
+    rounds follows from it alone, so every rank issues the same sequence of collectives whatever its own counts are (a rank
+    with nothing left to send or receive in a round takes part with zero-length messages)."""
     import torch
     import torch.distributed as dist
-    row_bytes = rows.element_size() * (rows[0].numel() if rows.dim() > 1 and rows.shape[0] else 1)
+    row_bytes = rows.element_size() * math.prod(rows.shape[1:])                 # from the shape: an empty send has rows too
     cap = max(1, _MSG_LIMIT // max(1, row_bytes))
     send_counts, recv_counts = [int(c) for c in send_counts], [int(c) for c in recv_counts]
-    if max(send_counts + recv_counts + [0]) <= cap:
+    global_max = int(global_max)
+    if max(send_counts + recv_counts + [0]) > global_max:
+        raise RuntimeError("all-to-all counts exceed the job-wide maximum they were announced with")
+    if global_max <= cap:
         dist.all_to_all_single(out, rows.contiguous(), recv_counts, send_counts, group=group)
         return
     world = len(send_counts)
     s_off = [sum(send_counts[:p]) for p in range(world)]
     r_off = [sum(recv_counts[:p]) for p in range(world)]
-    done = 0
-    while done < max(send_counts + recv_counts):
+    for done in range(0, global_max, cap):
         s_n = [min(cap, max(0, c - done)) for c in send_counts]
         r_n = [min(cap, max(0, c - done)) for c in recv_counts]
         piece = torch.cat([rows[s_off[p] + done:s_off[p] + done + s_n[p]] for p in range(world)])
@@ -539,7 +547,6 @@ def _all_to_all_rows(out, rows, recv_counts, send_counts, group) -> None:
         for p in range(world):
             out[r_off[p] + done:r_off[p] + done + r_n[p]] = got[at:at + r_n[p]]
             at += r_n[p]
-        done += cap
 
 
 def _all_gather_parts(table, mine, pad: int, group, async_op: bool = False):
@@ -572,7 +579,7 @@ def _exchange_rows(rows, counts, dev, group):
     matrix = parts.tolist()                                   # matrix[src][dst]
     recv_l = [int(matrix[src][rank]) for src in range(world)]
     out = torch.empty((sum(recv_l),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
-    _all_to_all_rows(out, rows, recv_l, counts, group)
+    _all_to_all_rows(out, rows, recv_l, counts, group, max(max(r) for r in matrix))
     return out, recv_l, matrix
 
 
@@ -589,7 +596,7 @@ def _exchange_rows_pair(rows_a, counts_a, rows_b, counts_b, dev, group):
     for rows, counts, off in ((rows_a, counts_a, 0), (rows_b, counts_b, world)):
         recv_l = [int(matrix[src][off + rank]) for src in range(world)]
         out = torch.empty((sum(recv_l),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
-        _all_to_all_rows(out, rows, recv_l, counts, group)
+        _all_to_all_rows(out, rows, recv_l, counts, group, max(max(r[off:off + world]) for r in matrix))
         outs.append(out)
     return outs
 
@@ -651,8 +658,9 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     if multi:
         r_rows, recv_cnt, matrix = _exchange_rows(rows, cnt, dev, group)
         kmer_base = sum(int(matrix[src][r]) for r in range(rank) for src in range(world))   # rows owned by lower ranks
+        tuple_max = max(max(r) for r in matrix)                  # the ranks travel back along the same matrix, transposed
     else:
-        r_rows, recv_cnt, kmer_base = rows, cnt, 0
+        r_rows, recv_cnt, kmer_base, tuple_max = rows, cnt, 0, 0
     t2 = time.perf_counter()
     ix, r_ranks = engine.slice_build(r_rows, kmer_base, record_offsets, is_targets)
     tm = dict(engine.timings(ix))
@@ -679,11 +687,11 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
         # How the edge owners get the hashes of their edges' endpoints: the whole rank -> hash table on every GPU (8 B per node
         # of the job: 0.64 GB at 15 000 genomes, 40 GB at configs[4] with k >= 19), or -- above SEQWIN_DIST_TABLE_LIMIT_MB,
         # default 4096 -- by asking the node owners for the distinct endpoints only (hash_route "requests", below).
-        by_request = hash_route(total_nodes) == "requests"
         table, pad, hash_work = None, max(1, max(node_cnt)), None
+        by_request = hash_route(world * pad) == "requests"
         if multi:
             ranks_by_row = torch.empty((occ.n,), dtype=torch.int32, device=dev)
-            _all_to_all_rows(ranks_by_row, r_ranks, cnt, recv_cnt, group)
+            _all_to_all_rows(ranks_by_row, r_ranks, cnt, recv_cnt, group, tuple_max)
             if not by_request:
                 mine = engine.node_hash_part(ix, pad)                           # this slice's hashes at the front of `pad` words
                 table = torch.empty((world * pad,), dtype=torch.int64, device=dev)
@@ -713,10 +721,10 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
             # node owners; the hashes come back in the same order
             req, req_cnt = engine.edge_hash_requests(ix, node_base)
             if multi:
-                got, got_cnt, _ = _exchange_rows(req, req_cnt, dev, group)
+                got, got_cnt, req_matrix = _exchange_rows(req, req_cnt, dev, group)
                 answers = engine.node_hash_lookup(ix, got)
                 replies = torch.empty((int(req.shape[0]),), dtype=torch.int64, device=dev)
-                _all_to_all_rows(replies, answers, req_cnt, got_cnt, group)
+                _all_to_all_rows(replies, answers, req_cnt, got_cnt, group, max(max(r) for r in req_matrix))
             else:
                 replies = engine.node_hash_lookup(ix, req)
             engine.edge_hash_attach(ix, replies)
@@ -729,7 +737,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
         rr = ((rr & (REP - 1)) if marked else rr) + node_base[rank]
         if multi:
             ranks_by_row = torch.empty((occ.n,), dtype=torch.int32, device=dev)
-            _all_to_all_rows(ranks_by_row, rr.to(torch.int32), cnt, recv_cnt, group)
+            _all_to_all_rows(ranks_by_row, rr.to(torch.int32), cnt, recv_cnt, group, tuple_max)
             parts = [torch.empty((max(1, max(node_cnt)),), dtype=torch.int64, device=dev) for _ in range(world)]
             dist.all_gather(parts, engine.node_hash_part(ix, max(1, max(node_cnt))), group=group)
             rank_hash = torch.cat([p[:c] for p, c in zip(parts, node_cnt)])

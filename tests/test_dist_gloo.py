@@ -273,6 +273,8 @@ def _worker(rank, world, port, paths, k, w, tar, out_path, mode):
     try:
         start, end = swdist.partition_assemblies(len(paths), world)[rank]
         eng = NumpyEngine()
+        if mode.endswith("+rounds"):               # every exchange in rounds of at most 48 bytes per peer (three 16-byte rows)
+            swdist._MSG_LIMIT, mode = 48, mode[:-len("+rounds")]
         eng.mark_repeats = mode != "tuples_rows"   # "tuples": adjacency in its pairs form; "tuples_rows": {pair, assembly} rows
         if mode == "tuples_requests":              # ... and the edge owners ask the node owners for hashes (no job-wide table)
             os.environ["SEQWIN_DIST_HASH_ROUTE"] = "requests"
@@ -322,6 +324,56 @@ def test_sharded_build_equals_single(tmp_path, world, case, mode):
     assert np.array_equal(got["sums"], exp_sums)
     for r in range(1, world):
         assert np.array_equal(np.load(str(out) + f".sums{r}.npy"), exp_sums)
+
+
+def _skewed_exchange_worker(rank, world, port, matrix, cap_rows, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
+    try:
+        swdist._MSG_LIMIT = cap_rows * 16
+        counts = matrix[rank]
+        # row (src, dst, i) -> [src << 40 | dst << 20 | i, its negation]; an empty send keeps its (0, 2) shape
+        rows = torch.tensor([[(rank << 40) | (d << 20) | i, -((rank << 40) | (d << 20) | i)] for d in range(world)
+                             for i in range(counts[d])], dtype=torch.int64).reshape(-1, 2)
+        got, recv, m = swdist._exchange_rows(rows, counts, torch.device("cpu"), None)
+        assert m == matrix and recv == [matrix[s][rank] for s in range(world)]
+        exp = [[(s << 40) | (rank << 20) | i, -((s << 40) | (rank << 20) | i)] for s in range(world) for i in range(matrix[s][rank])]
+        assert got.tolist() == exp, (rank, got.shape)
+        # and back along the transposed matrix (the way the node ranks and the hash replies travel)
+        back = torch.empty((sum(counts), 2), dtype=torch.int64)
+        swdist._all_to_all_rows(back, got, counts, recv, None, max(max(r) for r in m))
+        assert torch.equal(back, rows)
+        open(out_path + f".ok{rank}", "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("matrix", [[[5, 5, 5], [5, 5, 250], [5, 5, 5]], [[0, 0, 0], [0, 0, 301], [7, 0, 0]],
+                                    [[100, 100, 100], [100, 100, 100], [100, 100, 101]]])
+def test_rounds_follow_the_job_wide_maximum(tmp_path, matrix):
+    """Skewed counts with a cap of 100 rows per message: one pair of ranks needs three rounds, the others one (or none -- a
+    rank that sends nothing at all).  Every rank must issue the same number of collectives (decided from local
+    counts, rank 0 did one call and ranks 1 and 2 three, and gloo timed out)."""
+    out = str(tmp_path / "x")
+    mp.spawn(_skewed_exchange_worker, nprocs=3, args=(3, _free_port(), matrix, 100, out), join=True)
+    assert all(os.path.exists(out + f".ok{r}") for r in range(3))
+
+
+@pytest.mark.parametrize("mode", ["tuples+rounds", "tuples_requests+rounds", "tuples_rows+rounds"])
+def test_sharded_build_in_message_rounds(tmp_path, mode):
+    """The whole choreography with every per-peer message cut into rounds of three rows (what runs above 256 MiB per peer:
+    two GPUs at 15 000 genomes, configs[4])."""
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa"))]
+    k, w = 15, 20
+    tar = [i % 2 == 0 for i in range(len(paths))]
+    out = tmp_path / "merged.npz"
+    mp.spawn(_worker, nprocs=3, args=(3, _free_port(), paths, k, w, tar, str(out), mode), join=True)
+    got = np.load(out)
+    ek, en, ee, eo, _ = oracle.build(paths, k, w)
+    oracle.get_penalty(ek, en, eo, tar)
+    assert np.array_equal(got["kmers"], ek) and np.array_equal(got["nodes"], en)
+    assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
 
 
 @pytest.mark.parametrize("mode", ["tuples", "tuples_requests"])
@@ -374,6 +426,7 @@ def test_single_process_tuple_form_equals_oracle():
     k, n, e = sharded.export()
     assert np.array_equal(k, ek) and np.array_equal(n, en) and np.array_equal(e, ee)
     assert swdist.hash_route(10**6) == "table" and swdist.hash_route(5 * 10**9) == "requests"     # 8 MB / 40 GB of table
+    assert swdist.hash_route(8 * 68 * 10**6) == "requests"    # 8 owners padded to the largest slice: 4.35 GB though the nodes are fewer
 
 
 def test_rank_bounds():
