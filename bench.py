@@ -252,6 +252,18 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # per-phase device time of the LAST step's sharded build, max over ranks (stream events: no synchronisation inside the step)
+    dist_info = None
+    if use_dist:
+        ph = ix.phases_ms()
+        names = sorted(ph)
+        if world > 1:                                    # every rank walks the same phases (same route, same form)
+            tph = torch.tensor([ph[n] for n in names], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tph, op=dist.ReduceOp.MAX)
+            ph = dict(zip(names, tph.tolist()))
+        dist_info = dict(ix.info, phases_ms_max_over_ranks={n: round(ph[n], 3) for n in ph},
+                         collectives="issued" if (world > 1 or force_coll) else "skipped (one rank, SEQWIN_BENCH_FORCE_DIST)")
+
     nk, nn, ne = ix.sizes()
     tm = ix.timings()
     counts = torch.tensor([nk, nn, ne], dtype=torch.int64, device=red_dev)
@@ -324,6 +336,8 @@ def main() -> None:
             "counts": {"kmers": tot[0], "nodes": tot[1], "edges": tot[2]},
             "checksums": [f"{s:016x}" for s in sums],
         }
+        if dist_info is not None:
+            out["dist"] = dist_info
         if valu_insts:
             # explanatory (not the mandated roofline): integer VALU issue, 256 CU x 4 SIMD x 32 lanes x 2.4 GHz peak
             lane_ops = valu_insts * 64.0

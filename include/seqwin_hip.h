@@ -110,6 +110,10 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
  * gives that HBM back at once; SEQWIN_AMD_NO_RESIDENT=1 disables the mechanism. */
 void sw_graph_free(sw_graph *g);
 void sw_release_resident(void);
+/* Device memory comes from a caching pool (steady-state builds do no hipMalloc).  sw_pool_trim() hands every cached, unused
+ * block back to the driver -- for a host program that shares the GPU's memory with another allocator (torch's, in the
+ * multi-GPU choreography); the pool trims itself when one of its own hipMalloc calls fails. */
+void sw_pool_trim(void);
 /* out[3] = { occurrences of the resident index (0: none), sw_get_penalty calls served from it, sw_filter_kmers calls served from it } */
 void sw_resident_stats(uint64_t *out);
 
@@ -316,6 +320,11 @@ int sw_slice_edges(sw_index *ix, const void *adj_rows_dev, uint64_t m, uint64_t 
  * result; *ms (may be NULL) the device time. */
 int sw_sort_keys64(void *keys_dev, void *alt_dev, uint64_t n, uint64_t begin_bit, uint64_t end_bit, void *stream, int *sorted_in_alt,
                    double *ms);
+/* The pair form -- lsd_radix_sort (cpp/src/seqwin/build_internals.cpp:76-110) as the node sort uses it: n DEVICE u32 keys, each
+ * with a 16-byte payload, stably by key bits [0, end_bit), end_bit in {8, 16, 24, 32} (csrc/radix.hip's pair passes; rocPRIM's
+ * under SEQWIN_AMD_SORT=rocprim or SEQWIN_AMD_PAIR_SORT=rocprim).  Double buffers of n keys / n payloads each. */
+int sw_sort_pairs32(void *keys_dev, void *keys_alt_dev, void *vals_dev, void *vals_alt_dev, uint64_t n, uint64_t end_bit, void *stream,
+                    int *sorted_in_alt, double *ms);
 
 /* ---- pairs form of the adjacency exchange (what dist.py uses whenever every slice marked its ranks) ---------------------
  * The weight of an edge is the number of its adjacency records minus the records that repeat the pair inside one

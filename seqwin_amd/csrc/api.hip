@@ -430,6 +430,7 @@ struct GraphHost {   // result of sw_build: arrays stay in HBM until sw_graph_ex
     uint64_t n_assemblies = 0, total_bp = 0;
     bool exported = false;          // sw_graph_export has filled caller arrays from this index
     uint64_t identity[2] = {0, 0};  // device_identity at that moment
+    std::unique_ptr<MultiGraph> multi;   // SEQWIN_DEVICES: the graph as one slice per device instead of `ix`
 };
 
 // ---- the index of the last exported sw_build stays resident --------------------------------------------------------
@@ -985,6 +986,33 @@ int sw_sort_keys64(void *keys_dev, void *alt_dev, uint64_t n, uint64_t begin_bit
     });
 }
 
+int sw_sort_pairs32(void *keys_dev, void *keys_alt_dev, void *vals_dev, void *vals_alt_dev, uint64_t n, uint64_t end_bit, void *stream,
+                    int *sorted_in_alt, double *ms)
+{
+    return guarded([&] {
+        require_device();
+        if (end_bit == 0 || end_bit > 32 || end_bit % 8) raise(SW_ERR_VALUE, "end_bit must be 8, 16, 24 or 32");
+        StreamScope scope((hipStream_t)stream);
+        uint32_t *k = (uint32_t *)keys_dev, *ka = (uint32_t *)keys_alt_dev;
+        OccPay *v = (OccPay *)vals_dev, *va = (OccPay *)vals_alt_dev;
+        DevArray<uint32_t> fail(1);
+        SW_HIP(hipMemsetAsync(fail.p, 0, 4, (hipStream_t)stream));
+        Event e0, e1;
+        SW_HIP(hipEventRecord(e0, (hipStream_t)stream));
+        sort_pairs32(k, ka, v, va, n, (unsigned)end_bit, (hipStream_t)stream, fail.p);
+        SW_HIP(hipEventRecord(e1, (hipStream_t)stream));
+        uint32_t failed = 0;
+        SW_HIP(hipMemcpyAsync(&failed, fail.p, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        SW_HIP(hipEventSynchronize(e1));
+        SW_HIP(hipStreamSynchronize((hipStream_t)stream));
+        check_sort_failed(failed);
+        float t = 0.f;
+        SW_HIP(hipEventElapsedTime(&t, e0, e1));
+        if (ms) *ms = t;
+        *sorted_in_alt = (k == (uint32_t *)keys_alt_dev) ? 1 : 0;
+    });
+}
+
 int sw_index_ranks_marked(const sw_index *ix, int *marked)
 {
     return guarded([&] { *marked = ix->ranks_marked ? 1 : 0; });
@@ -1310,7 +1338,25 @@ int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t km
             }
         }
         const auto t0 = now();
-        if (chunked) {
+        const std::vector<int> devs = devices_from_env();
+        if (devs.size() > 1 && n_assemblies > 1) {
+            // one worker per listed device, the reference's partition of the assemblies, peer-to-peer exchanges (multi.hip)
+            g->g.multi.reset(new MultiGraph);
+            build_multi_device(assembly_paths, n_assemblies, kmerlen, windowsize, n_cpu, devs, *g->g.multi);
+            MultiGraph &m = *g->g.multi;
+            device_ms = ms(t0, now());
+            g->g.record_offsets = m.record_offsets;
+            g->g.ids_blob = m.ids_blob;
+            g->g.n_assemblies = m.n_assemblies;
+            g->g.total_bp = m.total_bp;
+            for (auto &sl : m.slices) {   // (sizes of the whole; the arrays stay per device until sw_graph_export)
+                g->g.ix.n_kmers += sl->n_kmers;
+                g->g.ix.n_nodes += sl->n_nodes;
+                g->g.ix.n_edges += sl->n_edges;
+            }
+            log_message("info", "MI355X build over %zu devices (SEQWIN_DEVICES), node hashes to the edge owners by %s", m.slices.size(),
+                        m.hash_route);
+        } else if (chunked) {
             build_chunked(assembly_paths, n_assemblies, kmerlen, windowsize, n_cpu, chunk_bp, g->g, &ingest_ms, &device_ms);
         } else {
             std::unique_ptr<sw_batch> b(new sw_batch);
@@ -1362,6 +1408,25 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
         const HostSpan spans[3] = {{kmers, ix.n_kmers * sizeof(sw_kmer)}, {nodes, ix.n_nodes * sizeof(sw_node)},
                                    {edges, ix.n_edges * sizeof(sw_edge)}};
         prefault(spans, 3);
+        if (h.multi) {
+            // the slices in owner order, each from its device (node ranges are already global: sw_slice_build's kmer_base)
+            int home = 0;
+            SW_HIP(hipGetDevice(&home));
+            uint64_t ko = 0, no = 0, eo = 0;
+            for (auto &sl : h.multi->slices) {
+                SW_HIP(hipSetDevice(sl->device));
+                if (sl->n_kmers) SW_HIP(hipMemcpy(kmers + ko, sl->kmers.p, sl->n_kmers * sizeof(sw_kmer), hipMemcpyDeviceToHost));
+                if (sl->n_nodes) SW_HIP(hipMemcpy(nodes + no, sl->nodes.p, sl->n_nodes * sizeof(sw_node), hipMemcpyDeviceToHost));
+                if (sl->n_edges) SW_HIP(hipMemcpy(edges + eo, sl->edges.p, sl->n_edges * sizeof(sw_edge), hipMemcpyDeviceToHost));
+                ko += sl->n_kmers;
+                no += sl->n_nodes;
+                eo += sl->n_edges;
+            }
+            SW_HIP(hipSetDevice(home));
+            memcpy(record_offsets, h.record_offsets.data(), h.record_offsets.size() * 4);
+            if (!h.ids_blob.empty()) memcpy(ids_blob, h.ids_blob.data(), h.ids_blob.size());
+            return;
+        }
         if (ix.n_kmers) SW_HIP(hipMemcpy(kmers, ix.kmers.p, ix.n_kmers * sizeof(sw_kmer), hipMemcpyDeviceToHost));
         if (ix.n_nodes) SW_HIP(hipMemcpy(nodes, ix.nodes.p, ix.n_nodes * sizeof(sw_node), hipMemcpyDeviceToHost));
         if (ix.n_edges) SW_HIP(hipMemcpy(edges, ix.edges.p, ix.n_edges * sizeof(sw_edge), hipMemcpyDeviceToHost));
@@ -1415,6 +1480,8 @@ void sw_resident_stats(uint64_t *out)
     out[1] = r.penalty_hits;
     out[2] = r.filter_hits;
 }
+
+void sw_pool_trim(void) { dev_pool_trim(); }
 
 void sw_release_resident(void)
 {

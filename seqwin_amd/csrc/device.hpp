@@ -3,6 +3,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <memory>
+#include <string>
+
 #include "common.hpp"
 
 namespace sw {
@@ -181,6 +184,19 @@ struct sw_index {
 
 namespace sw {
 
+// multi.hip: one build over several devices inside one process (SEQWIN_DEVICES).  slices[o] = owner o's hash range of the
+// graph, resident on its device; their concatenation in owner order is the single-device result.
+struct MultiGraph {
+    std::vector<std::unique_ptr<sw_index>> slices;
+    std::vector<uint32_t> record_offsets;
+    std::string ids_blob;
+    uint64_t n_assemblies = 0, total_bp = 0;
+    const char *hash_route = "";
+};
+std::vector<int> devices_from_env();   // SEQWIN_DEVICES: "all" or a list of device indices (repeats allowed); empty: one device
+void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, uint64_t w, uint64_t n_cpu, std::vector<int> devs,
+                        MultiGraph &out);
+
 Plan &get_plan(sw_batch &b, uint64_t k, uint64_t w, bool *cached = nullptr);
 
 // sketch.hip: runs the fused ntHash + window-minimum kernel over every tile of the plan.
@@ -221,6 +237,13 @@ void check_sort_failed(uint32_t fail_word);
 struct alignas(16) OccPay {
     uint32_t low, pos, rec, idx;
 };
+// radix.hip: stable sort of (key32, OccPay) pairs by key bits [0, end_bit), end_bit in {8, 16, 24, 32}; double buffers
+bool radix_pairs_available();   // false on a device that does not pass the LDS-atomic ranking self-check (rocPRIM sorts the pairs then)
+void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
+                        hipStream_t stream, uint32_t *d_fail);
+// index.hip: radix.hip's pair passes or rocPRIM's (small inputs, SEQWIN_AMD_SORT / SEQWIN_AMD_PAIR_SORT); d_fail as for sort_keys64
+void sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
+                  hipStream_t stream, uint32_t *d_fail);
 struct PartState;                       // index.hip: offsets of the last tuple partition (the way back walks them again)
 void part_state_delete(PartState *p);
 uint32_t occ_partition_owners(const struct OrderedOcc &occ);   // owners of the last tuple partition (0: none)

@@ -83,6 +83,23 @@ void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_
     keys_alt = dk.alternate();
 }
 
+// The node sort's phase 1: rocPRIM's onesweep pair passes by default; SEQWIN_AMD_PAIR_SORT=own takes radix.hip's pair passes
+// (hand-written, stable, tested against torch.sort in tests/tools/pair_sort_check.py and in the suite) -- measured on 745 M
+// pairs: 33.1 ms against 28.0 for rocPRIM (r04: 4096-element tiles, two workgroups per CU; the look-back and seven barriers of
+// a tile are not covered by the one other workgroup), so the library's passes stay the default here.
+bool sort_pairs_is_own(size_t n, unsigned bits)
+{
+    const char *e = getenv("SEQWIN_AMD_PAIR_SORT");
+    return e && !strcmp(e, "own") && bits % 8 == 0 && bits <= 32 && n < 0xFFFFFFFFull && radix_pairs_available();
+}
+
+void sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
+                  hipStream_t stream, uint32_t *d_fail)
+{
+    if (sort_pairs_is_own(n, end_bit)) radix_sort_pairs32(keys, keys_alt, vals, vals_alt, n, end_bit, stream, d_fail);
+    else sort_pairs(keys, keys_alt, vals, vals_alt, n, 0, end_bit, stream);
+}
+
 void check_sort_failed(uint32_t fail_word)
 {
     if (fail_word)
@@ -1862,6 +1879,7 @@ struct PaySort {
     RepairState rep;
     uint32_t cap = 0, kmask = ~0u;
     uint64_t n = 0;
+    DevArray<uint32_t> fail;           // radix.hip's passes: non-zero if one gave up waiting (read in settle_sort)
 };
 
 // Phases 1 and 2 are enqueued without any host round trip; the caller must call sort_pay_settle() once the
@@ -1883,7 +1901,9 @@ void sort_pay(uint64_t n, hipStream_t stream, PaySort &o)
         hipLaunchKernelGGL(k_rot_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, n, bits);
         SW_HIP(hipGetLastError());
     }
-    sort_pairs(keys, keys_alt, vals, vals_alt, n, 0, bits, stream);
+    o.fail.alloc(1);
+    SW_HIP(hipMemsetAsync(o.fail.p, 0, 4, stream));
+    sort_pairs32(keys, keys_alt, vals, vals_alt, n, bits, stream, o.fail.p);
     if (bits < 32) {
         hipLaunchKernelGGL(k_rot_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, n, 32 - bits);
         SW_HIP(hipGetLastError());
@@ -1949,11 +1969,13 @@ bool sort_pay_settle(PaySort &o, unsigned long long D, uint32_t status, hipStrea
 // number of distinct hashes (the run heads counted before the repair)
 uint64_t settle_sort(PaySort &ps, hipStream_t stream)
 {
-    uint32_t status = 0;
+    uint32_t status = 0, failed = 0;
     unsigned long long dh[2] = {0, 0};
     SW_HIP(hipMemcpyAsync(&status, ps.rep.status.p, 4, hipMemcpyDeviceToHost, stream));
     SW_HIP(hipMemcpyAsync(dh, ps.rep.n_desc.p, 16, hipMemcpyDeviceToHost, stream));
+    if (ps.fail.p) SW_HIP(hipMemcpyAsync(&failed, ps.fail.p, 4, hipMemcpyDeviceToHost, stream));
     SW_HIP(hipStreamSynchronize(stream));
+    check_sort_failed(failed);
     sort_pay_settle(ps, dh[0], status, stream);
     return dh[1];
 }

@@ -125,6 +125,86 @@ __device__ __forceinline__ void match_digit(uint32_t d, bool live, uint32_t &mlo
     }
 }
 
+// The property RANK = 1 rests on, checked on the device itself: 16 waves per workgroup (the occupancy of a pass) rank 96 rounds
+// of contended digit patterns -- one word for all lanes, both halves of one word, pairs, triples, the two halves of the wave
+// on one word, random digits, dead lanes -- once with the LDS atomic and once with ballots; any difference is counted.
+__global__ __launch_bounds__(1024) void k_rs_rank_selftest(uint32_t *__restrict__ mismatches)
+{
+    constexpr int BITS = 9;
+    constexpr uint32_t RADIX = 1u << BITS, WAVES = 16;
+    __shared__ uint16_t wa[WAVES][RADIX], wb[WAVES][RADIX];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    for (uint32_t i = tid; i < WAVES * RADIX; i += 1024) (&wa[0][0])[i] = (&wb[0][0])[i] = 0;
+    __syncthreads();
+    uint32_t bad = 0;
+    for (uint32_t r = 0; r < 96; ++r) {
+        uint32_t x = (lane * 0x9E3779B1u) ^ ((r + 1u) * 0x85EBCA6Bu) ^ ((wave + blockIdx.x * 16u + 1u) * 0xC2B2AE35u);
+        x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12;
+        uint32_t d;
+        switch (r & 7u) {
+        case 0: d = 7; break;
+        case 1: d = 10 + (lane & 1u); break;
+        case 2: d = lane >> 1; break;
+        case 3: d = 100 + lane % 3u; break;
+        case 4: d = (lane & 32u) ? 5u : 4u; break;
+        case 5: d = x & 15u; break;
+        case 6: d = 511u - lane; break;
+        default: d = x & 511u; break;
+        }
+        const bool live = (r % 5u != 4u) || ((x >> 20) & 3u) != 0;      // every fifth round a quarter of the lanes sits out
+        const uint32_t sh = (d & 1u) << 4;
+        uint32_t old = 0;
+        if (live) old = atomicAdd(reinterpret_cast<uint32_t *>(&wa[wave][d & ~1u]), 1u << sh);
+        const uint32_t rank_a = (old >> sh) & 0xFFFFu;
+        uint32_t mlo, mhi;
+        match_digit<BITS>(d, live, mlo, mhi);
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        uint32_t prior = 0;
+        if (live) prior = wb[wave][d];
+        const uint32_t rank_b = prior + below;
+        __builtin_amdgcn_wave_barrier();
+        if (live && below == 0) wb[wave][d] = (uint16_t)(prior + (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi));
+        __builtin_amdgcn_wave_barrier();
+        if (live && rank_a != rank_b) ++bad;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < WAVES * RADIX; i += 1024) bad += (&wa[0][0])[i] != (&wb[0][0])[i];
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+// 1: rank by LDS atomics, 0: by ballots.  SEQWIN_AMD_RADIX_RANK=ballot|atomic overrides ("atomic" still runs the check and
+// fails loudly if the device does not pass it).
+bool ballot_forced()
+{
+    const char *e = getenv("SEQWIN_AMD_RADIX_RANK");
+    return e && !strcmp(e, "ballot");
+}
+int rank_mode()
+{
+    static std::mutex &mu = *new std::mutex;
+    static std::map<int, int> &modes = *new std::map<int, int>;
+    const char *e = getenv("SEQWIN_AMD_RADIX_RANK");
+    if (e && !strcmp(e, "ballot")) return 0;
+    int dev = 0;
+    SW_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = modes.find(dev);
+    if (it == modes.end()) {
+        uint32_t *d_bad = nullptr, bad = 1;
+        SW_HIP(hipMalloc(&d_bad, 4));
+        SW_HIP(hipMemset(d_bad, 0, 4));
+        hipLaunchKernelGGL(k_rs_rank_selftest, dim3(512), dim3(1024), 0, nullptr, d_bad);
+        SW_HIP(hipGetLastError());
+        SW_HIP(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+        (void)hipFree(d_bad);
+        if (bad) fprintf(stderr, "[seqwin_amd] radix sort: the LDS-atomic ranking self-check found %u differences on device %d; ranking by ballots\n", bad, dev);
+        it = modes.emplace(dev, bad ? 0 : 1).first;
+    }
+    if (e && !strcmp(e, "atomic") && it->second != 1)
+        raise(SW_ERR_RUNTIME, "SEQWIN_AMD_RADIX_RANK=atomic, but this device does not serve the lanes of an LDS atomic in lane order");
+    return it->second;
+}
+
 // One pass: tile t = workgroup t takes THREADS x 16 consecutive keys, wave w of it the w-th 1024 of them, lane l item i the
 // key w * 1024 + i * 64 + l.  Two shapes: 512 threads with 8-bit digits (8192-key tiles, 72 KiB of LDS, two workgroups per CU)
 // and 1024 threads with 9-bit digits (16384-key tiles, 150 KiB: the same 32 keys per digit and tile, one pass fewer for the
@@ -251,7 +331,15 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict_
 // workgroup takes its tickets in increasing order and holds at most the current and the next one), so the waits terminate
 // whatever the residency.  The next tile's loads are issued once the current keys sit in LDS -- into the same registers -- and
 // are in flight during the look-back and the write-out; the look-back reads RS_LOOK predecessors per step (independent loads).
-template <int THREADS, int BITS>
+//
+// RANK = 1 (default where the device passes k_rs_rank_selftest): a key's place among the keys of its digit in its wave comes
+// from ONE LDS atomic with return on the wave's counter of that digit (two 16-bit counters per word: a wave holds 1024 keys)
+// instead of eight or nine ballots -- ~6 instead of ~45 vector instructions per key; ranking was 42 % of a tile (VALU issue).
+// Stability then rests on two properties of the LDS unit: the instructions of one wave are served in order, and the lanes of
+// one instruction that hit the same word are served in ascending lane order.  The second is not an architectural promise, so
+// it is CHECKED on the device before the first sort (contended patterns under full occupancy, every rank compared with the
+// ballot form's); a device that fails keeps RANK = 0.  The unstable passes (atomic cursors) need neither property.
+template <int THREADS, int BITS, int RANK>
 __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n,
                                                        uint32_t n_tiles, unsigned shift, unsigned bits,
                                                        const unsigned long long *__restrict__ digit_base,
@@ -299,15 +387,22 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
             const uint32_t li = wave * (64 * RS_ITEMS) + i * 64 + lane;
             const bool live = li < cnt_tile;
             const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
-            uint32_t mlo = 1u << (lane & 31u), mhi = 0;
-            if (!(dbg & 8u)) match_digit<BITS>(d, live, mlo, mhi);
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-            uint32_t prior = 0;
-            if (live) prior = whist[wave][d];
-            rank[i] = prior + below;
-            __builtin_amdgcn_wave_barrier();
-            if (live && below == 0) whist[wave][d] = (uint16_t)(prior + (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi));
-            __builtin_amdgcn_wave_barrier();
+            if constexpr (RANK == 1) {
+                const uint32_t sh = (d & 1u) << 4;
+                uint32_t old = 0;
+                if (live) old = atomicAdd(reinterpret_cast<uint32_t *>(&whist[wave][d & ~1u]), 1u << sh);   // ds_add_rtn_u32
+                rank[i] = (old >> sh) & 0xFFFFu;
+            } else {
+                uint32_t mlo = 1u << (lane & 31u), mhi = 0;
+                if (!(dbg & 8u)) match_digit<BITS>(d, live, mlo, mhi);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+                uint32_t prior = 0;
+                if (live) prior = whist[wave][d];
+                rank[i] = prior + below;
+                __builtin_amdgcn_wave_barrier();
+                if (live && below == 0) whist[wave][d] = (uint16_t)(prior + (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi));
+                __builtin_amdgcn_wave_barrier();
+            }
         }
         RS_STAMP(1);   // this wave's keys ranked
         __syncthreads();
@@ -429,6 +524,263 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
     }
 }
 
+
+// ---- pairs: 32-bit keys with a 16-byte payload (the node sort: key32 = top half of the hash, OccPay) ---------------------------
+// lsd_radix_sort of cpp/src/seqwin/build_internals.cpp:76-144 on the device, for the occurrences.  Same scheme as the keys-only
+// pass (tickets, ranking per wave, decoupled look-back, write-out through LDS in digit order) in a shape made for 20-byte
+// elements: 512 threads x 8 elements (4096-element tiles), 8-bit digits, the keys and then the payloads staged through ONE
+// 64 KiB LDS buffer -- 72 KiB per workgroup, two workgroups per CU, so one workgroup's look-back and barriers are covered by the
+// other's loads and stores.  A thread keeps the global place of "its" output slots from the key round for the payload round.
+// Ranking is by the LDS atomic only (k_rs_pass_p, RANK = 1): on a device that fails the self-check the pair sort is rocPRIM's.
+// Look-back records carry a 16-bit epoch (the pass number of this state buffer) above flag and count: a record of an earlier
+// pass -- or of an earlier sort -- reads as "not published", so the buffer is never cleared between passes (twelve passes per
+// build cleared 3.5 GB; the buffer is cleared once per 65 535 passes).
+constexpr unsigned long long RSE_VAL = (1ull << 46) - 1ull;
+__device__ __forceinline__ unsigned long long rse_pack(uint32_t epoch, uint32_t flag, unsigned long long v)
+{
+    return ((unsigned long long)epoch << 48) | ((unsigned long long)flag << 46) | v;
+}
+__device__ __forceinline__ uint32_t rse_flag(unsigned long long w, uint32_t epoch)   // 0: not published (in this epoch), 1: aggregate, 2: inclusive
+{
+    return (uint32_t)(w >> 48) == epoch ? (uint32_t)(w >> 46) & 3u : 0u;
+}
+
+constexpr int RP_THREADS = 512, RP_ITEMS = 8, RP_BITS = 8;
+__global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__restrict__ kin, const uint4 *__restrict__ pin,
+                                                             uint32_t *__restrict__ kout, uint4 *__restrict__ pout, uint64_t n,
+                                                             uint32_t n_tiles, unsigned shift,
+                                                             const unsigned long long *__restrict__ digit_base,
+                                                             unsigned long long *__restrict__ state, uint32_t epoch,
+                                                             uint32_t *__restrict__ ticket, uint32_t *__restrict__ fail)
+{
+    constexpr uint32_t THREADS = RP_THREADS, ITEMS = RP_ITEMS, RADIX = 1u << RP_BITS, WAVES = THREADS / 64, TILE = THREADS * ITEMS;
+    __shared__ uint4 sp[TILE];                        // the staging buffer: keys (as uint32) first, then payloads
+    __shared__ uint16_t whist[WAVES][RADIX];
+    __shared__ uint32_t lstart[RADIX];
+    __shared__ unsigned long long goff[RADIX];
+    __shared__ uint32_t wsum[RADIX / 64];
+    __shared__ uint32_t s_tile;
+    uint32_t *const skey = reinterpret_cast<uint32_t *>(sp);
+    const uint32_t tid0 = threadIdx.x;
+    if (tid0 == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    uint32_t tile = s_tile;
+    uint32_t key[ITEMS];
+    uint4 pay[ITEMS];
+    {
+        const uint32_t lane = tid0 & 63u, wave = tid0 >> 6;
+#pragma unroll
+        for (int i = 0; i < (int)ITEMS; ++i) {
+            const uint64_t g = (uint64_t)tile * TILE + wave * (64 * ITEMS) + i * 64 + lane;
+            const bool in_range = tile < n_tiles && g < n;
+            key[i] = in_range ? kin[g] : ~0u;
+            pay[i] = in_range ? pin[g] : uint4{0, 0, 0, 0};
+        }
+    }
+    while (tile < n_tiles) {
+        uint32_t tid = tid0;
+        asm volatile("" : "+v"(tid));     // (keeps the per-item addresses from being hoisted out of the loop into registers)
+        const uint32_t lane = tid & 63u, wave = tid >> 6;
+        uint32_t fut = 0;
+        if (tid == 0) fut = atomicAdd(ticket, 1u);
+        for (uint32_t i = tid; i < WAVES * RADIX / 2; i += THREADS) (reinterpret_cast<uint32_t *>(&whist[0][0]))[i] = 0;
+        __syncthreads();
+        const uint64_t t0 = (uint64_t)tile * TILE;
+        const uint32_t cnt_tile = (uint32_t)min((uint64_t)TILE, n - t0);
+        uint32_t pos[ITEMS];              // rank inside (wave, digit), later the element's place in the tile's digit order
+#pragma unroll
+        for (int i = 0; i < (int)ITEMS; ++i) {
+            const uint32_t li = wave * (64 * ITEMS) + i * 64 + lane;
+            const bool live = li < cnt_tile;
+            const uint32_t d = (key[i] >> shift) & (RADIX - 1u);
+            const uint32_t sh = (d & 1u) << 4;      // (ranking by the LDS atomic: see k_rs_pass_p, RANK = 1)
+            uint32_t old = 0;
+            if (live) old = atomicAdd(reinterpret_cast<uint32_t *>(&whist[wave][d & ~1u]), 1u << sh);
+            pos[i] = (old >> sh) & 0xFFFFu;
+        }
+        __syncthreads();
+        uint32_t total = 0, incl = 0;
+        unsigned long long pre[RS_LOOK];
+        unsigned long long *st = state + (size_t)tile * RADIX;
+        if (tid < RADIX) {
+            const uint32_t d = tid;
+#pragma unroll
+            for (uint32_t w = 0; w < WAVES; ++w) {
+                const uint32_t c = whist[w][d];
+                whist[w][d] = (uint16_t)total;
+                total += c;
+            }
+            __hip_atomic_store(&st[d], rse_pack(epoch, tile == 0 ? 2u : 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < RS_LOOK; ++j)
+                pre[j] = (int64_t)tile - 1 - j >= 0
+                             ? __hip_atomic_load(&state[(size_t)(tile - 1 - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : rse_pack(epoch, 2u, 0);
+            incl = total;
+            for (uint32_t dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t up = __shfl_up(incl, dd, 64);
+                if (lane >= dd) incl += up;
+            }
+            if (lane == 63) wsum[wave] = incl;
+        }
+        __syncthreads();
+        uint32_t before = 0;
+        if (tid < RADIX) {
+            before = incl - total;
+            for (uint32_t w = 0; w < wave; ++w) before += wsum[w];
+            lstart[tid] = before;
+        }
+        if (tid == 0) s_tile = fut;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < (int)ITEMS; ++i) {            // the keys in digit order, in LDS
+            const uint32_t li = wave * (64 * ITEMS) + i * 64 + lane;
+            const uint32_t d = (key[i] >> shift) & (RADIX - 1u);
+            pos[i] += lstart[d] + whist[wave][d];
+            if (li < cnt_tile) skey[pos[i]] = key[i];
+        }
+        const uint32_t ntile = s_tile;
+#pragma unroll
+        for (int i = 0; i < (int)ITEMS; ++i) {            // the next tile's keys: in flight during the look-back and both write-outs
+            const uint64_t g = (uint64_t)ntile * TILE + wave * (64 * ITEMS) + i * 64 + lane;
+            key[i] = (ntile < n_tiles && g < n) ? kin[g] : ~0u;
+        }
+        if (tid < RADIX) {                                // look-back, RS_LOOK predecessors per step
+            const uint32_t d = tid;
+            unsigned long long excl = 0;
+            if (tile) {
+                int64_t t = (int64_t)tile - 1;
+                uint32_t spins = 0;
+                bool done = false, first_step = true;
+                while (!done && t >= 0) {
+                    unsigned long long v[RS_LOOK];
+#pragma unroll
+                    for (int j = 0; j < RS_LOOK; ++j)
+                        v[j] = first_step ? pre[j]
+                               : t - j >= 0 ? __hip_atomic_load(&state[(size_t)(t - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                            : rse_pack(epoch, 2u, 0);
+                    first_step = false;
+                    int j = 0;
+#pragma unroll
+                    for (; j < RS_LOOK; ++j) {
+                        const uint32_t f = rse_flag(v[j], epoch);
+                        if (f == 0) break;              // not published yet: poll again from here
+                        excl += v[j] & RSE_VAL;
+                        if (f == 2) {
+                            done = true;
+                            break;
+                        }
+                    }
+                    if (done) break;
+                    t -= j;
+                    if (j < RS_LOOK) {
+                        if (++spins > RS_SPIN_LIMIT) {  // (the tile's owner is running -- tickets; see k_rs_pass_p)
+                            atomicOr(fail, 1u);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                __hip_atomic_store(&st[d], rse_pack(epoch, 2u, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            goff[d] = digit_base[d] + excl - before;
+        }
+        __syncthreads();
+        uint32_t dst[ITEMS];                              // global place of output slot j * THREADS + tid (n < 2^32)
+#pragma unroll
+        for (int j = 0; j < (int)ITEMS; ++j) {
+            const uint32_t t = j * THREADS + tid;
+            dst[j] = 0;
+            if (t < cnt_tile) {
+                const uint32_t k = skey[t];
+                dst[j] = (uint32_t)(goff[(k >> shift) & (RADIX - 1u)] + t);
+                kout[dst[j]] = k;
+            }
+        }
+        __syncthreads();                                  // the keys have left the buffer
+#pragma unroll
+        for (int i = 0; i < (int)ITEMS; ++i) {
+            const uint32_t li = wave * (64 * ITEMS) + i * 64 + lane;
+            if (li < cnt_tile) sp[pos[i]] = pay[i];
+        }
+#pragma unroll
+        for (int i = 0; i < (int)ITEMS; ++i) {            // the next tile's payloads
+            const uint64_t g = (uint64_t)ntile * TILE + wave * (64 * ITEMS) + i * 64 + lane;
+            pay[i] = (ntile < n_tiles && g < n) ? pin[g] : uint4{0, 0, 0, 0};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < (int)ITEMS; ++j) {
+            const uint32_t t = j * THREADS + tid;
+            if (t < cnt_tile) pout[dst[j]] = sp[t];
+        }
+        // (the next iteration writes sp / goff / s_tile only behind its own barriers; its first barrier also orders these reads)
+        tile = ntile;
+    }
+}
+
+// digit histograms of all four passes of a 32-bit key array in one sweep (3 GB at 15 000 genomes)
+__global__ __launch_bounds__(256) void k_rs_hist32(const uint32_t *__restrict__ keys, uint64_t n, unsigned n_passes,
+                                                   unsigned long long *__restrict__ hist)
+{
+    constexpr uint32_t RADIX = 1u << RP_BITS;
+    __shared__ uint32_t h[4 * RADIX];
+    for (uint32_t i = threadIdx.x; i < n_passes * RADIX; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint64_t chunk = 65536;
+    const uint64_t i0 = (uint64_t)blockIdx.x * chunk, i1 = min(n, i0 + chunk);
+    auto count = [&](uint32_t k) {
+        for (unsigned p = 0; p < n_passes; ++p) atomicAdd(&h[p * RADIX + ((k >> (RP_BITS * p)) & (RADIX - 1u))], 1u);
+    };
+    for (uint64_t i = i0 + 4 * threadIdx.x; i < i1; i += 1024) {
+        if (i + 3 < i1) {
+            const uint4 kk = *reinterpret_cast<const uint4 *>(keys + i);
+            count(kk.x); count(kk.y); count(kk.z); count(kk.w);
+        } else {
+            for (uint64_t j = i; j < i1; ++j) count(keys[j]);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_passes * RADIX; i += 256)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+// Look-back state that outlives the sorts: one buffer per (device, stream) -- sorts on one stream follow one another on the
+// device --, cleared when it is made and whenever its 16-bit epoch wraps.
+struct StateBuf {
+    unsigned long long *p = nullptr;
+    size_t words = 0;
+    uint32_t epoch = 0;
+};
+StateBuf &state_buf(hipStream_t stream, size_t words)
+{
+    static std::mutex &mu = *new std::mutex;
+    static std::map<std::pair<int, hipStream_t>, StateBuf> &bufs = *new std::map<std::pair<int, hipStream_t>, StateBuf>;
+    int dev = 0;
+    SW_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    StateBuf &b = bufs[std::make_pair(dev, stream)];
+    if (b.words < words) {
+        if (b.p) (void)hipFree(b.p);        // (waits for the device: nothing is reading it any more)
+        b.p = nullptr;
+        b.words = 0;
+        const size_t want = words + words / 4;
+        SW_HIP(hipMalloc(&b.p, want * 8));
+        b.words = want;
+        b.epoch = 0;
+        SW_HIP(hipMemsetAsync(b.p, 0, want * 8, stream));
+    }
+    return b;
+}
+uint32_t next_epoch(StateBuf &b, hipStream_t stream)
+{
+    if (++b.epoch >= 0xFFFFu) {             // every record in the buffer could alias a new epoch: start over
+        SW_HIP(hipMemsetAsync(b.p, 0, b.words * 8, stream));
+        b.epoch = 1;
+    }
+    return b.epoch;
+}
+
 template <int THREADS, int BITS>
 void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit, unsigned end_bit, hipStream_t stream, uint32_t *d_fail,
                  bool perm_hi32, unsigned long long *d_hist_given)
@@ -456,11 +808,12 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
             int per_cu = 0;
             hipDeviceProp_t prop;
             SW_HIP(hipGetDeviceProperties(&prop, dev));
-            SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pass_p<THREADS, BITS>, THREADS, 0));
+            SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pass_p<THREADS, BITS, 0>, THREADS, 0));
             g = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
         }
         grid_p = g;
     }
+    const bool atomic_rank = persistent && rank_mode() == 1;
     DevArray<unsigned long long> hist_own(d_hist_given ? 0 : (size_t)n_passes * RADIX), state((size_t)n_tiles * RADIX);
     struct { unsigned long long *p; } hist{d_hist_given ? d_hist_given : hist_own.p};   // ([pass][digit] counts; scanned in place below)
     const bool unstable = perm_hi32 && persistent && !getenv("SEQWIN_AMD_RADIX_STABLE_UNSORT");   // (A/B: the look-back form)
@@ -495,11 +848,16 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
         unsigned long long *cur = unstable && p == 0 ? cursor.p : nullptr;
         hipLaunchKernelGGL(k_rs_scan<BITS>, dim3(1), dim3(RADIX), 0, stream, hist.p + (size_t)p * RADIX, cur);
         if (!cur) SW_HIP(hipMemsetAsync(state.p, 0, state.bytes(), stream));
-        if (persistent)
-            hipLaunchKernelGGL((k_rs_pass_p<THREADS, BITS>), dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)grid_p)), dim3(THREADS), 0,
-                               stream, keys, alt, n, (uint32_t)n_tiles, sh, bits, hist.p + (size_t)p * RADIX, state.p, tickets.p + p, d_fail,
-                               dbg, cur, RS_CURSOR_STRIDE, 64u);
-        else
+        if (persistent) {
+            auto launch = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)grid_p)), dim3(THREADS), 0, stream, keys, alt, n,
+                                   (uint32_t)n_tiles, sh, bits, hist.p + (size_t)p * RADIX, state.p, tickets.p + p, d_fail, dbg, cur,
+                                   RS_CURSOR_STRIDE, 64u);
+            };
+            // (an unstable pass may rank by atomics on any device: the order inside a digit is free there)
+            if (cur ? !ballot_forced() : atomic_rank) launch(k_rs_pass_p<THREADS, BITS, 1>);
+            else launch(k_rs_pass_p<THREADS, BITS, 0>);
+        } else
             hipLaunchKernelGGL((k_rs_pass<THREADS, BITS>), dim3((unsigned)n_tiles), dim3(THREADS), 0, stream, keys, alt, n, sh, bits,
                                hist.p + (size_t)p * RADIX, state.p, d_fail);
         SW_HIP(hipGetLastError());
@@ -563,7 +921,7 @@ bool radix_unsort_perm(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned low
     SW_HIP(hipGetDevice(&dev));
     hipDeviceProp_t prop;
     SW_HIP(hipGetDeviceProperties(&prop, dev));
-    SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pass_p<THREADS, BITS>, THREADS, 0));
+    SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pass_p<THREADS, BITS, 0>, THREADS, 0));
     const unsigned grid = (unsigned)std::min<uint64_t>(n_tiles, (uint64_t)std::max(1, per_cu) * std::max(1, prop.multiProcessorCount));
     DevArray<unsigned long long> cur_a((size_t)RADIX * RS_CURSOR_STRIDE), cur_b((size_t)n_groups * RADIX);
     DevArray<uint32_t> tickets(2);
@@ -571,16 +929,68 @@ bool radix_unsort_perm(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned low
     hipLaunchKernelGGL(k_rs_perm_cursors, dim3(1), dim3(RADIX), 0, stream, cur_a.p, 1u, RADIX, RS_CURSOR_STRIDE, 64u, low_bits + 8);
     hipLaunchKernelGGL(k_rs_perm_cursors, dim3((n_groups * RADIX + 255) / 256), dim3(256), 0, stream, cur_b.p, n_groups, RADIX, 1u,
                        low_bits + 8, low_bits);
-    hipLaunchKernelGGL((k_rs_pass_p<THREADS, BITS>), dim3(grid), dim3(THREADS), 0, stream, keys, alt, n, (uint32_t)n_tiles,
+    // (both passes are unstable -- the order inside a bucket is free --, so they rank by LDS atomics on any device)
+    auto pass = ballot_forced() ? k_rs_pass_p<THREADS, BITS, 0> : k_rs_pass_p<THREADS, BITS, 1>;
+    hipLaunchKernelGGL(pass, dim3(grid), dim3(THREADS), 0, stream, (const uint64_t *)keys, alt, n, (uint32_t)n_tiles,
                        32u + low_bits + 8, hi_bits, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, tickets.p, d_fail,
                        0u, cur_a.p, RS_CURSOR_STRIDE, 64u);
     std::swap(keys, alt);
-    hipLaunchKernelGGL((k_rs_pass_p<THREADS, BITS>), dim3(grid), dim3(THREADS), 0, stream, keys, alt, n, (uint32_t)n_tiles, 32u + low_bits,
+    hipLaunchKernelGGL(pass, dim3(grid), dim3(THREADS), 0, stream, (const uint64_t *)keys, alt, n, (uint32_t)n_tiles, 32u + low_bits,
                        8u, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, tickets.p + 1, d_fail, 0u, cur_b.p, 1u,
                        low_bits + 8);
     std::swap(keys, alt);
     SW_HIP(hipGetLastError());
     return true;
+}
+
+bool radix_pairs_available() { return rank_mode() == 1; }   // (the pair passes rank by LDS atomics only)
+
+// Stable sort of (key32, 16-byte payload) pairs by bits [0, end_bit) of the keys, end_bit a multiple of 8 up to 32 (the node
+// sort: all 32).  Double buffers; on return keys / vals point at the sorted data.
+void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
+                        hipStream_t stream, uint32_t *d_fail)
+{
+    constexpr uint32_t RADIX = 1u << RP_BITS, TILE = RP_THREADS * RP_ITEMS;
+    if (n == 0 || end_bit == 0) return;
+    if (end_bit > 32 || end_bit % RP_BITS) raise(SW_ERR_RUNTIME, "radix_sort_pairs32: key bits must be a multiple of 8 up to 32");
+    if (n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "radix_sort_pairs32: more than 2^32-2 elements");
+    const unsigned n_passes = end_bit / RP_BITS;
+    const uint64_t n_tiles = (n + TILE - 1) / TILE;
+    int grid_p = 0;
+    {
+        static std::mutex &mu = *new std::mutex;
+        static std::map<int, int> &grids = *new std::map<int, int>;
+        int dev = 0;
+        SW_HIP(hipGetDevice(&dev));
+        std::lock_guard<std::mutex> lock(mu);
+        int &g = grids[dev];
+        if (!g) {
+            int per_cu = 0;
+            hipDeviceProp_t prop;
+            SW_HIP(hipGetDeviceProperties(&prop, dev));
+            SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pair_pass, RP_THREADS, 0));
+            g = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+        }
+        grid_p = g;
+    }
+    DevArray<unsigned long long> hist((size_t)n_passes * RADIX);
+    DevArray<uint32_t> tickets(n_passes);
+    SW_HIP(hipMemsetAsync(tickets.p, 0, tickets.bytes(), stream));
+    SW_HIP(hipMemsetAsync(hist.p, 0, hist.bytes(), stream));
+    hipLaunchKernelGGL(k_rs_hist32, dim3((unsigned)((n + 65535) / 65536)), dim3(256), 0, stream, keys, n, n_passes, hist.p);
+    SW_HIP(hipGetLastError());
+    StateBuf &sb = state_buf(stream, (size_t)n_tiles * RADIX);
+    for (unsigned p = 0; p < n_passes; ++p) {
+        hipLaunchKernelGGL(k_rs_scan<RP_BITS>, dim3(1), dim3(RADIX), 0, stream, hist.p + (size_t)p * RADIX, (unsigned long long *)nullptr);
+        const uint32_t epoch = next_epoch(sb, stream);
+        hipLaunchKernelGGL(k_rs_pair_pass, dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)grid_p)), dim3(RP_THREADS), 0, stream,
+                           (const uint32_t *)keys, reinterpret_cast<const uint4 *>(vals), keys_alt, reinterpret_cast<uint4 *>(vals_alt), n,
+                           (uint32_t)n_tiles, RP_BITS * p, (const unsigned long long *)(hist.p + (size_t)p * RADIX), sb.p, epoch,
+                           tickets.p + p, d_fail);
+        SW_HIP(hipGetLastError());
+        std::swap(keys, keys_alt);
+        std::swap(vals, vals_alt);
+    }
 }
 
 // which shape a sort of `bits` key bits takes: 0 = 512 threads x 8 bits, 1 = 1024 x 9, 2 = 1024 x 8, 3 = 512 x 9, 4 = 256 x 8 (the last three: A/B)

@@ -23,6 +23,12 @@ def set_device(device: int) -> None:
     check(lib.sw_set_device(ctypes.c_int(device)))
 
 
+def pool_trim() -> None:
+    """Hand the library's cached, unused device blocks back to the driver (for a process that shares HBM with torch)."""
+    lib.sw_pool_trim.restype = None
+    lib.sw_pool_trim()
+
+
 class Batch:
     """A set of assemblies, 2-bit packed and resident on the current device."""
 

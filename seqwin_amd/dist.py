@@ -330,18 +330,53 @@ class _Occ:
             pass
 
 
+class _PhaseClock:
+    """Phase boundaries of one sharded build.  With the HIP engine they are events on the current stream (no host
+    synchronisation while the build is issued; the elapsed times are read after the caller's fence), otherwise host clocks."""
+
+    def __init__(self, engine):
+        t = getattr(engine, "torch", None)
+        self._cuda = t.cuda if t is not None and getattr(engine, "gpu", None) is not None else None
+        self.marks = []
+        self.mark("start")
+
+    def mark(self, name: str) -> None:
+        if self._cuda is not None:
+            e = self._cuda.Event(enable_timing=True)
+            e.record()
+            self.marks.append((name, e))
+        else:
+            self.marks.append((name, time.perf_counter()))
+
+    def phases_ms(self) -> dict:
+        """{phase: ms between the previous mark and the phase's own}; waits for the last mark."""
+        out = {}
+        if self._cuda is not None:
+            self.marks[-1][1].synchronize()
+        for (_, a), (name, b) in zip(self.marks, self.marks[1:]):
+            ms = a.elapsed_time(b) if self._cuda is not None else (b - a) * 1e3
+            out[name] = out.get(name, 0.0) + ms
+        return out
+
+
 class ShardedIndex:
     """This rank's slice (a hash range) of the merged graph, plus the job-wide metadata."""
 
-    def __init__(self, engine, merged, record_offsets, timings, kmer_base, group=None):
+    def __init__(self, engine, merged, record_offsets, timings, kmer_base, group=None, clock=None, info=None):
         self.engine, self.merged, self.group = engine, merged, group
         self.record_offsets, self._timings, self.kmer_base = record_offsets, timings, kmer_base
+        self._clock, self.info = clock, dict(info or {})
 
     def sizes(self):
         return self.engine.sizes(self.merged)
 
     def timings(self) -> dict:
         return dict(self._timings)
+
+    def phases_ms(self) -> dict:
+        """Device time of the build's phases on this rank (sketch / partition / tuple exchange / slice build / ranks back /
+        adjacency / key exchange / slice edges / hash requests); call after a synchronisation point."""
+        return self._clock.phases_ms() if self._clock is not None else {}
 
     def export(self):
         return self.engine.export(self.merged)
@@ -549,6 +584,44 @@ def _all_to_all_rows(out, rows, recv_counts, send_counts, group, global_max: int
             at += r_n[p]
 
 
+_checked_groups = set()
+
+
+def check_collectives(dev, group=None) -> None:
+    """Start-up self-check of the collectives the build relies on, once per process and group: one all_to_all_single whose
+    per-peer messages are ONE ELEMENT LARGER than the round size the exchanges use (SEQWIN_DIST_MSG_LIMIT_MB, capped at
+    SEQWIN_DIST_SELFCHECK_MB, default 64, so that the check costs milliseconds), filled with a position-dependent pattern
+    and verified element for element on the receiver, plus an all_gather_into_tensor of the same size.  RCCL 2.26 at world
+    size 1 silently delivered only the first half of large messages (NOTES.md, round 3): a transport that does so for the
+    sizes in use fails HERE, loudly, instead of producing a graph with edges missing.  SEQWIN_DIST_SELFCHECK=0 skips it."""
+    import torch
+    import torch.distributed as dist
+    key = (id(group), str(dev))
+    if key in _checked_groups or os.environ.get("SEQWIN_DIST_SELFCHECK", "1") == "0" or not dist.is_initialized():
+        return
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    limit = min(_MSG_LIMIT, int(os.environ.get("SEQWIN_DIST_SELFCHECK_MB", "64")) << 20)
+    n = limit // 8 + 1                                              # int64 elements per peer
+    idx = torch.arange(n, dtype=torch.int64, device=dev)
+    send = torch.cat([idx * 1000003 + (rank * world + p) * 7919 for p in range(world)])
+    got = torch.empty_like(send)
+    dist.all_to_all_single(got, send, [n] * world, [n] * world, group=group)
+    bad = 0
+    for p in range(world):
+        bad += int((got[p * n:(p + 1) * n] != idx * 1000003 + (p * world + rank) * 7919).sum().item())
+    mine = idx * 31 + rank
+    table = torch.empty((world * n,), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(table, mine, group=group)
+    for p in range(world):
+        bad += int((table[p * n:(p + 1) * n] != idx * 31 + p).sum().item())
+    flag = torch.tensor([bad], dtype=torch.int64, device=dev)
+    dist.all_reduce(flag, group=group)
+    if int(flag.item()):
+        raise RuntimeError(f"collective self-check failed: {int(flag.item())} elements of {n}-element per-peer messages "
+                           f"({n * 8 >> 20} MiB) arrived wrong or not at all -- lower SEQWIN_DIST_MSG_LIMIT_MB")
+    _checked_groups.add(key)
+
+
 def _all_gather_parts(table, mine, pad: int, group, async_op: bool = False):
     """all_gather_into_tensor(table[world * pad], mine[pad]); in rounds through a staging buffer when a part exceeds _MSG_LIMIT."""
     import torch
@@ -624,10 +697,14 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     dev = engine.device
     multi = world > 1 or (_FORCE_COLLECTIVES and dist.is_initialized())
+    if multi:
+        check_collectives(dev, group)
     t0 = time.perf_counter()
+    clock = _PhaseClock(engine)
 
     occ = engine.sketch(shard, k, w)
     t1 = time.perf_counter()
+    clock.mark("sketch")
 
     # C0: record-count prefix (build_internals.cpp:334-355); depends only on the shard, so it is cached on it
     cached = getattr(shard, "_global_offsets", None)
@@ -655,6 +732,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     # C1: tuples to the owner of their hash range
     nb, _ = hash_bounds(world)
     rows, perm, cnt = engine.partition(occ, nb, rec_base[rank])
+    clock.mark("partition")
     if multi:
         r_rows, recv_cnt, matrix = _exchange_rows(rows, cnt, dev, group)
         kmer_base = sum(int(matrix[src][r]) for r in range(rank) for src in range(world))   # rows owned by lower ranks
@@ -662,10 +740,12 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     else:
         r_rows, recv_cnt, kmer_base, tuple_max = rows, cnt, 0, 0
     t2 = time.perf_counter()
+    clock.mark("tuple_exchange")
     ix, r_ranks = engine.slice_build(r_rows, kmer_base, record_offsets, is_targets)
     tm = dict(engine.timings(ix))
     n_nodes = engine.sizes(ix)[1]
     t3 = time.perf_counter()
+    clock.mark("slice_build")
 
     # C2: node ranks back to the sources; C3: rank -> hash table everywhere
     # A slice build marks, in bit 31 of the slice-local ranks it returns, the occurrences whose node recurs in their assembly:
@@ -682,6 +762,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
     total_nodes = node_base[-1]
     pairs = all_marked and not os.environ.get("SEQWIN_AMD_NO_PACKED_EDGES")
     rb = rank_bounds(world, total_nodes)
+    info = {"form": "pairs" if pairs else "rows", "hash_route": "table", "total_nodes": int(total_nodes)}
     if pairs:
         asm_bits = max(1, int(shard.n_assemblies_total).bit_length())
         # How the edge owners get the hashes of their edges' endpoints: the whole rank -> hash table on every GPU (8 B per node
@@ -689,6 +770,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
         # default 4096 -- by asking the node owners for the distinct endpoints only (hash_route "requests", below).
         table, pad, hash_work = None, max(1, max(node_cnt)), None
         by_request = hash_route(world * pad) == "requests"
+        info["hash_route"] = "requests" if by_request else "table"
         if multi:
             ranks_by_row = torch.empty((occ.n,), dtype=torch.int32, device=dev)
             _all_to_all_rows(ranks_by_row, r_ranks, cnt, recv_cnt, group, tuple_max)
@@ -700,7 +782,10 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
             ranks_by_row = r_ranks
             if not by_request:
                 table = engine.node_hash_part(ix, pad)
+        clock.mark("ranks_back")
         adj, acnt, cand, ccnt, key_bits = engine.adjacency_pairs(occ, ranks_by_row, node_base, shard.first_assembly, rb)
+        info["key_bits"] = [int(b) for b in key_bits]
+        clock.mark("adjacency")
         if multi:
             # (waited for BEFORE the next collective: torch runs synchronous collectives on the current stream and this one on
             #  its own -- two kernels of one communicator at once corrupt each other's data, seen at world size 1, r03)
@@ -715,7 +800,9 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
         else:
             r_adj, r_cand = adj, cand
         t4 = time.perf_counter()
+        clock.mark("key_exchange")
         engine.slice_edges_pairs(ix, r_adj, r_cand, key_bits, rb[rank - 1] if rank else 0, asm_bits, table, node_base, pad)
+        clock.mark("slice_edges")
         if by_request:
             # the edges hold global ranks: their distinct endpoints, as owner-local ranks grouped by node owner, go to the
             # node owners; the hashes come back in the same order
@@ -728,6 +815,7 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
             else:
                 replies = engine.node_hash_lookup(ix, req)
             engine.edge_hash_attach(ix, replies)
+            clock.mark("hash_requests")
     else:
         # {pair, assembly} rows or packed (pair, assembly) keys on GLOBAL 32-bit ranks (test knob; slices without marks)
         REP = 0x80000000
@@ -743,18 +831,22 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
             rank_hash = torch.cat([p[:c] for p, c in zip(parts, node_cnt)])
         else:
             ranks_by_row, rank_hash = rr.to(torch.int32), engine.node_hashes(ix)
+        clock.mark("ranks_back")
         n_bits = max(1, (total_nodes).bit_length())     # total_nodes <= 2^n_bits - 1
         asm_bits = adjacency_asm_bits(n_bits, shard.n_assemblies_total)
         adj, acnt = engine.adjacency(occ, perm, ranks_by_row, n_bits, asm_bits, shard.first_assembly, rb)
+        clock.mark("adjacency")
         r_adj = _exchange_rows(adj, acnt, dev, group)[0] if multi else adj
         t4 = time.perf_counter()
+        clock.mark("key_exchange")
         engine.slice_edges(ix, r_adj, n_bits, asm_bits, rank_hash)
+        clock.mark("slice_edges")
     tm.update(engine.timings(ix))
     t5 = time.perf_counter()
     tm.update(sketch_ms=occ.sketch_ms, n_occ_local=occ.n, sketch_wall_ms=(t1 - t0) * 1e3, tuple_exchange_wall_ms=(t2 - t1) * 1e3,
               slice_build_wall_ms=(t3 - t2) * 1e3, rank_adj_exchange_wall_ms=(t4 - t3) * 1e3, slice_edges_wall_ms=(t5 - t4) * 1e3)
     engine.free_occ(occ)
-    return ShardedIndex(engine, ix, record_offsets, tm, kmer_base, group)
+    return ShardedIndex(engine, ix, record_offsets, tm, kmer_base, group, clock=clock, info=info)
 
 
 def build_graph_distributed(assembly_paths, k: int, w: int, is_targets=None, n_cpu: int = 1, group=None):

@@ -267,6 +267,7 @@ def _free_port() -> int:
 
 
 def _worker(rank, world, port, paths, k, w, tar, out_path, mode):
+    os.environ["SEQWIN_DIST_SELFCHECK_MB"] = "1"   # (the start-up self-check of the collectives, at a CPU-sized message)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -324,6 +325,32 @@ def test_sharded_build_equals_single(tmp_path, world, case, mode):
     assert np.array_equal(got["sums"], exp_sums)
     for r in range(1, world):
         assert np.array_equal(np.load(str(out) + f".sums{r}.npy"), exp_sums)
+
+
+def test_collective_self_check_catches_a_truncating_transport(monkeypatch):
+    """What RCCL 2.26 did at world size 1 in round 3 -- the first half of a large all_to_all_single message delivered, the
+    rest of the output left untouched, no error -- must fail the start-up check instead of the graph."""
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    monkeypatch.setenv("SEQWIN_DIST_SELFCHECK_MB", "1")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        swdist._checked_groups.clear()
+        swdist.check_collectives(torch.device("cpu"))                # a sound transport passes (and is remembered)
+        assert swdist._checked_groups
+        swdist._checked_groups.clear()
+        real = dist.all_to_all_single
+
+        def half(out, inp, *a, **kw):
+            tmp = torch.empty_like(out)
+            real(tmp, inp, *a, **kw)
+            out[:out.numel() // 2] = tmp[:out.numel() // 2]
+        monkeypatch.setattr(dist, "all_to_all_single", half)
+        with pytest.raises(RuntimeError, match="self-check failed"):
+            swdist.check_collectives(torch.device("cpu"))
+        assert not swdist._checked_groups
+    finally:
+        dist.destroy_process_group()
 
 
 def _skewed_exchange_worker(rank, world, port, matrix, cap_rows, out_path):

@@ -216,6 +216,138 @@ def test_config3_sharded_full_size():
     assert [f"{v:016x}" for v in sums] == gold["checksums"]
 
 
+def _routed_lean(world, G, k, w, workload):
+    """routed_tuple_exchange (tests/test_gpu_dist.py: the all-to-all steps done by hand, P shards on ONE GPU) in its pairs +
+    requests form with only what a step needs kept in HBM: shards are generated and sketched one at a time (and again for the
+    adjacency: the generator is deterministic), the tuple rows go when the slices are built.  Returns
+    (sizes, checksums of the concatenated result, key_bits, total_nodes)."""
+    import torch
+
+    from seqwin_amd import dist as swdist
+    from seqwin_amd.device import pool_trim
+    _, rpg, rl, _, snp, _ = WORKLOADS[workload]
+    anc = G                                   # iid genomes: every genome its own ancestor, whatever G
+    eng = swdist.HipEngine()
+    parts = swdist.partition_assemblies(G, world)
+    tar = np.arange(G) % 2 == 0
+    record_offsets = (np.arange(G + 1, dtype=np.uint64) * rpg).astype(np.uint32)
+    nb, _ = swdist.hash_bounds(world)
+
+    def sketched(r):
+        a, b = parts[r]
+        sh = swdist.Shard(Batch.synthetic(b - a, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED, first_genome=a), a, G)
+        occ = eng.sketch(sh, k, w)
+        rows, _, cnt = eng.partition(occ, nb, a * rpg)              # (the handle remembers the partition for the adjacency)
+        return sh, occ, rows, cnt
+
+    def tidy():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        pool_trim()
+
+    rows, cnts = [], []
+    for r in range(world):
+        sh, occ, rw, cnt = sketched(r)
+        rows.append(rw)
+        cnts.append(cnt)
+        eng.free_occ(occ)
+        sh.batch.close()
+    cuts = [np.concatenate([[0], np.cumsum(c)]) for c in cnts]
+    slices, ranks, kbase = [], [], 0
+    for owner in range(world):
+        r_rows = torch.cat([rows[r][cuts[r][owner]:cuts[r][owner + 1]] for r in range(world)])
+        ix, r_ranks = eng.slice_build(r_rows, kbase, record_offsets, tar)
+        assert eng.ranks_marked(ix)
+        slices.append(ix)
+        ranks.append(r_ranks)
+        kbase += r_rows.shape[0]
+        del r_rows
+        tidy()
+    del rows
+    tidy()
+    node_cnt = [ix.sizes()[1] for ix in slices]
+    node_base = swdist.node_bases(node_cnt)
+    rb = swdist.rank_bounds(world, node_base[-1])
+    asm_bits = max(1, int(G).bit_length())
+    adj = []
+    for r in range(world):
+        sh, occ, rw, cnt = sketched(r)
+        assert cnt == cnts[r]
+        del rw
+        at = [int(sum(cnts[q][owner] for q in range(r))) for owner in range(world)]
+        by_row = torch.cat([ranks[owner][at[owner]:at[owner] + int(cnts[r][owner])] for owner in range(world)])
+        adj.append(eng.adjacency_pairs(occ, by_row, node_base, sh.first_assembly, rb))
+        eng.free_occ(occ)
+        sh.batch.close()
+        del by_row
+        tidy()
+    del ranks
+    tidy()
+    key_bits = adj[0][4]
+    assert all(a[4] == key_bits for a in adj)
+    acuts = [np.concatenate([[0], np.cumsum(a[1])]) for a in adj]
+    ccuts = [np.concatenate([[0], np.cumsum(a[3])]) for a in adj]
+    for owner in range(world):
+        keys = torch.cat([adj[r][0][acuts[r][owner]:acuts[r][owner + 1]] for r in range(world)])
+        cand = torch.cat([adj[r][2][ccuts[r][owner]:ccuts[r][owner + 1]] for r in range(world)])
+        eng.slice_edges_pairs(slices[owner], keys, cand, key_bits, rb[owner - 1] if owner else 0, asm_bits, None, node_base, max(node_cnt))
+        del keys, cand
+        tidy()
+    del adj
+    tidy()
+    # the edges hold global ranks: every edge owner asks the node owners for the hashes of its distinct endpoints
+    for q in range(world):
+        req, req_cnt = eng.edge_hash_requests(slices[q], node_base)
+        c = np.concatenate([[0], np.cumsum(req_cnt)])
+        answers = [eng.node_hash_lookup(slices[o], req[c[o]:c[o + 1]]) for o in range(world)]
+        eng.edge_hash_attach(slices[q], torch.cat(answers))
+        del req, answers
+        tidy()
+    sizes, sums = [0, 0, 0], [0, 0, 0]
+    for ix in slices:
+        share = ix.checksums(*sizes)
+        sums = [(a + b) % 2**64 for a, b in zip(sums, share)]
+        sizes = [a + b for a, b in zip(sizes, ix.sizes())]
+        ix.close()
+    tidy()
+    return tuple(sizes), tuple(sums), key_bits, node_base[-1]
+
+
+def test_config4_routed_with_more_than_2_31_nodes():
+    """BASELINE configs[4] routed for P = 8 on this one GPU with REAL data at the widths the job has: 44 800 iid genomes of 5 Mbp
+    (224 Gbp, k = 31: every minimizer its own node) give 2.2e9 nodes -- global ranks above 2^31 (the repeat mark's bit, the sign
+    of the int32 tensors the ranks travel in) and edge keys of 31 + 32 bits; the whole job (100 000 genomes, 5e9 nodes, 33-bit
+    ranks) needs ~410 GB for its eight slices on one card, this is the largest G whose slices fit 288 GB beside the steps'
+    work space (33-bit ranks: test_routed_tuple_exchange_with_33_bit_ranks, on a small job).  Shard-count invariance
+    (reference tests/smoke/test_graph.py:67-127) is the oracle: the same genomes routed for P = 8 and for P = 5 -- other
+    assembly ranges, other hash ranges, other rank ranges, other key widths -- must give the same arrays (sizes and
+    position-dependent checksums of the concatenated slices); one GPU's share of the same generator is tied to the compiled
+    reference by test_config4_slice."""
+    G, k, w = 44_800, 31, 200
+    s8, c8, bits8, nodes8 = _routed_lean(8, G, k, w, "random100k")
+    assert nodes8 > 2**31 and s8[0] > 2**31 and bits8[1] == 32, (nodes8, bits8)
+    assert 0.0097 < s8[0] / (G * 5_000_000) < 0.0102
+    s5, c5, bits5, nodes5 = _routed_lean(5, G, k, w, "random100k")
+    assert (s5, nodes5) == (s8, nodes8)
+    assert c5 == c8, ([f"{v:016x}" for v in c5], [f"{v:016x}" for v in c8])
+
+
+@pytest.mark.parametrize("k", [19, 31])
+def test_config4_share_through_the_sharded_path(k):
+    """One GPU's share of BASELINE configs[4] (12 500 x 5 Mbp iid genomes, 5.4e8 nodes at k >= 19) through
+    seqwin_amd.dist.build_sharded_index with every collective issued over RCCL (world size 1): the rank -> hash route must
+    come out as "requests" BY ITSELF (543 M nodes x 8 B > SEQWIN_DIST_TABLE_LIMIT_MB = 4096), per-peer messages above
+    256 MiB travel in rounds, and the line must reproduce the checksums committed for the direct build."""
+    gold = json.loads((GOLDEN / "bench_checksums.json").read_text())[f"random100k/k{k}/w200"]
+    env = {"SEQWIN_DIST_FORCE_COLLECTIVES": "1", "SEQWIN_BENCH_FORCE_DIST": "1"}
+    assert "SEQWIN_DIST_HASH_ROUTE" not in os.environ
+    line = _bench_line(["--workload", "random100k", "--scaling", "strong", "-k", str(k), "--steps", "1", "--warmup", "1"], env)
+    assert line["dist"]["hash_route"] == "requests" and line["dist"]["form"] == "pairs", line["dist"]
+    assert line["dist"]["collectives"] == "issued"
+    assert line["counts"] == gold["counts"] and line["checksums"] == gold["checksums"]
+    assert line["parity"]["n1_checksums_equal"] is True
+
+
 @pytest.mark.parametrize("k", [15, 19, 31])
 def test_config4_slice(tmp_path, k):
     """BASELINE configs[4] (100 000 x 5 Mbp iid-random genomes over 8 GPUs, k in {15, 19, 31}): one GPU's share,

@@ -25,11 +25,12 @@ for name, begin, end, make in [
     ("one digit value", 0, 16, lambda: torch.full((n,), 0x1234, dtype=torch.int64, device="cuda") + (torch.arange(n, device="cuda") << 20)),
 ]:
     keys = make()
-    for impl in ("own", "rocprim"):
+    for impl in ("own atomic", "own ballot", "rocprim"):
         if impl == "rocprim":
             os.environ["SEQWIN_AMD_SORT"] = "rocprim"
         else:
-            os.environ.pop("SEQWIN_AMD_SORT", None)
+            os.environ["SEQWIN_AMD_SORT"] = "own"    # (below 2^26 keys the library would take rocPRIM by itself)
+            os.environ["SEQWIN_AMD_RADIX_RANK"] = impl.split()[1]
         out, ms = sort(keys, begin, end)
         out, ms = sort(keys, begin, end)
         # expected: stable sort by the masked key field
@@ -38,11 +39,12 @@ for name, begin, end, make in [
             field = keys ^ (-2**63)
         order = torch.sort(field, stable=True).indices
         ok = bool(torch.equal(out, keys[order]))
-        print(f"{name:32s} {impl:8s} n={n}: {ms:8.3f} ms  {'OK' if ok else 'MISMATCH'}", flush=True)
+        print(f"{name:32s} {impl:11s} n={n}: {ms:8.3f} ms  {'OK' if ok else 'MISMATCH'}", flush=True)
         assert ok
 for small in (0, 1, 63, 64, 65, 4095, 4096, 4097, 100_001):
     keys = torch.randint(0, 2**30, (small,), dtype=torch.int64, device="cuda", generator=g)
-    os.environ.pop("SEQWIN_AMD_SORT", None)
+    os.environ["SEQWIN_AMD_SORT"] = "own"
+    os.environ["SEQWIN_AMD_RADIX_RANK"] = "atomic"
     out, _ = sort(keys, 3, 27)
     field = (keys >> 3) & ((1 << 24) - 1)
     assert torch.equal(out, keys[torch.sort(field, stable=True).indices]), small
