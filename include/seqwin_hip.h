@@ -103,6 +103,10 @@ int sw_graph_sizes(const sw_graph *g, uint64_t *n_kmers, uint64_t *n_nodes, uint
  * (python_bindings.cpp:21-39, 69-83) without foreign-owned memory outliving the call. */
 int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *edges,
                     uint32_t *record_offsets, char *ids_blob);
+/* Where the time of the sw_build that made g (and of its sw_graph_export) went, in ms: out[0] ingest + upload (host parse and
+ * 2-bit packing with the pipelined copy to HBM), [1] the device part (wall), [2] launch plan, [3] sketch kernel, [4] tuple
+ * order, [5] nodes stage, [6] edges stage, [7] sw_graph_export (0 before it ran). */
+int sw_graph_stats(const sw_graph *g, double *out8);
 
 /* Frees the graph handle.  The device index of an EXPORTED graph stays resident (one per process, replaced by the next
  * sw_build): sw_get_penalty / sw_filter_kmers work on it instead of uploading the caller's arrays again when those are
@@ -179,6 +183,12 @@ int sw_batch_synthetic_shard(uint64_t n_genomes, uint64_t records_per_genome, ui
 /* Copy the ASCII sequence of record `record_idx` (A/C/G/T, 'N' for invalid bases) back to the host;
  * used by tests to hand the same input to the oracle. *len_out receives the record length. */
 int sw_batch_record(const sw_batch *b, uint64_t record_idx, char *seq_out, uint64_t cap, uint64_t *len_out);
+/* Assemblies [first_assembly, first_assembly + n_assemblies) of a batch as plain FASTA files <dir>/g<global index>.fa (ids as
+ * ingested, sequence lines of line_width bases, 0 = one line per record; bases outside the valid runs are written as N),
+ * decoded from HBM by n_cpu host threads.  Tooling for the benchmarks and tests that feed a device-generated batch to the
+ * FASTA boundary and to the CPU reference. */
+int sw_batch_write_fasta(const sw_batch *b, uint64_t first_assembly, uint64_t n_assemblies, const char *dir, uint64_t n_cpu,
+                         uint64_t line_width);
 
 int sw_batch_info(const sw_batch *b, uint64_t *n_assemblies, uint64_t *n_records, uint64_t *total_bp,
                   uint64_t *device_bytes);

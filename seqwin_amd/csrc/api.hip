@@ -431,6 +431,7 @@ struct GraphHost {   // result of sw_build: arrays stay in HBM until sw_graph_ex
     bool exported = false;          // sw_graph_export has filled caller arrays from this index
     uint64_t identity[2] = {0, 0};  // device_identity at that moment
     std::unique_ptr<MultiGraph> multi;   // SEQWIN_DEVICES: the graph as one slice per device instead of `ix`
+    double ingest_ms = 0, device_ms = 0, export_ms = 0;   // sw_graph_stats
 };
 
 // ---- the index of the last exported sw_build stays resident --------------------------------------------------------
@@ -696,6 +697,82 @@ int sw_batch_record(const sw_batch *b, uint64_t record_idx, char *seq_out, uint6
         for (uint32_t q = h.rec_run_off[record_idx]; q < h.rec_run_off[record_idx + 1]; ++q)
             for (uint64_t p = h.run_pos[q]; p < (uint64_t)h.run_pos[q] + h.run_len[q]; ++p)
                 seq_out[p] = "ACGT"[(words[p / 16] >> (2 * (p % 16))) & 3u];
+    });
+}
+
+int sw_batch_write_fasta(const sw_batch *b, uint64_t first_assembly, uint64_t n_assemblies, const char *dir, uint64_t n_cpu,
+                         uint64_t line_width)
+{
+    return guarded([&] {
+        const HostBatch &h = b->host;
+        if (first_assembly > h.n_assemblies || n_assemblies > h.n_assemblies - first_assembly) raise(SW_ERR_VALUE, "assembly range out of bounds");
+        require_current_device(b->device, "the batch");
+        // ids by record (the blob holds them NUL-terminated in record order)
+        std::vector<const char *> id_of(b->n_records + 1, nullptr);
+        {
+            const char *p = h.ids_blob.data(), *end = p + h.ids_blob.size();
+            for (uint64_t r = 0; r < b->n_records && p < end; ++r) {
+                id_of[r] = p;
+                p += strlen(p) + 1;
+            }
+        }
+        char tab[256][4];
+        for (int v = 0; v < 256; ++v)
+            for (int j = 0; j < 4; ++j) tab[v][j] = "ACGT"[(v >> (2 * j)) & 3];
+        const unsigned n_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>({n_cpu, n_assemblies, (uint64_t)64}));
+        std::atomic<uint64_t> next{0};
+        std::mutex err_mu;
+        std::exception_ptr err;
+        auto work = [&] {
+            try {
+                SW_HIP(hipSetDevice(b->device));
+                std::vector<uint32_t> words;
+                std::string seq, out;
+                for (;;) {
+                    const uint64_t a = first_assembly + next.fetch_add(1);
+                    if (a >= first_assembly + n_assemblies) break;
+                    out.clear();
+                    for (uint32_t r = h.record_offsets[a]; r < h.record_offsets[a + 1]; ++r) {
+                        const uint64_t len = h.rec_len[r], w0 = h.rec_base[r] / 16, nw = (len + 15) / 16;
+                        words.resize(nw);
+                        if (nw) SW_HIP(hipMemcpy(words.data(), b->d_packed.p + w0, nw * 4, hipMemcpyDeviceToHost));
+                        seq.assign(len, 'N');
+                        for (uint32_t q = h.rec_run_off[r]; q < h.rec_run_off[r + 1]; ++q) {
+                            uint64_t p = h.run_pos[q];
+                            const uint64_t e = p + h.run_len[q];
+                            for (; p < e && (p & 3); ++p) seq[p] = "ACGT"[(words[p / 16] >> (2 * (p % 16))) & 3u];
+                            for (; p + 4 <= e; p += 4) memcpy(&seq[p], tab[(words[p / 16] >> (2 * (p % 16))) & 0xFFu], 4);
+                            for (; p < e; ++p) seq[p] = "ACGT"[(words[p / 16] >> (2 * (p % 16))) & 3u];
+                        }
+                        out += '>';
+                        out += id_of[r] ? id_of[r] : "";
+                        out += '\n';
+                        if (line_width == 0) {
+                            out += seq;
+                            out += '\n';
+                        } else {
+                            for (uint64_t p = 0; p < len; p += line_width) {
+                                out.append(seq, p, std::min<uint64_t>(line_width, len - p));
+                                out += '\n';
+                            }
+                        }
+                    }
+                    const std::string path = std::string(dir) + "/g" + std::to_string(a) + ".fa";
+                    FILE *f = fopen(path.c_str(), "wb");
+                    if (!f) raise(SW_ERR_RUNTIME, "cannot write %s", path.c_str());
+                    const size_t wrote = fwrite(out.data(), 1, out.size(), f);
+                    if (fclose(f) != 0 || wrote != out.size()) raise(SW_ERR_RUNTIME, "short write to %s", path.c_str());
+                }
+            } catch (...) {
+                std::lock_guard<std::mutex> g(err_mu);
+                if (!err) err = std::current_exception();
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < n_threads; ++t) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        if (err) std::rethrow_exception(err);
     });
 }
 
@@ -1378,6 +1455,8 @@ int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t km
         log_message("info", "MI355X index: %llu assemblies -> %llu minimizers, %llu nodes, %llu edges",
                     (unsigned long long)g->g.n_assemblies, (unsigned long long)g->g.ix.n_kmers, (unsigned long long)g->g.ix.n_nodes,
                     (unsigned long long)g->g.ix.n_edges);
+        g->g.ingest_ms = ingest_ms;
+        g->g.device_ms = device_ms;
         if (dbg)
             fprintf(stderr, "[seqwin_amd] sw_build: ingest+upload %.1f ms, device %.1f ms, total %.1f ms (%.1f Mbp%s)\n", ingest_ms,
                     device_ms, ms(t0, now()), g->g.total_bp / 1e6, chunked ? ", chunked" : "");
@@ -1398,11 +1477,26 @@ int sw_graph_sizes(const sw_graph *g, uint64_t *n_kmers, uint64_t *n_nodes, uint
     });
 }
 
+int sw_graph_stats(const sw_graph *g, double *out8)
+{
+    return guarded([&] {
+        const GraphHost &h = g->g;
+        const sw_timings &t = h.ix.timings;
+        const double v[8] = {h.ingest_ms, h.device_ms, t.plan_ms, t.sketch_ms, t.order_ms, t.nodes_ms, t.edges_ms, h.export_ms};
+        memcpy(out8, v, sizeof v);
+    });
+}
+
 int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *edges, uint32_t *record_offsets,
                     char *ids_blob)
 {
     return guarded([&] {
         const GraphHost &h = g->g;
+        struct ExportClock {   // (every way out of the call)
+            double *dst;
+            std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+            ~ExportClock() { *dst = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+        } clock{&const_cast<GraphHost &>(h).export_ms};
         const sw_index &ix = h.ix;   // D2H straight into the caller's (numpy) buffers
         const auto t0 = std::chrono::steady_clock::now();
         const HostSpan spans[3] = {{kmers, ix.n_kmers * sizeof(sw_kmer)}, {nodes, ix.n_nodes * sizeof(sw_node)},

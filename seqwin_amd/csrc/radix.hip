@@ -323,6 +323,20 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict_
     }
 }
 
+// Look-back records of the persistent passes carry a 16-bit epoch (the pass number of their state buffer) above flag and count:
+// a record of an earlier pass -- or of an earlier sort -- reads as "not published", so the buffer is never cleared between passes
+// (r03: twelve passes per build cleared 3.5 GB of state: 30 fills, 1 ms, 10.8 GB of counted writes); it is cleared when it is
+// made and once per 65 535 passes (state_buf / next_epoch below).
+constexpr unsigned long long RSE_VAL = (1ull << 46) - 1ull;
+__device__ __forceinline__ unsigned long long rse_pack(uint32_t epoch, uint32_t flag, unsigned long long v)
+{
+    return ((unsigned long long)epoch << 48) | ((unsigned long long)flag << 46) | v;
+}
+__device__ __forceinline__ uint32_t rse_flag(unsigned long long w, uint32_t epoch)   // 0: not published (in this epoch), 1: aggregate, 2: inclusive
+{
+    return (uint32_t)(w >> 48) == epoch ? (uint32_t)(w >> 46) & 3u : 0u;
+}
+
 // The same pass as a PERSISTENT kernel: a workgroup takes tiles from a ticket counter until none are left, and the keys of
 // its next tile are already on their way (registers) while it ranks, scans and writes the current one -- with one workgroup
 // of 150 KiB per CU the one-tile-per-workgroup form leaves the memory pipe idle during ranking and look-back and the ALUs idle
@@ -346,7 +360,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                                                        unsigned long long *__restrict__ state, uint32_t *__restrict__ ticket,
                                                        uint32_t *__restrict__ fail, uint32_t dbg,
                                                        unsigned long long *__restrict__ cursor, uint32_t cursor_stride,
-                                                       uint32_t group_shift)
+                                                       uint32_t group_shift, uint32_t epoch)
 {
     constexpr uint32_t RADIX = 1u << BITS, WAVES = THREADS / 64, TILE = THREADS * RS_ITEMS;
     static_assert(RADIX <= (uint32_t)THREADS, "one thread per digit");
@@ -369,6 +383,12 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
         key[i] = (tile < n_tiles && g < n) ? in[g] : ~0ull;
     }
     const uint32_t tid0 = threadIdx.x;
+    // The ticket of the tile AFTER the next is taken while the next tile's keys are requested (r04: taken at the top of an
+    // iteration, its ~2 us round trip sat in front of the ranking -- the wait for the tile's keys waits for every earlier
+    // global operation of the wave).  A workgroup so holds up to three tickets -- current, next, the one after -- in increasing
+    // order; the lowest unfinished tile is still some workgroup's current one or becomes it without waiting for anything.
+    uint32_t fut = 0;
+    if (tid0 == 0) fut = atomicAdd(ticket, 1u);
     while (tile < n_tiles) {
         // (opaque per iteration: otherwise the 16 + 16 + 16 load / LDS / store addresses derived from the thread index are
         // hoisted out of the loop and kept in ~100 registers across it)
@@ -376,22 +396,34 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
         asm volatile("" : "+v"(tid));
         const uint32_t lane = tid & 63u, wave = tid >> 6;
         RS_STAMP(0);
-        uint32_t fut = 0;
-        if (tid == 0) fut = atomicAdd(ticket, 1u);      // the next tile (the atomic's latency hides behind the ranking)
         for (uint32_t i = tid; i < WAVES * RADIX / 2; i += THREADS) (reinterpret_cast<uint32_t *>(&whist[0][0]))[i] = 0;
         __syncthreads();
         const uint64_t t0 = (uint64_t)tile * TILE;
         const uint32_t cnt_tile = (uint32_t)min((uint64_t)TILE, n - t0);
+        if constexpr (RANK == 1) {
+            // all sixteen atomics are issued before the first result is looked at (the LDS unit serves a wave's instructions in
+            // order, so the results are the ranks whatever the wave waits for): one exposed LDS round trip instead of sixteen
+#pragma unroll
+            for (int i = 0; i < RS_ITEMS; ++i) {
+                const uint32_t li = wave * (64 * RS_ITEMS) + i * 64 + lane;
+                const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
+                rank[i] = 0;
+                if (li < cnt_tile) rank[i] = atomicAdd(reinterpret_cast<uint32_t *>(&whist[wave][d & ~1u]), 1u << ((d & 1u) << 4));   // ds_add_rtn_u32
+            }
+#pragma unroll
+            for (int i = 0; i < RS_ITEMS; ++i) {
+                const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
+                rank[i] = (rank[i] >> ((d & 1u) << 4)) & 0xFFFFu;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < RS_ITEMS; ++i) {
             const uint32_t li = wave * (64 * RS_ITEMS) + i * 64 + lane;
             const bool live = li < cnt_tile;
             const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
             if constexpr (RANK == 1) {
-                const uint32_t sh = (d & 1u) << 4;
-                uint32_t old = 0;
-                if (live) old = atomicAdd(reinterpret_cast<uint32_t *>(&whist[wave][d & ~1u]), 1u << sh);   // ds_add_rtn_u32
-                rank[i] = (old >> sh) & 0xFFFFu;
+                (void)live;
+                (void)d;
             } else {
                 uint32_t mlo = 1u << (lane & 31u), mhi = 0;
                 if (!(dbg & 8u)) match_digit<BITS>(d, live, mlo, mhi);
@@ -426,12 +458,12 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                 const uint64_t group = group_shift < 64u ? (((uint64_t)tile * TILE) >> group_shift) : 0ull;
                 pre[0] = total ? atomicAdd(&cursor[(group * RADIX + d) * cursor_stride], (unsigned long long)total) : 0ull;
             } else {
-                __hip_atomic_store(&st[d], (tile == 0 ? RS_INC : RS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&st[d], rse_pack(epoch, tile == 0 ? 2u : 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int j = 0; j < RS_LOOK; ++j)   // the first look-back step: requested now, examined after the keys are placed in LDS
                     pre[j] = (int64_t)tile - 1 - j >= 0
                                  ? __hip_atomic_load(&state[(size_t)(tile - 1 - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                 : RS_INC;
+                                 : rse_pack(epoch, 2u, 0);
             }
             incl = total;
             for (uint32_t dd = 1; dd < 64; dd <<= 1) {
@@ -450,21 +482,32 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
         }
         if (tid == 0) s_tile = fut;
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < RS_ITEMS; ++i) {            // the tile in digit order, in LDS
-            const uint32_t li = wave * (64 * RS_ITEMS) + i * 64 + lane;
-            if (li < cnt_tile) {
-                const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
-                sk[lstart[d] + whist[wave][d] + rank[i]] = key[i];
-            }
-        }
-        RS_STAMP(4);   // keys in LDS in digit order
         const uint32_t ntile = s_tile;
+        // the tile in digit order, in LDS; then the next tile's keys are requested into the same registers (in flight during the
+        // write-out) and thread 0 takes the ticket after that one
+        auto place_and_fetch = [&]() {
 #pragma unroll
-        for (int i = 0; i < RS_ITEMS; ++i) {            // the next tile's keys are on their way during the look-back and the write-out
-            const uint64_t g = (uint64_t)ntile * TILE + wave * (64 * RS_ITEMS) + i * 64 + lane;
-            key[i] = (ntile < n_tiles && g < n && !(dbg & 4u)) ? in[g] : (dbg & 4u ? g * 0x9E3779B97F4A7C15ull : ~0ull);
-        }
+            for (int i = 0; i < RS_ITEMS; ++i) {
+                const uint32_t li = wave * (64 * RS_ITEMS) + i * 64 + lane;
+                if (li < cnt_tile) {
+                    const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
+                    sk[lstart[d] + whist[wave][d] + rank[i]] = key[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RS_ITEMS; ++i) {
+                const uint64_t g = (uint64_t)ntile * TILE + wave * (64 * RS_ITEMS) + i * 64 + lane;
+                key[i] = (ntile < n_tiles && g < n && !(dbg & 4u)) ? in[g] : (dbg & 4u ? g * 0x9E3779B97F4A7C15ull : ~0ull);
+            }
+            if (tid == 0) fut = atomicAdd(ticket, 1u);
+        };
+        // (r04) The waves that own no digit place their keys at once; the digit waves look back FIRST and place theirs afterwards:
+        // a tile's inclusive record is published a whole scatter phase earlier, so every later tile finds the end of its walk
+        // nearer (the walk is as long as the tiles that have published an aggregate but not yet their inclusive sum), and the
+        // look-back of these waves runs beside the LDS traffic of the others.
+        const bool digit_wave = tid < RADIX;            // (wave-uniform: RADIX is a multiple of 64)
+        if (!digit_wave || cursor) place_and_fetch();
+        RS_STAMP(4);   // keys in LDS in digit order (waves without a digit)
         if (tid < RADIX && cursor) {
             goff[tid] = pre[0] - before;                // (cursor[d] started at digit_base[d])
         } else if (tid < RADIX) {                       // look-back, four predecessors per step
@@ -475,20 +518,27 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                 uint32_t spins = 0;
                 bool done = false;
                 bool first_step = true;
+#ifdef SW_RS_STAMPS
+                uint32_t n_steps = 0, n_polls = 0;
+#endif
                 while (!done && t >= 0 && !(dbg & 1u)) {
+#ifdef SW_RS_STAMPS
+                    ++n_steps;
+#endif
                     unsigned long long v[RS_LOOK];
 #pragma unroll
                     for (int j = 0; j < RS_LOOK; ++j)
                         v[j] = first_step ? pre[j]
                                : t - j >= 0 ? __hip_atomic_load(&state[(size_t)(t - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                            : RS_INC;   // before the first tile: nothing
+                                            : rse_pack(epoch, 2u, 0);   // before the first tile: nothing
                     first_step = false;
                     int j = 0;
 #pragma unroll
                     for (; j < RS_LOOK; ++j) {
-                        if ((v[j] >> 62) == 0) break;   // not published yet: poll again from here
-                        excl += v[j] & RS_VAL;
-                        if ((v[j] >> 62) == 2) {
+                        const uint32_t f = rse_flag(v[j], epoch);
+                        if (f == 0) break;              // not published yet (in this pass): poll again from here
+                        excl += v[j] & RSE_VAL;
+                        if (f == 2) {
                             done = true;
                             break;
                         }
@@ -496,6 +546,9 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                     if (done) break;
                     t -= j;
                     if (j < RS_LOOK) {
+#ifdef SW_RS_STAMPS
+                        ++n_polls;
+#endif
                         if (++spins > RS_SPIN_LIMIT) {  // (never seen; the tile's owner is running, see above)
                             atomicOr(fail, 1u);
                             break;
@@ -503,11 +556,19 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                __hip_atomic_store(&st[d], RS_INC | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef SW_RS_STAMPS
+                if (g_rs_stamps && (tile & 63u) == 0 && tid == 0) {   // digit 0: steps, polls of an unpublished record, entries walked
+                    g_rs_stamps[(size_t)(tile >> 6) * 16 + 8] = n_steps;
+                    g_rs_stamps[(size_t)(tile >> 6) * 16 + 9] = n_polls;
+                    g_rs_stamps[(size_t)(tile >> 6) * 16 + 10] = (unsigned long long)((int64_t)tile - 1 - t);
+                }
+#endif
+                __hip_atomic_store(&st[d], rse_pack(epoch, 2u, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             goff[d] = digit_base[d] + excl - before;
         }
         RS_STAMP(5);   // digit 0's look-back done
+        if (digit_wave && !cursor) place_and_fetch();
         __syncthreads();
         RS_STAMP(6);   // every digit's
 #pragma unroll
@@ -535,16 +596,6 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
 // Look-back records carry a 16-bit epoch (the pass number of this state buffer) above flag and count: a record of an earlier
 // pass -- or of an earlier sort -- reads as "not published", so the buffer is never cleared between passes (twelve passes per
 // build cleared 3.5 GB; the buffer is cleared once per 65 535 passes).
-constexpr unsigned long long RSE_VAL = (1ull << 46) - 1ull;
-__device__ __forceinline__ unsigned long long rse_pack(uint32_t epoch, uint32_t flag, unsigned long long v)
-{
-    return ((unsigned long long)epoch << 48) | ((unsigned long long)flag << 46) | v;
-}
-__device__ __forceinline__ uint32_t rse_flag(unsigned long long w, uint32_t epoch)   // 0: not published (in this epoch), 1: aggregate, 2: inclusive
-{
-    return (uint32_t)(w >> 48) == epoch ? (uint32_t)(w >> 46) & 3u : 0u;
-}
-
 constexpr int RP_THREADS = 512, RP_ITEMS = 8, RP_BITS = 8;
 __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__restrict__ kin, const uint4 *__restrict__ pin,
                                                              uint32_t *__restrict__ kout, uint4 *__restrict__ pout, uint64_t n,
@@ -593,10 +644,13 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
             const uint32_t li = wave * (64 * ITEMS) + i * 64 + lane;
             const bool live = li < cnt_tile;
             const uint32_t d = (key[i] >> shift) & (RADIX - 1u);
-            const uint32_t sh = (d & 1u) << 4;      // (ranking by the LDS atomic: see k_rs_pass_p, RANK = 1)
-            uint32_t old = 0;
-            if (live) old = atomicAdd(reinterpret_cast<uint32_t *>(&whist[wave][d & ~1u]), 1u << sh);
-            pos[i] = (old >> sh) & 0xFFFFu;
+            pos[i] = 0;                             // (ranking by the LDS atomic: see k_rs_pass_p, RANK = 1; all issued, then all read)
+            if (live) pos[i] = atomicAdd(reinterpret_cast<uint32_t *>(&whist[wave][d & ~1u]), 1u << ((d & 1u) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < (int)ITEMS; ++i) {
+            const uint32_t d = (key[i] >> shift) & (RADIX - 1u);
+            pos[i] = (pos[i] >> ((d & 1u) << 4)) & 0xFFFFu;
         }
         __syncthreads();
         uint32_t total = 0, incl = 0;
@@ -814,7 +868,8 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
         grid_p = g;
     }
     const bool atomic_rank = persistent && rank_mode() == 1;
-    DevArray<unsigned long long> hist_own(d_hist_given ? 0 : (size_t)n_passes * RADIX), state((size_t)n_tiles * RADIX);
+    DevArray<unsigned long long> hist_own(d_hist_given ? 0 : (size_t)n_passes * RADIX), state(persistent ? 0 : (size_t)n_tiles * RADIX);
+    StateBuf *sb = persistent ? &state_buf(stream, (size_t)n_tiles * RADIX) : nullptr;   // (epoch-tagged records: never cleared per pass)
     struct { unsigned long long *p; } hist{d_hist_given ? d_hist_given : hist_own.p};   // ([pass][digit] counts; scanned in place below)
     const bool unstable = perm_hi32 && persistent && !getenv("SEQWIN_AMD_RADIX_STABLE_UNSORT");   // (A/B: the look-back form)
     DevArray<unsigned long long> cursor(unstable ? (size_t)RADIX * RS_CURSOR_STRIDE : 0);
@@ -847,12 +902,13 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
         // (only the FIRST pass may be unstable: the later ones must keep the order the earlier ones made)
         unsigned long long *cur = unstable && p == 0 ? cursor.p : nullptr;
         hipLaunchKernelGGL(k_rs_scan<BITS>, dim3(1), dim3(RADIX), 0, stream, hist.p + (size_t)p * RADIX, cur);
-        if (!cur) SW_HIP(hipMemsetAsync(state.p, 0, state.bytes(), stream));
+        if (!cur && !persistent) SW_HIP(hipMemsetAsync(state.p, 0, state.bytes(), stream));
         if (persistent) {
+            const uint32_t epoch = cur ? 0u : next_epoch(*sb, stream);
             auto launch = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)grid_p)), dim3(THREADS), 0, stream, keys, alt, n,
-                                   (uint32_t)n_tiles, sh, bits, hist.p + (size_t)p * RADIX, state.p, tickets.p + p, d_fail, dbg, cur,
-                                   RS_CURSOR_STRIDE, 64u);
+                                   (uint32_t)n_tiles, sh, bits, hist.p + (size_t)p * RADIX, sb->p, tickets.p + p, d_fail, dbg, cur,
+                                   RS_CURSOR_STRIDE, 64u, epoch);
             };
             // (an unstable pass may rank by atomics on any device: the order inside a digit is free there)
             if (cur ? !ballot_forced() : atomic_rank) launch(k_rs_pass_p<THREADS, BITS, 1>);
@@ -866,18 +922,20 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
             std::vector<unsigned long long> hs(n_st);
             SW_HIP(hipStreamSynchronize(stream));
             SW_HIP(hipMemcpy(hs.data(), stamps.p, stamps.bytes(), hipMemcpyDeviceToHost));
-            double acc[8] = {0};
+            double acc[8] = {0}, look[3] = {0};
             size_t cnt = 0;
             for (size_t t = 0; t + 16 <= n_st; t += 16) {
                 if (!hs[t] || !hs[t + 7]) continue;
                 for (int i = 1; i <= 7; ++i) acc[i] += (double)(hs[t + i] - hs[t + i - 1]);
+                for (int i = 0; i < 3; ++i) look[i] += (double)hs[t + 8 + i];
                 ++cnt;
             }
             static const char *nm[] = {"", "rank", "barrier", "totals+scan", "barrier+scatter", "lookback(d0)", "barrier", "write-out"};
             fprintf(stderr, "[rs stamps] %d x %d bits, pass %u, %zu tiles sampled; mean clocks:", THREADS, BITS, p, cnt);
             double sum = 0;
             for (int i = 1; i <= 7; ++i) { fprintf(stderr, " %s=%.0f", nm[i], cnt ? acc[i] / cnt : 0.0); sum += cnt ? acc[i] / cnt : 0.0; }
-            fprintf(stderr, " | tile %.0f\n", sum);
+            fprintf(stderr, " | tile %.0f | look-back of digit 0: %.1f steps, %.1f polls of an unpublished record, %.1f records behind\n", sum,
+                    cnt ? look[0] / cnt : 0.0, cnt ? look[1] / cnt : 0.0, cnt ? look[2] / cnt : 0.0);
         }
 #endif
         std::swap(keys, alt);
@@ -933,11 +991,11 @@ bool radix_unsort_perm(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned low
     auto pass = ballot_forced() ? k_rs_pass_p<THREADS, BITS, 0> : k_rs_pass_p<THREADS, BITS, 1>;
     hipLaunchKernelGGL(pass, dim3(grid), dim3(THREADS), 0, stream, (const uint64_t *)keys, alt, n, (uint32_t)n_tiles,
                        32u + low_bits + 8, hi_bits, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, tickets.p, d_fail,
-                       0u, cur_a.p, RS_CURSOR_STRIDE, 64u);
+                       0u, cur_a.p, RS_CURSOR_STRIDE, 64u, 0u);
     std::swap(keys, alt);
     hipLaunchKernelGGL(pass, dim3(grid), dim3(THREADS), 0, stream, (const uint64_t *)keys, alt, n, (uint32_t)n_tiles, 32u + low_bits,
                        8u, (const unsigned long long *)nullptr, (unsigned long long *)nullptr, tickets.p + 1, d_fail, 0u, cur_b.p, 1u,
-                       low_bits + 8);
+                       low_bits + 8, 0u);
     std::swap(keys, alt);
     SW_HIP(hipGetLastError());
     return true;

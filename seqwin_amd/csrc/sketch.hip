@@ -448,6 +448,7 @@ __global__ __launch_bounds__(BLOCK, 2) void sketch_generic_kernel(const SketchAr
 //    LDS per workgroup drops from 79 KiB to ~30 KiB -> 5 workgroups (20 waves) per CU instead of 2.
 // ================================================================================================
 constexpr uint32_t KF = 256;
+constexpr uint32_t KPAIR = 32;   // k up to which the warm-up reads the pair table (16 pair positions x 16 rows x 16 B = the 4 KiB of t4)
 constexpr uint32_t RC = 12;   // published suffix records per run (12 x 8 B: the most that keeps 5 workgroups per CU)
 // A/B switches (timing builds: tests/tools/build_variant.sh <name> -DSW_SK_AB=bits; 0 = the shipped kernel)
 //   1 the suffix-record pass tests the slot address against the end of the lane's area (r02) instead of clamping it
@@ -633,58 +634,95 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
             rhi ^= (uint32_t)(lr >> 32);
             sror1(rlo, rhi);
         };
-        // warm-up (first k-mer of the run): k = r + 4q bases; r single-base steps through the roll LUT,
-        // then q steps of 4 bases through the 256-entry table t4 (F' = srol^4(F) ^ F4[b], R' = sror^4(R) ^ R4[b]),
-        // read from LDS one step ahead of use
-        // All table rows of a batch are requested first (their addresses depend only on the bases) and the dependent
-        // rotate / xor chain runs afterwards: one exposed LDS round trip per batch instead of one per step.
-        {
-            const uint32_t r = k & 3u;                      // uniform
-            ulonglong2 ts[3];
+        // warm-up: the hashes of the first k-mer of the run.
+        if (k <= KPAIR) {
+            // (r04) k <= 32: no rotate at all.  F = XOR_i srol^(k-1-i)(S[b_i]) and R = XOR_i srol^i(S[~b_i])
+            // (nthash_kmer.hpp:22-54, 104-133), so a PAIR of bases at positions (2p, 2p + 1) contributes one row of a
+            // position-dependent table -- 16 rows of {F, R} per pair position, ceil(k / 2) <= 16 positions: the same 4 KiB the
+            // 4-base table takes, in the same place (get_plan writes whichever the k needs).  Per pair: one bit-field, one shift,
+            // one ds_read_b128, four XORs -- 66 VALU at k = 21 against ~150 for one single step + five 4-base steps with their
+            // split rotates (r03 stamps: 2 944 of a wave's 22 486 cycles).  The lane's bases are brought to bit 0 of two words
+            // by the wave-uniform phase; all rows of a batch of eight positions are requested before the first is used.
+            const uint32_t np = (k + 1u) >> 1;                       // uniform
+            const uint32_t so = 2u * ph;
+            const uint32_t b0 = __builtin_amdgcn_alignbit(wp[1], wp[0], so);   // bases 0..15 of the run
+            const uint32_t b1 = __builtin_amdgcn_alignbit(wp[2], wp[1], so);   // bases 16..31
+            const unsigned char *T2 = reinterpret_cast<const unsigned char *>(REC);
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if ((uint32_t)i < r) {
-                    const uint32_t idx = 16u | next_in();
-                    ts[i] = *reinterpret_cast<const ulonglong2 *>(LUT + 2 * idx);
+            for (int half = 0; half < 2; ++half) {
+                const uint32_t bw = half ? b1 : b0;
+                if ((uint32_t)(half * 8) < np) {                     // uniform
+                    ulonglong2 te[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if ((uint32_t)(half * 8 + i) < np) {
+                            const uint32_t off = (i == 0 ? (bw << 4) : (bw >> (4 * i - 4))) & 0xF0u;   // 16 B per row
+                            te[i] = *reinterpret_cast<const ulonglong2 *>(T2 + (half * 8 + i) * 256 + off);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if ((uint32_t)(half * 8 + i) < np) {
+                            flo ^= (uint32_t)te[i].x;
+                            fhi ^= (uint32_t)(te[i].x >> 32);
+                            rlo ^= (uint32_t)te[i].y;
+                            rhi ^= (uint32_t)(te[i].y >> 32);
+                        }
                 }
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                if ((uint32_t)i < r) apply(ts[i].x, ts[i].y);
-        }
-        {
-            auto next4 = [&]() -> uint32_t {             // next 4 bases as one byte (uniform control flow)
-                uint32_t b;
-                if (inl >= 4) {
-                    b = icur & 0xFFu;
-                    icur >>= 8;
-                    inl -= 4;
-                } else {
-                    b = (icur | (inxt << (2u * inl))) & 0xFFu;
-                    icur = inxt >> (2u * (4u - inl));
-                    inl += 12;
-                    inxt = *iwp++;
-                }
-                return b;
-            };
-            const uint32_t q = k >> 2;
-            const ulonglong2 *T4 = reinterpret_cast<const ulonglong2 *>(REC);
-            constexpr int WB = 8;                           // rows in flight (32 VGPRs, free at this point of the kernel)
-            for (uint32_t s4 = 0; s4 < q; s4 += WB) {
-                const uint32_t nb = min((uint32_t)WB, q - s4);   // uniform
-                ulonglong2 te[WB];
-#pragma unroll
-                for (int i = 0; i < WB; ++i)
-                    if ((uint32_t)i < nb) te[i] = T4[next4()];
-#pragma unroll
-                for (int i = 0; i < WB; ++i)
-                    if ((uint32_t)i < nb) {
-                        srol4(flo, fhi);
-                        flo ^= (uint32_t)te[i].x;
-                        fhi ^= (uint32_t)(te[i].x >> 32);
-                        sror4(rlo, rhi);
-                        rlo ^= (uint32_t)te[i].y;
-                        rhi ^= (uint32_t)(te[i].y >> 32);
+            }
+        } else {
+            // warm-up (first k-mer of the run): k = r + 4q bases; r single-base steps through the roll LUT,
+            // then q steps of 4 bases through the 256-entry table t4 (F' = srol^4(F) ^ F4[b], R' = sror^4(R) ^ R4[b]),
+            // read from LDS one step ahead of use
+            // All table rows of a batch are requested first (their addresses depend only on the bases) and the dependent
+            // rotate / xor chain runs afterwards: one exposed LDS round trip per batch instead of one per step.
+            {
+                const uint32_t r = k & 3u;                      // uniform
+                ulonglong2 ts[3];
+    #pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if ((uint32_t)i < r) {
+                        const uint32_t idx = 16u | next_in();
+                        ts[i] = *reinterpret_cast<const ulonglong2 *>(LUT + 2 * idx);
                     }
+    #pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if ((uint32_t)i < r) apply(ts[i].x, ts[i].y);
+            }
+            {
+                auto next4 = [&]() -> uint32_t {             // next 4 bases as one byte (uniform control flow)
+                    uint32_t b;
+                    if (inl >= 4) {
+                        b = icur & 0xFFu;
+                        icur >>= 8;
+                        inl -= 4;
+                    } else {
+                        b = (icur | (inxt << (2u * inl))) & 0xFFu;
+                        icur = inxt >> (2u * (4u - inl));
+                        inl += 12;
+                        inxt = *iwp++;
+                    }
+                    return b;
+                };
+                const uint32_t q = k >> 2;
+                const ulonglong2 *T4 = reinterpret_cast<const ulonglong2 *>(REC);
+                constexpr int WB = 8;                           // rows in flight (32 VGPRs, free at this point of the kernel)
+                for (uint32_t s4 = 0; s4 < q; s4 += WB) {
+                    const uint32_t nb = min((uint32_t)WB, q - s4);   // uniform
+                    ulonglong2 te[WB];
+    #pragma unroll
+                    for (int i = 0; i < WB; ++i)
+                        if ((uint32_t)i < nb) te[i] = T4[next4()];
+    #pragma unroll
+                    for (int i = 0; i < WB; ++i)
+                        if ((uint32_t)i < nb) {
+                            srol4(flo, fhi);
+                            flo ^= (uint32_t)te[i].x;
+                            fhi ^= (uint32_t)(te[i].x >> 32);
+                            sror4(rlo, rhi);
+                            rlo ^= (uint32_t)te[i].y;
+                            rhi ^= (uint32_t)(te[i].y >> 32);
+                        }
+                }
             }
         }
         // Rolls 1..L-1 of this lane take in-base (k + j - 1) and out-base (j - 1) of the run.  Both streams are
@@ -1430,7 +1468,26 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
 
     p.lut.alloc(40);
     SW_HIP(hipMemcpy(p.lut.p, lut, sizeof lut, hipMemcpyHostToDevice));
-    {   // 4-base warm-up table; byte b = c0 | c1 << 2 | c2 << 4 | c3 << 6 with c0 the earliest base
+    if (k <= KPAIR) {
+        // pair table of the rotate-free warm-up: row (p, b0 | b1 << 2) = {srol^(k-1-2p)(S[b0]) ^ srol^(k-2-2p)(S[b1]),
+        // srol^(2p)(S[~b0]) ^ srol^(2p+1)(S[~b1])}; at odd k the last position holds one base (b1 ignored)
+        std::vector<uint64_t> t2(512, 0);
+        const uint32_t np = ((uint32_t)k + 1u) / 2u;
+        for (uint32_t pp = 0; pp < np; ++pp)
+            for (int b = 0; b < 16; ++b) {
+                const int c0 = b & 3, c1 = b >> 2;
+                const uint32_t i0 = 2 * pp, i1 = 2 * pp + 1;
+                uint64_t f = host_srol(S[c0], (unsigned)(k - 1 - i0)), r = host_srol(S[3 - c0], i0);
+                if (i1 < k) {
+                    f ^= host_srol(S[c1], (unsigned)(k - 1 - i1));
+                    r ^= host_srol(S[3 - c1], i1);
+                }
+                t2[2 * (pp * 16 + b)] = f;
+                t2[2 * (pp * 16 + b) + 1] = r;
+            }
+        p.t4.alloc(512);
+        SW_HIP(hipMemcpy(p.t4.p, t2.data(), 512 * 8, hipMemcpyHostToDevice));
+    } else {   // 4-base warm-up table; byte b = c0 | c1 << 2 | c2 << 4 | c3 << 6 with c0 the earliest base
         std::vector<uint64_t> t4(512);
         auto host_sror = [&](uint64_t x, unsigned d) { return host_srol(x, 1023u - (d % 1023u)); };
         for (int b = 0; b < 256; ++b) {

@@ -824,3 +824,59 @@ def test_device_gz_ingest_matches_host_route(tmp_path, monkeypatch):
     with pytest.raises(ValueError, match="control byte"):
         KmerGraph([ctl], kmerlen=3, windowsize=1, n_cpu=1)
     assert _device_gz_batches() == n0 + 2
+
+
+# ---- one sw_build over several devices (SEQWIN_DEVICES, csrc/multi.hip) -------------------------------------------------------
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0", "0,0,0,0,0,0,0,0"])
+@pytest.mark.parametrize("route", [None, "requests"])
+def test_multi_device_build_equals_single_device(tmp_path, smoke_paths, monkeypatch, devices, route):
+    """KmerGraph(paths, ...) under SEQWIN_DEVICES -- one host thread and one stream per listed device inside the ONE sw_build
+    call, the reference's partition of the assemblies over its workers (build.cpp:342-367), tuple / rank / key exchanges by
+    peer copies -- must give the arrays of the single-device build (and of the oracle), whatever the number of shards: the
+    reference's thread-count invariance (tests/smoke/test_graph.py:67-127).  One GPU here, so the listed devices are logical
+    shards on card 0; more shards than assemblies are clamped (eight devices, four or six assemblies)."""
+    if route:
+        monkeypatch.setenv("SEQWIN_DIST_HASH_ROUTE", route)
+    synth = sorted((GOLDEN / "synth").glob("pan_*.fa")) + sorted((GOLDEN / "synth").glob("edge_*"))
+    lc = tmp_path / "lc.fa"     # tandem repeats: pairs that repeat inside an assembly (the candidate rows), every window a tie
+    lc.write_text(">at\n" + "AT" * 4000 + "\n>rep7\n" + "ACGGTCA" * 2000 + "\n>mix\n" + "A" * 500 + "N" + "C" * 700 + "ACGT" * 300 + "\n")
+    for paths, k, w in ((smoke_paths, 17, 10), (smoke_paths, 21, 200), (synth, 15, 20), (synth + [lc, lc], 11, 5), ([lc], 7, 3)):
+        monkeypatch.delenv("SEQWIN_DEVICES", raising=False)
+        one = _build(paths, k, w, n_cpu=2)
+        monkeypatch.setenv("SEQWIN_DEVICES", devices)
+        many = _build(paths, k, w, n_cpu=3)
+        for a, b in zip(one[:4], many[:4]):
+            assert a.dtype == b.dtype and np.array_equal(a, b), (devices, route, k, w)
+        assert one[4] == many[4]
+        exp = oracle.build(paths, k, w)
+        assert_graph_equal(many, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])), [list(t) for t in exp[4]])
+        if len(many[1]) and len(paths) >= 2:     # the calls Seqwin makes next run on the (host) arrays as usual
+            tar = [i % 2 == 0 for i in range(len(paths))]
+            oracle.get_penalty(exp[0], exp[1], exp[3], tar)
+            _get_penalty(many[0], many[1], many[3], tar)
+            assert np.array_equal(many[1], exp[1])
+
+
+def test_multi_device_build_on_a_synthetic_job(tmp_path, monkeypatch):
+    """The same on 24 genomes x 4 contigs x 60 kbp (5.8 Mbp, 58 k minimizers; FASTA written from the device generator): three and
+    five logical devices against the single-device build."""
+    from test_gpu_fullsize import write_fasta_sample
+    b = Batch.synthetic(24, 4, 60_000, n_ancestors=3, snp_ppm=20_000, seed=11)
+    paths, _ = write_fasta_sample(b, 24, str(tmp_path))
+    b.close()
+    one = _build(paths, 21, 200, n_cpu=4)
+    for devices in ("0,0,0", "0,0,0,0,0"):
+        monkeypatch.setenv("SEQWIN_DEVICES", devices)
+        many = _build(paths, 21, 200, n_cpu=4)
+        monkeypatch.delenv("SEQWIN_DEVICES")
+        assert all(np.array_equal(a, c) for a, c in zip(one[:4], many[:4])) and one[4] == many[4], devices
+
+
+def test_seqwin_devices_is_validated(smoke_paths, monkeypatch):
+    for bad in ("0,99", "zero", "0;1", "-1,0"):
+        monkeypatch.setenv("SEQWIN_DEVICES", bad)
+        with pytest.raises(ValueError, match="SEQWIN_DEVICES"):
+            _build(smoke_paths, 17, 10, n_cpu=1)
+    monkeypatch.setenv("SEQWIN_DEVICES", "0")          # one device: the ordinary build
+    assert len(_build(smoke_paths, 17, 10, n_cpu=1)[0])
