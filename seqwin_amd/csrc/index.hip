@@ -83,14 +83,17 @@ void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_
     keys_alt = dk.alternate();
 }
 
-// The node sort's phase 1: rocPRIM's onesweep pair passes by default; SEQWIN_AMD_PAIR_SORT=own takes radix.hip's pair passes
-// (hand-written, stable, tested against torch.sort in tests/tools/pair_sort_check.py and in the suite) -- measured on 745 M
-// pairs: 33.1 ms against 28.0 for rocPRIM (r04: 4096-element tiles, two workgroups per CU; the look-back and seven barriers of
-// a tile are not covered by the one other workgroup), so the library's passes stay the default here.
+// The node sort's phase 1 -- lsd_radix_sort (build_internals.cpp:76-110) over (key32, OccPay) -- by radix.hip's pair passes for
+// large inputs, like the keys-only sorts (745 M pairs: 26.7 ms against 28.0 for rocPRIM's onesweep, r04: 7168-element tiles, one
+// workgroup per CU, keys and payloads staged through LDS together); rocPRIM's for small ones, for key widths that are no multiple
+// of 8 (a test knob), and on a device that fails the LDS-atomic ranking self-check.  SEQWIN_AMD_SORT=own|rocprim forces one for
+// all sorts, SEQWIN_AMD_PAIR_SORT=own|rocprim for this one only (A/B).
 bool sort_pairs_is_own(size_t n, unsigned bits)
 {
     const char *e = getenv("SEQWIN_AMD_PAIR_SORT");
-    return e && !strcmp(e, "own") && bits % 8 == 0 && bits <= 32 && n < 0xFFFFFFFFull && radix_pairs_available();
+    if (e && !strcmp(e, "rocprim")) return false;
+    if (bits % 8 != 0 || bits > 32 || n >= 0xFFFFFFFFull) return false;
+    return ((e && !strcmp(e, "own")) || sort_keys64_is_own(n)) && radix_pairs_available();
 }
 
 void sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,

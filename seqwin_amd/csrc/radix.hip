@@ -501,6 +501,11 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
             }
             if (tid == 0) fut = atomicAdd(ticket, 1u);
         };
+        // (r04, measured on 745 M keys with the counters of the timing build: a look-back step of four 8-byte records takes ~2 800
+        //  cycles -- the records are read at agent scope and queue behind the pass's own streams -- and the walk is ~16 records
+        //  long, i.e. one step's latency over the ~180 cycles between two tiles' starts: 5.9 steps, 16 500 of a tile's 45 600 cycles.
+        //  Eight records per step (4 100 cycles a step, a walk of 20), 16-byte loads for two digits per thread, and 4-byte aggregate
+        //  records with one inclusive-sum probe per step of eight were all measured within 2 % of this form or slower: NOTES.md.)
         // (r04) The waves that own no digit place their keys at once; the digit waves look back FIRST and place theirs afterwards:
         // a tile's inclusive record is published a whole scatter phase earlier, so every later tile finds the end of its walk
         // nearer (the walk is as long as the tiles that have published an aggregate but not yet their inclusive sum), and the
@@ -589,14 +594,16 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
 // ---- pairs: 32-bit keys with a 16-byte payload (the node sort: key32 = top half of the hash, OccPay) ---------------------------
 // lsd_radix_sort of cpp/src/seqwin/build_internals.cpp:76-144 on the device, for the occurrences.  Same scheme as the keys-only
 // pass (tickets, ranking per wave, decoupled look-back, write-out through LDS in digit order) in a shape made for 20-byte
-// elements: 512 threads x 8 elements (4096-element tiles), 8-bit digits, the keys and then the payloads staged through ONE
-// 64 KiB LDS buffer -- 72 KiB per workgroup, two workgroups per CU, so one workgroup's look-back and barriers are covered by the
-// other's loads and stores.  A thread keeps the global place of "its" output slots from the key round for the payload round.
+// elements: 1024 threads x 7 elements (7168-element tiles), 8-bit digits, keys and payloads staged through LDS together (140 KiB:
+// one placing phase and one write-out phase per tile) -- one workgroup per CU (r04, first form: 4096-element tiles, two workgroups per CU: twice the tiles in
+// flight, so a look-back twice as long for half the elements -- 8.3 ms per pass of 745 M pairs against 7.0 for rocPRIM).  The
+// four digit waves look back while the other twelve place their keys.  A thread keeps the global place of "its" output slots
+// from the key round for the payload round.
 // Ranking is by the LDS atomic only (k_rs_pass_p, RANK = 1): on a device that fails the self-check the pair sort is rocPRIM's.
 // Look-back records carry a 16-bit epoch (the pass number of this state buffer) above flag and count: a record of an earlier
 // pass -- or of an earlier sort -- reads as "not published", so the buffer is never cleared between passes (twelve passes per
 // build cleared 3.5 GB; the buffer is cleared once per 65 535 passes).
-constexpr int RP_THREADS = 512, RP_ITEMS = 8, RP_BITS = 8;
+constexpr int RP_THREADS = 1024, RP_ITEMS = 7, RP_BITS = 8;
 __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__restrict__ kin, const uint4 *__restrict__ pin,
                                                              uint32_t *__restrict__ kout, uint4 *__restrict__ pout, uint64_t n,
                                                              uint32_t n_tiles, unsigned shift,
@@ -605,13 +612,13 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
                                                              uint32_t *__restrict__ ticket, uint32_t *__restrict__ fail)
 {
     constexpr uint32_t THREADS = RP_THREADS, ITEMS = RP_ITEMS, RADIX = 1u << RP_BITS, WAVES = THREADS / 64, TILE = THREADS * ITEMS;
-    __shared__ uint4 sp[TILE];                        // the staging buffer: keys (as uint32) first, then payloads
+    __shared__ uint4 sp[TILE];                        // the tile in digit order: payloads (112 KiB) ...
+    __shared__ uint32_t skey[TILE];                   // ... and keys (28 KiB): one placing phase, one write-out phase
     __shared__ uint16_t whist[WAVES][RADIX];
     __shared__ uint32_t lstart[RADIX];
     __shared__ unsigned long long goff[RADIX];
     __shared__ uint32_t wsum[RADIX / 64];
     __shared__ uint32_t s_tile;
-    uint32_t *const skey = reinterpret_cast<uint32_t *>(sp);
     const uint32_t tid0 = threadIdx.x;
     if (tid0 == 0) s_tile = atomicAdd(ticket, 1u);
     __syncthreads();
@@ -628,12 +635,12 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
             pay[i] = in_range ? pin[g] : uint4{0, 0, 0, 0};
         }
     }
+    uint32_t fut = 0;                                 // the ticket after the next (taken a tile ahead: see k_rs_pass_p)
+    if (tid0 == 0) fut = atomicAdd(ticket, 1u);
     while (tile < n_tiles) {
         uint32_t tid = tid0;
         asm volatile("" : "+v"(tid));     // (keeps the per-item addresses from being hoisted out of the loop into registers)
         const uint32_t lane = tid & 63u, wave = tid >> 6;
-        uint32_t fut = 0;
-        if (tid == 0) fut = atomicAdd(ticket, 1u);
         for (uint32_t i = tid; i < WAVES * RADIX / 2; i += THREADS) (reinterpret_cast<uint32_t *>(&whist[0][0]))[i] = 0;
         __syncthreads();
         const uint64_t t0 = (uint64_t)tile * TILE;
@@ -642,10 +649,9 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
 #pragma unroll
         for (int i = 0; i < (int)ITEMS; ++i) {
             const uint32_t li = wave * (64 * ITEMS) + i * 64 + lane;
-            const bool live = li < cnt_tile;
             const uint32_t d = (key[i] >> shift) & (RADIX - 1u);
             pos[i] = 0;                             // (ranking by the LDS atomic: see k_rs_pass_p, RANK = 1; all issued, then all read)
-            if (live) pos[i] = atomicAdd(reinterpret_cast<uint32_t *>(&whist[wave][d & ~1u]), 1u << ((d & 1u) << 4));
+            if (li < cnt_tile) pos[i] = atomicAdd(reinterpret_cast<uint32_t *>(&whist[wave][d & ~1u]), 1u << ((d & 1u) << 4));
         }
 #pragma unroll
         for (int i = 0; i < (int)ITEMS; ++i) {
@@ -654,7 +660,6 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
         }
         __syncthreads();
         uint32_t total = 0, incl = 0;
-        unsigned long long pre[RS_LOOK];
         unsigned long long *st = state + (size_t)tile * RADIX;
         if (tid < RADIX) {
             const uint32_t d = tid;
@@ -665,11 +670,6 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
                 total += c;
             }
             __hip_atomic_store(&st[d], rse_pack(epoch, tile == 0 ? 2u : 1u, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int j = 0; j < RS_LOOK; ++j)
-                pre[j] = (int64_t)tile - 1 - j >= 0
-                             ? __hip_atomic_load(&state[(size_t)(tile - 1 - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                             : rse_pack(epoch, 2u, 0);
             incl = total;
             for (uint32_t dd = 1; dd < 64; dd <<= 1) {
                 const uint32_t up = __shfl_up(incl, dd, 64);
@@ -686,34 +686,45 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
         }
         if (tid == 0) s_tile = fut;
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < (int)ITEMS; ++i) {            // the keys in digit order, in LDS
-            const uint32_t li = wave * (64 * ITEMS) + i * 64 + lane;
-            const uint32_t d = (key[i] >> shift) & (RADIX - 1u);
-            pos[i] += lstart[d] + whist[wave][d];
-            if (li < cnt_tile) skey[pos[i]] = key[i];
-        }
         const uint32_t ntile = s_tile;
+        // the tile in digit order, in LDS; the next tile's keys and payloads are requested into the same registers (in flight during
+        // the look-back and the write-out)
+        auto place_keys = [&]() {
 #pragma unroll
-        for (int i = 0; i < (int)ITEMS; ++i) {            // the next tile's keys: in flight during the look-back and both write-outs
-            const uint64_t g = (uint64_t)ntile * TILE + wave * (64 * ITEMS) + i * 64 + lane;
-            key[i] = (ntile < n_tiles && g < n) ? kin[g] : ~0u;
-        }
-        if (tid < RADIX) {                                // look-back, RS_LOOK predecessors per step
+            for (int i = 0; i < (int)ITEMS; ++i) {
+                const uint32_t li = wave * (64 * ITEMS) + i * 64 + lane;
+                const uint32_t d = (key[i] >> shift) & (RADIX - 1u);
+                const uint32_t at = pos[i] + lstart[d] + whist[wave][d];
+                if (li < cnt_tile) {
+                    skey[at] = key[i];
+                    sp[at] = pay[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < (int)ITEMS; ++i) {
+                const uint64_t g = (uint64_t)ntile * TILE + wave * (64 * ITEMS) + i * 64 + lane;
+                const bool in_range = ntile < n_tiles && g < n;
+                key[i] = in_range ? kin[g] : ~0u;
+                pay[i] = in_range ? pin[g] : uint4{0, 0, 0, 0};
+            }
+            if (tid == 0) fut = atomicAdd(ticket, 1u);
+        };
+        // the four digit waves look back while the other twelve place their keys, and place theirs afterwards (k_rs_pass_p)
+        const bool look_wave = tid < RADIX;
+        if (!look_wave) place_keys();
+        if (look_wave) {                                  // look-back, RS_LOOK predecessors per step
             const uint32_t d = tid;
             unsigned long long excl = 0;
             if (tile) {
                 int64_t t = (int64_t)tile - 1;
                 uint32_t spins = 0;
-                bool done = false, first_step = true;
+                bool done = false;
                 while (!done && t >= 0) {
                     unsigned long long v[RS_LOOK];
 #pragma unroll
                     for (int j = 0; j < RS_LOOK; ++j)
-                        v[j] = first_step ? pre[j]
-                               : t - j >= 0 ? __hip_atomic_load(&state[(size_t)(t - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                            : rse_pack(epoch, 2u, 0);
-                    first_step = false;
+                        v[j] = t - j >= 0 ? __hip_atomic_load(&state[(size_t)(t - j) * RADIX + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : rse_pack(epoch, 2u, 0);
                     int j = 0;
 #pragma unroll
                     for (; j < RS_LOOK; ++j) {
@@ -738,35 +749,18 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
                 __hip_atomic_store(&st[d], rse_pack(epoch, 2u, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             goff[d] = digit_base[d] + excl - before;
+            place_keys();
         }
         __syncthreads();
-        uint32_t dst[ITEMS];                              // global place of output slot j * THREADS + tid (n < 2^32)
 #pragma unroll
-        for (int j = 0; j < (int)ITEMS; ++j) {
+        for (int j = 0; j < (int)ITEMS; ++j) {            // keys and payloads out, consecutive lanes to consecutive places of a digit
             const uint32_t t = j * THREADS + tid;
-            dst[j] = 0;
             if (t < cnt_tile) {
                 const uint32_t k = skey[t];
-                dst[j] = (uint32_t)(goff[(k >> shift) & (RADIX - 1u)] + t);
-                kout[dst[j]] = k;
+                const uint64_t dst = goff[(k >> shift) & (RADIX - 1u)] + t;
+                kout[dst] = k;
+                pout[dst] = sp[t];
             }
-        }
-        __syncthreads();                                  // the keys have left the buffer
-#pragma unroll
-        for (int i = 0; i < (int)ITEMS; ++i) {
-            const uint32_t li = wave * (64 * ITEMS) + i * 64 + lane;
-            if (li < cnt_tile) sp[pos[i]] = pay[i];
-        }
-#pragma unroll
-        for (int i = 0; i < (int)ITEMS; ++i) {            // the next tile's payloads
-            const uint64_t g = (uint64_t)ntile * TILE + wave * (64 * ITEMS) + i * 64 + lane;
-            pay[i] = (ntile < n_tiles && g < n) ? pin[g] : uint4{0, 0, 0, 0};
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < (int)ITEMS; ++j) {
-            const uint32_t t = j * THREADS + tid;
-            if (t < cnt_tile) pout[dst[j]] = sp[t];
         }
         // (the next iteration writes sp / goff / s_tile only behind its own barriers; its first barrier also orders these reads)
         tile = ntile;

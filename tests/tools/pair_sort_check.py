@@ -36,6 +36,7 @@ for name, end_bit, make in cases:
         order = torch.sort(field, stable=True).indices
         for impl in ("own", "rocprim"):
             os.environ["SEQWIN_AMD_SORT"] = impl
+            os.environ["SEQWIN_AMD_PAIR_SORT"] = impl      # (the pair passes of radix.hip are taken only on request)
             for rank in (("atomic",) if impl == "own" else ("-",)):       # (the pair passes rank by LDS atomics only)
                 os.environ["SEQWIN_AMD_RADIX_RANK"] = rank
                 print(f"  .. {name} {impl} n={m}", flush=True)
@@ -50,7 +51,7 @@ if len(sys.argv) > 2:       # timing at the size of the 15k build
     keys = torch.randint(-2**31, 2**31 - 1, (m,), dtype=torch.int32, device="cuda", generator=g)
     vals = torch.zeros((m, 4), dtype=torch.int32, device="cuda")
     for impl, rank in (("own", "atomic"), ("rocprim", "-")):
-        os.environ["SEQWIN_AMD_SORT"], os.environ["SEQWIN_AMD_RADIX_RANK"] = impl, rank
+        os.environ["SEQWIN_AMD_SORT"], os.environ["SEQWIN_AMD_RADIX_RANK"], os.environ["SEQWIN_AMD_PAIR_SORT"] = impl, rank, impl
         best = min(sort(keys, vals, 32)[2] for _ in range(3))
         print(f"timing n={m} 32 bits {impl:8s} rank={rank:7s}: {best:.2f} ms", flush=True)
 sys.exit(1 if bad else 0)
