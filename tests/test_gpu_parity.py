@@ -714,9 +714,40 @@ def test_resident_index_serves_get_penalty_and_filter_kmers(tmp_path, monkeypatc
 
 
 @pytest.mark.parametrize("impl", ["own", "rocprim"])
+def test_sort_pairs32_is_a_stable_radix_sort(impl, monkeypatch):
+    """sw_sort_pairs32 = lsd_radix_sort (build_internals.cpp:76-110) as the node sort uses it: 32-bit keys with a 16-byte payload,
+    csrc/radix.hip's pair passes (7168-element tiles, ranks from LDS atomics, look-back with epoch-tagged records -- several sorts
+    in a row share the state buffer) or rocPRIM; sizes around the tile, long runs of equal keys, one key value, 8 ... 32 key bits."""
+    import ctypes
+
+    import torch
+    from seqwin_amd._lib import c_u64, c_vp, check, lib
+    monkeypatch.setenv("SEQWIN_AMD_SORT", impl)
+    monkeypatch.setenv("SEQWIN_AMD_PAIR_SORT", impl)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for n, end_bit, hi in [(1, 32, 2**31), (5, 8, 2**31), (7167, 32, 2**31), (7168, 16, 2**31), (7169, 32, 2**31), (14_337, 24, 2**31),
+                           (1_000_003, 32, 2**31), (3_000_000, 32, 1000), (2_000_000, 32, 1), (500_000, 16, 2**31)]:
+        keys = (torch.randint(0, hi, (n,), dtype=torch.int64, device="cuda", generator=g) * (2_000_003 if hi <= 1000 else 1)).to(torch.int32)
+        vals = torch.stack([torch.arange(n, device="cuda", dtype=torch.int32)] * 4, dim=1).contiguous()   # payload: where the pair stood
+        vals[:, 1] ^= 0x5A5A5A5A
+        vals[:, 3] = keys
+        k, ka, v, va = keys.clone(), torch.empty_like(keys), vals.clone(), torch.empty_like(vals)
+        flag = ctypes.c_int()
+        check(lib.sw_sort_pairs32(c_vp(k.data_ptr()), c_vp(ka.data_ptr()), c_vp(v.data_ptr()), c_vp(va.data_ptr()), c_u64(n),
+                                  c_u64(end_bit), c_vp(0), ctypes.byref(flag), None))
+        ok, ov = (ka, va) if flag.value else (k, v)
+        field = (keys.to(torch.int64) & 0xFFFFFFFF) & ((1 << end_bit) - 1)
+        order = torch.sort(field, stable=True).indices
+        assert torch.equal(ok, keys[order]) and torch.equal(ov, vals[order]), (impl, n, end_bit, hi)
+    with pytest.raises(ValueError):
+        check(lib.sw_sort_pairs32(c_vp(0), c_vp(0), c_vp(0), c_vp(0), c_u64(0), c_u64(12), c_vp(0), ctypes.byref(flag), None))
+
+
+@pytest.mark.parametrize("impl", ["own", "rocprim"])
 def test_sort_keys64_is_a_stable_radix_sort(impl, monkeypatch):
     """sw_sort_keys64 = lsd_radix_sort_key (build_internals.cpp:76-144) on the device: csrc/radix.hip (hand-written onesweep,
-    8192-key tiles, ballot ranking, decoupled look-back) or rocPRIM; any bit range, sizes around the tile, heavy ties."""
+    16384-key tiles, ranks from LDS atomics -- SEQWIN_AMD_RADIX_RANK=ballot: from ballots --, decoupled look-back) or rocPRIM; any
+    bit range, sizes around the tile, heavy ties."""
     import ctypes
 
     import torch
