@@ -536,8 +536,12 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
 {
     using C = FastCfg<L, B>;
     constexpr uint32_t LM = L - 1;
-    constexpr uint32_t LSH = (L == 32) ? 5 : 4;
-    static_assert(L == 32 || L == 16, "run length must be 16 or 32");
+    constexpr uint32_t LSH = (L == 32) ? 5 : (L == 16) ? 4 : (L == 8) ? 3 : 2;
+    // (r04) L = 8 for 8 <= w < 16 and L = 4 for 4 <= w < 8: the window logic needs w >= L (a window then holds the start of the
+    // lane's run, or lies to the left of it), so small windows take short runs; a lane's first base is then no longer on a word
+    // boundary of the staged stream for every lane (bit phase per lane instead of per wave: the funnel shifts take a register).
+    static_assert(L == 32 || L == 16 || L == 8 || L == 4, "run length must be 4, 8, 16 or 32");
+    constexpr int NWL = (L + 15) / 16;                // staged words that hold a run's own bases
     static_assert((size_t)B * RC * 8 >= 4096, "the warm-up table shares the suffix-record area");
     __shared__ __align__(16) unsigned char smem[C::bytes];   // static: LDS addresses are compile-time constants
     uint64_t *REC = reinterpret_cast<uint64_t *>(smem + C::off_REC);
@@ -615,8 +619,10 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
 
     if (n) {
         // ---- phase 1: ntHash over this lane's L k-mers -------------------------------------------
-        const uint32_t *wp = STG + tid * (L / 16);
-        uint32_t icur = wp[0] >> (2u * ph), inxt = wp[1], inl = 16u - ph;
+        const uint32_t boff = ph + tid * L;           // the lane's first base in the staged stream
+        const uint32_t *wp = STG + (boff >> 4);
+        const uint32_t lph = boff & 15u;              // (= ph, wave-uniform, when L is a multiple of 16)
+        uint32_t icur = wp[0] >> (2u * lph), inxt = wp[1], inl = 16u - lph;
         const uint32_t *iwp = wp + 2;
         auto next_in = [&]() -> uint32_t {
             if (inl == 0) { icur = inxt; inxt = *iwp++; inl = 16; }
@@ -644,7 +650,7 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
             // split rotates (r03 stamps: 2 944 of a wave's 22 486 cycles).  The lane's bases are brought to bit 0 of two words
             // by the wave-uniform phase; all rows of a batch of eight positions are requested before the first is used.
             const uint32_t np = (k + 1u) >> 1;                       // uniform
-            const uint32_t so = 2u * ph;
+            const uint32_t so = 2u * lph;
             const uint32_t b0 = __builtin_amdgcn_alignbit(wp[1], wp[0], so);   // bases 0..15 of the run
             const uint32_t b1 = __builtin_amdgcn_alignbit(wp[2], wp[1], so);   // bases 16..31
             const unsigned char *T2 = reinterpret_cast<const unsigned char *>(REC);
@@ -730,14 +736,14 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
         // pair of every roll is a compile-time bit field: no per-step refill test, 4 VALU per LUT index.
         // The two 2-bit fields are interleaved once per word into 4-bit LUT rows ((out << 2) | in): rows of the even
         // bases in `ev`, of the odd bases in `od` -> one shift + one mask per roll.
-        uint32_t ev[L / 16], od[L / 16];
+        uint32_t ev[NWL], od[NWL];
         {
-            const uint32_t so = 2u * ph;
-            const uint32_t pk = ph + k;
+            const uint32_t so = 2u * lph;
+            const uint32_t pk = lph + k;
             const uint32_t *wi = wp + (pk >> 4);
             const uint32_t si = 2u * (pk & 15u);
 #pragma unroll
-            for (int q = 0; q < L / 16; ++q) {
+            for (int q = 0; q < NWL; ++q) {
                 const uint32_t ob = __builtin_amdgcn_alignbit(wp[q + 1], wp[q], so);
                 const uint32_t ib = __builtin_amdgcn_alignbit(wi[q + 1], wi[q], si);
                 ev[q] = (ib & 0x33333333u) | ((ob & 0x33333333u) << 2);
@@ -1045,8 +1051,7 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
                                  : [lc] "v"(lc_h), [pre] "v"(pre_h), [pb] "v"(pre_bit)
                                  : "vcc", "scc");   // s_and_saveexec writes SCC
                 }
-                if (L == 32) atomicOr(&EM[tid], own);
-                else atomicOr(&EM[tid >> 1], own << ((tid & 1u) * 16u));
+                atomicOr(&EM[(tid * L) >> 5], own << ((tid * L) & 31u));   // the lane's L bits of the emit bitmap
             }
         } else {
 #pragma unroll
@@ -1086,11 +1091,8 @@ template <int L, int B> __global__ __launch_bounds__(B, 4) void sketch_fast_kern
     // ---- phase 3: compact the set bits in position order (hashes come from registers) -----------
     uint32_t bits = 0;
     if (n) {
-        if (L == 32) {
-            bits = EM[tid];
-        } else {
-            bits = (EM[tid >> 1] >> ((tid & 1u) * 16u)) & 0xFFFFu;
-        }
+        bits = EM[(tid * L) >> 5] >> ((tid * L) & 31u);
+        if (L < 32) bits &= (1u << (L & 31)) - 1u;
         if (n < (uint32_t)L) bits &= (1u << n) - 1u;
         if (!SK_TWO_BARRIERS && !first) {
             // the winner of the window just before the tile belongs to the previous tile: its owner lane drops it from its
@@ -1290,7 +1292,10 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
     p.lds_bytes = lds_bytes_for(L);
     // fast class: single-segment records, k <= KF, power-of-two run length
     const char *force = getenv("SEQWIN_AMD_SKETCH");   // "generic" disables the fast path (debug / A-B)
-    p.Lf = (k <= KF && !(force && !strcmp(force, "generic"))) ? (w >= 32 ? 32u : (w >= 16 ? 16u : 0u)) : 0u;
+    // (r04: runs of 8 and 4 for windows below 16 -- the fast kernel needs w >= L; SEQWIN_AMD_SKETCH=nosmall: the generic kernel, as before)
+    const bool small_ok = !(force && !strcmp(force, "nosmall"));
+    p.Lf = (k <= KF && !(force && !strcmp(force, "generic")))
+               ? (w >= 32 ? 32u : (w >= 16 ? 16u : (small_ok && w >= 8 ? 8u : (small_ok && w >= 4 ? 4u : 0u)))) : 0u;
     if (p.Lf == 32 && force && !strcmp(force, "fast16")) p.Lf = 16;   // A/B: half the LDS per workgroup
     // Overflow tiles of the fast class are redone by the generic kernel, whose run length must be odd and <= w and
     // whose tile (256 * Lg elements) must hold the fast tile: Lg = Lf + 1 when w > Lf; when w == Lf the fast tiles
@@ -1629,8 +1634,12 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
 #endif
                 if (plan.Lf == 32 && c == 0) hipLaunchKernelGGL((sketch_fast_kernel<32, BLOCK>), dim3(nt), dim3(BLOCK), 0, cs, a);
                 else if (plan.Lf == 32) hipLaunchKernelGGL((sketch_fast_kernel<32, 64>), dim3(nt), dim3(64), 0, cs, a);
-                else if (c == 0) hipLaunchKernelGGL((sketch_fast_kernel<16, BLOCK>), dim3(nt), dim3(BLOCK), 0, cs, a);
-                else hipLaunchKernelGGL((sketch_fast_kernel<16, 64>), dim3(nt), dim3(64), 0, cs, a);
+                else if (plan.Lf == 16 && c == 0) hipLaunchKernelGGL((sketch_fast_kernel<16, BLOCK>), dim3(nt), dim3(BLOCK), 0, cs, a);
+                else if (plan.Lf == 16) hipLaunchKernelGGL((sketch_fast_kernel<16, 64>), dim3(nt), dim3(64), 0, cs, a);
+                else if (plan.Lf == 8 && c == 0) hipLaunchKernelGGL((sketch_fast_kernel<8, BLOCK>), dim3(nt), dim3(BLOCK), 0, cs, a);
+                else if (plan.Lf == 8) hipLaunchKernelGGL((sketch_fast_kernel<8, 64>), dim3(nt), dim3(64), 0, cs, a);
+                else if (c == 0) hipLaunchKernelGGL((sketch_fast_kernel<4, BLOCK>), dim3(nt), dim3(BLOCK), 0, cs, a);
+                else hipLaunchKernelGGL((sketch_fast_kernel<4, 64>), dim3(nt), dim3(64), 0, cs, a);
                 SW_HIP(hipGetLastError());
             }
             if (c == 1 && side) SW_HIP(hipEventRecord(evj, side));

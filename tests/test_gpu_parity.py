@@ -521,11 +521,13 @@ def test_tile_slots_and_shared_overflow_area(tmp_path, slot_cap, monkeypatch):
     assert Batch.from_fasta(paths).build_index(21, 200).timings()["sketch_launches"] == 1
 
 
-@pytest.mark.parametrize("w", [16, 17, 31, 32, 33])
+@pytest.mark.parametrize("w", [4, 5, 7, 8, 9, 10, 15, 16, 17, 31, 32, 33])
 def test_window_equal_to_run_length_and_overflow_tiles(tmp_path, w, monkeypatch):
-    """w == L (16 / 32) is the corner where the window never reaches past the previous run, and the tiles the
+    """w == L (4 / 8 / 16 / 32) is the corner where the window never reaches past the previous run, and the tiles the
     fast kernel hands to the generic kernel (more suffix records than it publishes) must still fit that kernel's
-    geometry (run length <= w).  Found by tests/tools/fuzz_gpu.py; SEQWIN_AMD_RC forces the hand-over for most tiles."""
+    geometry (run length <= w).  Found by tests/tools/fuzz_gpu.py; SEQWIN_AMD_RC forces the hand-over for most tiles.
+    (r04: windows of 4 ... 15 take the fast kernel with runs of 4 / 8 -- bit phase per lane, four or eight lanes per word
+    of the emit bitmap.)"""
     rng = np.random.default_rng(w)
     p = tmp_path / "long.fa"
     p.write_text(">a\n" + "".join(rng.choice(list("ACGT"), 70000)) + "\n>b\n" + "".join(rng.choice(list("ACGT"), 8193)) + "\n")
@@ -537,9 +539,33 @@ def test_window_equal_to_run_length_and_overflow_tiles(tmp_path, w, monkeypatch)
             monkeypatch.setenv("SEQWIN_AMD_RC", rc)
         got = _build([p], 21, w)
         assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])))
-        if w >= 16:   # the hand-over really happens when forced, and only rarely otherwise
+        if w >= 8:    # the hand-over really happens when forced, and only rarely otherwise (runs of 4 never hold more than two records)
             t = Batch.from_fasta([p]).build_index(21, w).timings()
             assert (t["ovf_tiles"] >= t["n_tiles"] // 2) if rc else (t["ovf_tiles"] <= max(1, t["n_tiles"] // 4))
+
+
+@pytest.mark.parametrize("w", [4, 6, 8, 10, 13, 15])
+def test_small_windows_fast_class_equals_generic_kernel_and_oracle(tmp_path, w, monkeypatch):
+    """Windows below 16 through the fast kernel (runs of 8 for 8 <= w < 16, of 4 for 4 <= w < 8; r04) against the generic kernel
+    they used to take (SEQWIN_AMD_SKETCH=nosmall) and against the oracle: long and short records (both tile classes), invalid
+    bases (gap tiles go to the generic kernel's list mode), homopolymers and tandem repeats (every window a tie), several k
+    (pair-table warm-up up to 32, the stepped one above), lower-case and IUPAC."""
+    rng = np.random.default_rng(100 + w)
+    def seq(n):
+        return "".join(rng.choice(list("ACGT"), n))
+    a = tmp_path / "a.fa"
+    a.write_text(">long\n" + seq(60_000) + "\n>short1\n" + seq(700) + "\n>short2\n" + seq(90) + "\n>gaps\n" + seq(5000) + "N" * 7 + seq(3000)
+                 + "NN" + seq(40) + "R" + seq(9000) + "\n>tiny\n" + seq(w + 20) + "\n")
+    b = tmp_path / "b.fa"
+    b.write_text(">polyA\n" + "A" * 9000 + "\n>at\n" + "AT" * 4000 + "\n>rep7\n" + "ACGGTCA" * 1500 + "\n>lower\n" + seq(12_000).lower() + "\n")
+    for k in (5, 17, 21, 32, 33, 40):
+        exp = oracle.build([a, b], k, w)
+        monkeypatch.delenv("SEQWIN_AMD_SKETCH", raising=False)
+        got = _build([a, b], k, w, n_cpu=2)
+        assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])), [list(t) for t in exp[4]])
+        monkeypatch.setenv("SEQWIN_AMD_SKETCH", "nosmall")
+        old = _build([a, b], k, w, n_cpu=2)
+        assert all(np.array_equal(x, y) for x, y in zip(got[:4], old[:4])), (k, w)
 
 
 def test_pipelined_and_plain_upload_give_the_same_batch(tmp_path, monkeypatch):
