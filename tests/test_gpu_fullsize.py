@@ -62,6 +62,36 @@ def test_config1_full_size_equals_reference(tmp_path):
     assert v["weight_sum"] == int(ee["weight"].sum())
 
 
+def test_config1_multi_device_build_equals_single_device(tmp_path, monkeypatch):
+    """configs[1] (512 genomes, 2.46 Gbp, 24.6 M minimizers) as FASTA through ONE sw_build over four and seven logical devices
+    (SEQWIN_DEVICES, csrc/multi.hip: worker threads, peer copies, both ways of bringing node hashes to the edge owners) against
+    the single-device build of the same files -- KmerGraph's arrays, bit for bit -- with this library's radix passes forced for
+    every sort (the slices are below the size where they are the default)."""
+    from bench import write_fasta_fast
+    from seqwin_amd import KmerGraph
+    G, rpg, rl, anc, snp, _ = WORKLOADS["salmonella500"]
+    b = Batch.synthetic(G, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED)
+    paths, bp = write_fasta_fast(b, G, str(tmp_path), 16)
+    b.close()
+    assert bp == G * rpg * rl
+
+    def arrays():
+        g = KmerGraph(paths, kmerlen=21, windowsize=200, n_cpu=16)
+        return g.kmers, g.nodes, g.edges, g.record_offsets, g.record_ids
+    monkeypatch.delenv("SEQWIN_DEVICES", raising=False)
+    one = arrays()
+    gold = json.loads((GOLDEN / "bench_checksums.json").read_text()).get("salmonella500/k21/w200")
+    if gold:
+        assert gold["counts"] == {"kmers": len(one[0]), "nodes": len(one[1]), "edges": len(one[2])}
+    for devices, env in (("0,0,0,0", {}), ("0,0,0,0,0,0,0", {"SEQWIN_DIST_HASH_ROUTE": "requests", "SEQWIN_AMD_SORT": "own"})):
+        monkeypatch.setenv("SEQWIN_DEVICES", devices)
+        for key, v in env.items():
+            monkeypatch.setenv(key, v)
+        many = arrays()
+        assert all(np.array_equal(a, c) for a, c in zip(one[:4], many[:4])) and one[4] == many[4], devices
+        del many
+
+
 KNOBS = [
     {"SEQWIN_AMD_NO_PACKED_EDGES": "1"},                                   # 15k: 2 x 27 + 14 > 64 -> k_adj + pair sort
     {"SEQWIN_AMD_SORT_KEYBITS": "10"},                                     # many shared phase-1 keys: general repair
@@ -76,6 +106,9 @@ KNOBS = [
     {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_EDGE_SKIP_PASSES": "2"},        # ... all of rank_hi left to the repair (wave and workgroup forms)
     {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_EDGE_SKIP_PASSES": "3"},        # ... runs too long for it: the sort runs again on all bits
     {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_EDGE_SKIP_PASSES": "0"},        # ... off
+    {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_RADIX_RANK": "ballot"},         # radix.hip's passes ranking by ballots (pairs then go to rocPRIM)
+    {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_PAIR_SORT": "rocprim"},         # keys-only sorts own, node pairs by rocPRIM
+    {"SEQWIN_AMD_SORT": "rocprim", "SEQWIN_AMD_PAIR_SORT": "own"},         # ... and the other way round
     {"SEQWIN_AMD_WINDOW_SPLIT": "8,4"},                                    # windows above 8 as if above SW_MAX_WINDOW: sketch with w' = 4, select
     {"SEQWIN_AMD_WINDOW_SPLIT": "100,64", "SEQWIN_AMD_RANKS": "table"},
 ]
