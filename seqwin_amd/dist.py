@@ -303,6 +303,9 @@ class HipEngine:
     def free_occ(self, occ) -> None:
         occ.close()
 
+    def close_index(self, ix) -> None:
+        ix.close()
+
     def export(self, ix):
         return ix.export()
 
@@ -847,6 +850,99 @@ def build_sharded_index(shard: Shard, k: int, w: int, is_targets, engine=None, g
               slice_build_wall_ms=(t3 - t2) * 1e3, rank_adj_exchange_wall_ms=(t4 - t3) * 1e3, slice_edges_wall_ms=(t5 - t4) * 1e3)
     engine.free_occ(occ)
     return ShardedIndex(engine, ix, record_offsets, tm, kmer_base, group, clock=clock, info=info)
+
+
+def count_nodes_allreduce(shard: Shard, k: int, w: int, is_targets, engine=None, group=None):
+    """Count-only path (SURVEY 8e "C2"; the north_star's "per-GPU minimizer tables merged by a single RCCL reduce"): the
+    per-minimizer target / non-target genome counts and the penalty of the WHOLE job on every rank, without exchanging any
+    occurrence.  Every rank indexes its own shard; the ranks agree on one sorted dictionary of minimizer hashes (an all-gather
+    of each rank's distinct hashes, 8 B per local node), scatter their local counts into a dense [n_nodes, 2] u32 vector over
+    that dictionary, and ONE all_reduce(sum) merges them -- an assembly lives in exactly one shard, so counts add
+    (cpp/src/seqwin/build_internals.cpp:283-285; counting rule and penalty: cpp/src/seqwin/filter.cpp:62-136).
+
+    Returns (hash u64[n_nodes] ascending, n_tar u32, n_neg u32, penalty f64) as numpy arrays, identical on every rank and equal to
+    the ``hash / n_tar / n_neg / penalty`` fields of the merged graph's nodes.  No kmers, no edges: for consumers that only rank
+    minimizers (the full graph takes build_sharded_index)."""
+    import torch
+    import torch.distributed as dist
+
+    engine = engine or HipEngine()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    multi = world > 1 or (_FORCE_COLLECTIVES and dist.is_initialized())
+    dev = engine.device
+    tar_all = np.ascontiguousarray(np.asarray(is_targets, np.bool_).ravel())
+    if len(tar_all) != shard.n_assemblies_total:
+        raise ValueError("len(is_targets) must equal the number of assemblies of the job")
+    n_tar_total, n_neg_total = int(tar_all.sum()), int((~tar_all).sum())
+    if n_tar_total == 0:
+        raise ValueError("is_targets must contain at least one target assembly")          # filter.cpp:55-57
+    if n_neg_total == 0:
+        raise ValueError("is_targets must contain at least one non-target assembly")      # filter.cpp:58-60
+    if multi:
+        check_collectives(dev, group)
+
+    # -- this shard: occurrences grouped by node (hash order), each with its record; counts per node and class ----------------
+    ix = engine.local_index(shard, k, w)
+    offs = np.asarray(engine.record_offsets(shard), np.int64)            # local record offsets of the shard's assemblies
+    rows = engine.occ_rows(ix, 0).to(dev)                                # [n, 2]: hash, pos | record << 32, in node order
+    n = int(rows.shape[0])
+    M63 = -(1 << 63)
+    if n:
+        h = rows[:, 0]
+        rec = (rows[:, 1] >> 32) & 0xFFFFFFFF
+        rec_asm = torch.from_numpy(np.repeat(np.arange(len(offs) - 1, dtype=np.int64), np.diff(offs))).to(dev)
+        asm = rec_asm[rec]                                               # local assembly of every occurrence
+        tar_local = torch.from_numpy(tar_all[shard.first_assembly:shard.first_assembly + len(offs) - 1].copy()).to(dev)
+        head = torch.ones(n, dtype=torch.bool, device=dev)
+        head[1:] = h[1:] != h[:-1]                                       # first occurrence of its node
+        first = head.clone()
+        first[1:] |= asm[1:] != asm[:-1]                                 # ... of its assembly in its node (occurrences are record-ordered)
+        is_t = tar_local[asm]
+        node_of = torch.cumsum(head.to(torch.int64), 0) - 1
+        n_local = int(node_of[-1].item()) + 1
+        cnt = torch.zeros((n_local, 2), dtype=torch.int64, device=dev)
+        cnt[:, 0].index_add_(0, node_of, (first & is_t).to(torch.int64))
+        cnt[:, 1].index_add_(0, node_of, (first & ~is_t).to(torch.int64))
+        hashes = h[head] ^ M63                                           # unsigned order as signed order
+    else:
+        n_local = 0
+        cnt = torch.zeros((0, 2), dtype=torch.int64, device=dev)
+        hashes = torch.zeros((0,), dtype=torch.int64, device=dev)
+    del rows
+
+    # -- one dictionary for all ranks: the sorted union of the ranks' distinct hashes -------------------------------------------
+    if multi:
+        sizes = _gather_ints(n_local, dev, group)
+        pad = max(1, max(sizes))
+        mine = torch.zeros((pad,), dtype=torch.int64, device=dev)
+        mine[:n_local] = hashes
+        table = torch.empty((world * pad,), dtype=torch.int64, device=dev)
+        _all_gather_parts(table, mine, pad, group)
+        parts = [table[r * pad:r * pad + sizes[r]] for r in range(world)]
+        dictionary = torch.unique(torch.cat(parts))                      # (sorted)
+    else:
+        dictionary = hashes                                              # (already sorted and distinct)
+    n_nodes = int(dictionary.shape[0])
+
+    # -- the single reduce: dense counts over the dictionary ------------------------------------------------------------------------
+    dense = torch.zeros((n_nodes, 2), dtype=torch.int32, device=dev)
+    if n_local:
+        at = torch.searchsorted(dictionary, hashes)
+        dense[at] = cnt.to(torch.int32)
+    if multi:
+        dist.all_reduce(dense, group=group)
+    n_tar = dense[:, 0].to(torch.float64)
+    n_neg = dense[:, 1].to(torch.float64)
+    # filter.cpp:132-134, every operation on its own (no fused multiply-add): bit-identical to the reference's f64 penalty
+    ft = n_tar * (1.0 / n_tar_total)
+    fn = n_neg * (1.0 / n_neg_total)
+    a = 1.0 - ft
+    a = a * a
+    b = fn * fn
+    penalty = torch.sqrt(a + b)
+    engine.close_index(ix) if hasattr(engine, "close_index") else None
+    return ((dictionary ^ M63).cpu().numpy().view(np.uint64), dense[:, 0].cpu().numpy().astype(np.uint32),
+            dense[:, 1].cpu().numpy().astype(np.uint32), penalty.cpu().numpy())
 
 
 def build_graph_distributed(assembly_paths, k: int, w: int, is_targets=None, n_cpu: int = 1, group=None):

@@ -327,6 +327,56 @@ def test_sharded_build_equals_single(tmp_path, world, case, mode):
         assert np.array_equal(np.load(str(out) + f".sums{r}.npy"), exp_sums)
 
 
+def _counts_worker(rank, world, port, paths, k, w, tar, out_path):
+    os.environ["SEQWIN_DIST_SELFCHECK_MB"] = "1"
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        start, end = swdist.partition_assemblies(len(paths), world)[rank]
+        eng = NumpyEngine()
+        mine = paths[start:end]
+        eng._offs = oracle.build(mine, k, w)[3]
+        h, nt, nn, pen = swdist.count_nodes_allreduce(swdist.Shard(mine, start, len(paths)), k, w, tar, engine=eng)
+        np.savez(out_path + f".r{rank}.npz", hash=h, n_tar=nt, n_neg=nn, penalty=pen)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_count_only_allreduce_equals_the_merged_graph(tmp_path, world):
+    """SURVEY 8e C2 / the north_star's "single RCCL reduce": every rank counts its own shard, one dictionary, one all_reduce of the
+    dense count vectors -- hash, n_tar, n_neg and the f64 penalty of every node of the whole job on every rank, bit for bit what
+    get_penalty leaves in the merged graph (shards with only targets, only non-targets or no assembly at all included)."""
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa")) + sorted((GOLDEN / "synth").glob("edge_*"))]
+    k, w = 15, 20
+    tar = [i < 3 for i in range(len(paths))]                       # the first shard(s) hold targets only
+    out = str(tmp_path / "counts")
+    mp.spawn(_counts_worker, nprocs=world, args=(world, _free_port(), paths, k, w, tar, out), join=True)
+    ek, en, ee, eo, _ = oracle.build(paths, k, w)
+    oracle.get_penalty(ek, en, eo, tar)
+    for r in range(world):
+        got = np.load(out + f".r{r}.npz")
+        assert np.array_equal(got["hash"], en["hash"]) and np.array_equal(got["n_tar"], en["n_tar"]), r
+        assert np.array_equal(got["n_neg"], en["n_neg"]) and np.array_equal(got["penalty"], en["penalty"]), r   # f64, tolerance 0
+
+
+def test_count_only_path_single_process_and_validation():
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa"))]
+    k, w = 11, 5
+    tar = [i % 2 == 0 for i in range(len(paths))]
+    eng = NumpyEngine()
+    eng._offs = oracle.build(paths, k, w)[3]
+    h, nt, nn, pen = swdist.count_nodes_allreduce(swdist.Shard(paths, 0, len(paths)), k, w, tar, engine=eng)
+    ek, en, ee, eo, _ = oracle.build(paths, k, w)
+    oracle.get_penalty(ek, en, eo, tar)
+    assert np.array_equal(h, en["hash"]) and np.array_equal(nt, en["n_tar"]) and np.array_equal(nn, en["n_neg"])
+    assert np.array_equal(pen, en["penalty"])
+    for bad in ([True] * len(paths), [False] * len(paths), tar[:-1]):
+        with pytest.raises(ValueError):
+            swdist.count_nodes_allreduce(swdist.Shard(paths, 0, len(paths)), k, w, bad, engine=eng)
+
+
 def test_collective_self_check_catches_a_truncating_transport(monkeypatch):
     """What RCCL 2.26 did at world size 1 in round 3 -- the first half of a large all_to_all_single message delivered, the
     rest of the output left untouched, no error -- must fail the start-up check instead of the graph."""

@@ -162,7 +162,58 @@ def _rccl_worker(rank, port, paths, k, w, tar, out_path):
         shard = d.Shard(Batch.from_fasta(paths, n_cpu=2), 0, len(paths))
         sharded = d.build_sharded_index(shard, k, w, tar)          # every collective is issued, over RCCL
         kmers, nodes, edges = sharded.export()
-        np.savez(out_path, kmers=kmers, nodes=nodes, edges=edges, record_offsets=sharded.record_offsets)
+        ch, cnt, cnn, cpen = d.count_nodes_allreduce(shard, k, w, tar)   # the count-only path: all-gather + ONE all_reduce, over RCCL
+        np.savez(out_path, kmers=kmers, nodes=nodes, edges=edges, record_offsets=sharded.record_offsets, c_hash=ch, c_tar=cnt,
+                 c_neg=cnn, c_pen=cpen)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_count_only_allreduce_on_the_gpu(tmp_path):
+    """dist.count_nodes_allreduce with the HIP engine (device-resident occurrence rows, torch ops on the GPU for the counts, the f64
+    penalty computed there): single process, and two / three processes sharing the GPU with real collectives over gloo -- against
+    the nodes get_penalty leaves (bit-identical, penalty included)."""
+    import socket
+
+    import torch.multiprocessing as mp
+    b = Batch.synthetic(24, 4, 40000, n_ancestors=3, snp_ppm=10000, seed=5)
+    tar = np.arange(24) < 9
+    direct = b.build_index(21, 200, tar)
+    N = direct.export()[1]
+    h, nt, nn, pen = swdist.count_nodes_allreduce(swdist.Shard(b, 0, 24), 21, 200, tar)
+    assert np.array_equal(h, N["hash"]) and np.array_equal(nt, N["n_tar"]) and np.array_equal(nn, N["n_neg"])
+    assert np.array_equal(pen, N["penalty"])
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa")) + sorted((GOLDEN / "synth").glob("edge_*"))]
+    tar2 = [i < 3 for i in range(len(paths))]
+    ek, en, ee, eo, _ = oracle.build(paths, 15, 20)
+    oracle.get_penalty(ek, en, eo, tar2)
+    for world in (2, 3):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        out = str(tmp_path / f"c{world}")
+        mp.spawn(_gloo_counts_worker, nprocs=world, args=(world, port, paths, 15, 20, tar2, out), join=True)
+        for r in range(world):
+            got = np.load(out + f".r{r}.npz")
+            assert np.array_equal(got["hash"], en["hash"]) and np.array_equal(got["n_tar"], en["n_tar"])
+            assert np.array_equal(got["n_neg"], en["n_neg"]) and np.array_equal(got["penalty"], en["penalty"])
+
+
+def _gloo_counts_worker(rank, world, port, paths, k, w, tar, out_path):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SEQWIN_DIST_SELFCHECK_MB"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seqwin_amd.device import set_device
+        set_device(0)
+        start, end = swdist.partition_assemblies(len(paths), world)[rank]
+        shard = swdist.Shard(Batch.from_fasta(paths[start:end], n_cpu=2), start, len(paths))
+        h, nt, nn, pen = swdist.count_nodes_allreduce(shard, k, w, tar, engine=swdist.HipEngine("host"))
+        np.savez(out_path + f".r{rank}.npz", hash=h, n_tar=nt, n_neg=nn, penalty=pen)
     finally:
         dist.destroy_process_group()
 
@@ -185,6 +236,8 @@ def test_rccl_collectives_world1(tmp_path):
     oracle.get_penalty(ek, en, eo, tar)
     assert np.array_equal(got["kmers"], ek) and np.array_equal(got["nodes"], en)
     assert np.array_equal(got["edges"], ee) and np.array_equal(got["record_offsets"], eo)
+    assert np.array_equal(got["c_hash"], en["hash"]) and np.array_equal(got["c_tar"], en["n_tar"])       # the count-only path over RCCL
+    assert np.array_equal(got["c_neg"], en["n_neg"]) and np.array_equal(got["c_pen"], en["penalty"])
 
 
 def routed_tuple_exchange(paths, world, k, w, tar, packed=True, pairs=None, shards=None, sums_only=False, requests=False):
