@@ -384,7 +384,7 @@ def main() -> None:
         achieved = sk_bytes / (sk_ms * 1e-3) / 1e9
         plan_L = 32 if w >= 32 else 16 if w >= 16 else 8 if w >= 8 else 4
         dom_kernel = {"sketch_ms": f"sketch_fast_kernel<{plan_L}, 256>" if (k <= 256 and w >= 4) else "sketch_generic_kernel",
-                      "nodes_ms": "nodes stage: rocprim onesweep pair passes + k_nodes + unsort (no single dominant kernel)",
+                      "nodes_ms": "nodes stage: k_rs_pair_pass radix passes + k_nodes + unsort (no single dominant kernel)",
                       "edges_ms": "edges stage: k_rs_pass_p radix passes + run lengths (no single dominant kernel)"}[dominant]
         # whole path, SURVEY 8d: 0.25 N_bp + 40 N_occ + 40 N_adj + 40 N_node + 24 N_edge  (N_adj ~= N_occ)
         tot = counts.tolist()
