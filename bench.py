@@ -429,6 +429,15 @@ def main() -> None:
             "counts": {"kmers": tot[0], "nodes": tot[1], "edges": tot[2]},
             "checksums": [f"{s:016x}" for s in sums],
         }
+        try:   # how the radix passes rank on this device (the LDS-atomic form needs the device's self-check to pass)
+            import ctypes
+
+            from seqwin_amd._lib import check, lib
+            rm = ctypes.c_int(-1)
+            check(lib.sw_radix_rank_mode(ctypes.byref(rm)))
+            out["radix_rank"] = {1: "lds_atomic (device self-check passed)", 0: "ballot"}.get(rm.value, str(rm.value))
+        except Exception as e:   # (an older library)
+            out["radix_rank"] = f"unknown ({e})"
         if dist_info is not None:
             out["dist"] = dist_info
         if valu_insts:

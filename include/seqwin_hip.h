@@ -333,6 +333,10 @@ int sw_sort_keys64(void *keys_dev, void *alt_dev, uint64_t n, uint64_t begin_bit
 /* The pair form -- lsd_radix_sort (cpp/src/seqwin/build_internals.cpp:76-110) as the node sort uses it: n DEVICE u32 keys, each
  * with a 16-byte payload, stably by key bits [0, end_bit), end_bit in {8, 16, 24, 32} (csrc/radix.hip's pair passes; rocPRIM's
  * under SEQWIN_AMD_SORT=rocprim or SEQWIN_AMD_PAIR_SORT=rocprim).  Double buffers of n keys / n payloads each. */
+/* How the radix passes rank keys inside a wave on the current device: *mode = 1 by one LDS atomic per key -- the device passed
+ * the start-up check that the lanes of one LDS atomic are served in lane order (what keeps those passes stable) --, 0 by ballots
+ * (the check failed, or SEQWIN_AMD_RADIX_RANK=ballot).  Runs the check if it has not run yet. */
+int sw_radix_rank_mode(int *mode);
 int sw_sort_pairs32(void *keys_dev, void *keys_alt_dev, void *vals_dev, void *vals_alt_dev, uint64_t n, uint64_t end_bit, void *stream,
                     int *sorted_in_alt, double *ms);
 

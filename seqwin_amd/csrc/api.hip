@@ -1063,6 +1063,14 @@ int sw_sort_keys64(void *keys_dev, void *alt_dev, uint64_t n, uint64_t begin_bit
     });
 }
 
+int sw_radix_rank_mode(int *mode)
+{
+    return guarded([&] {
+        require_device();
+        *mode = radix_rank_mode();
+    });
+}
+
 int sw_sort_pairs32(void *keys_dev, void *keys_alt_dev, void *vals_dev, void *vals_alt_dev, uint64_t n, uint64_t end_bit, void *stream,
                     int *sorted_in_alt, double *ms)
 {

@@ -238,6 +238,7 @@ struct alignas(16) OccPay {
     uint32_t low, pos, rec, idx;
 };
 // radix.hip: stable sort of (key32, OccPay) pairs by key bits [0, end_bit), end_bit in {8, 16, 24, 32}; double buffers
+int radix_rank_mode();          // how radix.hip ranks keys inside a wave on the current device: 1 LDS atomics, 0 ballots (runs the self-check once)
 bool radix_pairs_available();   // false on a device that does not pass the LDS-atomic ranking self-check (rocPRIM sorts the pairs then)
 void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
                         hipStream_t stream, uint32_t *d_fail);

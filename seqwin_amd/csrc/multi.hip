@@ -281,7 +281,12 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
                 node_base.assign(1, 0);
                 uint64_t mx = 1;
                 for (uint32_t o = 0; o < P; ++o) {
-                    if (!sh[o].marked) raise(SW_ERR_RUNTIME, "multi-device build: a slice holds 2^31 nodes or more (use more devices)");
+                    uint64_t rows_o = 0;
+                    for (uint32_t q = 0; q < P; ++q) rows_o += sh[q].cnt[o];
+                    // (a slice that received no tuple returns no rank: whatever it reports must not stop the job -- a job without any
+                    //  record reports "unmarked" for every slice; found by the SEQWIN_DEVICES fuzz campaign, r04)
+                    if (!sh[o].marked && rows_o)
+                        raise(SW_ERR_RUNTIME, "multi-device build: a slice holds 2^31 nodes or more (use more devices)");
                     node_base.push_back(node_base.back() + sh[o].n_nodes);
                     mx = std::max(mx, sh[o].n_nodes);
                 }

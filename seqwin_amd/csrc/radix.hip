@@ -996,6 +996,7 @@ bool radix_unsort_perm(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned low
 }
 
 bool radix_pairs_available() { return rank_mode() == 1; }   // (the pair passes rank by LDS atomics only)
+int radix_rank_mode() { return rank_mode(); }               // 1: LDS atomics (the device passed the self-check), 0: ballots
 
 // Stable sort of (key32, 16-byte payload) pairs by bits [0, end_bit) of the keys, end_bit a multiple of 8 up to 32 (the node
 // sort: all 32).  Double buffers; on return keys / vals point at the sorted data.

@@ -930,6 +930,28 @@ def test_multi_device_build_on_a_synthetic_job(tmp_path, monkeypatch):
         assert all(np.array_equal(a, c) for a, c in zip(one[:4], many[:4])) and one[4] == many[4], devices
 
 
+def test_multi_device_build_without_any_record_or_minimizer(tmp_path, monkeypatch):
+    """Assemblies without a record, or without a k-mer: every slice of the multi-device build is empty (found by the SEQWIN_DEVICES
+    fuzz campaign: a slice that received nothing reports no rank marks, which must not be taken for "2^31 nodes")."""
+    empty = [tmp_path / f"e{i}.fa" for i in range(3)]
+    for p in empty:
+        p.write_text("")
+    short = [tmp_path / f"s{i}.fa" for i in range(3)]
+    for i, p in enumerate(short):
+        p.write_text(f">r{i}\nACGTACGT\n>q{i}\nNNNN\n")
+    monkeypatch.setenv("SEQWIN_DEVICES", "0,0,0")
+    for paths in (empty, short, empty + short):
+        kmers, nodes, edges, offs, ids = _build(paths, 21, 200, n_cpu=2)
+        assert len(kmers) == 0 and len(nodes) == 0 and len(edges) == 0
+        exp = oracle.build(paths, 21, 200)
+        assert np.array_equal(offs, exp[3]) and [tuple(t) for t in ids] == [tuple(t) for t in exp[4]]
+    one = tmp_path / "one.fa"
+    one.write_text(">a\n" + "ACGGTCA" * 200 + "\n")                       # all minimizers come from one of the shards
+    got = _build(empty + [one] + short, 7, 5, n_cpu=2)
+    exp = oracle.build(empty + [one] + short, 7, 5)
+    assert_graph_equal(got, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])), [list(t) for t in exp[4]])
+
+
 def test_seqwin_devices_is_validated(smoke_paths, monkeypatch):
     for bad in ("0,99", "zero", "0;1", "-1,0"):
         monkeypatch.setenv("SEQWIN_DEVICES", bad)
