@@ -453,6 +453,19 @@ Resident &resident()
     static Resident *r = new Resident;   // leaked on purpose (see pool())
     return *r;
 }
+// The same for a graph built over several devices (SEQWIN_DEVICES): its slices stay on their devices, and sw_get_penalty scores
+// every slice where it lies -- one host thread per slice -- when the caller's arrays still are the exported ones.  (Uploading
+// 9 GB of kmers and nodes of a 15 000-genome graph to one device from pageable memory would cost seconds.)
+struct ResidentMulti {
+    std::mutex mu;
+    std::unique_ptr<MultiGraph> mg;
+    uint64_t n_kmers = 0, n_nodes = 0, kmer_sum = 0, node_sum = 0, penalty_hits = 0;
+};
+ResidentMulti &resident_multi()
+{
+    static ResidentMulti *r = new ResidentMulti;
+    return *r;
+}
 
 // the sums of k_identity (index.hip) over host arrays, on n_threads threads
 }  // namespace
@@ -1401,6 +1414,11 @@ int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t km
             std::lock_guard<std::mutex> lock(r.mu);
             r.ix.reset();
         }
+        {
+            ResidentMulti &rm = resident_multi();
+            std::lock_guard<std::mutex> lock(rm.mu);
+            rm.mg.reset();
+        }
         std::unique_ptr<sw_graph> g(new sw_graph);
         double ingest_ms = 0, device_ms = 0;
         // SEQWIN_AMD_LOWMEM_CHUNK_MBP: bases (in Mbp) per chunk of a low-memory build (default 4096: ~1 GiB packed);
@@ -1524,6 +1542,22 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
                 no += sl->n_nodes;
                 eo += sl->n_edges;
             }
+            if (kmers && nodes && ix.n_kmers && !getenv("SEQWIN_AMD_NO_RESIDENT")) {   // identity of the whole from the slices' shares
+                GraphHost &hm = const_cast<GraphHost &>(h);
+                uint64_t kb = 0, nb = 0, sum[2] = {0, 0};
+                for (auto &sl : h.multi->slices) {
+                    SW_HIP(hipSetDevice(sl->device));
+                    uint64_t part[2];
+                    device_identity(*sl, 0, part, kb, nb);
+                    sum[0] += part[0];
+                    sum[1] += part[1];
+                    kb += sl->n_kmers;
+                    nb += sl->n_nodes;
+                }
+                hm.identity[0] = sum[0];
+                hm.identity[1] = sum[1];
+                hm.exported = true;
+            }
             SW_HIP(hipSetDevice(home));
             memcpy(record_offsets, h.record_offsets.data(), h.record_offsets.size() * 4);
             if (!h.ids_blob.empty()) memcpy(ids_blob, h.ids_blob.data(), h.ids_blob.size());
@@ -1548,6 +1582,22 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
 
 void sw_graph_free(sw_graph *g)
 {
+    if (g && g->g.exported && g->g.multi) {   // a multi-device graph: its slices stay on their devices for sw_get_penalty
+        ResidentMulti &rm = resident_multi();
+        std::lock_guard<std::mutex> lock(rm.mu);
+        rm.mg = std::move(g->g.multi);
+        rm.n_kmers = rm.n_nodes = 0;
+        for (auto &sl : rm.mg->slices) {
+            sl->edges.release();              // (get_penalty reads kmers and nodes only)
+            sl->n_edges = 0;
+            rm.n_kmers += sl->n_kmers;
+            rm.n_nodes += sl->n_nodes;
+        }
+        rm.kmer_sum = g->g.identity[0];
+        rm.node_sum = g->g.identity[1];
+        delete g;
+        return;
+    }
     if (g && g->g.exported) {   // the exported index stays resident for the get_penalty / filter_kmers calls that follow
         Resident &r = resident();
         std::lock_guard<std::mutex> lock(r.mu);
@@ -1581,12 +1631,23 @@ void sw_resident_stats(uint64_t *out)
     out[0] = r.ix ? r.ix->n_kmers : 0;
     out[1] = r.penalty_hits;
     out[2] = r.filter_hits;
+    {
+        ResidentMulti &rm = resident_multi();
+        std::lock_guard<std::mutex> mlock(rm.mu);
+        if (rm.mg) out[0] += rm.n_kmers;
+        out[1] += rm.penalty_hits;
+    }
 }
 
 void sw_pool_trim(void) { dev_pool_trim(); }
 
 void sw_release_resident(void)
 {
+    {
+        ResidentMulti &rm = resident_multi();
+        std::lock_guard<std::mutex> lock(rm.mu);
+        rm.mg.reset();
+    }
     Resident &r = resident();
     std::lock_guard<std::mutex> lock(r.mu);
     r.ix.reset();
@@ -1618,6 +1679,57 @@ int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint6
         DevArray<uint8_t> d_tar(n_assemblies);
         if (n_records) SW_HIP(hipMemcpy(d_rec_asm.p, rec_asm.data(), (size_t)n_records * 4, hipMemcpyHostToDevice));
         SW_HIP(hipMemcpy(d_tar.p, is_targets, n_assemblies, hipMemcpyHostToDevice));
+        {   // a graph built over several devices whose slices are still where they were built: score every slice in place
+            ResidentMulti &rm = resident_multi();
+            std::unique_lock<std::mutex> mlock(rm.mu);
+            if (rm.mg && rm.n_kmers == n_kmers && rm.n_nodes == n_nodes) {
+                uint64_t id[2];
+                host_identity(kmers, n_kmers, nodes, n_nodes, (unsigned)std::min<uint64_t>(std::max<uint64_t>(n_cpu, 1), 64), id);
+                if (id[0] == rm.kmer_sum && id[1] == rm.node_sum) {
+                    MultiGraph &mg = *rm.mg;
+                    const size_t S = mg.slices.size();
+                    std::vector<uint64_t> kb(S + 1, 0), nbv(S + 1, 0), errs(S, 0);
+                    for (size_t q = 0; q < S; ++q) {
+                        kb[q + 1] = kb[q] + mg.slices[q]->n_kmers;
+                        nbv[q + 1] = nbv[q] + mg.slices[q]->n_nodes;
+                    }
+                    int home = 0;
+                    SW_HIP(hipGetDevice(&home));
+                    std::mutex emu;
+                    std::exception_ptr eptr;
+                    auto work = [&](size_t q) {
+                        try {
+                            sw_index &sl = *mg.slices[q];
+                            SW_HIP(hipSetDevice(sl.device));
+                            if (sl.n_nodes) {
+                                DevArray<uint32_t> ra(n_records);
+                                DevArray<uint8_t> tg(n_assemblies);
+                                if (n_records) SW_HIP(hipMemcpy(ra.p, rec_asm.data(), (size_t)n_records * 4, hipMemcpyHostToDevice));
+                                SW_HIP(hipMemcpy(tg.p, is_targets, n_assemblies, hipMemcpyHostToDevice));
+                                slice_get_penalty(sl, kb[q], ra.p, n_records, tg.p, n_tar, n_neg, 0, &errs[q]);
+                                SW_HIP(hipMemcpy(nodes + nbv[q], sl.nodes.p, sl.n_nodes * sizeof(sw_node), hipMemcpyDeviceToHost));
+                            }
+                        } catch (...) {
+                            std::lock_guard<std::mutex> g(emu);
+                            if (!eptr) eptr = std::current_exception();
+                        }
+                    };
+                    std::vector<std::thread> th;
+                    for (size_t q = 1; q < S; ++q) th.emplace_back(work, q);
+                    if (S) work(0);
+                    for (auto &t : th) t.join();
+                    SW_HIP(hipSetDevice(home));
+                    if (eptr) std::rethrow_exception(eptr);
+                    uint64_t err = 0;
+                    for (uint64_t e : errs) err |= e;
+                    if (err & 1) raise(SW_ERR_VALUE, "node range is outside kmers");
+                    if (err & 2) raise(SW_ERR_VALUE, "record_idx is outside record_offsets range");
+                    if (err & 4) raise(SW_ERR_VALUE, "record_idx must be nondecreasing within each node range");
+                    ++rm.penalty_hits;
+                    return;
+                }
+            }
+        }
         // the arrays of the last sw_build are usually still in HBM (Resident): use them when the caller's are the same
         Resident &res = resident();
         ResidentLock rlock(res.mu);

@@ -286,7 +286,9 @@ void device_filter_kmers(const sw_kmer *d_kmers, uint64_t n_kmers, const sw_node
                          const uint64_t *d_used_sorted, uint64_t n_used, hipStream_t stream,
                          DevArray<sw_kmer> &kmers_out, DevArray<sw_node> &nodes_out, uint64_t *n_kmers_out,
                          uint64_t *n_nodes_out);
-void device_identity(const sw_index &ix, hipStream_t stream, uint64_t *sums2);
+void device_identity(const sw_index &ix, hipStream_t stream, uint64_t *sums2, uint64_t kbase = 0, uint64_t nbase = 0);
+void slice_get_penalty(sw_index &ix, uint64_t kmer_base, const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,
+                       uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, uint64_t *err_flags_host);
 void device_checksums(const sw_index &ix, hipStream_t stream, uint64_t *sums3, uint64_t kbase = 0, uint64_t nbase = 0,
                       uint64_t ebase = 0);
 void index_threshold_sums(const sw_index &ix, hipStream_t stream, uint64_t *sums3);

@@ -2681,6 +2681,22 @@ void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nod
     *err_flags_host = penalty_finish(job);
 }
 
+// get_penalty on ONE slice of a multi-device graph: the slice's nodes hold global occurrence ranges [kmer_base + ...), its kmers
+// are local -- the ranges are taken down to the slice, scored, and put back.
+void slice_get_penalty(sw_index &ix, uint64_t kmer_base, const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,
+                       uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, uint64_t *err_flags_host)
+{
+    *err_flags_host = 0;
+    if (!ix.n_nodes) return;
+    hipLaunchKernelGGL(k_rebase_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, (uint64_t)0 - kmer_base);
+    SW_HIP(hipGetLastError());
+    device_get_penalty(ix.kmers.p, ix.n_kmers, ix.nodes.p, ix.n_nodes, d_rec_asm, n_records, d_is_target, n_targets, n_non_targets,
+                       stream, err_flags_host);
+    hipLaunchKernelGGL(k_rebase_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, kmer_base);
+    SW_HIP(hipGetLastError());
+    SW_HIP(hipStreamSynchronize(stream));
+}
+
 void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assemblies, OrderedOcc &occ,
                  const uint8_t *d_is_target, uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, sw_index &ix)
 {
@@ -3625,13 +3641,14 @@ void index_verify(const sw_index &ix, uint64_t n_assemblies, bool scored, hipStr
 
 // identity of an index's immutable part (kmers; nodes' hash / start / stop): what sw_get_penalty compares a caller's host
 // arrays with before it reuses the still-resident index of the last sw_build (api.hip: host_identity is the same sums)
-__global__ void k_identity(const sw_kmer *kmers, uint64_t nk, const sw_node *nodes, uint64_t nn, unsigned long long *sums)
+__global__ void k_identity(const sw_kmer *kmers, uint64_t nk, const sw_node *nodes, uint64_t nn, unsigned long long *sums,
+                           uint64_t kbase, uint64_t nbase)   // (bases: the slice's place in the whole, multi-device graphs)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t G = 0x9E3779B97F4A7C15ULL;
     uint64_t a = 0, b = 0;
-    if (i < nk) a = mix64(i * G + ((uint64_t)kmers[i].pos | ((uint64_t)kmers[i].record_idx << 32)));
-    if (i < nn) b = mix64(i * G + nodes[i].hash) + mix64(nodes[i].start * 3 + 1) + mix64(nodes[i].stop * 5 + 2);
+    if (i < nk) a = mix64((kbase + i) * G + ((uint64_t)kmers[i].pos | ((uint64_t)kmers[i].record_idx << 32)));
+    if (i < nn) b = mix64((nbase + i) * G + nodes[i].hash) + mix64(nodes[i].start * 3 + 1) + mix64(nodes[i].stop * 5 + 2);
     for (int d = 32; d; d >>= 1) {
         a += __shfl_down(a, d, 64);
         b += __shfl_down(b, d, 64);
@@ -3642,13 +3659,14 @@ __global__ void k_identity(const sw_kmer *kmers, uint64_t nk, const sw_node *nod
     }
 }
 
-void device_identity(const sw_index &ix, hipStream_t stream, uint64_t *sums2)
+void device_identity(const sw_index &ix, hipStream_t stream, uint64_t *sums2, uint64_t kbase, uint64_t nbase)
 {
     DevArray<unsigned long long> sums(2);
     SW_HIP(hipMemsetAsync(sums.p, 0, 16, stream));
     const uint64_t n = std::max(ix.n_kmers, ix.n_nodes);
     if (n) {
-        hipLaunchKernelGGL(k_identity, dim3(blocks_for(n)), dim3(TPB), 0, stream, ix.kmers.p, ix.n_kmers, ix.nodes.p, ix.n_nodes, sums.p);
+        hipLaunchKernelGGL(k_identity, dim3(blocks_for(n)), dim3(TPB), 0, stream, ix.kmers.p, ix.n_kmers, ix.nodes.p, ix.n_nodes, sums.p,
+                           kbase, nbase);
         SW_HIP(hipGetLastError());
     }
     unsigned long long h[2];

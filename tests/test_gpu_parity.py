@@ -908,11 +908,31 @@ def test_multi_device_build_equals_single_device(tmp_path, smoke_paths, monkeypa
         assert one[4] == many[4]
         exp = oracle.build(paths, k, w)
         assert_graph_equal(many, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])), [list(t) for t in exp[4]])
-        if len(many[1]) and len(paths) >= 2:     # the calls Seqwin makes next run on the (host) arrays as usual
+        if len(many[1]) and len(paths) >= 2:
+            # the call Seqwin makes next: the slices are still on their devices and are scored there (no upload) ...
             tar = [i % 2 == 0 for i in range(len(paths))]
             oracle.get_penalty(exp[0], exp[1], exp[3], tar)
+            hits = _resident_stats()[1]
             _get_penalty(many[0], many[1], many[3], tar)
             assert np.array_equal(many[1], exp[1])
+            assert _resident_stats()[1] == hits + 1, "the resident slices did not serve get_penalty"
+            # ... again with other targets (the resident nodes now hold counts; the identity covers hash / start / stop) ...
+            tar2 = [i % 3 == 0 for i in range(len(paths))]
+            if any(tar2) and not all(tar2):
+                exp2 = [a.copy() for a in exp[:2]]
+                oracle.get_penalty(exp2[0], exp2[1], exp[3], tar2)
+                _get_penalty(many[0], many[1], many[3], tar2)
+                assert np.array_equal(many[1], exp2[1]) and _resident_stats()[1] == hits + 2
+            # ... and once the slices are gone: the ordinary upload route, same result
+            from seqwin_amd._lib import lib as _l
+            _l.sw_release_resident.restype = None
+            _l.sw_release_resident()
+            n2 = many[1].copy()
+            n2["n_tar"] = 0
+            n2["n_neg"] = 0
+            n2["penalty"] = 0.0
+            _get_penalty(many[0], n2, many[3], tar)
+            assert np.array_equal(n2, exp[1]) and _resident_stats()[1] == hits + (2 if any(tar2) and not all(tar2) else 1)
 
 
 def test_multi_device_build_on_a_synthetic_job(tmp_path, monkeypatch):
