@@ -11,8 +11,8 @@
 // run-length pass yields `nodes`.  Edges are sorted as (rank_lo, rank_hi) pairs of dense node ranks
 // (rank order == hash order), stably, so equal pairs stay in assembly order and the number of
 // assemblies containing a pair is a count of assembly changes inside its run.
-// Device-wide sort / scan come from rocPRIM (a plain library primitive); every kernel in this file
-// is domain-specific glue around them.
+// The large sorts are radix.hip's (this library's onesweep passes: pairs for the nodes, keys for the edges and the unsort); rocPRIM
+// supplies the small ones, the prefix sums over block counts, and -- behind knobs -- the library forms of the large primitives.
 #include <cstdlib>
 #include <cstring>  // rocprim's texture iterator needs ::memset declared first
 #include <map>
@@ -1017,6 +1017,7 @@ struct RankHash {
 };
 
 // one thread per run of equal wide keys (see k_edges_runs)
+template <bool RUNS = false>
 __global__ void k_edges_runs_wide(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ usum, uint64_t n_edges,
                                   unsigned hi_bits, uint64_t lo_base, const RankHash H, sw_edge *__restrict__ edges)
 {
@@ -1027,7 +1028,7 @@ __global__ void k_edges_runs_wide(const uint64_t *__restrict__ ukeys, const uint
     const uint64_t v = hi_bits >= 64 ? key : (key & ((1ull << hi_bits) - 1ull));
     edges[e].first = H(u);
     edges[e].second = H(v);
-    edges[e].weight = usum[e];
+    edges[e].weight = RUNS ? usum[e + 1] - usum[e] : usum[e];
 }
 
 struct RepeatFlag {   // 1 where a sorted candidate row repeats the (pair, assembly) of its predecessor
@@ -1070,7 +1071,108 @@ __global__ void k_drop_sentinel_run(const uint64_t *__restrict__ ukeys, uint64_t
     if (n && ukeys[n - 1] == sentinel) *count = n - 1;   // the run of record boundaries (all keys == sentinel) is no edge
 }
 
+// ---- run lengths of the sorted pair keys (r04; rocprim::run_length_encode before) ------------------------------------------------
+// One streaming pass: a thread holds eight consecutive keys (one 64-byte load), a key that differs from its predecessor heads a
+// run; the number of heads before a tile comes from a chained look-back over per-tile totals (tiles numbered by a ticket, so a
+// predecessor is always running -- as in k_nodes); every head writes its key and its POSITION: the length of run e is
+// start[e + 1] - start[e] (start[n_runs] = m is written by the last tile), taken by the kernel that turns runs into edges.
+constexpr int RLE_THREADS = 1024, RLE_ITEMS = 8;
+constexpr uint32_t RLE_TILE = RLE_THREADS * RLE_ITEMS;
+__global__ __launch_bounds__(RLE_THREADS) void k_rle_keys(const uint64_t *__restrict__ keys, uint64_t m, uint64_t *__restrict__ ukeys,
+                                                           uint32_t *__restrict__ ustart, unsigned long long *__restrict__ tile_state,
+                                                           uint32_t *__restrict__ ticket, uint32_t *__restrict__ n_runs_out)
+{
+    __shared__ uint32_t s_tile, s_excl, s_wave[RLE_THREADS / 64];
+    __shared__ uint64_t s_last[RLE_THREADS / 64];        // last key of every wave (the predecessor of the next wave's first)
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    // wave w takes keys [t0 + w * 512, + 512), item j of lane l the key w * 512 + j * 64 + l: every load is 512 contiguous bytes,
+    // and a key's predecessor sits in the lane below (lane 0: lane 63 of the item before)
+    const uint64_t t0 = (uint64_t)tile * RLE_TILE, w0 = t0 + (uint64_t)wave * (64 * RLE_ITEMS);
+    uint64_t k[RLE_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RLE_ITEMS; ++j) {
+        const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+        k[j] = i < m ? keys[i] : 0ull;
+    }
+    if (lane == 63) s_last[wave] = k[RLE_ITEMS - 1];
+    __syncthreads();
+    uint64_t carry = wave ? s_last[wave - 1] : (t0 ? keys[t0 - 1] : 0ull);   // the key before the wave's first (unused at position 0)
+    uint32_t cnt[RLE_ITEMS], below[RLE_ITEMS], total_w = 0, headm = 0;
+#pragma unroll
+    for (int j = 0; j < RLE_ITEMS; ++j) {
+        const uint64_t i = w0 + (uint64_t)j * 64 + lane;
+        uint64_t prev = __shfl_up(k[j], 1, 64);
+        if (lane == 0) prev = carry;
+        const bool head = i < m && (i == 0 || k[j] != prev);
+        const unsigned long long b = __ballot(head);
+        below[j] = total_w + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));   // heads of the wave before this key
+        cnt[j] = (uint32_t)__popcll(b);
+        total_w += cnt[j];
+        if (head) headm |= 1u << j;
+        carry = __shfl(k[j], 63, 64);
+    }
+    if (lane == 0) s_wave[wave] = total_w;
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t wc = lane < RLE_THREADS / 64 ? s_wave[lane] : 0u;
+        uint32_t winc = wc;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(winc, d, 64);
+            if (lane >= d) winc += up;
+        }
+        const uint32_t total = __shfl(winc, RLE_THREADS / 64 - 1, 64);
+        if (lane < RLE_THREADS / 64) s_wave[lane] = winc - wc;            // exclusive offsets of the waves
+        if (lane == 0)
+            __hip_atomic_store(&tile_state[tile], (tile == 0 ? TS_INC : TS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        if (tile) {
+            int64_t look = (int64_t)tile - 1;
+            for (;;) {
+                const int64_t idx = look - lane;   // lane 0 reads the nearest predecessor
+                const unsigned long long st = idx >= 0 ? __hip_atomic_load(&tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                       : TS_INC;   // before the first tile: nothing
+                const unsigned long long inc = __ballot((st >> 62) == 2), none = __ballot((st >> 62) == 0);
+                const uint32_t first_inc = inc ? (uint32_t)__builtin_ctzll(inc) : 64u;
+                const unsigned long long needed = first_inc >= 63 ? ~0ull : ((2ull << first_inc) - 1ull);
+                if (none & needed) {   // a predecessor in reach has not published yet (it is running: tickets)
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                uint32_t v = (lane <= first_inc) ? (uint32_t)st : 0u;
+                for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
+                excl += v;
+                if (first_inc < 64) break;
+                look -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(&tile_state[tile], TS_INC | (unsigned long long)(excl + total), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_excl = excl;
+            if (t0 + RLE_TILE >= m) {            // the last tile: the number of runs, and the end of the last run
+                *n_runs_out = excl + total;
+                ustart[excl + total] = (uint32_t)m;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t base = s_excl + s_wave[wave];
+#pragma unroll
+    for (int j = 0; j < RLE_ITEMS; ++j)
+        if ((headm >> j) & 1u) {
+            ukeys[base + below[j]] = k[j];
+            ustart[base + below[j]] = (uint32_t)(w0 + (uint64_t)j * 64 + lane);
+        }
+    (void)cnt;
+}
+
 // one thread per run of equal pairs: pair = (ukeys >> pshift) & pmask, weight = distinct assemblies in the run
+// (RUNS: usum holds the START of every run and of the end, k_rle_keys: weight = the run's length)
+template <bool RUNS = false>
 __global__ void k_edges_runs(const uint64_t *__restrict__ ukeys, const uint32_t *__restrict__ usum, unsigned pshift, uint64_t pmask,
                              uint64_t n_edges, unsigned nb, const sw_node *__restrict__ nodes,
                              const uint64_t *__restrict__ rank_hash, sw_edge *__restrict__ edges)
@@ -1081,7 +1183,7 @@ __global__ void k_edges_runs(const uint64_t *__restrict__ ukeys, const uint32_t 
     const uint32_t u = (uint32_t)(pair >> nb), v = (uint32_t)(pair & ((1ull << nb) - 1ull));
     edges[e].first = rank_hash ? rank_hash[u] : nodes[u].hash;
     edges[e].second = rank_hash ? rank_hash[v] : nodes[v].hash;
-    edges[e].weight = usum[e];
+    edges[e].weight = RUNS ? usum[e + 1] - usum[e] : usum[e];
 }
 
 // ---- tuple-exchange form of the multi-GPU build (dist.py) ---------------------------------------------
@@ -2512,13 +2614,13 @@ void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t 
         uint32_t n_edges = 0, failed = 0;
         SW_HIP(hipMemcpyAsync(&n_edges, ucount.p, 4, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipMemcpyAsync(&failed, sort_fail.p, 4, hipMemcpyDeviceToHost, stream));
-        SW_HIP(hipStreamSynchronize(stream));   // (tmp is released here, after the pass has finished)
+        SW_HIP(hipStreamSynchronize(stream));   // (the pass's scratch is released after this)
         check_sort_failed(failed);
         ix.n_edges = n_edges;
     }
     if (ix.n_edges == 0) return;
     ix.edges.alloc(ix.n_edges);
-    hipLaunchKernelGGL(k_edges_runs, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, usum.p, pshift, pmask,
+    hipLaunchKernelGGL(k_edges_runs<false>, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, usum.p, pshift, pmask,
                        (uint64_t)ix.n_edges, nb, ix.nodes.p, rank_hash, ix.edges.p);
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));
@@ -2564,13 +2666,29 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
     RepairState rep;
     if (low_bits) enqueue_repair(EdgeKeyView{keys, low_bits}, ~0ull, m, nullptr, 0, rep, stream);
     DevArray<uint64_t> ukeys(m);
-    DevArray<uint32_t> ucnt(m), ucount(1);
+    DevArray<uint32_t> ucnt(m + 1), ucount(1);
     unsigned long long n_cand = host_n_cand;
+    // run lengths by this library's streaming pass (k_rle_keys: ucnt then holds the START of every run, and m behind the last);
+    // SEQWIN_AMD_RLE=rocprim: rocprim::run_length_encode (ucnt = the lengths) -- A/B, and what rounds 1-3 ran
+    const char *rle_env = getenv("SEQWIN_AMD_RLE");
+    const bool own_rle = !(rle_env && !strcmp(rle_env, "rocprim"));
     for (int attempt = 0;; ++attempt) {
-        size_t tmp_bytes = 0;
-        SW_HIP(rocprim::run_length_encode(nullptr, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
-        DevArray<unsigned char> tmp(tmp_bytes);
-        SW_HIP(rocprim::run_length_encode(tmp.p, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
+        if (own_rle) {
+            const unsigned blocks = (unsigned)((m + RLE_TILE - 1) / RLE_TILE);
+            DevArray<unsigned long long> tile_state(blocks);
+            DevArray<uint32_t> ticket(1);
+            SW_HIP(hipMemsetAsync(tile_state.p, 0, (size_t)blocks * 8, stream));
+            SW_HIP(hipMemsetAsync(ticket.p, 0, 4, stream));
+            hipLaunchKernelGGL(k_rle_keys, dim3(blocks), dim3(RLE_THREADS), 0, stream, (const uint64_t *)keys, m, ukeys.p, ucnt.p, tile_state.p,
+                               ticket.p, ucount.p);
+            SW_HIP(hipGetLastError());
+        } else {
+            size_t tmp_bytes = 0;
+            SW_HIP(rocprim::run_length_encode(nullptr, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
+            DevArray<unsigned char> tmp(tmp_bytes);
+            SW_HIP(rocprim::run_length_encode(tmp.p, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
+            SW_HIP(hipStreamSynchronize(stream));   // (tmp is released here)
+        }
         hipLaunchKernelGGL(k_drop_sentinel_run, dim3(1), dim3(1), 0, stream, ukeys.p, sentinel, ucount.p);
         SW_HIP(hipGetLastError());
         uint32_t n_edges = 0, failed = 0, left = 0;
@@ -2578,7 +2696,7 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
         SW_HIP(hipMemcpyAsync(&failed, sort_fail.p, 4, hipMemcpyDeviceToHost, stream));
         if (low_bits && attempt == 0) SW_HIP(hipMemcpyAsync(&left, rep.status.p, 4, hipMemcpyDeviceToHost, stream));
         if (d_n_cand) SW_HIP(hipMemcpyAsync(&n_cand, d_n_cand, 8, hipMemcpyDeviceToHost, stream));
-        SW_HIP(hipStreamSynchronize(stream));   // (tmp is released here, after the pass has finished)
+        SW_HIP(hipStreamSynchronize(stream));   // (the pass's scratch is released after this)
         check_sort_failed(failed);
         if (low_bits && attempt == 0 && getenv("SEQWIN_AMD_DEBUG_EDGE_REPAIR")) {
             unsigned long long nd[2] = {0, 0};
@@ -2598,11 +2716,17 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
     if (ix.n_edges == 0) return;
     ix.edges.alloc(ix.n_edges);
     if (rank_hash_ready) SW_HIP(hipStreamWaitEvent(stream, rank_hash_ready, 0));   // (rank_hash is written on another stream)
-    if (wide)
-        hipLaunchKernelGGL(k_edges_runs_wide, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, ucnt.p, (uint64_t)ix.n_edges,
+    if (wide && own_rle)
+        hipLaunchKernelGGL(k_edges_runs_wide<true>, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, ucnt.p, (uint64_t)ix.n_edges,
                            wide->hi_bits, wide->lo_base, wide->hash, ix.edges.p);
+    else if (wide)
+        hipLaunchKernelGGL(k_edges_runs_wide<false>, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, ucnt.p, (uint64_t)ix.n_edges,
+                           wide->hi_bits, wide->lo_base, wide->hash, ix.edges.p);
+    else if (own_rle)
+        hipLaunchKernelGGL(k_edges_runs<true>, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, ucnt.p, 0u, ~0ull,
+                           (uint64_t)ix.n_edges, nb, ix.nodes.p, rank_hash, ix.edges.p);
     else
-        hipLaunchKernelGGL(k_edges_runs, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, ucnt.p, 0u, ~0ull,
+        hipLaunchKernelGGL(k_edges_runs<false>, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, ucnt.p, 0u, ~0ull,
                            (uint64_t)ix.n_edges, nb, ix.nodes.p, rank_hash, ix.edges.p);
     SW_HIP(hipGetLastError());
     if (n_cand) {
@@ -2664,7 +2788,7 @@ void edges_from_adjacency(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, ui
     }
     if (ix.n_edges == 0) return;
     ix.edges.alloc(ix.n_edges);
-    hipLaunchKernelGGL(k_edges_runs, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, usum.p, 0u, ~0ull,
+    hipLaunchKernelGGL(k_edges_runs<false>, dim3(blocks_for(ix.n_edges)), dim3(TPB), 0, stream, ukeys.p, usum.p, 0u, ~0ull,
                        (uint64_t)ix.n_edges, nb, ix.nodes.p, rank_hash, ix.edges.p);
     SW_HIP(hipGetLastError());
     SW_HIP(hipStreamSynchronize(stream));

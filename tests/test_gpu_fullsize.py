@@ -109,6 +109,7 @@ KNOBS = [
     {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_RADIX_RANK": "ballot"},         # radix.hip's passes ranking by ballots (pairs then go to rocPRIM)
     {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_PAIR_SORT": "rocprim"},         # keys-only sorts own, node pairs by rocPRIM
     {"SEQWIN_AMD_SORT": "rocprim", "SEQWIN_AMD_PAIR_SORT": "own"},         # ... and the other way round
+    {"SEQWIN_AMD_RLE": "rocprim"},                                         # run lengths by rocprim::run_length_encode (default: k_rle_keys)
     {"SEQWIN_AMD_WINDOW_SPLIT": "8,4"},                                    # windows above 8 as if above SW_MAX_WINDOW: sketch with w' = 4, select
     {"SEQWIN_AMD_WINDOW_SPLIT": "100,64", "SEQWIN_AMD_RANKS": "table"},
 ]
