@@ -61,8 +61,6 @@ def write_fasta_sample(batch, n, tmp):
 def write_fasta_fast(batch, n, directory, n_cpu):
     """First n assemblies of a device batch as FASTA files, decoded by the library's host threads (sw_batch_write_fasta)
     -> (paths, bases).  (write_fasta_sample above is the per-record Python form the tests use on small samples.)"""
-    import ctypes
-
     from seqwin_amd._lib import c_u64, check, lib
     check(lib.sw_batch_write_fasta(batch._h, c_u64(0), c_u64(n), os.fsencode(directory), c_u64(n_cpu), c_u64(80)))
     offs = batch.record_offsets()

@@ -461,7 +461,15 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
     };
 
     std::vector<std::thread> th;
-    for (uint32_t p = 0; p < P; ++p) th.emplace_back(worker, p);
+    try {
+        for (uint32_t p = 0; p < P; ++p) th.emplace_back(worker, p);
+    } catch (...) {              // a thread could not be started: the ones that run must not wait for it for ever
+        {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (!err) err = std::current_exception();
+        }
+        meet.fail();
+    }
     for (auto &t : th) t.join();
     SW_HIP(hipSetDevice(home));
     if (err) std::rethrow_exception(err);
