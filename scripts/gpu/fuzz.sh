@@ -1,6 +1,6 @@
 # differential fuzz campaign on the GPU box: five processes share the card (six make four of them crawl).
-# usage (through gpurun): bash scripts/gpu/fuzz.sh <tag> [seconds] [gz|multi]      gz: the two device-gzip-ingest campaigns instead;
-#                                                                                 multi: sw_build over logical devices (SEQWIN_DEVICES) instead
+# usage (through gpurun): bash scripts/gpu/fuzz.sh <tag> [seconds] [gz|multi|stage]      gz: the two device-gzip-ingest campaigns instead;
+#                                                                                 multi: sw_build over logical devices (SEQWIN_DEVICES) instead; stage: the node sort reading the sketch stage (SEQWIN_AMD_ORDER=stage)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O; cd $R; T=${2:-240}
 if [ "$3" = "gz" ]; then
 FUZZ_GZ=1 SEQWIN_AMD_DEVICE_INFLATE=1 python3 tests/tools/fuzz_gpu.py $T 26 > $O/fuzz_device_gz.log 2>&1 &
@@ -10,6 +10,11 @@ SEQWIN_DEVICES=0,0 python3 tests/tools/fuzz_gpu.py $T 31 > $O/fuzz_devices2.log 
 SEQWIN_DEVICES=0,0,0 SEQWIN_DIST_HASH_ROUTE=requests SEQWIN_AMD_SORT=own python3 tests/tools/fuzz_gpu.py $T 32 > $O/fuzz_devices3_requests_own.log 2>&1 &
 SEQWIN_DEVICES=0,0,0,0,0 SEQWIN_AMD_RC=3 SEQWIN_AMD_SLOT_CAP=3 python3 tests/tools/fuzz_gpu.py $T 33 > $O/fuzz_devices5_rc3.log 2>&1 &
 SEQWIN_AMD_SORT=own SEQWIN_AMD_RADIX_RANK=ballot python3 tests/tools/fuzz_gpu.py $T 34 > $O/fuzz_own_ballot.log 2>&1 &
+elif [ "$3" = "stage" ]; then
+SEQWIN_AMD_ORDER=stage python3 tests/tools/fuzz_gpu.py $T 41 > $O/fuzz_stage.log 2>&1 &
+SEQWIN_AMD_ORDER=stage SEQWIN_AMD_RC=3 SEQWIN_AMD_SLOT_CAP=3 python3 tests/tools/fuzz_gpu.py $T 42 > $O/fuzz_stage_rc3.log 2>&1 &
+SEQWIN_AMD_ORDER=stage SEQWIN_AMD_SORT=own SEQWIN_AMD_UNSORT_DIRECT=4 SEQWIN_AMD_WINDOW_SPLIT=8,4 python3 tests/tools/fuzz_gpu.py $T 43 > $O/fuzz_stage_own.log 2>&1 &
+SEQWIN_AMD_ORDER=stage SEQWIN_AMD_SKETCH=nosmall SEQWIN_AMD_NO_PACKED_EDGES=1 SEQWIN_AMD_CHECK_ORDER=1 python3 tests/tools/fuzz_gpu.py $T 44 > $O/fuzz_stage_knobs.log 2>&1 &
 else
 python3 tests/tools/fuzz_gpu.py $T 21 > $O/fuzz_default.log 2>&1 &
 SEQWIN_AMD_SORT=own SEQWIN_AMD_EDGE_SKIP_PASSES=2 SEQWIN_AMD_UNSORT_DIRECT=4 SEQWIN_AMD_WINDOW_SPLIT=8,4 python3 tests/tools/fuzz_gpu.py $T 22 > $O/fuzz_unsort_winsplit.log 2>&1 &

@@ -548,8 +548,8 @@ void do_index_build(sw_batch &b, uint64_t k, uint64_t w, const uint8_t *is_targe
     run_sketch(b, plan, stream, sk, &sketch_ms);
     SW_HIP(hipEventRecord(e1, stream));
     OrderedOcc occ;
-    order_tuples(sk, plan, stream, occ, true);
     const uint64_t launches = sk.launches, ovf_tiles = sk.n_ovf_tiles;
+    order_tuples(sk, plan, stream, occ, true, true);   // (may take the stage along: the node sort then reads it itself)
     sk = SketchOut();
     SW_HIP(hipEventRecord(e2, stream));
     ix.device = b.device;

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <memory>
 #include <string>
 
@@ -240,8 +241,26 @@ struct alignas(16) OccPay {
 // radix.hip: stable sort of (key32, OccPay) pairs by key bits [0, end_bit), end_bit in {8, 16, 24, 32}; double buffers
 int radix_rank_mode();          // how radix.hip ranks keys inside a wave on the current device: 1 LDS atomics, 0 ballots (runs the self-check once)
 bool radix_pairs_available();   // false on a device that does not pass the LDS-atomic ranking self-check (rocPRIM sorts the pairs then)
+// The sketch stage as the input of the sort's first pass (no ordered copy in between: the pass does what k_order does on
+// the way in).  Dense index g = place of a tuple in (record_idx, pos) order; tile T holds [dst_off[T], dst_off[T] + tile_count[T]).
+constexpr uint32_t STAGE_WIN = 32;                 // tiles from the first of a wave's 448 tuples on that the pass resolves without a search
+constexpr uint32_t STAGE_ROW = STAGE_WIN + 9;      // 8-byte words of a directory row (radix.hip, k_rs_stage_prepare)
+constexpr uint32_t STAGE_PAD = 1;                  // dst_off has n_tiles + STAGE_PAD entries; the pad entry holds n
+struct StageSource {
+    const uint64_t *stage_hash, *stage_kmer;       // canonical hash (extend_hashes is applied by the reader), pos | record_idx << 32
+    const uint32_t *tile_count;
+    const uint64_t *tile_offset;                   // where a tile's tuples lie in the stage
+    const uint64_t *dst_off;                       // exclusive sum of tile_count (padded, see above)
+    uint32_t n_tiles;
+    uint64_t mult;                                 // extend_hashes multiplier of the plan
+    uint32_t *rec_out;                             // record_idx of every tuple, dense order (the adjacency reads it)
+    const unsigned long long *chunk_dir;           // (filled in by radix_sort_pairs32) one row per 448 dense indices
+};
+// src: pass 0 reads the stage and writes (keys_alt, vals_alt); after_first() runs once that pass is enqueued and must leave
+// (keys, vals) pointing at n-element buffers (the stage may be released there: the pool is stream-ordered)
 void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
-                        hipStream_t stream, uint32_t *d_fail);
+                        hipStream_t stream, uint32_t *d_fail, const StageSource *src = nullptr,
+                        const std::function<void()> &after_first = std::function<void()>());
 // index.hip: radix.hip's pair passes or rocPRIM's (small inputs, SEQWIN_AMD_SORT / SEQWIN_AMD_PAIR_SORT); d_fail as for sort_keys64
 void sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
                   hipStream_t stream, uint32_t *d_fail);
@@ -257,6 +276,12 @@ struct OrderedOcc {
     DevArray<OccPay> pay;
     DevArray<uint32_t> rec;    // record_idx in (record_idx, pos) order
     DevArray<uint64_t> cand_rows;   // pairs form of the adjacency exchange: {pair key, assembly} of the candidate records, by owner
+    // staged index form: key32 / pay are not made; the node sort's first pass reads the sketch stage (StageSource) and writes rec
+    bool staged = false;
+    SketchOut stage;
+    DevArray<uint64_t> dst_off;
+    uint32_t stage_tiles = 0;
+    uint64_t stage_mult = 0;
     uint64_t n = 0;
     PartState *part = nullptr;
     OrderedOcc() = default;
@@ -266,13 +291,17 @@ struct OrderedOcc {
         if (this != &o) {
             hash = std::move(o.hash); kmer = std::move(o.kmer); key32 = std::move(o.key32); pay = std::move(o.pay);
             rec = std::move(o.rec); cand_rows = std::move(o.cand_rows); n = o.n; o.n = 0;
+            staged = o.staged; o.staged = false; stage = std::move(o.stage); dst_off = std::move(o.dst_off);
+            stage_tiles = o.stage_tiles; stage_mult = o.stage_mult;
             part_state_delete(part); part = o.part; o.part = nullptr;
         }
         return *this;
     }
     ~OrderedOcc() { part_state_delete(part); }
 };
-void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out, bool index_form = false);
+// take_stage (index form only): if the node sort can read the stage itself, `sk` is moved into `out` (out.staged) instead of
+// being copied into key32 / pay
+void order_tuples(SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out, bool index_form = false, bool take_stage = false);
 // index-form streams of consecutive assembly chunks -> one stream (chunk c's records follow rec_base[c] earlier ones);
 // the chunks are emptied
 void concat_occ(std::vector<OrderedOcc> &chunks, const std::vector<uint64_t> &rec_base, hipStream_t stream, OrderedOcc &out);

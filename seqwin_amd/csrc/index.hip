@@ -1985,6 +1985,8 @@ struct PaySort {
     uint32_t cap = 0, kmask = ~0u;
     uint64_t n = 0;
     DevArray<uint32_t> fail;           // radix.hip's passes: non-zero if one gave up waiting (read in settle_sort)
+    OrderedOcc *staged = nullptr;      // the occurrences still lie in the sketch stage (order_tuples, take_stage): key_a / pay_a are
+                                       // allocated by the sort once its first pass has read the stage, which is released there
 };
 
 // Phases 1 and 2 are enqueued without any host round trip; the caller must call sort_pay_settle() once the
@@ -2002,16 +2004,41 @@ void sort_pay(uint64_t n, hipStream_t stream, PaySort &o)
     o.pay_b.alloc(n);
     uint32_t *keys = o.key_a.p, *keys_alt = o.key_b.p;
     OccPay *vals = o.pay_a.p, *vals_alt = o.pay_b.p;
-    if (bits < 32) {   // test knob: the top `bits` bits rotated down to bit 0, sorted there, rotated back (no bit is lost)
-        hipLaunchKernelGGL(k_rot_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, n, bits);
-        SW_HIP(hipGetLastError());
-    }
-    o.fail.alloc(1);
-    SW_HIP(hipMemsetAsync(o.fail.p, 0, 4, stream));
-    sort_pairs32(keys, keys_alt, vals, vals_alt, n, bits, stream, o.fail.p);
-    if (bits < 32) {
-        hipLaunchKernelGGL(k_rot_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, n, 32 - bits);
-        SW_HIP(hipGetLastError());
+    if (o.staged) {   // (order_tuples made sure: 32 key bits, radix.hip's pair passes)
+        OrderedOcc &occ = *o.staged;
+        StageSource S{};
+        S.stage_hash = occ.stage.stage_hash.p;
+        S.stage_kmer = occ.stage.stage_kmer.p;
+        S.tile_count = occ.stage.tile_count.p;
+        S.tile_offset = occ.stage.tile_offset.p;
+        S.dst_off = occ.dst_off.p;
+        S.n_tiles = occ.stage_tiles;
+        S.mult = occ.stage_mult;
+        S.rec_out = occ.rec.p;
+        o.fail.alloc(1);
+        SW_HIP(hipMemsetAsync(o.fail.p, 0, 4, stream));
+        radix_sort_pairs32(keys, keys_alt, vals, vals_alt, n, 32, stream, o.fail.p, &S, [&] {
+            occ.stage = SketchOut();           // (stream-ordered pool: the blocks' next users follow the pass on this stream)
+            occ.dst_off.release();
+            occ.staged = false;
+            o.key_a.alloc(n);
+            o.pay_a.alloc(n);
+            keys = o.key_a.p;
+            vals = o.pay_a.p;
+        });
+        o.staged = nullptr;
+    } else {
+        if (bits < 32) {   // test knob: the top `bits` bits rotated down to bit 0, sorted there, rotated back (no bit is lost)
+            hipLaunchKernelGGL(k_rot_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, n, bits);
+            SW_HIP(hipGetLastError());
+        }
+        o.fail.alloc(1);
+        SW_HIP(hipMemsetAsync(o.fail.p, 0, 4, stream));
+        sort_pairs32(keys, keys_alt, vals, vals_alt, n, bits, stream, o.fail.p);
+        if (bits < 32) {
+            hipLaunchKernelGGL(k_rot_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, n, 32 - bits);
+            SW_HIP(hipGetLastError());
+        }
     }
     o.key32 = keys;
     o.pay = vals;
@@ -2412,12 +2439,43 @@ __global__ void k_lw_emit(const uint64_t *__restrict__ canon, const uint64_t *__
 
 }  // namespace
 
-void order_tuples(const SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out, bool index_form)
+// Staged index form: the node sort's first pass reads the stage (radix.hip, k_rs_pair_pass<true>), so the ordered copy
+// (k_order: 40 B per tuple, and the pass's own 20 B read of it) is never made.  Taken when that pass is this library's, the
+// tiles hold enough tuples for its tile window to cover a wave's share (STAGE_WIN), and nothing asks for the arrays themselves.
+// SEQWIN_AMD_ORDER=copy keeps k_order (A/B, tests).
+static bool stage_fits_sort(uint64_t n, uint32_t n_tiles)
+{
+    if (const char *e = getenv("SEQWIN_AMD_ORDER")) {
+        if (!strcmp(e, "copy")) return false;
+        if (!strcmp(e, "stage")) return n > 0 && radix_pairs_available() && !getenv("SEQWIN_AMD_SORT_KEYBITS");
+    }
+    return n > 0 && sort_pairs_is_own(n, 32) && !getenv("SEQWIN_AMD_SORT_KEYBITS") && n / 16 >= n_tiles;
+}
+
+__global__ void k_fill_u64(uint64_t *p, uint32_t n, uint64_t v)
+{
+    if (threadIdx.x < n) p[threadIdx.x] = v;
+}
+
+void order_tuples(SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOcc &out, bool index_form, bool take_stage)
 {
     const bool large = plan.w_full > plan.w;   // the stage holds a superset: the minimizers of plan.w (see above)
     out.n = sk.n_occ;
+    out.staged = false;
     if (!large && out.n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
     const bool table_ranks = index_form && ranks_by_table();
+    if (take_stage && index_form && !large && !table_ranks && plan.n_tiles && stage_fits_sort(sk.n_occ, plan.n_tiles)) {
+        out.rec.alloc(out.n);
+        out.dst_off.alloc((size_t)plan.n_tiles + STAGE_PAD);
+        exclusive_sum(rocprim::make_transform_iterator(sk.tile_count.p, U32ToU64()), out.dst_off.p, plan.n_tiles, (uint64_t)0, stream);
+        hipLaunchKernelGGL(k_fill_u64, dim3(1), dim3(64), 0, stream, out.dst_off.p + plan.n_tiles, STAGE_PAD, out.n);
+        SW_HIP(hipGetLastError());
+        out.stage = std::move(sk);
+        out.stage_tiles = plan.n_tiles;
+        out.stage_mult = plan.mult;
+        out.staged = true;
+        return;
+    }
     auto alloc_out = [&](uint64_t n) {
         if (index_form) {
             out.key32.alloc(n);
@@ -2855,9 +2913,10 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
                                n_records, rec_flag.p);
             SW_HIP(hipGetLastError());
         }
-        PaySort ps;   // the sort input written by k_order is consumed in place
+        PaySort ps;   // the sort input written by k_order is consumed in place (staged: the sort reads the sketch stage itself)
         ps.key_a = std::move(occ.key32);
         ps.pay_a = std::move(occ.pay);
+        if (occ.staged) ps.staged = &occ;
         group_occurrences(ps, n, 0, rec_flag.p, stream, ix, by_table ? nullptr : rank.p, bits ? &tbits : nullptr,
                           bits ? &nbits : nullptr, pair_edges ? &rep_marked : nullptr);
         if (by_table) ranks_from_table(ix, occ.hash.p, n, stream, rank.p);

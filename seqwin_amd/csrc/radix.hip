@@ -591,6 +591,17 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
 }
 
 
+// (place in the stage - dense index) of the tile that holds dense index g, searched from tile `lo` on: dst_off[lo] <= g < n
+__device__ __forceinline__ unsigned long long stage_search(const StageSource &S, uint32_t lo, uint64_t g)
+{
+    uint32_t hi = S.n_tiles;   // dst_off[hi] = n > g; the answer is the last tile whose first dense index is <= g
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (S.dst_off[mid] <= g) lo = mid; else hi = mid;
+    }
+    return S.tile_offset[lo] - S.dst_off[lo];
+}
+
 // ---- pairs: 32-bit keys with a 16-byte payload (the node sort: key32 = top half of the hash, OccPay) ---------------------------
 // lsd_radix_sort of cpp/src/seqwin/build_internals.cpp:76-144 on the device, for the occurrences.  Same scheme as the keys-only
 // pass (tickets, ranking per wave, decoupled look-back, write-out through LDS in digit order) in a shape made for 20-byte
@@ -603,13 +614,19 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
 // Look-back records carry a 16-bit epoch (the pass number of this state buffer) above flag and count: a record of an earlier
 // pass -- or of an earlier sort -- reads as "not published", so the buffer is never cleared between passes (twelve passes per
 // build cleared 3.5 GB; the buffer is cleared once per 65 535 passes).
+// STAGE (the first pass of the node sort): the tile's elements are read from the sketch stage -- what k_order did in a pass
+// of its own (16 B read + 24 B written per tuple, and 20 B read again here); how an element finds its place in the stage is
+// described at `fetch` below.  The registers hold the raw tuple (canonical hash, pos | record << 32) until the tile is ranked:
+// extend_hashes (hashing_internals.hpp:89-103), the split into key and payload and the store of the record index happen there.
 constexpr int RP_THREADS = 1024, RP_ITEMS = 7, RP_BITS = 8;
+template <bool STAGE>
 __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__restrict__ kin, const uint4 *__restrict__ pin,
                                                              uint32_t *__restrict__ kout, uint4 *__restrict__ pout, uint64_t n,
                                                              uint32_t n_tiles, unsigned shift,
                                                              const unsigned long long *__restrict__ digit_base,
                                                              unsigned long long *__restrict__ state, uint32_t epoch,
-                                                             uint32_t *__restrict__ ticket, uint32_t *__restrict__ fail)
+                                                             uint32_t *__restrict__ ticket, uint32_t *__restrict__ fail,
+                                                             const StageSource S)
 {
     constexpr uint32_t THREADS = RP_THREADS, ITEMS = RP_ITEMS, RADIX = 1u << RP_BITS, WAVES = THREADS / 64, TILE = THREADS * ITEMS;
     __shared__ uint4 sp[TILE];                        // the tile in digit order: payloads (112 KiB) ...
@@ -625,16 +642,62 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
     uint32_t tile = s_tile;
     uint32_t key[ITEMS];
     uint4 pay[ITEMS];
-    {
-        const uint32_t lane = tid0 & 63u, wave = tid0 >> 6;
-#pragma unroll
-        for (int i = 0; i < (int)ITEMS; ++i) {
-            const uint64_t g = (uint64_t)tile * TILE + wave * (64 * ITEMS) + i * 64 + lane;
-            const bool in_range = tile < n_tiles && g < n;
-            key[i] = in_range ? kin[g] : ~0u;
-            pay[i] = in_range ? pin[g] : uint4{0, 0, 0, 0};
+    // STAGE: a wave takes 448 consecutive dense indices (a "chunk"); k_rs_stage_prepare has left one directory row per chunk
+    // (STAGE_ROW words: lane j requests word j -- the digit waves before their look-back, so that it has arrived when they come
+    // back): words 0 .. STAGE_WIN-1 = (place in the stage - first dense index) of the chunk's tiles, in order; the next seven =
+    // a 448-bit map with a mark at the first index of every tile but the first; then the first dense index behind the row's
+    // tiles (n: none) and the first tile.  An element's tile is the number of marks up to its own index; elements behind the
+    // row (more than STAGE_WIN tiles in 448 tuples) search dst_off.
+    struct Window {
+        unsigned long long word;
+        bool ok;                     // (wave-uniform) the wave has elements in the tile
+    };
+    auto fetch_window = [&](uint32_t tl, uint32_t lane, uint32_t wave) __attribute__((always_inline)) {
+        Window w{0ull, false};
+        if constexpr (STAGE) {
+            const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+            const uint64_t chunk = (uint64_t)tl * WAVES + wv;               // (wave-uniform; TILE = WAVES chunks)
+            w.ok = tl < n_tiles && chunk * (64 * ITEMS) < n;
+            if (w.ok && lane < STAGE_ROW) w.word = S.chunk_dir[chunk * STAGE_ROW + lane];
         }
-    }
+        return w;
+    };
+    // requests the elements of tile `tl` into key / pay (STAGE: the raw tuples into pay, see above)
+    auto fetch = [&](uint32_t tl, uint32_t lane, uint32_t wave, const Window &w) __attribute__((always_inline)) {
+        if constexpr (!STAGE) {
+#pragma unroll
+            for (int i = 0; i < (int)ITEMS; ++i) {
+                const uint64_t g = (uint64_t)tl * TILE + wave * (64 * ITEMS) + i * 64 + lane;
+                const bool in_range = tl < n_tiles && g < n;
+                key[i] = in_range ? kin[g] : ~0u;
+                pay[i] = in_range ? pin[g] : uint4{0, 0, 0, 0};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < (int)ITEMS; ++i) pay[i] = uint4{0, 0, 0, 0};
+            const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+            const uint64_t c0 = ((uint64_t)tl * WAVES + wv) * (64 * ITEMS);   // (wave-uniform)
+            if (w.ok) {
+                const unsigned long long d_end = __shfl(w.word, (int)(STAGE_WIN + 7), 64);
+                uint32_t before = 0;
+#pragma unroll
+                for (int i = 0; i < (int)ITEMS; ++i) {
+                    const unsigned long long m = __shfl(w.word, (int)STAGE_WIN + i, 64);   // (constant lane: v_readlane)
+                    const uint64_t g = c0 + i * 64 + lane;
+                    const uint32_t r = before + (uint32_t)__popcll(m & ((2ull << lane) - 1ull));   // marks at or before this index
+                    before += (uint32_t)__popcll(m);
+                    unsigned long long delta = __shfl(w.word, (int)min(r, STAGE_WIN - 1u), 64);
+                    if (g < n) {
+                        if (g >= d_end) delta = stage_search(S, (uint32_t)__shfl(w.word, (int)(STAGE_WIN + 8), 64) + STAGE_WIN, g);
+                        const uint2 h = *reinterpret_cast<const uint2 *>(S.stage_hash + (g + delta));
+                        const uint2 km = *reinterpret_cast<const uint2 *>(S.stage_kmer + (g + delta));
+                        pay[i] = uint4{h.x, h.y, km.x, km.y};
+                    }
+                }
+            }
+        }
+    };
+    fetch(tile, tid0 & 63u, tid0 >> 6, fetch_window(tile, tid0 & 63u, tid0 >> 6));
     uint32_t fut = 0;                                 // the ticket after the next (taken a tile ahead: see k_rs_pass_p)
     if (tid0 == 0) fut = atomicAdd(ticket, 1u);
     while (tile < n_tiles) {
@@ -642,9 +705,22 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
         asm volatile("" : "+v"(tid));     // (keeps the per-item addresses from being hoisted out of the loop into registers)
         const uint32_t lane = tid & 63u, wave = tid >> 6;
         for (uint32_t i = tid; i < WAVES * RADIX / 2; i += THREADS) (reinterpret_cast<uint32_t *>(&whist[0][0]))[i] = 0;
-        __syncthreads();
         const uint64_t t0 = (uint64_t)tile * TILE;
         const uint32_t cnt_tile = (uint32_t)min((uint64_t)TILE, n - t0);
+        if constexpr (STAGE) {
+#pragma unroll
+            for (int i = 0; i < (int)ITEMS; ++i) {   // raw tuple -> (key, payload); the record index goes to the adjacency's array
+                const uint32_t li = wave * (64 * ITEMS) + i * 64 + lane;
+                unsigned long long h = ((unsigned long long)pay[i].y << 32) | pay[i].x;
+                h *= S.mult;
+                h ^= h >> 27;
+                const uint32_t rec = pay[i].w;
+                key[i] = li < cnt_tile ? (uint32_t)(h >> 32) : ~0u;
+                pay[i] = uint4{(uint32_t)h, pay[i].z, rec, (uint32_t)(t0 + li)};   // OccPay: low, pos, rec, idx
+                if (li < cnt_tile) S.rec_out[t0 + li] = rec;
+            }
+        }
+        __syncthreads();
         uint32_t pos[ITEMS];              // rank inside (wave, digit), later the element's place in the tile's digit order
 #pragma unroll
         for (int i = 0; i < (int)ITEMS; ++i) {
@@ -689,7 +765,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
         const uint32_t ntile = s_tile;
         // the tile in digit order, in LDS; the next tile's keys and payloads are requested into the same registers (in flight during
         // the look-back and the write-out)
-        auto place_keys = [&]() {
+        auto place_keys = [&](const Window &win) {
 #pragma unroll
             for (int i = 0; i < (int)ITEMS; ++i) {
                 const uint32_t li = wave * (64 * ITEMS) + i * 64 + lane;
@@ -700,18 +776,13 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
                     sp[at] = pay[i];
                 }
             }
-#pragma unroll
-            for (int i = 0; i < (int)ITEMS; ++i) {
-                const uint64_t g = (uint64_t)ntile * TILE + wave * (64 * ITEMS) + i * 64 + lane;
-                const bool in_range = ntile < n_tiles && g < n;
-                key[i] = in_range ? kin[g] : ~0u;
-                pay[i] = in_range ? pin[g] : uint4{0, 0, 0, 0};
-            }
+            fetch(ntile, lane, wave, win);
             if (tid == 0) fut = atomicAdd(ticket, 1u);
         };
         // the four digit waves look back while the other twelve place their keys, and place theirs afterwards (k_rs_pass_p)
         const bool look_wave = tid < RADIX;
-        if (!look_wave) place_keys();
+        const Window win = fetch_window(ntile, lane, wave);
+        if (!look_wave) place_keys(win);
         if (look_wave) {                                  // look-back, RS_LOOK predecessors per step
             const uint32_t d = tid;
             unsigned long long excl = 0;
@@ -749,7 +820,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
                 __hip_atomic_store(&st[d], rse_pack(epoch, 2u, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             goff[d] = digit_base[d] + excl - before;
-            place_keys();
+            place_keys(win);
         }
         __syncthreads();
 #pragma unroll
@@ -786,6 +857,89 @@ __global__ __launch_bounds__(256) void k_rs_hist32(const uint32_t *__restrict__ 
             count(kk.x); count(kk.y); count(kk.z); count(kk.w);
         } else {
             for (uint64_t j = i; j < i1; ++j) count(keys[j]);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_passes * RADIX; i += 256)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+// ---- the sketch stage as the first pair pass's input: directory + digit counts -------------------------------------------------
+// chunk_tile[c] = the tile that holds dense index 448 c (every chunk start lies in exactly one non-empty tile)
+__global__ void k_rs_chunk_tiles(const uint32_t *__restrict__ tile_count, const uint64_t *__restrict__ dst_off, uint32_t n_tiles,
+                                 uint32_t *__restrict__ chunk_tile)
+{
+    constexpr uint64_t CHUNK = 64 * RP_ITEMS;
+    const uint32_t T = blockIdx.x * blockDim.x + threadIdx.x;
+    if (T >= n_tiles) return;
+    const uint32_t c = tile_count[T];
+    const uint64_t d = dst_off[T];
+    for (uint64_t m = (d + CHUNK - 1) / CHUNK; m * CHUNK < d + c; ++m) chunk_tile[m] = T;
+}
+
+// One wave per chunk of 448 dense indices: lane j looks at tile T0 + j (T0 = chunk_tile: a window of STAGE_WIN tiles); a
+// non-empty tile that starts inside the chunk marks its first index in the chunk's 448-bit map and leaves (its place in the
+// stage - its first dense index) at its number among the marking tiles -- the directory row k_rs_pair_pass<true> reads
+// (layout: see its `fetch`).  The chunk's hashes are read on the way for the digit counts of all passes (k_rs_hist32's job:
+// the keys do not exist yet).
+__global__ __launch_bounds__(256) void k_rs_stage_prepare(const StageSource S, const uint32_t *__restrict__ chunk_tile, uint64_t n,
+                                                          unsigned n_passes, unsigned long long *__restrict__ chunk_dir,
+                                                          unsigned long long *__restrict__ hist)
+{
+    constexpr uint32_t RADIX = 1u << RP_BITS, CHUNK = 64 * RP_ITEMS;
+    __shared__ uint32_t h[4 * RADIX];
+    __shared__ unsigned long long s_row[4][STAGE_ROW];
+    for (uint32_t i = threadIdx.x; i < n_passes * RADIX; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK;
+    for (uint64_t chunk = (uint64_t)blockIdx.x * 4u + wv; chunk < n_chunks; chunk += (uint64_t)gridDim.x * 4u) {
+        const uint64_t c0 = chunk * CHUNK;
+        const uint32_t T0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk_tile[chunk]);
+        const uint32_t Tj = T0 + lane;
+        const bool in_win = lane < STAGE_WIN && Tj < S.n_tiles;
+        const unsigned long long dj = lane <= STAGE_WIN ? S.dst_off[min(Tj, S.n_tiles)] : ~0ull;   // (dst_off[n_tiles] = n)
+        const unsigned long long oj = in_win ? S.tile_offset[Tj] - dj : 0ull;
+        const uint32_t cj = in_win ? S.tile_count[Tj] : 0u;
+        const bool marks = in_win && lane >= 1u && cj != 0u && dj < c0 + CHUNK;   // (dj > c0: tile T0 holds c0)
+        const unsigned long long bal = __ballot(marks);
+        const uint32_t rank = 1u + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (lane < STAGE_ROW) s_row[wv][lane] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0u) {
+            s_row[wv][0] = oj;
+            s_row[wv][STAGE_WIN + 8] = T0;
+        }
+        if (lane == STAGE_WIN) s_row[wv][STAGE_WIN + 7] = dj;   // first dense index behind the window (n: none)
+        if (marks) {
+            const uint32_t rel = (uint32_t)(dj - c0);
+            atomicOr(&s_row[wv][STAGE_WIN + (rel >> 6)], 1ull << (rel & 63u));
+            s_row[wv][rank] = oj;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const unsigned long long word = lane < STAGE_ROW ? s_row[wv][lane] : 0ull;
+        if (lane < STAGE_ROW) chunk_dir[chunk * STAGE_ROW + lane] = word;
+        __builtin_amdgcn_wave_barrier();   // (the row is zeroed again only after every lane has read it)
+        const unsigned long long d_end = __shfl(word, (int)(STAGE_WIN + 7), 64);
+        uint32_t before = 0;
+#pragma unroll
+        for (int i = 0; i < RP_ITEMS; ++i) {
+            const unsigned long long m = __shfl(word, (int)STAGE_WIN + i, 64);
+            const uint64_t g = c0 + i * 64 + lane;
+            const uint32_t r = before + (uint32_t)__popcll(m & ((2ull << lane) - 1ull));
+            before += (uint32_t)__popcll(m);
+            unsigned long long delta = __shfl(word, (int)min(r, STAGE_WIN - 1u), 64);
+            if (g < n) {
+                if (g >= d_end) delta = stage_search(S, T0 + STAGE_WIN, g);
+                unsigned long long v = S.stage_hash[g + delta];
+                v *= S.mult;                                 // extend_hashes, hashing_internals.hpp:89-103
+                v ^= v >> 27;
+                const uint32_t k = (uint32_t)(v >> 32);
+                for (unsigned p = 0; p < n_passes; ++p) atomicAdd(&h[p * RADIX + ((k >> (RP_BITS * p)) & (RADIX - 1u))], 1u);
+            }
         }
     }
     __syncthreads();
@@ -1001,7 +1155,7 @@ int radix_rank_mode() { return rank_mode(); }               // 1: LDS atomics (t
 // Stable sort of (key32, 16-byte payload) pairs by bits [0, end_bit) of the keys, end_bit a multiple of 8 up to 32 (the node
 // sort: all 32).  Double buffers; on return keys / vals point at the sorted data.
 void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
-                        hipStream_t stream, uint32_t *d_fail)
+                        hipStream_t stream, uint32_t *d_fail, const StageSource *src, const std::function<void()> &after_first)
 {
     constexpr uint32_t RADIX = 1u << RP_BITS, TILE = RP_THREADS * RP_ITEMS;
     if (n == 0 || end_bit == 0) return;
@@ -1021,7 +1175,7 @@ void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, Occ
             int per_cu = 0;
             hipDeviceProp_t prop;
             SW_HIP(hipGetDeviceProperties(&prop, dev));
-            SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pair_pass, RP_THREADS, 0));
+            SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pair_pass<false>, RP_THREADS, 0));
             g = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
         }
         grid_p = g;
@@ -1030,17 +1184,44 @@ void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, Occ
     DevArray<uint32_t> tickets(n_passes);
     SW_HIP(hipMemsetAsync(tickets.p, 0, tickets.bytes(), stream));
     SW_HIP(hipMemsetAsync(hist.p, 0, hist.bytes(), stream));
-    hipLaunchKernelGGL(k_rs_hist32, dim3((unsigned)((n + 65535) / 65536)), dim3(256), 0, stream, keys, n, n_passes, hist.p);
+    StageSource stage{};
+    DevArray<uint32_t> chunk_tile;                 // (released on return: their next users follow the passes on this stream)
+    DevArray<unsigned long long> chunk_dir;
+    if (src) {
+        constexpr uint64_t CHUNK = 64 * RP_ITEMS;
+        static_assert(TILE == (RP_THREADS / 64) * CHUNK, "a tile is one chunk per wave");
+        const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK;
+        stage = *src;
+        chunk_tile.alloc(n_chunks);
+        chunk_dir.alloc(n_chunks * STAGE_ROW);
+        stage.chunk_dir = chunk_dir.p;
+        hipLaunchKernelGGL(k_rs_chunk_tiles, dim3((stage.n_tiles + 255u) / 256u), dim3(256), 0, stream, stage.tile_count, stage.dst_off,
+                           stage.n_tiles, chunk_tile.p);
+        hipLaunchKernelGGL(k_rs_stage_prepare, dim3((unsigned)std::min<uint64_t>(2048, (n_chunks + 3) / 4)), dim3(256), 0, stream, stage,
+                           (const uint32_t *)chunk_tile.p, n, n_passes, chunk_dir.p, hist.p);
+    } else {
+        hipLaunchKernelGGL(k_rs_hist32, dim3((unsigned)((n + 65535) / 65536)), dim3(256), 0, stream, keys, n, n_passes, hist.p);
+    }
     SW_HIP(hipGetLastError());
     StateBuf &sb = state_buf(stream, (size_t)n_tiles * RADIX);
+    const StageSource none{};
     for (unsigned p = 0; p < n_passes; ++p) {
         hipLaunchKernelGGL(k_rs_scan<RP_BITS>, dim3(1), dim3(RADIX), 0, stream, hist.p + (size_t)p * RADIX, (unsigned long long *)nullptr);
         const uint32_t epoch = next_epoch(sb, stream);
-        hipLaunchKernelGGL(k_rs_pair_pass, dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)grid_p)), dim3(RP_THREADS), 0, stream,
-                           (const uint32_t *)keys, reinterpret_cast<const uint4 *>(vals), keys_alt, reinterpret_cast<uint4 *>(vals_alt), n,
-                           (uint32_t)n_tiles, RP_BITS * p, (const unsigned long long *)(hist.p + (size_t)p * RADIX), sb.p, epoch,
-                           tickets.p + p, d_fail);
-        SW_HIP(hipGetLastError());
+        const dim3 grid((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)grid_p));
+        if (p == 0 && src) {
+            hipLaunchKernelGGL(k_rs_pair_pass<true>, grid, dim3(RP_THREADS), 0, stream, (const uint32_t *)nullptr, (const uint4 *)nullptr,
+                               keys_alt, reinterpret_cast<uint4 *>(vals_alt), n, (uint32_t)n_tiles, 0u,
+                               (const unsigned long long *)hist.p, sb.p, epoch, tickets.p, d_fail, stage);
+            SW_HIP(hipGetLastError());
+            if (after_first) after_first();
+        } else {
+            hipLaunchKernelGGL(k_rs_pair_pass<false>, grid, dim3(RP_THREADS), 0, stream, (const uint32_t *)keys,
+                               reinterpret_cast<const uint4 *>(vals), keys_alt, reinterpret_cast<uint4 *>(vals_alt), n, (uint32_t)n_tiles,
+                               RP_BITS * p, (const unsigned long long *)(hist.p + (size_t)p * RADIX), sb.p, epoch, tickets.p + p, d_fail,
+                               none);
+            SW_HIP(hipGetLastError());
+        }
         std::swap(keys, keys_alt);
         std::swap(vals, vals_alt);
     }
