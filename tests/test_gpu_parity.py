@@ -979,3 +979,37 @@ def test_seqwin_devices_is_validated(smoke_paths, monkeypatch):
             _build(smoke_paths, 17, 10, n_cpu=1)
     monkeypatch.setenv("SEQWIN_DEVICES", "0")          # one device: the ordinary build
     assert len(_build(smoke_paths, 17, 10, n_cpu=1)[0])
+
+
+@pytest.mark.parametrize("devices", [None, "0,0,0"])
+def test_pipelined_download_equals_plain_copy(tmp_path, smoke_paths, monkeypatch, devices):
+    """sw_graph_export / sw_index_export bring large results to the host through a ring of pinned slots and several copying
+    threads (api.hip: download); below 256 MiB they use one hipMemcpy per array.  Both must give the same bytes: the ring is
+    forced on small graphs here (every chunk partial, arrays of a few bytes, empty arrays), with and without slices on several
+    logical devices, and runs at its own size on a 2 Gbp batch (chunks of 8 MiB, whole and partial)."""
+    if devices:
+        monkeypatch.setenv("SEQWIN_DEVICES", devices)
+    synth = sorted((GOLDEN / "synth").glob("pan_*.fa")) + sorted((GOLDEN / "synth").glob("edge_*"))
+    empty = tmp_path / "empty.fa"
+    empty.write_text("")
+    for paths, k, w in ((smoke_paths, 17, 10), (synth, 15, 20), ([empty, empty], 21, 200)):
+        monkeypatch.setenv("SEQWIN_AMD_PLAIN_DOWNLOAD", "1")
+        plain = _build(paths, k, w, n_cpu=2)
+        monkeypatch.delenv("SEQWIN_AMD_PLAIN_DOWNLOAD")
+        monkeypatch.setenv("SEQWIN_AMD_DOWNLOAD_PIPELINE_MB", "0")
+        ring = _build(paths, k, w, n_cpu=2)
+        monkeypatch.delenv("SEQWIN_AMD_DOWNLOAD_PIPELINE_MB")
+        for a, b in zip(plain[:4], ring[:4]):
+            assert a.dtype == b.dtype and np.array_equal(a, b), (k, w)
+    if devices:
+        return
+    from seqwin_amd.device import Batch
+    b = Batch.synthetic(400, 50, 100000, n_ancestors=7, snp_ppm=10000, seed=11)
+    ix = b.build_index(21, 200, [i % 2 == 0 for i in range(400)])
+    monkeypatch.setenv("SEQWIN_AMD_PLAIN_DOWNLOAD", "1")
+    plain = ix.export()
+    monkeypatch.delenv("SEQWIN_AMD_PLAIN_DOWNLOAD")
+    ring = ix.export()
+    assert sum(a.nbytes for a in ring) > 256 << 20
+    for a, b2 in zip(plain, ring):
+        assert np.array_equal(a, b2)
