@@ -924,6 +924,138 @@ __global__ __launch_bounds__(256) void k_adj_pairs(const Rec rec, const uint32_t
     }
 }
 
+// The unsort's last step and k_adj_pairs in one kernel (single-GPU build, ranks with repeat marks): a workgroup scatters a bucket
+// of 2^14 consecutive indices inside LDS as k_unsort_bucket does and writes the adjacency keys of those occurrences from
+// there -- the rank array (4 B written and read again per occurrence) is never made.  The pair that straddles two buckets is
+// left to k_adj_bounds (the first and last rank of every bucket go to edge_rank).
+template <class Rec>
+__global__ __launch_bounds__(1024) void k_unsort_adj(const uint64_t *__restrict__ uval, uint64_t n, const Rec rec,
+                                                     const uint32_t *__restrict__ rec_asm, uint32_t asm_base, unsigned nb, uint64_t sentinel,
+                                                     uint64_t *__restrict__ key, uint64_t *__restrict__ cand_key,
+                                                     uint32_t *__restrict__ cand_asm, unsigned long long *__restrict__ n_cand,
+                                                     unsigned long long *__restrict__ hist, unsigned hbits, unsigned hpasses,
+                                                     unsigned end_bit, uint32_t *__restrict__ edge_rank, uint32_t per_wg)
+{
+    __shared__ uint32_t sr[UNSORT_RANGE];
+    extern __shared__ uint32_t sh_hist[];   // (hpasses << hbits counters, dynamic: 12 KB at 15 000 genomes lets two workgroups share a CU)
+    if (hist)
+        for (uint32_t i = threadIdx.x; i < (hpasses << hbits); i += 1024) sh_hist[i] = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t q = 0; q < per_wg; ++q) {
+        const uint64_t bkt = (uint64_t)blockIdx.x * per_wg + q, b0 = bkt * UNSORT_RANGE;
+        if (b0 >= n) break;   // (workgroup-uniform)
+        const uint32_t cnt = (uint32_t)min((uint64_t)UNSORT_RANGE, n - b0);
+        __syncthreads();      // the previous bucket's ranks have been read (first round: the counters are zero)
+        for (uint32_t t = threadIdx.x; t < cnt; t += 1024) {
+            const uint64_t v = uval[b0 + t];
+            sr[(uint32_t)(v >> 32) & (UNSORT_RANGE - 1u)] = (uint32_t)v;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            edge_rank[2 * bkt] = sr[0];
+            edge_rank[2 * bkt + 1] = sr[cnt - 1];
+        }
+        for (uint32_t it = 0; it < UNSORT_RANGE / 4096u; ++it) {
+            const uint32_t t0 = (it * 1024u + threadIdx.x) * 4u;   // pairs (t0 + j, t0 + j + 1), j < 4, that lie inside the bucket
+            const uint64_t i0 = b0 + t0;
+            uint32_t r[5], k[5];
+            uint64_t out[4];
+            uint32_t cm = 0;   // bit j: record i0 + j is a candidate
+            if (t0 + 1 < cnt) {
+                if (t0 + 4 < cnt) {
+                    rec.load4(i0, r);
+                    r[4] = rec.at(i0 + 4);
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) k[j] = sr[t0 + j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        r[j] = (t0 + j < cnt) ? rec.at(i0 + j) : 0xFFFFFFFFu;
+                        k[j] = (t0 + j < cnt) ? sr[t0 + j] : 0u;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool pair = t0 + j + 1 < cnt && r[j] == r[j + 1];
+                    uint32_t u = k[j] & ~RANK_REP, v = k[j + 1] & ~RANK_REP;
+                    if (v < u) { const uint32_t t = u; u = v; v = t; }
+                    out[j] = pair ? (((uint64_t)u << nb) | v) : sentinel;
+                    if (pair && ((k[j] | k[j + 1]) & RANK_REP)) cm |= 1u << j;
+                }
+                if (t0 + 4 < cnt) {
+                    *reinterpret_cast<ulonglong2 *>(key + i0) = make_ulonglong2(out[0], out[1]);
+                    *reinterpret_cast<ulonglong2 *>(key + i0 + 2) = make_ulonglong2(out[2], out[3]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (t0 + j + 1 < cnt) key[i0 + j] = out[j];
+                }
+                if (hist) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (t0 + j + 1 < cnt)
+                            for (unsigned p = 0; p < hpasses; ++p) {
+                                const unsigned shp = hbits * p, wd = min(hbits, end_bit - shp);
+                                atomicAdd(&sh_hist[(p << hbits) + ((uint32_t)(out[j] >> shp) & ((1u << wd) - 1u))], 1u);
+                            }
+                }
+            }
+            if (__any(cm != 0)) {   // rare: one atomic per wave that has candidates
+                const uint32_t c = (uint32_t)__popc(cm);
+                uint32_t incl = c;
+                for (uint32_t d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += up;
+                }
+                const uint32_t total = __shfl(incl, 63, 64);
+                unsigned long long base = 0;
+                if (lane == 63) base = atomicAdd(n_cand, (unsigned long long)total);
+                base = __shfl(base, 63, 64) + (incl - c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((cm >> j) & 1u) {
+                        cand_key[base] = out[j];
+                        cand_asm[base] = asm_base + rec_asm[r[j]];
+                        ++base;
+                    }
+            }
+        }
+    }
+    if (hist) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (hpasses << hbits); i += 1024)
+            if (sh_hist[i]) atomicAdd(&hist[i], (unsigned long long)sh_hist[i]);
+    }
+}
+
+// the pairs (last occurrence of bucket b, first of bucket b + 1)
+template <class Rec>
+__global__ void k_adj_bounds(const uint32_t *__restrict__ edge_rank, uint32_t n_buckets, const Rec rec, const uint32_t *__restrict__ rec_asm,
+                             uint32_t asm_base, unsigned nb, uint64_t sentinel, uint64_t *__restrict__ key, uint64_t *__restrict__ cand_key,
+                             uint32_t *__restrict__ cand_asm, unsigned long long *__restrict__ n_cand, unsigned long long *__restrict__ hist,
+                             unsigned hbits, unsigned hpasses, unsigned end_bit)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b + 1 >= n_buckets) return;
+    const uint64_t i = (uint64_t)(b + 1) * UNSORT_RANGE - 1;   // (i + 1 < n: bucket b + 1 exists)
+    const uint32_t ka = edge_rank[2 * b + 1], kb = edge_rank[2 * (b + 1)], ra = rec.at(i), rb = rec.at(i + 1);
+    uint32_t u = ka & ~RANK_REP, v = kb & ~RANK_REP;
+    if (v < u) { const uint32_t t = u; u = v; v = t; }
+    const bool pair = ra == rb;
+    const uint64_t out = pair ? (((uint64_t)u << nb) | v) : sentinel;
+    key[i] = out;
+    if (hist)
+        for (unsigned p = 0; p < hpasses; ++p) {
+            const unsigned shp = hbits * p, wd = min(hbits, end_bit - shp);
+            atomicAdd(&hist[(p << hbits) + ((uint32_t)(out >> shp) & ((1u << wd) - 1u))], 1ull);
+        }
+    if (pair && ((ka | kb) & RANK_REP)) {
+        const unsigned long long at = atomicAdd(n_cand, 1ull);
+        cand_key[at] = out;
+        cand_asm[at] = asm_base + rec_asm[ra];
+    }
+}
+
 // ---- multi-GPU form: the ranks come back slice-LOCAL (with the repeat mark), together with the owner of every tuple ------
 // Global rank = node_base[owner] + local rank, up to 2^hi_bits - 1 -- more than 32 bits for the 5e9 distinct minimizers of
 // 100 000 random genomes (the reference indexes nodes with size_t, cpp/include/seqwin/graph.hpp:28-41).  An edge belongs to
@@ -2116,9 +2248,16 @@ uint64_t settle_sort(PaySort &ps, hipStream_t stream)
 // (rank_out, may be null), and -- with rec_flag -- the first-of-assembly bitmaps for the counts (tbits / nbits non-null)
 // and / or the repeated-in-assembly mark in bit 31 of the rank words (*rep_marked, if the node count allows it).
 // ps.key_a / ps.pay_a hold the n occurrences on entry.  Returns the number of nodes.
+// hold (single-GPU build): when the ranks come back through the bucketed unsort AND carry the repeat marks, its last step is
+// left to the caller, who writes the adjacency keys from the buckets (k_unsort_adj) instead of a rank array: hold->sorted then
+// points at the (index << 32 | rank) words grouped by bucket and rank_out stays unwritten.
+struct UnsortHold {
+    DevArray<uint64_t> a, b;
+    const uint64_t *sorted = nullptr;
+};
 uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_t *rec_flag, hipStream_t stream, sw_index &ix,
                            uint32_t *rank_out, DevArray<unsigned long long> *tbits, DevArray<unsigned long long> *nbits,
-                           bool *rep_marked = nullptr)
+                           bool *rep_marked = nullptr, UnsortHold *hold = nullptr)
 {
     sort_pay(n, stream, ps);
     const uint64_t node_cap = settle_sort(ps, stream);   // >= the number of nodes, within ~2 descents of it
@@ -2164,9 +2303,13 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
             if (!(sort_keys64_is_own(n) && radix_unsort_perm(v, v_alt, n, UNSORT_BITS, nbit, stream, words.p + 2)))
                 sort_keys64(v, v_alt, n, 32 + UNSORT_BITS, 32 + nbit, stream, words.p + 2, true);   // (the indices are a permutation)
         }
-        hipLaunchKernelGGL(k_unsort_bucket, dim3((unsigned)((n + UNSORT_RANGE - 1) / UNSORT_RANGE)), dim3(1024), 0, stream, v, n,
-                           rank_out);
-        SW_HIP(hipGetLastError());
+        if (hold && rep && nbit > UNSORT_BITS && !getenv("SEQWIN_AMD_ADJ_SEPARATE")) {
+            hold->sorted = v;
+        } else {
+            hipLaunchKernelGGL(k_unsort_bucket, dim3((unsigned)((n + UNSORT_RANGE - 1) / UNSORT_RANGE)), dim3(1024), 0, stream, v, n,
+                               rank_out);
+            SW_HIP(hipGetLastError());
+        }
     }
     SW_HIP(hipMemcpyAsync(back, words.p + 1, 8, hipMemcpyDeviceToHost, stream));
     SW_HIP(hipStreamSynchronize(stream));   // n_nodes has arrived
@@ -2177,6 +2320,10 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     if (!bits && n_nodes) {   // (with the bitmaps the caller runs k_pen_bits, which completes the nodes as well)
         hipLaunchKernelGGL(k_node_stops, dim3(blocks_for(n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, (uint64_t)n_nodes, base + n);
         SW_HIP(hipGetLastError());
+    }
+    if (hold && hold->sorted) {
+        hold->a = std::move(uv0);
+        hold->b = std::move(uv1);
     }
     // (the sort buffers go back to the pool here; later users are ordered after these kernels on this stream, or fenced)
     return n_nodes;
@@ -2904,6 +3051,7 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
     DevArray<uint32_t> rec_flag;
     DevArray<unsigned long long> tbits, nbits;
     DevArray<uint64_t> node_hash;   // dense copy of the node hashes, written by k_pen_bits on the counts stream
+    UnsortHold unsort_hold;         // the unsort's buckets, when the adjacency keys are written straight from them
     // -- nodes: stable radix sort of the occurrences by hash, run-length heads, ranks back in stream order ------
     if (n) {
         const bool bits = want_counts && !check_order;
@@ -2918,7 +3066,7 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
         ps.pay_a = std::move(occ.pay);
         if (occ.staged) ps.staged = &occ;
         group_occurrences(ps, n, 0, rec_flag.p, stream, ix, by_table ? nullptr : rank.p, bits ? &tbits : nullptr,
-                          bits ? &nbits : nullptr, pair_edges ? &rep_marked : nullptr);
+                          bits ? &nbits : nullptr, pair_edges ? &rep_marked : nullptr, pair_edges ? &unsort_hold : nullptr);
         if (by_table) ranks_from_table(ix, occ.hash.p, n, stream, rank.p);
     } else {
         ix.n_nodes = 0;
@@ -2976,8 +3124,22 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
                 SW_HIP(hipMemsetAsync(ehist.p, 0, ehist.bytes(), stream));
                 iters = 32;
             }
-            hipLaunchKernelGGL(k_adj_pairs<RecArray>, dim3((adj_blocks + iters - 1) / iters), dim3(256), 0, stream, RecArray{occ.rec.p},
-                               rank.p, d_rec_asm, 0u, n, nb, sentinel, k0.p, ck.p, ca.p, n_cand.p, ehist.p, hbits, hpasses, 2 * nb, iters);
+            if (unsort_hold.sorted) {
+                const uint32_t n_buckets = (uint32_t)((n + UNSORT_RANGE - 1) / UNSORT_RANGE), per_wg = 2;
+                DevArray<uint32_t> edge_rank(2 * (size_t)n_buckets);
+                hipLaunchKernelGGL(k_unsort_adj<RecArray>, dim3((n_buckets + per_wg - 1) / per_wg), dim3(1024),
+                                   ehist.p ? ((size_t)hpasses << hbits) * 4 : 0, stream, unsort_hold.sorted,
+                                   n, RecArray{occ.rec.p}, d_rec_asm, 0u, nb, sentinel, k0.p, ck.p, ca.p, n_cand.p, ehist.p, hbits, hpasses,
+                                   2 * nb, edge_rank.p, per_wg);
+                hipLaunchKernelGGL(k_adj_bounds<RecArray>, dim3((n_buckets + 255) / 256), dim3(256), 0, stream, edge_rank.p, n_buckets,
+                                   RecArray{occ.rec.p}, d_rec_asm, 0u, nb, sentinel, k0.p, ck.p, ca.p, n_cand.p, ehist.p, hbits, hpasses,
+                                   2 * nb);
+                unsort_hold.a.release();   // (stream-ordered pool, as edge_rank at the end of this block)
+                unsort_hold.b.release();
+            } else {
+                hipLaunchKernelGGL(k_adj_pairs<RecArray>, dim3((adj_blocks + iters - 1) / iters), dim3(256), 0, stream, RecArray{occ.rec.p},
+                                   rank.p, d_rec_asm, 0u, n, nb, sentinel, k0.p, ck.p, ca.p, n_cand.p, ehist.p, hbits, hpasses, 2 * nb, iters);
+            }
             SW_HIP(hipGetLastError());
             edges_from_pairs(k0.p, k1.p, m, sentinel, nb, ab, ck.p, ca.p, n_cand.p, 0, node_hash.p, stream, ix,
                              node_hash.p ? (hipEvent_t)ev[5] : (hipEvent_t) nullptr, ehist.p);
