@@ -260,10 +260,12 @@ struct StageSource {
 // (keys, vals) pointing at n-element buffers (the stage may be released there: the pool is stream-ordered)
 void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
                         hipStream_t stream, uint32_t *d_fail, const StageSource *src = nullptr,
-                        const std::function<void()> &after_first = std::function<void()>());
+                        const std::function<void()> &after_first = std::function<void()>(), uint32_t *low_out = nullptr);
+// (low_out: the last pass also writes OccPay::low of every element, in sorted order, into this array)
 // index.hip: radix.hip's pair passes or rocPRIM's (small inputs, SEQWIN_AMD_SORT / SEQWIN_AMD_PAIR_SORT); d_fail as for sort_keys64
-void sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
-                  hipStream_t stream, uint32_t *d_fail);
+// returns true if low_out (may be null) was written (radix.hip's passes only)
+bool sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
+                  hipStream_t stream, uint32_t *d_fail, uint32_t *low_out = nullptr);
 struct PartState;                       // index.hip: offsets of the last tuple partition (the way back walks them again)
 void part_state_delete(PartState *p);
 uint32_t occ_partition_owners(const struct OrderedOcc &occ);   // owners of the last tuple partition (0: none)

@@ -96,11 +96,15 @@ bool sort_pairs_is_own(size_t n, unsigned bits)
     return ((e && !strcmp(e, "own")) || sort_keys64_is_own(n)) && radix_pairs_available();
 }
 
-void sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
-                  hipStream_t stream, uint32_t *d_fail)
+bool sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
+                  hipStream_t stream, uint32_t *d_fail, uint32_t *low_out)
 {
-    if (sort_pairs_is_own(n, end_bit)) radix_sort_pairs32(keys, keys_alt, vals, vals_alt, n, end_bit, stream, d_fail);
-    else sort_pairs(keys, keys_alt, vals, vals_alt, n, 0, end_bit, stream);
+    if (sort_pairs_is_own(n, end_bit)) {
+        radix_sort_pairs32(keys, keys_alt, vals, vals_alt, n, end_bit, stream, d_fail, nullptr, std::function<void()>(), low_out);
+        return low_out != nullptr && n != 0 && end_bit != 0;
+    }
+    sort_pairs(keys, keys_alt, vals, vals_alt, n, 0, end_bit, stream);
+    return false;
 }
 
 void check_sort_failed(uint32_t fail_word)
@@ -1637,6 +1641,14 @@ struct PayView {   // key32[q] = top half of the hash, pay[q].low = its low half
     __device__ void load(uint64_t q, uint32_t &k, OccPay &v) const { k = key32[q]; v = pay[q]; }
     __device__ void store(uint64_t q, uint32_t k, const OccPay &v) const { key32[q] = k; pay[q] = v; }
 };
+struct LowView {   // the descent sweeps' view of the occurrences when the sort's last pass left the low halves in an array of
+                   // their own (4 B per element instead of the 16-byte payloads' lines): key32[q], low32[q]
+    using Key = uint32_t;
+    const uint32_t *key32;
+    const uint32_t *low32;
+    __device__ uint32_t key(uint64_t q) const { return key32[q]; }
+    __device__ uint64_t low(uint64_t q) const { return low32[q]; }
+};
 struct EdgeKeyView {   // 64-bit adjacency keys sorted on bits [low_bits, 64) only: phase-1 key = those bits, the whole key orders the rest
     using Key = uint64_t;
     using Elem = uint64_t;
@@ -1694,6 +1706,37 @@ __device__ __forceinline__ uint32_t descents_of_thread(const PayView &V, uint32_
     }
     uint32_t kp = q0 ? V.key32[q0 - 1] : 0;
     uint64_t lp = q0 ? V.pay[q0 - 1].low : 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint64_t q = q0 + i;
+        if (q >= n) break;
+        if (q && (kq[i] & kmask) == (kp & kmask) && (kq[i] < kp || (kq[i] == kp && lq[i] < lp))) m |= 1u << i;
+        if (q == 0 || kq[i] != kp || lq[i] != lp) hm |= 1u << i;
+        kp = kq[i];
+        lp = lq[i];
+    }
+    if (heads) *heads = (uint32_t)__popc(hm);
+    return m;
+}
+
+__device__ __forceinline__ uint32_t descents_of_thread(const LowView &V, uint32_t kmask, uint64_t n, uint64_t q0, uint32_t *heads = nullptr)
+{
+    uint32_t m = 0, hm = 0;
+    if (heads) *heads = 0;
+    if (q0 >= n) return 0;
+    uint32_t kq[4], lq[4];
+    if (q0 + 4 <= n) {
+        const uint4 kv = *reinterpret_cast<const uint4 *>(V.key32 + q0), lv = *reinterpret_cast<const uint4 *>(V.low32 + q0);
+        kq[0] = kv.x; kq[1] = kv.y; kq[2] = kv.z; kq[3] = kv.w;
+        lq[0] = lv.x; lq[1] = lv.y; lq[2] = lv.z; lq[3] = lv.w;
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) {
+            kq[i] = (q0 + i < n) ? V.key32[q0 + i] : 0u;
+            lq[i] = (q0 + i < n) ? V.low32[q0 + i] : 0u;
+        }
+    }
+    uint32_t kp = q0 ? V.key32[q0 - 1] : 0, lp = q0 ? V.low32[q0 - 1] : 0;
 #pragma unroll
     for (uint32_t i = 0; i < 4; ++i) {
         const uint64_t q = q0 + i;
@@ -2019,8 +2062,10 @@ struct RepairState {
 
 // enqueue: list the descents of the phase-1 order, repair short runs in place.  `bad` (may be null) also receives the
 // masked keys of the descents, ascending, for a general repair.
-template <class View>
-void enqueue_repair(const View &V, typename View::Key kmask, uint64_t n, uint32_t *bad, uint32_t cap, RepairState &r, hipStream_t stream)
+// W: the view the two sweeps read (the same elements as V; LowView for the occurrences where the compact low halves exist)
+template <class View, class Sweep>
+void enqueue_repair(const View &V, const Sweep &W, typename View::Key kmask, uint64_t n, uint32_t *bad, uint32_t cap, RepairState &r,
+                    hipStream_t stream)
 {
     const uint32_t n_blocks = (uint32_t)((n + DESC_BLOCK - 1) / DESC_BLOCK);
     const uint32_t max_desc = (uint32_t)std::min<uint64_t>(REPAIR_MAX_DESC, std::max<uint64_t>(n, 1));
@@ -2033,10 +2078,10 @@ void enqueue_repair(const View &V, typename View::Key kmask, uint64_t n, uint32_
     r.slot_q.alloc((size_t)n_blocks * DESC_SLOT);
     r.slot_k.alloc((size_t)n_blocks * DESC_SLOT);
     SW_HIP(hipMemsetAsync(r.status.p, 0, 8, stream));
-    hipLaunchKernelGGL(k_count_descents<View>, dim3(n_blocks), dim3(256), 0, stream, V, kmask, n, r.blk_cnt.p, r.slot_q.p, r.slot_k.p);
+    hipLaunchKernelGGL(k_count_descents<Sweep>, dim3(n_blocks), dim3(256), 0, stream, W, kmask, n, r.blk_cnt.p, r.slot_q.p, r.slot_k.p);
     SW_HIP(hipGetLastError());
     exclusive_sum(r.blk_cnt.p, r.blk_off.p, n_blocks, 0ull, stream);   // both halves at once: neither sum reaches 2^32
-    hipLaunchKernelGGL(k_list_descents<View>, dim3(n_blocks), dim3(256), 0, stream, V, kmask, n, r.blk_cnt.p, r.blk_off.p,
+    hipLaunchKernelGGL(k_list_descents<Sweep>, dim3(n_blocks), dim3(256), 0, stream, W, kmask, n, r.blk_cnt.p, r.blk_off.p,
                        n_blocks, bad, cap, r.bad_q.p, max_desc, r.n_desc.p, r.slot_q.p, r.slot_k.p);
     hipLaunchKernelGGL(k_repair_wave<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, kmask, n, r.bad_q.p, r.n_desc.p,
                        r.big.p, r.status.p + 1, r.status.p);
@@ -2117,6 +2162,7 @@ struct PaySort {
     uint32_t cap = 0, kmask = ~0u;
     uint64_t n = 0;
     DevArray<uint32_t> fail;           // radix.hip's passes: non-zero if one gave up waiting (read in settle_sort)
+    DevArray<uint32_t> low;            // OccPay::low in sorted order, from the sort's last pass (radix.hip): what the descent sweeps read
     OrderedOcc *staged = nullptr;      // the occurrences still lie in the sketch stage (order_tuples, take_stage): key_a / pay_a are
                                        // allocated by the sort once its first pass has read the stage, which is released there
 };
@@ -2136,6 +2182,8 @@ void sort_pay(uint64_t n, hipStream_t stream, PaySort &o)
     o.pay_b.alloc(n);
     uint32_t *keys = o.key_a.p, *keys_alt = o.key_b.p;
     OccPay *vals = o.pay_a.p, *vals_alt = o.pay_b.p;
+    bool have_low = false;   // the last pass left the low halves in o.low (SEQWIN_AMD_DESC_LOW=0: A/B, the sweeps read the payloads)
+    const bool want_low = bits == 32 && !(getenv("SEQWIN_AMD_DESC_LOW") && atoi(getenv("SEQWIN_AMD_DESC_LOW")) == 0);
     if (o.staged) {   // (order_tuples made sure: 32 key bits, radix.hip's pair passes)
         OrderedOcc &occ = *o.staged;
         StageSource S{};
@@ -2149,6 +2197,8 @@ void sort_pay(uint64_t n, hipStream_t stream, PaySort &o)
         S.rec_out = occ.rec.p;
         o.fail.alloc(1);
         SW_HIP(hipMemsetAsync(o.fail.p, 0, 4, stream));
+        if (want_low) o.low.alloc(n);
+        have_low = want_low && n != 0;
         radix_sort_pairs32(keys, keys_alt, vals, vals_alt, n, 32, stream, o.fail.p, &S, [&] {
             occ.stage = SketchOut();           // (stream-ordered pool: the blocks' next users follow the pass on this stream)
             occ.dst_off.release();
@@ -2157,7 +2207,7 @@ void sort_pay(uint64_t n, hipStream_t stream, PaySort &o)
             o.pay_a.alloc(n);
             keys = o.key_a.p;
             vals = o.pay_a.p;
-        });
+        }, o.low.p);
         o.staged = nullptr;
     } else {
         if (bits < 32) {   // test knob: the top `bits` bits rotated down to bit 0, sorted there, rotated back (no bit is lost)
@@ -2166,7 +2216,8 @@ void sort_pay(uint64_t n, hipStream_t stream, PaySort &o)
         }
         o.fail.alloc(1);
         SW_HIP(hipMemsetAsync(o.fail.p, 0, 4, stream));
-        sort_pairs32(keys, keys_alt, vals, vals_alt, n, bits, stream, o.fail.p);
+        if (want_low && sort_pairs_is_own(n, bits)) o.low.alloc(n);
+        have_low = sort_pairs32(keys, keys_alt, vals, vals_alt, n, bits, stream, o.fail.p, o.low.p);
         if (bits < 32) {
             hipLaunchKernelGGL(k_rot_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, n, 32 - bits);
             SW_HIP(hipGetLastError());
@@ -2176,7 +2227,8 @@ void sort_pay(uint64_t n, hipStream_t stream, PaySort &o)
     o.pay = vals;
     o.cap = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(1u << 16, n / 16));
     o.bad.alloc(o.cap);
-    enqueue_repair(PayView{keys, vals}, o.kmask, n, o.bad.p, o.cap, o.rep, stream);
+    if (have_low) enqueue_repair(PayView{keys, vals}, LowView{keys, o.low.p}, o.kmask, n, o.bad.p, o.cap, o.rep, stream);
+    else enqueue_repair(PayView{keys, vals}, PayView{keys, vals}, o.kmask, n, o.bad.p, o.cap, o.rep, stream);
 }
 
 // General repair, for what the in-place pass left (status != 0).  Returns true if the order changed.
@@ -2869,7 +2921,7 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
     sort_keys64(keys, keys_alt, m, low_bits, key_bits, stream, sort_fail.p, false,
                 d_hist ? d_hist + ((size_t)skip << digit_bits) : nullptr, key_bits);   // (d_hist: the digit counts k_adj_pairs took)
     RepairState rep;
-    if (low_bits) enqueue_repair(EdgeKeyView{keys, low_bits}, ~0ull, m, nullptr, 0, rep, stream);
+    if (low_bits) enqueue_repair(EdgeKeyView{keys, low_bits}, EdgeKeyView{keys, low_bits}, ~0ull, m, nullptr, 0, rep, stream);
     DevArray<uint64_t> ukeys(m);
     DevArray<uint32_t> ucnt(m + 1), ucount(1);
     unsigned long long n_cand = host_n_cand;

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
                                                              const unsigned long long *__restrict__ digit_base,
                                                              unsigned long long *__restrict__ state, uint32_t epoch,
                                                              uint32_t *__restrict__ ticket, uint32_t *__restrict__ fail,
-                                                             const StageSource S)
+                                                             const StageSource S, uint32_t *__restrict__ lowout)
 {
     constexpr uint32_t THREADS = RP_THREADS, ITEMS = RP_ITEMS, RADIX = 1u << RP_BITS, WAVES = THREADS / 64, TILE = THREADS * ITEMS;
     __shared__ uint4 sp[TILE];                        // the tile in digit order: payloads (112 KiB) ...
@@ -829,8 +829,10 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
             if (t < cnt_tile) {
                 const uint32_t k = skey[t];
                 const uint64_t dst = goff[(k >> shift) & (RADIX - 1u)] + t;
+                const uint4 pv = sp[t];
                 kout[dst] = k;
-                pout[dst] = sp[t];
+                pout[dst] = pv;
+                if (lowout) lowout[dst] = pv.x;   // (the sort's last pass: OccPay::low in an array of its own for the descent sweeps)
             }
         }
         // (the next iteration writes sp / goff / s_tile only behind its own barriers; its first barrier also orders these reads)
@@ -1155,7 +1157,8 @@ int radix_rank_mode() { return rank_mode(); }               // 1: LDS atomics (t
 // Stable sort of (key32, 16-byte payload) pairs by bits [0, end_bit) of the keys, end_bit a multiple of 8 up to 32 (the node
 // sort: all 32).  Double buffers; on return keys / vals point at the sorted data.
 void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
-                        hipStream_t stream, uint32_t *d_fail, const StageSource *src, const std::function<void()> &after_first)
+                        hipStream_t stream, uint32_t *d_fail, const StageSource *src, const std::function<void()> &after_first,
+                        uint32_t *low_out)
 {
     constexpr uint32_t RADIX = 1u << RP_BITS, TILE = RP_THREADS * RP_ITEMS;
     if (n == 0 || end_bit == 0) return;
@@ -1212,14 +1215,15 @@ void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, Occ
         if (p == 0 && src) {
             hipLaunchKernelGGL(k_rs_pair_pass<true>, grid, dim3(RP_THREADS), 0, stream, (const uint32_t *)nullptr, (const uint4 *)nullptr,
                                keys_alt, reinterpret_cast<uint4 *>(vals_alt), n, (uint32_t)n_tiles, 0u,
-                               (const unsigned long long *)hist.p, sb.p, epoch, tickets.p, d_fail, stage);
+                               (const unsigned long long *)hist.p, sb.p, epoch, tickets.p, d_fail, stage,
+                               n_passes == 1 ? low_out : (uint32_t *)nullptr);
             SW_HIP(hipGetLastError());
             if (after_first) after_first();
         } else {
             hipLaunchKernelGGL(k_rs_pair_pass<false>, grid, dim3(RP_THREADS), 0, stream, (const uint32_t *)keys,
                                reinterpret_cast<const uint4 *>(vals), keys_alt, reinterpret_cast<uint4 *>(vals_alt), n, (uint32_t)n_tiles,
                                RP_BITS * p, (const unsigned long long *)(hist.p + (size_t)p * RADIX), sb.p, epoch, tickets.p + p, d_fail,
-                               none);
+                               none, p + 1 == n_passes ? low_out : (uint32_t *)nullptr);
             SW_HIP(hipGetLastError());
         }
         std::swap(keys, keys_alt);
