@@ -969,8 +969,8 @@ __global__ __launch_bounds__(1024) void k_unsort_adj(const uint64_t *__restrict_
                 if (t0 + 4 < cnt) {
                     rec.load4(i0, r);
                     r[4] = rec.at(i0 + 4);
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) k[j] = sr[t0 + j];
+                    const uint4 kv = *reinterpret_cast<const uint4 *>(&sr[t0]);
+                    k[0] = kv.x; k[1] = kv.y; k[2] = kv.z; k[3] = kv.w; k[4] = sr[t0 + 4];
                 } else {
 #pragma unroll
                     for (int j = 0; j < 5; ++j) {
@@ -3177,7 +3177,8 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
                 iters = 32;
             }
             if (unsort_hold.sorted) {
-                const uint32_t n_buckets = (uint32_t)((n + UNSORT_RANGE - 1) / UNSORT_RANGE), per_wg = 2;
+                const uint32_t n_buckets = (uint32_t)((n + UNSORT_RANGE - 1) / UNSORT_RANGE);
+                const uint32_t per_wg = 4;   // buckets per workgroup between two flushes of its digit counts (1 / 2 / 4: 5.85 / 5.74 / 5.69 ms)
                 DevArray<uint32_t> edge_rank(2 * (size_t)n_buckets);
                 hipLaunchKernelGGL(k_unsort_adj<RecArray>, dim3((n_buckets + per_wg - 1) / per_wg), dim3(1024),
                                    ehist.p ? ((size_t)hpasses << hbits) * 4 : 0, stream, unsort_hold.sorted,
