@@ -927,6 +927,7 @@ __global__ __launch_bounds__(256) void k_rs_stage_prepare(const StageSource S, c
         __builtin_amdgcn_wave_barrier();   // (the row is zeroed again only after every lane has read it)
         const unsigned long long d_end = __shfl(word, (int)(STAGE_WIN + 7), 64);
         uint32_t before = 0;
+        unsigned long long hv[RP_ITEMS];   // (all seven hashes requested before the first is counted)
 #pragma unroll
         for (int i = 0; i < RP_ITEMS; ++i) {
             const unsigned long long m = __shfl(word, (int)STAGE_WIN + i, 64);
@@ -934,10 +935,16 @@ __global__ __launch_bounds__(256) void k_rs_stage_prepare(const StageSource S, c
             const uint32_t r = before + (uint32_t)__popcll(m & ((2ull << lane) - 1ull));
             before += (uint32_t)__popcll(m);
             unsigned long long delta = __shfl(word, (int)min(r, STAGE_WIN - 1u), 64);
+            hv[i] = 0;
             if (g < n) {
                 if (g >= d_end) delta = stage_search(S, T0 + STAGE_WIN, g);
-                unsigned long long v = S.stage_hash[g + delta];
-                v *= S.mult;                                 // extend_hashes, hashing_internals.hpp:89-103
+                hv[i] = S.stage_hash[g + delta];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RP_ITEMS; ++i) {
+            if (c0 + i * 64 + lane < n) {
+                unsigned long long v = hv[i] * S.mult;       // extend_hashes, hashing_internals.hpp:89-103
                 v ^= v >> 27;
                 const uint32_t k = (uint32_t)(v >> 32);
                 for (unsigned p = 0; p < n_passes; ++p) atomicAdd(&h[p * RADIX + ((k >> (RP_BITS * p)) & (RADIX - 1u))], 1u);
