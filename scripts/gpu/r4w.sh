@@ -7,7 +7,7 @@ for v in fused; do
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 tot=sum(float(r['TotalDurationNs']) for r in rows if 'k_synth' not in r['Name'] and 'k_checksum' not in r['Name'])/5e6
-sel=[(r['Name'].split('(anonymous namespace)::')[-1][:24], round(float(r['AverageNs'])/1e3,1)) for r in rows if any(k in r['Name'] for k in ('k_unsort','k_adj','k_pen_bits','stage_prepare','k_rle','k_edges_runs','pair_pass'))]
+sel=[(r['Name'].split('(anonymous namespace)::')[-1][:24], round(float(r['AverageNs'])/1e3,1)) for r in rows if any(k in r['Name'] for k in ('k_unsort','k_adj','k_pen_bits','stage_prepare','k_rle','k_edges_runs','pair_pass','k_nodes'))]
 print(sys.argv[2], round(tot,2), sel)
 PY
 done
