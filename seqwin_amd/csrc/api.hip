@@ -1890,8 +1890,8 @@ int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint6
         if (err & 2) raise(SW_ERR_VALUE, "record_idx is outside record_offsets range");                    // filter.cpp:104-106,120-122
         if (err & 4) raise(SW_ERR_VALUE, "record_idx must be nondecreasing within each node range");        // filter.cpp:113-115
         const HostSpan span[1] = {{nodes, n_nodes * sizeof(sw_node)}};
-        (void)span;
-        SW_HIP(hipMemcpy(nodes, dn, n_nodes * sizeof(sw_node), hipMemcpyDeviceToHost));
+        const void *const from[1] = {dn};
+        download(span, from, 1);
     });
 }
 

@@ -3,6 +3,7 @@ reference's wire formats, validates arguments before touching a device, refuses 
 and its host FASTA reader / 2-bit packer agrees with the oracle's reader byte for byte."""
 import ctypes
 import gzip
+import random
 import re
 from pathlib import Path
 
@@ -107,8 +108,27 @@ def _canon(seq: bytes) -> bytes:
     return seq.translate(bytes(t))
 
 
+def _line_length_file(tmp_path):
+    """Sequence lines of every length 1 .. 200 (whole 32- and 64-byte steps, masked tails, the split of a step into two
+    32-base blocks), every 7th line with invalid bases at both ends and in the middle, every 11th with a blank inside."""
+    rng = random.Random(5)
+    out = [b">lens"]
+    for n in list(range(1, 201)) + [255, 256, 257, 1000]:
+        line = bytearray(rng.choice(b"ACGTacgtU") for _ in range(n))
+        if n % 7 == 0:
+            line[0] = ord("N"); line[-1] = ord("n"); line[n // 2] = ord("R")
+        if n % 11 == 0:
+            line[n // 3] = ord(" ")
+        out.append(bytes(line))
+        if n % 13 == 0:
+            out.append(b">r%d x" % n)
+    p = tmp_path / "line_lengths.fa"
+    p.write_bytes(b"\n".join(out) + b"\n")
+    return p
+
+
 def test_host_ingest_matches_oracle_reader(tmp_path):
-    files = sorted((GOLDEN / "synth").glob("*")) + sorted((GOLDEN / "smoke").glob("*/*.fasta"))
+    files = sorted((GOLDEN / "synth").glob("*")) + sorted((GOLDEN / "smoke").glob("*/*.fasta")) + [_line_length_file(tmp_path)]
     tricky = tmp_path / "tricky.fa"
     tricky.write_bytes(b"\n  \n>id1 desc more\r\nACGT acgt\tNN\r\n\r\n>id2\n>id3\tx\nAC\x0bGT\n  GG  \n>id4\nACGTNRYKMacgtnU-*\nTTTT")
     gz = tmp_path / "t.fa.gz"
@@ -215,9 +235,11 @@ def test_host_ingest_under_sanitizers(tmp_path):
     assert [(i, len(q)) for i, q in oracle.read_fasta(trunc)] == [("t", 40000), ("u", 21)]
     files += [gz, hdr, blank, trunc] + sorted((GOLDEN / "synth").glob("edge_*"))
     env = dict(__import__("os").environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-    for n_cpu, scalar in ((1, False), (3, False), (2, True)):
-        e = dict(env, **({"SEQWIN_AMD_SCALAR_INGEST": "1"} if scalar else {}))
-        dump = tmp_path / f"dump_{n_cpu}_{int(scalar)}.bin"
+    files.append(_line_length_file(tmp_path))
+    # the packer a host offers by default (64 bytes per step with AVX-512 BW, else 32 with AVX2), the 32-byte one, the byte loop
+    for n_cpu, scalar in ((1, ""), (3, ""), (2, "SEQWIN_AMD_NO_AVX512"), (2, "SEQWIN_AMD_SCALAR_INGEST")):
+        e = dict(env, **({scalar: "1"} if scalar else {}))
+        dump = tmp_path / f"dump_{n_cpu}_{scalar}.bin"
         out = subprocess.run([str(exe), str(n_cpu), str(dump)] + [str(f) for f in files], capture_output=True, text=True, env=e)
         assert out.returncode == 0 and "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
         offs, ids, seqs, bp = _host_ingest(files, n_cpu)
