@@ -607,13 +607,13 @@ def check_collectives(dev, group=None) -> None:
     n = limit // 8 + 1                                              # int64 elements per peer
     idx = torch.arange(n, dtype=torch.int64, device=dev)
     send = torch.cat([idx * 1000003 + (rank * world + p) * 7919 for p in range(world)])
-    got = torch.empty_like(send)
+    got = torch.full_like(send, -1)   # (poisoned: a block of the caching allocator may still hold an earlier check's pattern)
     dist.all_to_all_single(got, send, [n] * world, [n] * world, group=group)
     bad = 0
     for p in range(world):
         bad += int((got[p * n:(p + 1) * n] != idx * 1000003 + (p * world + rank) * 7919).sum().item())
     mine = idx * 31 + rank
-    table = torch.empty((world * n,), dtype=torch.int64, device=dev)
+    table = torch.full((world * n,), -1, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(table, mine, group=group)
     for p in range(world):
         bad += int((table[p * n:(p + 1) * n] != idx * 31 + p).sum().item())
