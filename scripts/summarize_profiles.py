@@ -50,8 +50,8 @@ def short(name: str) -> str:
 
 
 def one(pattern):
-    g = glob.glob(pattern, recursive=True)
-    return g[0] if g else None
+    g = glob.glob(pattern, recursive=True)   # (a directory that was profiled into twice holds two runs: the newest counts)
+    return max(g, key=os.path.getmtime) if g else None
 
 
 def agg(path, names):
