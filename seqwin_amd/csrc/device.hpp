@@ -255,6 +255,8 @@ struct StageSource {
     uint64_t mult;                                 // extend_hashes multiplier of the plan
     uint32_t *rec_out;                             // record_idx of every tuple, dense order (the adjacency reads it)
     const unsigned long long *chunk_dir;           // (filled in by radix_sort_pairs32) one row per 448 dense indices
+    const uint64_t *rows;                          // non-null: the source is n rows of (out_hash, pos | record_idx << 32) instead
+                                                   // (a slice's received tuples: only this field is read)
 };
 // src: pass 0 reads the stage and writes (keys_alt, vals_alt); after_first() runs once that pass is enqueued and must leave
 // (keys, vals) pointing at n-element buffers (the stage may be released there: the pool is stream-ordered)

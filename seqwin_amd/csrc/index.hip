@@ -2195,6 +2195,8 @@ struct PaySort {
     uint64_t n = 0;
     DevArray<uint32_t> fail;           // radix.hip's passes: non-zero if one gave up waiting (read in settle_sort)
     DevArray<uint32_t> low;            // OccPay::low in sorted order, from the sort's last pass (radix.hip): what the descent sweeps read
+    const uint64_t *rows_src = nullptr;   // the occurrences are rows of (out_hash, pos | record << 32) (a slice's received tuples): the
+                                          // sort's first pass reads them itself; key_a / pay_a are allocated by the sort
     OrderedOcc *staged = nullptr;      // the occurrences still lie in the sketch stage (order_tuples, take_stage): key_a / pay_a are
                                        // allocated by the sort once its first pass has read the stage, which is released there
 };
@@ -2241,6 +2243,19 @@ void sort_pay(uint64_t n, hipStream_t stream, PaySort &o)
             vals = o.pay_a.p;
         }, o.low.p);
         o.staged = nullptr;
+    } else if (o.rows_src) {   // (merge_build made sure: 32 key bits, radix.hip's pair passes)
+        StageSource S{};
+        S.rows = o.rows_src;
+        o.fail.alloc(1);
+        SW_HIP(hipMemsetAsync(o.fail.p, 0, 4, stream));
+        if (want_low) o.low.alloc(n);
+        have_low = want_low && n != 0;
+        radix_sort_pairs32(keys, keys_alt, vals, vals_alt, n, 32, stream, o.fail.p, &S, [&] {
+            o.key_a.alloc(n);
+            o.pay_a.alloc(n);
+            keys = o.key_a.p;
+            vals = o.pay_a.p;
+        }, o.low.p);
     } else {
         if (bits < 32) {   // test knob: the top `bits` bits rotated down to bit 0, sorted there, rotated back (no bit is lost)
             hipLaunchKernelGGL(k_rot_keys, dim3(blocks_for(n)), dim3(TPB), 0, stream, keys, n, bits);
@@ -3303,10 +3318,15 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
     const bool slice = d_rank_out && m == 0 && d_rec_asm && n_records && !getenv("SEQWIN_AMD_CHECK_ORDER");
     if (n) {
         PaySort ps;
-        ps.key_a.alloc(n);
-        ps.pay_a.alloc(n);
-        hipLaunchKernelGGL(k_rows_to_pay, dim3(blocks_for(n)), dim3(TPB), 0, stream, d_occ_rows, n, ps.key_a.p, ps.pay_a.p);
-        SW_HIP(hipGetLastError());
+        const char *order = getenv("SEQWIN_AMD_ORDER");   // ("copy": A/B, as for the sketch stage of the single-GPU build)
+        if (sort_pairs_is_own(n, 32) && !getenv("SEQWIN_AMD_SORT_KEYBITS") && !(order && !strcmp(order, "copy"))) {
+            ps.rows_src = d_occ_rows;   // the sort's first pass reads the rows
+        } else {
+            ps.key_a.alloc(n);
+            ps.pay_a.alloc(n);
+            hipLaunchKernelGGL(k_rows_to_pay, dim3(blocks_for(n)), dim3(TPB), 0, stream, d_occ_rows, n, ps.key_a.p, ps.pay_a.p);
+            SW_HIP(hipGetLastError());
+        }
         // stable: ties keep source-rank order; d_rank_out[j] = node rank of received row j -- with RANK_REP in bit 31 where the
         // node recurs in the occurrence's assembly (record table given, fewer than 2^31 nodes)
         DevArray<uint32_t> rec_flag;

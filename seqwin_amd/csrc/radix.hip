@@ -619,7 +619,9 @@ __device__ __forceinline__ unsigned long long stage_search(const StageSource &S,
 // described at `fetch` below.  The registers hold the raw tuple (canonical hash, pos | record << 32) until the tile is ranked:
 // extend_hashes (hashing_internals.hpp:89-103), the split into key and payload and the store of the record index happen there.
 constexpr int RP_THREADS = 1024, RP_ITEMS = 7, RP_BITS = 8;
-template <bool STAGE>
+// SRC = 2 (the first pass of a slice's node sort, multi-GPU forms): the elements are the received tuples themselves, rows of
+// (out_hash, pos | record << 32) -- the copy k_rows_to_pay made of them (16 B read + 20 B written per tuple) is not needed.
+template <int SRC>
 __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__restrict__ kin, const uint4 *__restrict__ pin,
                                                              uint32_t *__restrict__ kout, uint4 *__restrict__ pout, uint64_t n,
                                                              uint32_t n_tiles, unsigned shift,
@@ -628,6 +630,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
                                                              uint32_t *__restrict__ ticket, uint32_t *__restrict__ fail,
                                                              const StageSource S, uint32_t *__restrict__ lowout)
 {
+    constexpr bool STAGE = SRC == 1, ROWS = SRC == 2;
     constexpr uint32_t THREADS = RP_THREADS, ITEMS = RP_ITEMS, RADIX = 1u << RP_BITS, WAVES = THREADS / 64, TILE = THREADS * ITEMS;
     __shared__ uint4 sp[TILE];                        // the tile in digit order: payloads (112 KiB) ...
     __shared__ uint32_t skey[TILE];                   // ... and keys (28 KiB): one placing phase, one write-out phase
@@ -664,7 +667,13 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
     };
     // requests the elements of tile `tl` into key / pay (STAGE: the raw tuples into pay, see above)
     auto fetch = [&](uint32_t tl, uint32_t lane, uint32_t wave, const Window &w) __attribute__((always_inline)) {
-        if constexpr (!STAGE) {
+        if constexpr (ROWS) {
+#pragma unroll
+            for (int i = 0; i < (int)ITEMS; ++i) {   // (raw row: out_hash low / high, pos, record)
+                const uint64_t g = (uint64_t)tl * TILE + wave * (64 * ITEMS) + i * 64 + lane;
+                pay[i] = (tl < n_tiles && g < n) ? reinterpret_cast<const uint4 *>(S.rows)[g] : uint4{0, 0, 0, 0};
+            }
+        } else if constexpr (!STAGE) {
 #pragma unroll
             for (int i = 0; i < (int)ITEMS; ++i) {
                 const uint64_t g = (uint64_t)tl * TILE + wave * (64 * ITEMS) + i * 64 + lane;
@@ -707,6 +716,14 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
         for (uint32_t i = tid; i < WAVES * RADIX / 2; i += THREADS) (reinterpret_cast<uint32_t *>(&whist[0][0]))[i] = 0;
         const uint64_t t0 = (uint64_t)tile * TILE;
         const uint32_t cnt_tile = (uint32_t)min((uint64_t)TILE, n - t0);
+        if constexpr (ROWS) {
+#pragma unroll
+            for (int i = 0; i < (int)ITEMS; ++i) {   // row -> (key, payload)
+                const uint32_t li = wave * (64 * ITEMS) + i * 64 + lane;
+                key[i] = li < cnt_tile ? pay[i].y : ~0u;
+                pay[i] = uint4{pay[i].x, pay[i].z, pay[i].w, (uint32_t)(t0 + li)};   // OccPay: low, pos, rec, idx
+            }
+        }
         if constexpr (STAGE) {
 #pragma unroll
             for (int i = 0; i < (int)ITEMS; ++i) {   // raw tuple -> (key, payload); the record index goes to the adjacency's array
@@ -860,6 +877,30 @@ __global__ __launch_bounds__(256) void k_rs_hist32(const uint32_t *__restrict__ 
         } else {
             for (uint64_t j = i; j < i1; ++j) count(keys[j]);
         }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_passes * RADIX; i += 256)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+// ... and from rows of (out_hash, pos | record << 32) (SRC = 2)
+__global__ __launch_bounds__(256) void k_rs_hist32_rows(const uint4 *__restrict__ rows, uint64_t n, unsigned n_passes,
+                                                        unsigned long long *__restrict__ hist)
+{
+    constexpr uint32_t RADIX = 1u << RP_BITS;
+    __shared__ uint32_t h[4 * RADIX];
+    for (uint32_t i = threadIdx.x; i < n_passes * RADIX; i += 256) h[i] = 0;
+    __syncthreads();
+    const uint64_t chunk = 16384;
+    const uint64_t i0 = (uint64_t)blockIdx.x * chunk, i1 = min(n, i0 + chunk);
+    for (uint64_t i = i0 + threadIdx.x; i < i1; i += 1024) {   // four rows in flight per thread
+        uint32_t k[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[j] = i + 256u * j < i1 ? rows[i + 256u * j].y : 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i + 256u * j < i1)
+                for (unsigned p = 0; p < n_passes; ++p) atomicAdd(&h[p * RADIX + ((k[j] >> (RP_BITS * p)) & (RADIX - 1u))], 1u);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < n_passes * RADIX; i += 256)
@@ -1185,7 +1226,7 @@ void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, Occ
             int per_cu = 0;
             hipDeviceProp_t prop;
             SW_HIP(hipGetDeviceProperties(&prop, dev));
-            SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pair_pass<false>, RP_THREADS, 0));
+            SW_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_rs_pair_pass<0>, RP_THREADS, 0));
             g = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
         }
         grid_p = g;
@@ -1197,7 +1238,11 @@ void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, Occ
     StageSource stage{};
     DevArray<uint32_t> chunk_tile;                 // (released on return: their next users follow the passes on this stream)
     DevArray<unsigned long long> chunk_dir;
-    if (src) {
+    if (src && src->rows) {
+        stage = *src;
+        hipLaunchKernelGGL(k_rs_hist32_rows, dim3((unsigned)((n + 16383) / 16384)), dim3(256), 0, stream,
+                           reinterpret_cast<const uint4 *>(src->rows), n, n_passes, hist.p);
+    } else if (src) {
         constexpr uint64_t CHUNK = 64 * RP_ITEMS;
         static_assert(TILE == (RP_THREADS / 64) * CHUNK, "a tile is one chunk per wave");
         const uint64_t n_chunks = (n + CHUNK - 1) / CHUNK;
@@ -1220,14 +1265,15 @@ void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, Occ
         const uint32_t epoch = next_epoch(sb, stream);
         const dim3 grid((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)grid_p));
         if (p == 0 && src) {
-            hipLaunchKernelGGL(k_rs_pair_pass<true>, grid, dim3(RP_THREADS), 0, stream, (const uint32_t *)nullptr, (const uint4 *)nullptr,
+            auto first = src->rows ? k_rs_pair_pass<2> : k_rs_pair_pass<1>;
+            hipLaunchKernelGGL(first, grid, dim3(RP_THREADS), 0, stream, (const uint32_t *)nullptr, (const uint4 *)nullptr,
                                keys_alt, reinterpret_cast<uint4 *>(vals_alt), n, (uint32_t)n_tiles, 0u,
                                (const unsigned long long *)hist.p, sb.p, epoch, tickets.p, d_fail, stage,
                                n_passes == 1 ? low_out : (uint32_t *)nullptr);
             SW_HIP(hipGetLastError());
             if (after_first) after_first();
         } else {
-            hipLaunchKernelGGL(k_rs_pair_pass<false>, grid, dim3(RP_THREADS), 0, stream, (const uint32_t *)keys,
+            hipLaunchKernelGGL(k_rs_pair_pass<0>, grid, dim3(RP_THREADS), 0, stream, (const uint32_t *)keys,
                                reinterpret_cast<const uint4 *>(vals), keys_alt, reinterpret_cast<uint4 *>(vals_alt), n, (uint32_t)n_tiles,
                                RP_BITS * p, (const unsigned long long *)(hist.p + (size_t)p * RADIX), sb.p, epoch, tickets.p + p, d_fail,
                                none, p + 1 == n_passes ? low_out : (uint32_t *)nullptr);
