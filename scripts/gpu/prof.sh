@@ -9,7 +9,8 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SA
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof/fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_fetch.log 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof/write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_write.log 2>&1 &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_w10/stats -- python3 $R/bench.py --workload salmonella500 -w 10 --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_w10.log 2>&1 &&
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rand19/stats -- python3 $R/bench.py --workload random100k -k 19 --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_rand19.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rand19/stats -- python3 $R/bench.py --workload random100k -k 19 --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_rand19.log 2>&1 &&
+SEQWIN_BENCH_FORCE_DIST=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_dist1/stats -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_dist1.log 2>&1
 echo rc=$?
 grep "^{" $O/prof_w10.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('w10', d['value'], d['ms_per_step'], d['stages_ms'], d['roofline']['kernel'], d['roofline']['frac'])"
 grep "^{" $O/prof_rand19.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('rand19', d['value'], d['ms_per_step'], d['stages_ms'])"
