@@ -60,10 +60,11 @@ void sort_pairs(K *&keys, K *&keys_alt, V *&vals, V *&vals_alt, size_t n, unsign
 // check_sort_failed() then raises instead of the device hanging.
 bool sort_keys64_is_own(size_t n)
 {
-    // measured per build: 745 M keys 211.1 against 214.5 ms with rocPRIM; 24 M keys 7.90 against 7.68 ms (the
-    // per-pass state resets and launches weigh more on few tiles) -> the own passes from 2^26 keys on
+    // measured per build, edges stage (r04d, gpurun_out/r4v; keys = occurrences): 0.38 M keys 0.30 against 0.23 ms with rocPRIM,
+    // 3 M 0.41 / 0.37, 6 M 0.53 / 0.55, 12 M 0.76 / 0.81, 24 M 1.22 / 1.47 (the launches and the look-back of few tiles weigh
+    // more on small inputs) -> the own passes from 2^23 keys on (r03, with ballot ranking and state resets: from 2^26)
     const char *e = getenv("SEQWIN_AMD_SORT");
-    const bool own = e ? !strcmp(e, "own") : n >= (1ull << 26);
+    const bool own = e ? !strcmp(e, "own") : n >= (1ull << 23);
     return own && !(e && !strcmp(e, "rocprim"));
 }
 
@@ -88,12 +89,17 @@ void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_
 // workgroup per CU, keys and payloads staged through LDS together); rocPRIM's for small ones, for key widths that are no multiple
 // of 8 (a test knob), and on a device that fails the LDS-atomic ranking self-check.  SEQWIN_AMD_SORT=own|rocprim forces one for
 // all sorts, SEQWIN_AMD_PAIR_SORT=own|rocprim for this one only (A/B).
+// From 2^20 pairs on (r04d: nodes stage 0.27 against 0.38 ms at 0.76 M occurrences, 0.42 / 0.47 at 3 M, 0.99 / 1.05 at 12 M --
+// with the first pass reading the sketch stage, which comes with these passes; at 0.38 M the whole build is the same either way).
 bool sort_pairs_is_own(size_t n, unsigned bits)
 {
-    const char *e = getenv("SEQWIN_AMD_PAIR_SORT");
+    const char *e = getenv("SEQWIN_AMD_PAIR_SORT"), *all = getenv("SEQWIN_AMD_SORT");
     if (e && !strcmp(e, "rocprim")) return false;
     if (bits % 8 != 0 || bits > 32 || n >= 0xFFFFFFFFull) return false;
-    return ((e && !strcmp(e, "own")) || sort_keys64_is_own(n)) && radix_pairs_available();
+    bool own = n >= (1ull << 20);
+    if (all) own = !strcmp(all, "own");
+    if (e && !strcmp(e, "own")) own = true;
+    return own && radix_pairs_available();
 }
 
 bool sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,

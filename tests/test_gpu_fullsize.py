@@ -100,7 +100,7 @@ KNOBS = [
     {"SEQWIN_AMD_UNSORT_DIRECT": "4"},                                     # node ranks return through the bucketed unsort (default above 2^25 occurrences)
     {"SEQWIN_AMD_UNSORT_DIRECT": "4", "SEQWIN_AMD_SORT_KEYBITS": "12", "SEQWIN_AMD_NO_PACKED_EDGES": "1"},
     {"SEQWIN_AMD_RANKS": "table"},                                         # ... or through the open-addressing hash table (A/B path)
-    {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_UNSORT_DIRECT": "4"},           # csrc/radix.hip for the keys-only sorts (default from 2^26 keys on)
+    {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_UNSORT_DIRECT": "4"},           # csrc/radix.hip for the keys-only sorts (default from 2^23 keys on)
     {"SEQWIN_AMD_SORT": "rocprim"},
     {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_EDGE_SKIP_PASSES": "1"},        # edge sort in two phases: radix passes on the upper digits, in-place repair
     {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_EDGE_SKIP_PASSES": "2"},        # ... all of rank_hi left to the repair (wave and workgroup forms)
@@ -113,7 +113,7 @@ KNOBS = [
     {"SEQWIN_AMD_UNSORT_DIRECT": "4", "SEQWIN_AMD_ADJ_SEPARATE": "1"},    # ... with the rank array and k_adj_pairs (default there: keys straight from the buckets, k_unsort_adj)
     {"SEQWIN_AMD_UNSORT_DIRECT": "4", "SEQWIN_AMD_SORT": "rocprim"},      # k_unsort_adj without digit counts
     {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_DESC_LOW": "0"},               # descent sweeps of the node sort on the payloads (default with radix.hip: on the compact low halves its last pass writes)
-    {"SEQWIN_AMD_ORDER": "stage"},                                         # node sort's first pass reads the sketch stage (default from 2^26 occurrences on)
+    {"SEQWIN_AMD_ORDER": "stage"},                                         # node sort's first pass reads the sketch stage (default from 2^20 occurrences on)
     {"SEQWIN_AMD_ORDER": "stage", "SEQWIN_AMD_RC": "3", "SEQWIN_AMD_UNSORT_DIRECT": "4"},   # ... with tiles in the overflow area
     {"SEQWIN_AMD_ORDER": "copy", "SEQWIN_AMD_SORT": "own"},                # ... k_order's copy in front of radix.hip's passes
     {"SEQWIN_AMD_WINDOW_SPLIT": "8,4"},                                    # windows above 8 as if above SW_MAX_WINDOW: sketch with w' = 4, select
