@@ -1,3 +1,3 @@
-# round 4, call Z: the multi-device and gzip fuzz campaigns after the last changes (rows read by the slices' node sort; raw file buffer, 64-byte packer)
-export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd $R
-bash scripts/gpu/fuzz.sh r4z_multi ${1:-180} multi && bash scripts/gpu/fuzz.sh r4z_gz ${1:-180} gz
+# round 4, call Z: the whole GPU suite with radix.hip's sorts, the stage order and the bucketed unsort forced on every input, however small
+export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r4z; mkdir -p $O; cd $R
+SEQWIN_AMD_SORT=own SEQWIN_AMD_UNSORT_DIRECT=4 timeout -k 10 1100 python3 -m pytest tests -q -m gpu > $O/tests_own.log 2>&1; tail -n 15 $O/tests_own.log
