@@ -337,6 +337,12 @@ int sw_sort_keys64(void *keys_dev, void *alt_dev, uint64_t n, uint64_t begin_bit
  * the start-up check that the lanes of one LDS atomic are served in lane order (what keeps those passes stable) --, 0 by ballots
  * (the check failed, or SEQWIN_AMD_RADIX_RANK=ballot).  Runs the check if it has not run yet. */
 int sw_radix_rank_mode(int *mode);
+/* Always-on order guards (r05): the kernels that stream over the sorted occurrences (k_nodes) and the sorted edge keys
+ * (k_rle_keys) count every place where (hash, stream index) resp. the key does not ascend -- the stability contract of
+ * lsd_radix_sort, cpp/src/seqwin/build_internals.cpp:76-144.  A build that sees such a place logs a WARNING, switches the device
+ * to ballot / rocPRIM ranking for the rest of the process and sorts again (bit-identical result).  These counters say how often
+ * that happened in this process (0 on a healthy device; SEQWIN_AMD_FAULT_INJECT=rank makes the suite take the path). */
+int sw_order_guard_trips(uint64_t *node_sort, uint64_t *edge_sort);
 int sw_sort_pairs32(void *keys_dev, void *keys_alt_dev, void *vals_dev, void *vals_alt_dev, uint64_t n, uint64_t end_bit, void *stream,
                     int *sorted_in_alt, double *ms);
 

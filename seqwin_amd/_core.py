@@ -59,7 +59,7 @@ def _split_ids(blob: bytes, record_offsets: np.ndarray) -> list[tuple[str, ...]]
 
 
 # Native log lines go to Python's root logger, as log_python does in the reference (cpp/src/utils/logging.cpp:9-29).
-_LOG_FN = ctypes.CFUNCTYPE(None, ctypes.c_char_p, ctypes.c_char_p)
+from ._abi import LOG_FN as _LOG_FN  # noqa: E402  (CFUNCTYPE(None, c_char_p, c_char_p): sw_log_fn)
 
 
 def _forward_log(level, message):
@@ -71,8 +71,6 @@ def _forward_log(level, message):
 
 
 _log_callback = _LOG_FN(_forward_log)       # kept alive for the lifetime of the module
-lib.sw_set_log_callback.argtypes = [_LOG_FN]
-lib.sw_set_log_callback.restype = None
 lib.sw_set_log_callback(_log_callback)
 
 

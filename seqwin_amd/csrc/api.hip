@@ -731,6 +731,18 @@ static void log_message(const char *level, const char *fmt, ...)
     fn(level, buf);
 }
 
+}   // extern "C"
+static std::atomic<uint64_t> g_guard_trips[2];
+void sw::order_guard_tripped(int which, uint32_t places)
+{
+    g_guard_trips[which ? 1 : 0].fetch_add(1);
+    const char *what = which ? "edge-key sort" : "node sort";
+    fprintf(stderr, "[seqwin_amd] WARNING: order guard: the %s came out of order in %u places (LDS-atomic ranking of the radix passes); "
+                    "re-sorting with ballot / rocPRIM ranking, which this device keeps for the rest of the process\n", what, places);
+    log_message("warning", "order guard: the %s came out of order in %u places; re-sorted with ballot / rocPRIM ranking", what, places);
+}
+extern "C" {
+
 int sw_device_count(void)
 {
     int n = 0;
@@ -1205,6 +1217,14 @@ int sw_radix_rank_mode(int *mode)
     return guarded([&] {
         require_device();
         *mode = radix_rank_mode();
+    });
+}
+
+int sw_order_guard_trips(uint64_t *node_sort, uint64_t *edge_sort)
+{
+    return guarded([&] {
+        if (node_sort) *node_sort = g_guard_trips[0].load();
+        if (edge_sort) *edge_sort = g_guard_trips[1].load();
     });
 }
 

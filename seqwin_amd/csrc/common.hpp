@@ -33,6 +33,9 @@ struct Error : std::runtime_error {
 }
 
 void set_last_error(const char *msg);
+// api.hip: an always-on order guard of the index build tripped (which: 0 node sort, 1 edge-key sort); counted (sw_order_guard_trips),
+// logged as a WARNING through the log callback and on stderr.  The caller then re-sorts without the LDS-atomic ranking.
+void order_guard_tripped(int which, uint32_t places);
 
 template <class F> int guarded(F &&f)
 {

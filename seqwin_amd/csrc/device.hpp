@@ -241,6 +241,7 @@ struct alignas(16) OccPay {
 // radix.hip: stable sort of (key32, OccPay) pairs by key bits [0, end_bit), end_bit in {8, 16, 24, 32}; double buffers
 int radix_rank_mode();          // how radix.hip ranks keys inside a wave on the current device: 1 LDS atomics, 0 ballots (runs the self-check once)
 bool radix_pairs_available();   // false on a device that does not pass the LDS-atomic ranking self-check (rocPRIM sorts the pairs then)
+void radix_demote_rank();       // an order guard (k_nodes, k_rle_keys, k_check_ascending) tripped: ballots / rocPRIM on this device from now on
 // The sketch stage as the input of the sort's first pass (no ordered copy in between: the pass does what k_order does on
 // the way in).  Dense index g = place of a tuple in (record_idx, pos) order; tile T holds [dst_off[T], dst_off[T] + tile_count[T]).
 constexpr uint32_t STAGE_WIN = 32;                 // tiles from the first of a wave's 448 tuples on that the pass resolves without a search

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
                                                uint64_t *__restrict__ uval,
                                                unsigned long long *__restrict__ tbits, unsigned long long *__restrict__ nbits,
                                                unsigned long long *__restrict__ tile_state, uint32_t *__restrict__ ticket,
-                                               uint32_t *__restrict__ n_nodes_out)
+                                               uint32_t *__restrict__ n_nodes_out, uint32_t *__restrict__ order_bad)
 {
     __shared__ uint32_t s_tile, s_excl;
     __shared__ uint32_t s_row[NODES_ROWS * NODES_WAVES];   // heads of (row, wave): counts, then exclusive offsets
@@ -296,6 +296,7 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
     const uint64_t s0 = (uint64_t)tile * NODES_TILE;
     uint32_t k[NODES_ROWS][2], within[NODES_ROWS], headm = 0, prec[NODES_ROWS];
     OccPay p[NODES_ROWS][2];
+    bool misorder = false;
 #pragma unroll
     for (int r = 0; r < NODES_ROWS; ++r) {
         const uint64_t s = s0 + (uint64_t)r * NODES_ROW + 2 * threadIdx.x;   // occurrences s, s + 1
@@ -312,22 +313,35 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
             p[r][0] = pay[s];
         }
         // the occurrence before s: the odd one of the lane below, or (lane 0) a load
-        uint32_t pk = __shfl_up(k[r][1], 1, 64), plow = __shfl_up(p[r][1].low, 1, 64);
+        uint32_t pk = __shfl_up(k[r][1], 1, 64), plow = __shfl_up(p[r][1].low, 1, 64), pidx = __shfl_up(p[r][1].idx, 1, 64);
         prec[r] = __shfl_up(p[r][1].rec, 1, 64);
         if (lane == 0 && s < n && s) {
             pk = key32[s - 1];
             const OccPay q = pay[s - 1];
             plow = q.low;
             prec[r] = q.rec;
+            pidx = q.idx;
         }
         const bool h0 = s < n && (s == 0 || k[r][0] != pk || p[r][0].low != plow);
         const bool h1 = s + 1 < n && (k[r][1] != k[r][0] || p[r][1].low != p[r][0].low);
+        // Always-on order guard (r05): what arrives here must be THE stable sort by hash of the (record_idx, pos) stream
+        // (build_internals.cpp:76-144, 173, 203-218) -- hashes ascending, and inside a run of equal hashes the stream indices
+        // ascending.  The radix passes rank by an LDS atomic whose lane order is checked at start-up but is no architectural
+        // promise (radix.hip); a violation is counted here and group_occurrences re-sorts without that ranking.
+#ifndef SW_NO_ORDER_GUARD   // (A/B timing of the guard only: tests/tools/build_variant.sh noguard -DSW_NO_ORDER_GUARD)
+        if (s < n && s && (k[r][0] < pk || (k[r][0] == pk && (p[r][0].low < plow || (!h0 && p[r][0].idx <= pidx))))) misorder = true;
+        if (s + 1 < n && (k[r][1] < k[r][0] || (k[r][1] == k[r][0] && (p[r][1].low < p[r][0].low || (!h1 && p[r][1].idx <= p[r][0].idx)))))
+            misorder = true;
+#else
+        (void)pidx;
+#endif
         const unsigned long long b0 = __ballot(h0), b1 = __ballot(h1), lt = (1ull << lane) - 1ull;
         within[r] = (uint32_t)__popcll(b0 & lt) + (uint32_t)__popcll(b1 & lt);   // heads of the wave's row before occurrence s
         if (h0) headm |= 1u << (2 * r);
         if (h1) headm |= 2u << (2 * r);
         if (lane == 0) s_row[r * NODES_WAVES + wave] = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
     }
+    if (misorder) atomicAdd(order_bad, 1u);   // (never, on a device whose LDS unit serves the lanes of an atomic in lane order)
     __syncthreads();
     if (wave == 0) {
         // exclusive offsets of the (row, wave) groups (two per lane), the tile's total, then the look-back
@@ -1239,6 +1253,13 @@ struct AsmChangeAny {
     }
 };
 
+// order guard of the keys-only sorts where no kernel of ours streams over the sorted keys anyway (rocPRIM run lengths)
+__global__ void k_check_ascending(const uint64_t *__restrict__ keys, uint64_t m, uint32_t *__restrict__ order_bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i && i < m && keys[i] < keys[i - 1]) atomicAdd(order_bad, 1u);
+}
+
 __global__ void k_drop_sentinel_run(const uint64_t *__restrict__ ukeys, uint64_t sentinel, uint32_t *__restrict__ count)
 {
     const uint32_t n = *count;
@@ -1254,7 +1275,8 @@ constexpr int RLE_THREADS = 1024, RLE_ITEMS = 8;
 constexpr uint32_t RLE_TILE = RLE_THREADS * RLE_ITEMS;
 __global__ __launch_bounds__(RLE_THREADS) void k_rle_keys(const uint64_t *__restrict__ keys, uint64_t m, uint64_t *__restrict__ ukeys,
                                                            uint32_t *__restrict__ ustart, unsigned long long *__restrict__ tile_state,
-                                                           uint32_t *__restrict__ ticket, uint32_t *__restrict__ n_runs_out)
+                                                           uint32_t *__restrict__ ticket, uint32_t *__restrict__ n_runs_out,
+                                                           uint32_t *__restrict__ order_bad)
 {
     __shared__ uint32_t s_tile, s_excl, s_wave[RLE_THREADS / 64];
     __shared__ uint64_t s_last[RLE_THREADS / 64];        // last key of every wave (the predecessor of the next wave's first)
@@ -1275,12 +1297,16 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_keys(const uint64_t *__rest
     __syncthreads();
     uint64_t carry = wave ? s_last[wave - 1] : (t0 ? keys[t0 - 1] : 0ull);   // the key before the wave's first (unused at position 0)
     uint32_t cnt[RLE_ITEMS], below[RLE_ITEMS], total_w = 0, headm = 0;
+    bool misorder = false;
 #pragma unroll
     for (int j = 0; j < RLE_ITEMS; ++j) {
         const uint64_t i = w0 + (uint64_t)j * 64 + lane;
         uint64_t prev = __shfl_up(k[j], 1, 64);
         if (lane == 0) prev = carry;
         const bool head = i < m && (i == 0 || k[j] != prev);
+#ifndef SW_NO_ORDER_GUARD
+        if (i < m && i && k[j] < prev) misorder = true;   // always-on order guard (r05): the keys must arrive ascending
+#endif
         const unsigned long long b = __ballot(head);
         below[j] = total_w + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));   // heads of the wave before this key
         cnt[j] = (uint32_t)__popcll(b);
@@ -1289,6 +1315,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_keys(const uint64_t *__rest
         carry = __shfl(k[j], 63, 64);
     }
     if (lane == 0) s_wave[wave] = total_w;
+    if (misorder) atomicAdd(order_bad, 1u);
     __syncthreads();
     if (wave == 0) {
         const uint32_t wc = lane < RLE_THREADS / 64 ? s_wave[lane] : 0u;
@@ -1898,7 +1925,14 @@ __global__ __launch_bounds__(256) void k_list_descents(const View V, typename Vi
 // k_repair_sort (a workgroup per run, in LDS).
 // Anything the fast path does not take (more than REPAIR_MAX_DESC descents, a run longer than REPAIR_MAX_RUN)
 // raises `status` and is left to the general repair of the caller.
-constexpr uint32_t REPAIR_MAX_DESC = 1u << 22;   // 15k genomes: 7.3e5 descents (79 M nodes); 2^22 covers ~190 M nodes
+// r05: one THREAD per descent first (k_repair_thread) -- a run of up to REPAIR_THREAD_RUN elements (two different hashes that
+// share their top half: the rule) is delimited, ranked and rewritten by one lane; only the owners of longer runs are listed
+// (`mid`) for the wave form.  With that the in-place route takes 2^26 descents: one GPU's share of 100 000 iid genomes
+// (5.4e8 nodes -> n^2 / 2^33 = 3.4e7 shared top halves, 1.7e7 descents) went through the general repair before -- k_bad_runs +
+// gather + an 8-pass rocPRIM pair sort + scatter, 12 ms per build (profiles/r04d_random100k_k19_kernel_stats.txt).
+constexpr uint32_t REPAIR_MAX_DESC = 1u << 26;   // 15k genomes: 7.3e5 descents (79 M nodes); 5.4e8 nodes: 1.7e7
+constexpr uint32_t REPAIR_MAX_MID = 1u << 22;    // owners of runs longer than REPAIR_THREAD_RUN (15k genomes: a node has up to 500 occurrences)
+constexpr uint32_t REPAIR_THREAD_RUN = 6;
 constexpr uint32_t REPAIR_MAX_RUN = 2048;
 constexpr uint32_t REPAIR_GRID = 2048;
 
@@ -1913,21 +1947,66 @@ __device__ __forceinline__ uint32_t readlane_key(uint32_t v, uint32_t lane) { re
 __device__ __forceinline__ uint64_t readlane_key(uint64_t v, uint32_t lane) { return readlane64(v, lane); }
 
 template <class View>
-__global__ __launch_bounds__(256) void k_repair_wave(const View V, typename View::Key kmask, uint64_t n, const uint32_t *__restrict__ bad_q,
-                                                     const unsigned long long *__restrict__ n_desc, uint32_t *__restrict__ big,
-                                                     uint32_t *__restrict__ n_big, uint32_t *__restrict__ status)
+__global__ __launch_bounds__(256) void k_repair_thread(const View V, typename View::Key kmask, uint64_t n, const uint32_t *__restrict__ bad_q,
+                                                       const unsigned long long *__restrict__ n_desc, uint32_t *__restrict__ mid,
+                                                       uint32_t *__restrict__ n_mid, uint32_t *__restrict__ status)
 {
+    constexpr uint32_t RT = REPAIR_THREAD_RUN;
     const unsigned long long D = *n_desc;
     if (D > REPAIR_MAX_DESC) {
         if (blockIdx.x == 0 && threadIdx.x == 0) *status = 1u;
         return;
     }
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
-    for (uint32_t b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < D; b += n_waves) {   // (wave-uniform)
+    const uint64_t n_threads = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < D; b += n_threads) {
         const uint32_t q = bad_q[b];
         const typename View::Key k = V.key(q) & kmask;
         if (b && (V.key(bad_q[b - 1]) & kmask) == k) continue;   // an earlier descent of the same run owns it
+        uint64_t a = q, e = (uint64_t)q + 1;                     // [a, e) belongs to the run
+        while (a > 0 && e - a <= RT && (V.key(a - 1) & kmask) == k) --a;
+        while (e < n && e - a <= RT && (V.key(e) & kmask) == k) ++e;
+        const uint32_t len = (uint32_t)(e - a);
+        if (len > RT) {                                          // the wave form's (k_repair_wave walks this list)
+            const uint32_t s = atomicAdd(n_mid, 1u);
+            if (s < REPAIR_MAX_MID) mid[s] = (uint32_t)b;
+            else *status = 1u;
+            continue;
+        }
+        typename View::Key ki[RT];
+        typename View::Elem vi[RT];
+#pragma unroll
+        for (uint32_t i = 0; i < RT; ++i)
+            if (i < len) V.load(a + i, ki[i], vi[i]);
+        uint32_t rank[RT];
+#pragma unroll
+        for (uint32_t i = 0; i < RT; ++i) {
+            rank[i] = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < RT; ++j)
+                if (i < len && j < len && j != i) {
+                    const uint64_t li = View::low_of(vi[i]), lj = View::low_of(vi[j]);
+                    rank[i] += (ki[j] < ki[i] || (ki[j] == ki[i] && (lj < li || (lj == li && j < i)))) ? 1u : 0u;
+                }
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < RT; ++i)
+            if (i < len && rank[i] != i) V.store(a + rank[i], ki[i], vi[i]);   // (all of the run's loads have returned: the ranks depend on them)
+    }
+}
+
+template <class View>
+__global__ __launch_bounds__(256) void k_repair_wave(const View V, typename View::Key kmask, uint64_t n, const uint32_t *__restrict__ bad_q,
+                                                     const unsigned long long *__restrict__ n_desc, const uint32_t *__restrict__ mid,
+                                                     const uint32_t *__restrict__ n_mid, uint32_t *__restrict__ big,
+                                                     uint32_t *__restrict__ n_big, uint32_t *__restrict__ status)
+{
+    if (*n_desc > REPAIR_MAX_DESC) return;                       // (k_repair_thread has raised status)
+    const uint32_t M = min(*n_mid, REPAIR_MAX_MID);              // owners of runs the thread form left (wave-uniform)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t bi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); bi < M; bi += n_waves) {   // (wave-uniform)
+        const uint32_t q = bad_q[mid[bi]];
+        const typename View::Key k = V.key(q) & kmask;
         uint64_t a = q, e = (uint64_t)q + 1;                     // [a, e) belongs to the run
         bool too_long = false;
         for (;;) {                                               // leftwards: positions a-1, a-2, ..
@@ -1957,7 +2036,7 @@ __global__ __launch_bounds__(256) void k_repair_wave(const View V, typename View
         }
         if (len > 64) {
             if (lane == 0) {
-                const uint32_t s = atomicAdd(n_big, 1u);         // (at most one entry per owner: <= D <= the list's size)
+                const uint32_t s = atomicAdd(n_big, 1u);         // (at most one entry per listed owner: <= REPAIR_MAX_MID, the list's size)
                 big[2 * s] = (uint32_t)a;
                 big[2 * s + 1] = len;
             }
@@ -2095,7 +2174,8 @@ struct RepairState {
     DevArray<unsigned long long> n_desc;   // [0] descents, [1] run heads before the repair
     DevArray<unsigned long long> blk_cnt, blk_off;
     DevArray<uint32_t> slot_q, slot_k;   // per block of the descent passes: its first DESC_SLOT descents (position, masked key)
-    DevArray<uint32_t> bad_q, big, status;   // status: [0] leftovers for the general repair, [1] the number of listed long runs
+    DevArray<uint32_t> bad_q, mid, big, status;   // status: [0] leftovers for the general repair, [1] listed long runs (> 64), [2] listed
+                                                  // owners of runs the thread form left (> REPAIR_THREAD_RUN)
 };
 
 // enqueue: list the descents of the phase-1 order, repair short runs in place.  `bad` (may be null) also receives the
@@ -2107,22 +2187,26 @@ void enqueue_repair(const View &V, const Sweep &W, typename View::Key kmask, uin
 {
     const uint32_t n_blocks = (uint32_t)((n + DESC_BLOCK - 1) / DESC_BLOCK);
     const uint32_t max_desc = (uint32_t)std::min<uint64_t>(REPAIR_MAX_DESC, std::max<uint64_t>(n, 1));
+    const uint32_t max_mid = std::min(max_desc, REPAIR_MAX_MID);
     r.bad_q.alloc(max_desc);
-    r.big.alloc(2 * (size_t)max_desc);
+    r.mid.alloc(max_mid);
+    r.big.alloc(2 * (size_t)max_mid);
     r.n_desc.alloc(2);
-    r.status.alloc(2);
+    r.status.alloc(3);
     r.blk_cnt.alloc(n_blocks);
     r.blk_off.alloc(n_blocks);
     r.slot_q.alloc((size_t)n_blocks * DESC_SLOT);
     r.slot_k.alloc((size_t)n_blocks * DESC_SLOT);
-    SW_HIP(hipMemsetAsync(r.status.p, 0, 8, stream));
+    SW_HIP(hipMemsetAsync(r.status.p, 0, 12, stream));
     hipLaunchKernelGGL(k_count_descents<Sweep>, dim3(n_blocks), dim3(256), 0, stream, W, kmask, n, r.blk_cnt.p, r.slot_q.p, r.slot_k.p);
     SW_HIP(hipGetLastError());
     exclusive_sum(r.blk_cnt.p, r.blk_off.p, n_blocks, 0ull, stream);   // both halves at once: neither sum reaches 2^32
     hipLaunchKernelGGL(k_list_descents<Sweep>, dim3(n_blocks), dim3(256), 0, stream, W, kmask, n, r.blk_cnt.p, r.blk_off.p,
                        n_blocks, bad, cap, r.bad_q.p, max_desc, r.n_desc.p, r.slot_q.p, r.slot_k.p);
+    hipLaunchKernelGGL(k_repair_thread<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, kmask, n, r.bad_q.p, r.n_desc.p, r.mid.p,
+                       r.status.p + 2, r.status.p);
     hipLaunchKernelGGL(k_repair_wave<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, kmask, n, r.bad_q.p, r.n_desc.p,
-                       r.big.p, r.status.p + 1, r.status.p);
+                       (const uint32_t *)r.mid.p, (const uint32_t *)(r.status.p + 2), r.big.p, r.status.p + 1, r.status.p);
     hipLaunchKernelGGL(k_repair_sort<View>, dim3(REPAIR_GRID), dim3(256), 0, stream, V, r.status.p + 1, r.big.p);
     SW_HIP(hipGetLastError());
 }
@@ -2360,6 +2444,55 @@ struct UnsortHold {
     DevArray<uint64_t> a, b;
     const uint64_t *sorted = nullptr;
 };
+
+// ---- recovery when k_nodes' order guard trips (r05) ---------------------------------------------------------------------------
+// The sorted arrays still hold every occurrence with its place in the (record_idx, pos) stream (OccPay::idx), so the stream can
+// be restored without the sketch stage (released by the sort's first pass): scatter every element to its index, then sort by the
+// whole 64-bit hash with rocPRIM's radix sort (ballot-free match-any ranking, stable by construction) -- exactly
+// lsd_radix_sort (build_internals.cpp:76-144) on the original stream.  Slow (8 passes of 24 B) and never taken on a device whose
+// LDS unit behaves as the start-up self-check saw it; taken in the suite through SEQWIN_AMD_FAULT_INJECT=rank.
+__global__ void k_restore_stream(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay, uint64_t n, uint64_t *__restrict__ key64,
+                                 OccPay *__restrict__ out, uint32_t *__restrict__ bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const OccPay q = pay[i];
+    if (q.idx >= n) {
+        atomicAdd(bad, 1u);
+        return;
+    }
+    key64[q.idx] = ((uint64_t)key32[i] << 32) | q.low;
+    out[q.idx] = q;
+}
+__global__ void k_split_restored(const uint64_t *__restrict__ key64, const OccPay *__restrict__ pay, uint64_t n, uint32_t *__restrict__ key32,
+                                 uint32_t *__restrict__ bad)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key32[i] = (uint32_t)(key64[i] >> 32);
+    if (pay[i].idx == 0xFFFFFFFFu) atomicAdd(bad, 1u);   // a place of the stream nothing was scattered to: the passes lost an element
+}
+void resort_pay_stable(PaySort &ps, uint64_t n, hipStream_t stream)
+{
+    OccPay *cur = ps.pay, *other = (ps.pay == ps.pay_a.p) ? ps.pay_b.p : ps.pay_a.p;
+    if (!other || !cur) raise(SW_ERR_RUNTIME, "internal error: the node sort's second buffer is gone");
+    DevArray<uint64_t> k0(n), k1(n);
+    DevArray<uint32_t> bad(1);
+    SW_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
+    SW_HIP(hipMemsetAsync(other, 0xFF, n * sizeof(OccPay), stream));
+    hipLaunchKernelGGL(k_restore_stream, dim3(blocks_for(n)), dim3(TPB), 0, stream, ps.key32, cur, n, k0.p, other, bad.p);
+    SW_HIP(hipGetLastError());
+    uint64_t *k = k0.p, *k_alt = k1.p;
+    OccPay *v = other, *v_alt = cur;
+    sort_pairs(k, k_alt, v, v_alt, n, 0, 64, stream);
+    hipLaunchKernelGGL(k_split_restored, dim3(blocks_for(n)), dim3(TPB), 0, stream, k, v, n, ps.key32, bad.p);
+    SW_HIP(hipGetLastError());
+    uint32_t nbad = 0;
+    SW_HIP(hipMemcpyAsync(&nbad, bad.p, 4, hipMemcpyDeviceToHost, stream));
+    SW_HIP(hipStreamSynchronize(stream));   // (k0 / k1 are released on return)
+    if (nbad) raise(SW_ERR_RUNTIME, "internal error: the node sort lost %u occurrences (not a permutation of its input)", nbad);
+    ps.pay = v;
+}
 uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_t *rec_flag, hipStream_t stream, sw_index &ix,
                            uint32_t *rank_out, DevArray<unsigned long long> *tbits, DevArray<unsigned long long> *nbits,
                            bool *rep_marked = nullptr, UnsortHold *hold = nullptr)
@@ -2381,43 +2514,53 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     }
     const unsigned blocks = (unsigned)((n + NODES_TILE - 1) / NODES_TILE);
     DevArray<unsigned long long> tile_state(blocks);
-    DevArray<uint32_t> words(3);   // [0] tile tickets, [1] the number of nodes, [2] the unsort's radix passes gave up
-    SW_HIP(hipMemsetAsync(tile_state.p, 0, (size_t)blocks * 8, stream));
-    SW_HIP(hipMemsetAsync(words.p, 0, 12, stream));
-    {
-        auto launch = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(blocks), dim3(NODES_THREADS), 0, stream, ps.key32, ps.pay, n, base, rec_flag, ix.kmers.p,
-                               ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uv0.p, bits ? tbits->p : (unsigned long long *)nullptr,
-                               bits ? nbits->p : (unsigned long long *)nullptr, tile_state.p, words.p, words.p + 1);
-        };
-        if (bits && rep) launch(k_nodes<true, true>);
-        else if (bits) launch(k_nodes<true, false>);
-        else if (rep) launch(k_nodes<false, true>);
-        else launch(k_nodes<false, false>);
-    }
-    SW_HIP(hipGetLastError());
-    uint32_t back[2] = {0, 0};   // the number of nodes, the sort's failure word (read after the unsort has been enqueued)
-    if (rank_out && !direct) {
-        unsigned nbit = 1;
-        while (nbit < 32 && (1ull << nbit) < n) ++nbit;          // indices < 2^nbit
-        uv1.alloc(n);
-        uint64_t *v = uv0.p;
-        if (nbit > UNSORT_BITS) {   // buckets of 2^14 consecutive indices: sort on the index's bits above those
-            // (begin_bit > 0 of rocPRIM's radix sort is checked on this stack by scripts/micro/sort_beginbit.hip)
-            uint64_t *v_alt = uv1.p;
-            if (!(sort_keys64_is_own(n) && radix_unsort_perm(v, v_alt, n, UNSORT_BITS, nbit, stream, words.p + 2)))
-                sort_keys64(v, v_alt, n, 32 + UNSORT_BITS, 32 + nbit, stream, words.p + 2, true);   // (the indices are a permutation)
+    DevArray<uint32_t> words(4);   // [0] tile tickets, [1] the number of nodes, [2] the unsort's radix passes gave up, [3] order-guard violations
+    uint32_t back[3] = {0, 0, 0};  // words 1 .. 3 (read after the unsort has been enqueued)
+    if (rank_out && !direct) uv1.alloc(n);
+    for (int attempt = 0;; ++attempt) {
+        SW_HIP(hipMemsetAsync(tile_state.p, 0, (size_t)blocks * 8, stream));
+        SW_HIP(hipMemsetAsync(words.p, 0, 16, stream));
+        {
+            auto launch = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(blocks), dim3(NODES_THREADS), 0, stream, ps.key32, ps.pay, n, base, rec_flag, ix.kmers.p,
+                                   ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uv0.p, bits ? tbits->p : (unsigned long long *)nullptr,
+                                   bits ? nbits->p : (unsigned long long *)nullptr, tile_state.p, words.p, words.p + 1, words.p + 3);
+            };
+            if (bits && rep) launch(k_nodes<true, true>);
+            else if (bits) launch(k_nodes<true, false>);
+            else if (rep) launch(k_nodes<false, true>);
+            else launch(k_nodes<false, false>);
         }
-        if (hold && rep && nbit > UNSORT_BITS && !getenv("SEQWIN_AMD_ADJ_SEPARATE")) {
-            hold->sorted = v;
-        } else {
-            hipLaunchKernelGGL(k_unsort_bucket, dim3((unsigned)((n + UNSORT_RANGE - 1) / UNSORT_RANGE)), dim3(1024), 0, stream, v, n,
-                               rank_out);
-            SW_HIP(hipGetLastError());
+        SW_HIP(hipGetLastError());
+        if (rank_out && !direct) {
+            unsigned nbit = 1;
+            while (nbit < 32 && (1ull << nbit) < n) ++nbit;          // indices < 2^nbit
+            uint64_t *v = uv0.p;
+            if (nbit > UNSORT_BITS) {   // buckets of 2^14 consecutive indices: sort on the index's bits above those
+                // (begin_bit > 0 of rocPRIM's radix sort is checked on this stack by scripts/micro/sort_beginbit.hip)
+                uint64_t *v_alt = uv1.p;
+                if (!(sort_keys64_is_own(n) && radix_unsort_perm(v, v_alt, n, UNSORT_BITS, nbit, stream, words.p + 2)))
+                    sort_keys64(v, v_alt, n, 32 + UNSORT_BITS, 32 + nbit, stream, words.p + 2, true);   // (the indices are a permutation)
+            }
+            if (hold && rep && nbit > UNSORT_BITS && !getenv("SEQWIN_AMD_ADJ_SEPARATE")) {
+                hold->sorted = v;
+            } else {
+                hipLaunchKernelGGL(k_unsort_bucket, dim3((unsigned)((n + UNSORT_RANGE - 1) / UNSORT_RANGE)), dim3(1024), 0, stream, v, n,
+                                   rank_out);
+                SW_HIP(hipGetLastError());
+            }
         }
+        SW_HIP(hipMemcpyAsync(back, words.p + 1, 12, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipStreamSynchronize(stream));   // n_nodes has arrived
+        if (back[2] == 0) break;
+        // k_nodes saw occurrences out of (hash, stream index) order: the LDS-atomic ranking of the radix passes did not keep
+        // the lane order on this device (or SEQWIN_AMD_FAULT_INJECT=rank).  Nothing of this attempt is kept.
+        if (attempt)
+            raise(SW_ERR_RUNTIME, "internal error: the node sort is still out of order after the rocPRIM re-sort (%u places)", back[2]);
+        order_guard_tripped(0, back[2]);
+        radix_demote_rank();
+        resort_pay_stable(ps, n, stream);
     }
-    SW_HIP(hipMemcpyAsync(back, words.p + 1, 8, hipMemcpyDeviceToHost, stream));
-    SW_HIP(hipStreamSynchronize(stream));   // n_nodes has arrived
     const uint32_t n_nodes = back[0];
     check_sort_failed(back[1]);
     if (n_nodes > node_cap) raise(SW_ERR_RUNTIME, "internal error: %u nodes exceed the bound %llu", n_nodes, (unsigned long long)node_cap);
@@ -2902,6 +3045,19 @@ void edges_from_packed(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t 
     {
         const unsigned sort_bits = 2 * nb + ab;
         sort_keys64(keys, keys_alt, m, 0, sort_bits, stream, sort_fail.p);
+        if (sort_keys64_is_own(m) && radix_rank_mode() == 1) {   // order guard (r05; this legacy form synchronises here, the default forms do not)
+            DevArray<uint32_t> bad(1);
+            uint32_t descents = 0;
+            SW_HIP(hipMemsetAsync(bad.p, 0, 4, stream));
+            hipLaunchKernelGGL(k_check_ascending, dim3(blocks_for(m)), dim3(TPB), 0, stream, (const uint64_t *)keys, m, bad.p);
+            SW_HIP(hipMemcpyAsync(&descents, bad.p, 4, hipMemcpyDeviceToHost, stream));
+            SW_HIP(hipStreamSynchronize(stream));
+            if (descents) {
+                order_guard_tripped(1, descents);
+                radix_demote_rank();
+                sort_keys64(keys, keys_alt, m, 0, sort_bits, stream, sort_fail.p);
+            }
+        }
     }
     // One run-length pass over the sorted keys (rocprim::reduce_by_key, decoupled look-back): runs = equal pairs, value of
     // an element = 1 where the whole key (pair, assembly) differs from its predecessor, so a run's sum is the number of
@@ -2976,13 +3132,15 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
     RepairState rep;
     if (low_bits) enqueue_repair(EdgeKeyView{keys, low_bits}, EdgeKeyView{keys, low_bits}, ~0ull, m, nullptr, 0, rep, stream);
     DevArray<uint64_t> ukeys(m);
-    DevArray<uint32_t> ucnt(m + 1), ucount(1);
+    DevArray<uint32_t> ucnt(m + 1), ucount(2);   // ucount[1]: places where the sorted keys descend (order guard, r05)
     unsigned long long n_cand = host_n_cand;
     // run lengths by this library's streaming pass (k_rle_keys: ucnt then holds the START of every run, and m behind the last);
     // SEQWIN_AMD_RLE=rocprim: rocprim::run_length_encode (ucnt = the lengths) -- A/B, and what rounds 1-3 ran
     const char *rle_env = getenv("SEQWIN_AMD_RLE");
     const bool own_rle = !(rle_env && !strcmp(rle_env, "rocprim"));
+    bool demoted = false;
     for (int attempt = 0;; ++attempt) {
+        SW_HIP(hipMemsetAsync(ucount.p + 1, 0, 4, stream));
         if (own_rle) {
             const unsigned blocks = (unsigned)((m + RLE_TILE - 1) / RLE_TILE);
             DevArray<unsigned long long> tile_state(blocks);
@@ -2990,9 +3148,10 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
             SW_HIP(hipMemsetAsync(tile_state.p, 0, (size_t)blocks * 8, stream));
             SW_HIP(hipMemsetAsync(ticket.p, 0, 4, stream));
             hipLaunchKernelGGL(k_rle_keys, dim3(blocks), dim3(RLE_THREADS), 0, stream, (const uint64_t *)keys, m, ukeys.p, ucnt.p, tile_state.p,
-                               ticket.p, ucount.p);
+                               ticket.p, ucount.p, ucount.p + 1);
             SW_HIP(hipGetLastError());
         } else {
+            hipLaunchKernelGGL(k_check_ascending, dim3(blocks_for(m)), dim3(TPB), 0, stream, (const uint64_t *)keys, m, ucount.p + 1);
             size_t tmp_bytes = 0;
             SW_HIP(rocprim::run_length_encode(nullptr, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
             DevArray<unsigned char> tmp(tmp_bytes);
@@ -3001,8 +3160,9 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
         }
         hipLaunchKernelGGL(k_drop_sentinel_run, dim3(1), dim3(1), 0, stream, ukeys.p, sentinel, ucount.p);
         SW_HIP(hipGetLastError());
-        uint32_t n_edges = 0, failed = 0, left = 0;
+        uint32_t n_edges = 0, failed = 0, left = 0, descents = 0;
         SW_HIP(hipMemcpyAsync(&n_edges, ucount.p, 4, hipMemcpyDeviceToHost, stream));
+        SW_HIP(hipMemcpyAsync(&descents, ucount.p + 1, 4, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipMemcpyAsync(&failed, sort_fail.p, 4, hipMemcpyDeviceToHost, stream));
         if (low_bits && attempt == 0) SW_HIP(hipMemcpyAsync(&left, rep.status.p, 4, hipMemcpyDeviceToHost, stream));
         if (d_n_cand) SW_HIP(hipMemcpyAsync(&n_cand, d_n_cand, 8, hipMemcpyDeviceToHost, stream));
@@ -3017,6 +3177,18 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
                     nd[0], st[1], st[0]);
         }
         if (left) {   // the in-place repair left runs unsorted: the keys are still the same multiset, sort them on all bits
+            sort_keys64(keys, keys_alt, m, 0, key_bits, stream, sort_fail.p);
+            continue;
+        }
+        if (descents) {
+            // the sorted keys descend somewhere although sort and repair reported nothing: the LDS-atomic ranking of the radix
+            // passes did not keep the lane order (or SEQWIN_AMD_FAULT_INJECT=rank).  The keys are still the same multiset: sort
+            // them again, on all bits, ranking by ballots.
+            if (demoted)
+                raise(SW_ERR_RUNTIME, "internal error: the edge keys are still out of order after the ballot-ranked re-sort (%u places)", descents);
+            order_guard_tripped(1, descents);
+            radix_demote_rank();
+            demoted = true;
             sort_keys64(keys, keys_alt, m, 0, key_bits, stream, sort_fail.p);
             continue;
         }

@@ -179,10 +179,20 @@ bool ballot_forced()
     const char *e = getenv("SEQWIN_AMD_RADIX_RANK");
     return e && !strcmp(e, "ballot");
 }
-int rank_mode()
+std::mutex &rank_mu()
 {
     static std::mutex &mu = *new std::mutex;
+    return mu;
+}
+std::map<int, int> &rank_modes()
+{
     static std::map<int, int> &modes = *new std::map<int, int>;
+    return modes;
+}
+int rank_mode()
+{
+    std::mutex &mu = rank_mu();
+    std::map<int, int> &modes = rank_modes();
     const char *e = getenv("SEQWIN_AMD_RADIX_RANK");
     if (e && !strcmp(e, "ballot")) return 0;
     int dev = 0;
@@ -203,6 +213,15 @@ int rank_mode()
     if (e && !strcmp(e, "atomic") && it->second != 1)
         raise(SW_ERR_RUNTIME, "SEQWIN_AMD_RADIX_RANK=atomic, but this device does not serve the lanes of an LDS atomic in lane order");
     return it->second;
+}
+
+// SEQWIN_AMD_FAULT_INJECT=rank (tests): the first wave of every tile of the LDS-atomic passes swaps the ranks of neighbouring
+// lanes that hold the same digit -- exactly the failure the stability of these passes rests on NOT happening.  The ballot
+// passes and rocPRIM's have no such hook, so a build recovers once the guards have demoted the device.
+static uint32_t fault_rank()
+{
+    const char *e = getenv("SEQWIN_AMD_FAULT_INJECT");
+    return (e && !strcmp(e, "rank")) ? 1u : 0u;
 }
 
 // One pass: tile t = workgroup t takes THREADS x 16 consecutive keys, wave w of it the w-th 1024 of them, lane l item i the
@@ -414,6 +433,15 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass_p(const uint64_t *__restric
             for (int i = 0; i < RS_ITEMS; ++i) {
                 const uint32_t d = (uint32_t)(key[i] >> shift) & dmask;
                 rank[i] = (rank[i] >> ((d & 1u) << 4)) & 0xFFFFu;
+            }
+            if ((dbg & 16u) && !cursor && wave == 0) {   // SEQWIN_AMD_FAULT_INJECT=rank (tests): see fault_rank()
+#pragma unroll
+                for (int i = 0; i < RS_ITEMS; ++i) {
+                    const uint32_t li = i * 64 + lane;
+                    const uint32_t d = li < cnt_tile ? ((uint32_t)(key[i] >> shift) & dmask) : ~lane;
+                    const uint32_t od = __shfl_xor(d, 1, 64), orank = __shfl_xor(rank[i], 1, 64);
+                    if (od == d) rank[i] = orank;
+                }
             }
         }
 #pragma unroll
@@ -628,7 +656,7 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
                                                              const unsigned long long *__restrict__ digit_base,
                                                              unsigned long long *__restrict__ state, uint32_t epoch,
                                                              uint32_t *__restrict__ ticket, uint32_t *__restrict__ fail,
-                                                             const StageSource S, uint32_t *__restrict__ lowout)
+                                                             const StageSource S, uint32_t *__restrict__ lowout, uint32_t fault)
 {
     constexpr bool STAGE = SRC == 1, ROWS = SRC == 2;
     constexpr uint32_t THREADS = RP_THREADS, ITEMS = RP_ITEMS, RADIX = 1u << RP_BITS, WAVES = THREADS / 64, TILE = THREADS * ITEMS;
@@ -750,6 +778,15 @@ __global__ __launch_bounds__(RP_THREADS) void k_rs_pair_pass(const uint32_t *__r
         for (int i = 0; i < (int)ITEMS; ++i) {
             const uint32_t d = (key[i] >> shift) & (RADIX - 1u);
             pos[i] = (pos[i] >> ((d & 1u) << 4)) & 0xFFFFu;
+        }
+        if (fault && wave == 0) {   // SEQWIN_AMD_FAULT_INJECT=rank (tests): see fault_rank()
+#pragma unroll
+            for (int i = 0; i < (int)ITEMS; ++i) {
+                const uint32_t li = i * 64 + lane;
+                const uint32_t d = li < cnt_tile ? ((key[i] >> shift) & (RADIX - 1u)) : ~lane;
+                const uint32_t od = __shfl_xor(d, 1, 64), opos = __shfl_xor(pos[i], 1, 64);
+                if (od == d) pos[i] = opos;
+            }
         }
         __syncthreads();
         uint32_t total = 0, incl = 0;
@@ -1044,8 +1081,9 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
     const bool persistent = !(kind && !strcmp(kind, "classic"));
     uint32_t dbg = 0;
 #ifdef SW_RADIX_ABLATION     // timing experiments only (tests/tools/sort_time.py with SEQWIN_AMD_RADIX_DEBUG; the output is NOT sorted): 1 no look-back, 2 no stores, 4 no loads, 8 no ranking
-    if (const char *e = getenv("SEQWIN_AMD_RADIX_DEBUG")) dbg = (uint32_t)atoi(e);
+    if (const char *e = getenv("SEQWIN_AMD_RADIX_DEBUG")) dbg = (uint32_t)atoi(e) & 15u;
 #endif
+    if (fault_rank()) dbg |= 16u;
     // resident workgroups of the persistent form (per template instance; taken from the first device that sorts -- any number
     // is correct, tiles are handed out by tickets)
     int grid_p = 0;
@@ -1202,6 +1240,16 @@ bool radix_unsort_perm(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned low
 bool radix_pairs_available() { return rank_mode() == 1; }   // (the pair passes rank by LDS atomics only)
 int radix_rank_mode() { return rank_mode(); }               // 1: LDS atomics (the device passed the self-check), 0: ballots
 
+// The always-on order guards of the consumers (index.hip: k_nodes, k_rle_keys, k_check_ascending) found a result of the
+// LDS-atomic ranking out of order: the current device ranks by ballots from here on (pairs: rocPRIM), for the rest of the process.
+void radix_demote_rank()
+{
+    int dev = 0;
+    SW_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(rank_mu());
+    rank_modes()[dev] = 0;
+}
+
 // Stable sort of (key32, 16-byte payload) pairs by bits [0, end_bit) of the keys, end_bit a multiple of 8 up to 32 (the node
 // sort: all 32).  Double buffers; on return keys / vals point at the sorted data.
 void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, OccPay *&vals_alt, uint64_t n, unsigned end_bit,
@@ -1260,6 +1308,7 @@ void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, Occ
     SW_HIP(hipGetLastError());
     StateBuf &sb = state_buf(stream, (size_t)n_tiles * RADIX);
     const StageSource none{};
+    const uint32_t fault = fault_rank();
     for (unsigned p = 0; p < n_passes; ++p) {
         hipLaunchKernelGGL(k_rs_scan<RP_BITS>, dim3(1), dim3(RADIX), 0, stream, hist.p + (size_t)p * RADIX, (unsigned long long *)nullptr);
         const uint32_t epoch = next_epoch(sb, stream);
@@ -1269,14 +1318,14 @@ void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, Occ
             hipLaunchKernelGGL(first, grid, dim3(RP_THREADS), 0, stream, (const uint32_t *)nullptr, (const uint4 *)nullptr,
                                keys_alt, reinterpret_cast<uint4 *>(vals_alt), n, (uint32_t)n_tiles, 0u,
                                (const unsigned long long *)hist.p, sb.p, epoch, tickets.p, d_fail, stage,
-                               n_passes == 1 ? low_out : (uint32_t *)nullptr);
+                               n_passes == 1 ? low_out : (uint32_t *)nullptr, fault);
             SW_HIP(hipGetLastError());
             if (after_first) after_first();
         } else {
             hipLaunchKernelGGL(k_rs_pair_pass<0>, grid, dim3(RP_THREADS), 0, stream, (const uint32_t *)keys,
                                reinterpret_cast<const uint4 *>(vals), keys_alt, reinterpret_cast<uint4 *>(vals_alt), n, (uint32_t)n_tiles,
                                RP_BITS * p, (const unsigned long long *)(hist.p + (size_t)p * RADIX), sb.p, epoch, tickets.p + p, d_fail,
-                               none, p + 1 == n_passes ? low_out : (uint32_t *)nullptr);
+                               none, p + 1 == n_passes ? low_out : (uint32_t *)nullptr, fault);
             SW_HIP(hipGetLastError());
         }
         std::swap(keys, keys_alt);

@@ -25,7 +25,6 @@ def set_device(device: int) -> None:
 
 def pool_trim() -> None:
     """Hand the library's cached, unused device blocks back to the driver (for a process that shares HBM with torch)."""
-    lib.sw_pool_trim.restype = None
     lib.sw_pool_trim()
 
 

@@ -791,6 +791,78 @@ def test_sort_keys64_is_a_stable_radix_sort(impl, monkeypatch):
         assert torch.equal(out, keys[torch.sort(field, stable=True).indices]), (n, begin, end)
 
 
+_ORDER_GUARD_CHILD = r"""
+import ctypes, json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["SW_ROOT"])
+sys.path.insert(0, os.path.join(os.environ["SW_ROOT"], "tests"))
+import oracle
+from bench import SEED, write_fasta_sample
+from seqwin_amd._lib import check, lib
+from seqwin_amd.device import Batch
+
+def trips():
+    a, b = ctypes.c_uint64(), ctypes.c_uint64()
+    check(lib.sw_order_guard_trips(ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
+
+def mode():
+    m = ctypes.c_int(-1)
+    check(lib.sw_radix_rank_mode(ctypes.byref(m)))
+    return m.value
+
+ng, rpg, rl, k, w = 12, 5, 60000, 21, 200
+b = Batch.synthetic(ng, rpg, rl, n_ancestors=3, snp_ppm=10000, seed=SEED)
+tar = [i < ng // 2 for i in range(ng)]
+paths, _ = write_fasta_sample(b, ng, os.environ["SW_TMP"])
+ek, en, ee, eo, _ = oracle.build(paths, k, w)
+oracle.get_penalty(ek, en, eo, tar)
+out = {"mode_before": mode(), "trips_before": trips()}
+os.environ["SEQWIN_AMD_FAULT_INJECT"] = "rank"          # from here on the LDS-atomic passes mis-rank neighbouring equal digits
+for rnd in ("first", "second"):
+    ix = b.build_index(k, w, tar)
+    K, N, E = ix.export()
+    out[rnd + "_equal"] = bool(np.array_equal(K, ek) and np.array_equal(N, en) and np.array_equal(E, ee))
+    out[rnd + "_trips"] = trips()
+    out[rnd + "_mode"] = mode()
+    ix.close()
+print("RESULT " + json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("which", ["nodes", "edges"])
+def test_order_guard_detects_and_recovers_from_misranked_passes(which, tmp_path):
+    """The radix passes rank by one LDS atomic per key and are stable only while the LDS unit serves the lanes of an atomic in lane
+    order -- checked at start-up, but no architectural promise.  k_nodes and k_rle_keys therefore
+    check the order of what they stream over in EVERY build: (hash, stream index) ascending, edge keys ascending -- the stability
+    contract of lsd_radix_sort, build_internals.cpp:76-144.  SEQWIN_AMD_FAULT_INJECT=rank makes the first wave of every tile swap
+    the ranks of neighbouring lanes with equal digits: the build must notice (sw_order_guard_trips), switch the device to ballot /
+    rocPRIM ranking, sort again and still return the oracle's arrays; the next build stays on the safe ranking and trips nothing.
+    which = nodes: the pair passes of the node sort are hit first (the edge sort then already runs on ballots);
+    which = edges: the pairs go through rocPRIM, so the keys-only passes of the edge sort are the ones that mis-rank.
+    (Own process: the demotion lasts for the rest of the process.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    env = dict(os.environ, SW_ROOT=str(ROOT), SW_TMP=str(tmp_path), SEQWIN_AMD_SORT="own", SEQWIN_AMD_UNSORT_DIRECT="4")
+    env.pop("SEQWIN_AMD_RADIX_RANK", None)
+    if which == "edges":
+        env["SEQWIN_AMD_PAIR_SORT"] = "rocprim"
+    r = subprocess.run([sys.executable, "-c", _ORDER_GUARD_CHILD], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    assert out["mode_before"] == 1 and out["trips_before"] == [0, 0], out        # a healthy device: atomics, nothing tripped
+    assert out["first_equal"] and out["second_equal"], out                      # recovered: the oracle's arrays, twice
+    hit = 0 if which == "nodes" else 1
+    assert out["first_trips"][hit] == 1 and out["first_trips"][1 - hit] == 0, out
+    assert out["first_mode"] == 0 and out["second_mode"] == 0, out              # demoted to ballots / rocPRIM
+    assert out["second_trips"] == out["first_trips"], out                       # ... and the next build trips nothing
+    assert "order guard" in r.stderr                                            # logged
+
+
 def _device_gz_batches() -> int:
     import ctypes
     from seqwin_amd._lib import lib
