@@ -452,6 +452,20 @@ def main() -> None:
         dist_info = dict(ix.info, phases_ms_max_over_ranks={n: round(ph[n], 3) for n in ph},
                          collectives="issued" if (world > 1 or force_coll) else "skipped (one rank, SEQWIN_BENCH_FORCE_DIST)")
 
+    # who ran: one entry per rank -- device index, UUID and PCI bus id of the GPU it drove -- gathered over the job's own process
+    # group, so that a SCALE record can show N ranks on N distinct GPUs over RCCL
+    try:
+        prop = torch.cuda.get_device_properties(local_rank)
+        me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": prop.name,
+              "uuid": str(getattr(prop, "uuid", "")), "pci_bus_id": getattr(prop, "pci_bus_id", None), "host": os.uname().nodename,
+              "pid": os.getpid()}
+    except Exception as e:
+        me = {"rank": rank, "error": str(e)}
+    ranks_info = [me]
+    if world > 1:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+
     nk, nn, ne = ix.sizes()
     tm = ix.timings()
     counts = torch.tensor([nk, nn, ne], dtype=torch.int64, device=red_dev)
@@ -489,6 +503,7 @@ def main() -> None:
         traffic, traffic_src, valu_insts = None, None, None
         try:
             tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+            tj = tj.get("entries", {}).get(f"{args.workload}/k{k}/w{w}", tj if "entries" not in tj else {})   # one entry per (workload, k, w)
             import hashlib
             same_kernel = tj.get("sketch_hip_sha256") == hashlib.sha256(
                 (ROOT / "seqwin_amd" / "csrc" / "sketch.hip").read_bytes()).hexdigest()   # stale profile -> traffic null
@@ -533,8 +548,17 @@ def main() -> None:
             out["radix_rank"] = {1: "lds_atomic (device self-check passed)", 0: "ballot"}.get(rm.value, str(rm.value))
         except Exception as e:   # (an older library)
             out["radix_rank"] = f"unknown ({e})"
-        if dist_info is not None:
-            out["dist"] = dist_info
+        if dist_info is None:
+            dist_info = {}
+        dist_info.update(world=world, backend=(dist.get_backend() if dist.is_initialized() else None),
+                         process_group_size=(dist.get_world_size() if dist.is_initialized() else 1),
+                         distinct_gpus=len({(r.get("host"), r.get("uuid") or r.get("pci_bus_id") or r.get("device")) for r in ranks_info}),
+                         ranks=ranks_info)
+        try:
+            dist_info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        out["dist"] = dist_info
         if valu_insts:
             # explanatory (not the mandated roofline): integer VALU issue, 256 CU x 4 SIMD x 32 lanes x 2.4 GHz peak
             lane_ops = valu_insts * 64.0

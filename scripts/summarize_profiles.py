@@ -154,7 +154,15 @@ def main():
             import hashlib
             src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "seqwin_amd", "csrc", "sketch.hip")
             traffic["sketch_hip_sha256"] = hashlib.sha256(open(src, "rb").read()).hexdigest()
-            json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
+            # one entry per (workload, k, w): the default workload and the configs[4] sweep (r05) live side by side
+            try:
+                allt = json.load(open("profiles/traffic.json"))
+                if "entries" not in allt:
+                    allt = {"entries": {f"{allt['workload']}/k{allt['k']}/w{allt['w']}": allt}}
+            except Exception:
+                allt = {"entries": {}}
+            allt["entries"][f"{a.workload}/k{a.k}/w{a.w}"] = traffic
+            json.dump(allt, open("profiles/traffic.json", "w"), indent=1, sort_keys=True)
         print(open(a.out_prefix + "_hbm_traffic.txt").read())
         print(traffic)
 

@@ -39,7 +39,8 @@ struct Pool {
     std::mutex mu;
     std::multimap<std::pair<int, size_t>, FreeBlock> free_blocks;  // (device, size) -> block
     std::map<void *, std::pair<int, size_t>> live;                 // ptr -> (device, size)
-    std::vector<hipEvent_t> spare_events;
+    std::map<int, std::vector<hipEvent_t>> spare_events;             // per device: an event is recorded on streams of the device it
+                                                                   // was created on (hipEventRecord rejects it elsewhere: ADVICE r4)
     uint64_t total = 0;
 };
 Pool &pool()
@@ -60,15 +61,21 @@ struct AllocCtx {
 };
 thread_local AllocCtx g_alloc_ctx;
 
-hipEvent_t take_event(Pool &p)   // p.mu held
+hipEvent_t take_event(Pool &p, int dev)   // p.mu held; dev = the calling thread's current device (where a new event is created)
 {
-    if (!p.spare_events.empty()) {
-        hipEvent_t e = p.spare_events.back();
-        p.spare_events.pop_back();
+    auto &spare = p.spare_events[dev];
+    if (!spare.empty()) {
+        hipEvent_t e = spare.back();
+        spare.pop_back();
         return e;
     }
     hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (cur != dev) (void)hipSetDevice(dev);   // (an event belongs to the device that was current when it was made)
+    const hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (cur != dev && cur >= 0) (void)hipSetDevice(cur);
+    if (err != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
@@ -115,13 +122,13 @@ void *dev_alloc(size_t bytes)
             p.free_blocks.erase(it);
             bool ok = true;
             if (blk.main != T) {   // released under another stream: fence on that stream's work up to now
-                hipEvent_t e = take_event(p);
+                hipEvent_t e = take_event(p, dev);
                 ok = e && hipEventRecord(e, blk.main) == hipSuccess && hipStreamWaitEvent(T, e, 0) == hipSuccess;
-                if (e) p.spare_events.push_back(e);
+                if (e) p.spare_events[dev].push_back(e);
             }
-            for (auto &se : blk.side) {
+            for (auto &se : blk.side) {   // (a block's events belong to its device = dev: blocks are keyed by device)
                 if (se.first != T && ok) ok = hipStreamWaitEvent(T, se.second, 0) == hipSuccess;
-                p.spare_events.push_back(se.second);
+                p.spare_events[dev].push_back(se.second);
             }
             if (!ok) {   // could not order the hand-over on the device: order it on the host
                 (void)hipGetLastError();
@@ -168,18 +175,19 @@ void dev_free(void *ptr)
     blk.ptr = ptr;
     blk.main = g_alloc_ctx.main;
     bool ok = true;
+    const int dev = key.first;                 // (the block's device: the releasing thread works on it, its side streams live there)
     for (hipStream_t s : g_alloc_ctx.side) {   // forked streams that may still use the block: fence them precisely, here
-        hipEvent_t e = take_event(p);
+        hipEvent_t e = take_event(p, dev);
         if (!e || hipEventRecord(e, s) != hipSuccess) {
             (void)hipGetLastError();
-            if (e) p.spare_events.push_back(e);
+            if (e) p.spare_events[dev].push_back(e);
             ok = false;
             break;
         }
         blk.side.emplace_back(s, e);
     }
     if (!ok) {   // no fence possible (runtime error state): do not cache the block; hipFree waits for the device
-        for (auto &se : blk.side) p.spare_events.push_back(se.second);
+        for (auto &se : blk.side) p.spare_events[dev].push_back(se.second);
         p.total -= key.second;
         lock.unlock();
         (void)hipFree(ptr);
@@ -198,10 +206,11 @@ void dev_pool_trim()
         p.free_blocks.clear();
         for (auto &b : blocks) {
             p.total -= b.first.second;
-            for (auto &se : b.second.side) p.spare_events.push_back(se.second);
+            for (auto &se : b.second.side) p.spare_events[b.first.first].push_back(se.second);
         }
     }
     for (auto &b : blocks) (void)hipFree(b.second.ptr);   // hipFree waits for outstanding work on the block's device
+    (void)radix_trim_state();   // the radix passes' look-back state (0.27 GB per (device, stream) after a 745 M-element sort)
 }
 
 uint64_t dev_pool_bytes() { return pool().total; }
@@ -219,6 +228,15 @@ void require_device()
               e == hipSuccess ? "0 devices" : hipGetErrorString(e));
     }
 }
+
+// restores the calling thread's device on every way out of a scope that visits other devices
+struct DeviceGuard {
+    int home = 0;
+    DeviceGuard() { SW_HIP(hipGetDevice(&home)); }
+    ~DeviceGuard() { (void)hipSetDevice(home); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
 
 // Objects live on the device that was current when they were created; one process (or thread) per GPU is the model.
 void require_current_device(int device, const char *what)
@@ -242,7 +260,7 @@ void prefault(const HostSpan *spans, int n_spans)
     size_t total = 0;
     for (int i = 0; i < n_spans; ++i) total += spans[i].p ? spans[i].n : 0;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    const unsigned nt = (total >= (32u << 20) && !getenv("SEQWIN_AMD_NO_PREFAULT")) ? std::min(8u, hw) : 1u;
+    const unsigned nt = (total >= (32u << 20) && !SW_AB_GETENV("SEQWIN_AMD_NO_PREFAULT")) ? std::min(8u, hw) : 1u;
     if (nt <= 1) return;
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; ++t)
@@ -732,6 +750,19 @@ static void log_message(const char *level, const char *fmt, ...)
 }
 
 }   // extern "C"
+void sw::log_info(const char *fmt, ...)
+{
+    sw_log_fn fn = g_log_fn.load();
+    const bool echo = getenv("SEQWIN_AMD_LOG_STDERR") != nullptr;
+    if (!fn && !echo) return;
+    char buf[768];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (fn) fn("info", buf);
+    if (echo) fprintf(stderr, "[seqwin_amd] %s\n", buf);
+}
 static std::atomic<uint64_t> g_guard_trips[2];
 void sw::order_guard_tripped(int which, uint32_t places)
 {
@@ -1601,8 +1632,11 @@ int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t km
                 g->g.ix.n_nodes += sl->n_nodes;
                 g->g.ix.n_edges += sl->n_edges;
             }
-            log_message("info", "MI355X build over %zu devices (SEQWIN_DEVICES), node hashes to the edge owners by %s", m.slices.size(),
-                        m.hash_route);
+            log_message("info", "MI355X build over %zu devices (SEQWIN_DEVICES), node hashes to the edge owners by %s; %s", m.slices.size(),
+                        m.hash_route, m.copy_route.c_str());
+            if (chunked)   // (a shard per device is the memory bound of this route: the request is not an error, but it is not honoured)
+                log_message("warning", "low_memory / SEQWIN_AMD_HBM_BUDGET_GB are not applied under SEQWIN_DEVICES: every device holds its "
+                                       "whole shard (1 / %zu of the job)", m.slices.size());
         } else if (chunked) {
             build_chunked(assembly_paths, n_assemblies, kmerlen, windowsize, n_cpu, chunk_bp, g->g, &ingest_ms, &device_ms);
         } else {
@@ -1673,8 +1707,7 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
                                    {edges, ix.n_edges * sizeof(sw_edge)}};
         if (h.multi) {
             // the slices in owner order, each from its device (node ranges are already global: sw_slice_build's kmer_base)
-            int home = 0;
-            SW_HIP(hipGetDevice(&home));
+            DeviceGuard home;   // (download / device_identity may throw on another device)
             uint64_t ko = 0, no = 0, eo = 0;
             for (auto &sl : h.multi->slices) {
                 SW_HIP(hipSetDevice(sl->device));
@@ -1703,7 +1736,6 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
                 hm.identity[1] = sum[1];
                 hm.exported = true;
             }
-            SW_HIP(hipSetDevice(home));
             memcpy(record_offsets, h.record_offsets.data(), h.record_offsets.size() * 4);
             if (!h.ids_blob.empty()) memcpy(ids_blob, h.ids_blob.data(), h.ids_blob.size());
             return;
@@ -1839,8 +1871,7 @@ int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint6
                         kb[q + 1] = kb[q] + mg.slices[q]->n_kmers;
                         nbv[q + 1] = nbv[q] + mg.slices[q]->n_nodes;
                     }
-                    int home = 0;
-                    SW_HIP(hipGetDevice(&home));
+                    DeviceGuard home;   // (this thread scores slice 0 on that slice's device)
                     std::mutex emu;
                     std::exception_ptr eptr;
                     auto work = [&](size_t q) {
@@ -1861,10 +1892,14 @@ int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint6
                         }
                     };
                     std::vector<std::thread> th;
-                    for (size_t q = 1; q < S; ++q) th.emplace_back(work, q);
+                    size_t started = 1;
+                    try {
+                        for (size_t q = 1; q < S; ++q, ++started) th.emplace_back(work, q);
+                    } catch (...) {   // a thread could not be started: its slices are scored on this thread (joinable threads must be joined)
+                    }
                     if (S) work(0);
+                    for (size_t q = started; q < S; ++q) work(q);
                     for (auto &t : th) t.join();
-                    SW_HIP(hipSetDevice(home));
                     if (eptr) std::rethrow_exception(eptr);
                     uint64_t err = 0;
                     for (uint64_t e : errs) err |= e;

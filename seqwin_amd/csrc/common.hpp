@@ -14,6 +14,18 @@
 
 #include "../../include/seqwin_hip.h"
 
+// A/B switches.  Alternatives that lost their measurement and are the default for no input (the one-tile-per-workgroup radix
+// pass, the extra tile shapes, the look-back form of the unsort, rocPRIM's run-length pass, the descent sweeps over the payloads,
+// the "tails" tile plan, ...) are compiled OUT of the release library: their environment variables read as
+// unset and their kernels are not instantiated.  `make -C seqwin_amd/csrc ab` builds libseqwin_hip_ab.so with -DSW_AB, where
+// they are live (tests/tools/*_time.py, NOTES.md).  Switches that force a size-dependent DEFAULT path on small inputs (the
+// suite's way of reaching the 15 000-genome branches), debug output and the fault injection stay in the release library.
+#ifdef SW_AB
+#define SW_AB_GETENV(name) getenv(name)
+#else
+#define SW_AB_GETENV(name) ((const char *)nullptr)
+#endif
+
 namespace sw {
 
 // ---- error plumbing: C++ exceptions inside, int codes at the C ABI -------------------------
@@ -36,6 +48,7 @@ void set_last_error(const char *msg);
 // api.hip: an always-on order guard of the index build tripped (which: 0 node sort, 1 edge-key sort); counted (sw_order_guard_trips),
 // logged as a WARNING through the log callback and on stderr.  The caller then re-sorts without the LDS-atomic ranking.
 void order_guard_tripped(int which, uint32_t places);
+void log_info(const char *fmt, ...);   // api.hip: an "info" line through the log callback (sw_set_log_callback; dropped if none)
 
 template <class F> int guarded(F &&f)
 {

@@ -193,6 +193,7 @@ struct MultiGraph {
     std::string ids_blob;
     uint64_t n_assemblies = 0, total_bp = 0;
     const char *hash_route = "";
+    std::string copy_route;   // how the exchanges travelled: peer access per device pair, or staged through the host (multi.hip: Routes)
 };
 std::vector<int> devices_from_env();   // SEQWIN_DEVICES: "all" or a list of device indices (repeats allowed); empty: one device
 void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, uint64_t w, uint64_t n_cpu, std::vector<int> devs,
@@ -241,6 +242,7 @@ struct alignas(16) OccPay {
 // radix.hip: stable sort of (key32, OccPay) pairs by key bits [0, end_bit), end_bit in {8, 16, 24, 32}; double buffers
 int radix_rank_mode();          // how radix.hip ranks keys inside a wave on the current device: 1 LDS atomics, 0 ballots (runs the self-check once)
 bool radix_pairs_available();   // false on a device that does not pass the LDS-atomic ranking self-check (rocPRIM sorts the pairs then)
+uint64_t radix_trim_state();    // frees the look-back state buffers of idle (device, stream) pairs; called by dev_pool_trim
 void radix_demote_rank();       // an order guard (k_nodes, k_rle_keys, k_check_ascending) tripped: ballots / rocPRIM on this device from now on
 // The sketch stage as the input of the sort's first pass (no ordered copy in between: the pass does what k_order does on
 // the way in).  Dense index g = place of a tuple in (record_idx, pos) order; tile T holds [dst_off[T], dst_off[T] + tile_count[T]).

@@ -280,7 +280,8 @@ constexpr uint8_t OWNER_DROP = 0xFF;   // owner byte of a key that is no row (re
 template <bool BITS, bool REP>
 __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restrict__ key32, const OccPay *__restrict__ pay, uint64_t n,
                                                uint64_t base, const uint32_t *__restrict__ rec_flag, sw_kmer *__restrict__ kmers,
-                                               sw_node *__restrict__ nodes, uint32_t *__restrict__ rank_direct,
+                                               uint64_t *__restrict__ node_hash, uint32_t *__restrict__ node_start,
+                                               uint32_t *__restrict__ rank_direct,
                                                uint64_t *__restrict__ uval,
                                                unsigned long long *__restrict__ tbits, unsigned long long *__restrict__ nbits,
                                                unsigned long long *__restrict__ tile_state, uint32_t *__restrict__ ticket,
@@ -445,10 +446,11 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
             const bool head = e ? h1 : h0;
             if (head) {   // (heads are live)
                 const uint32_t nid = e ? nid1 : nid0;
-                // hash and start in ONE 16-byte store; stop (= the next node's start) and the zeroed counts are filled in by
-                // k_pen_bits / k_node_stops, which stream over the nodes anyway (six scattered stores per head cost ~2 ms here)
-                static_assert(offsetof(sw_node, hash) == 0 && offsetof(sw_node, start) == 8, "hash, start lead the node");
-                *reinterpret_cast<ulonglong2 *>(&nodes[nid]) = make_ulonglong2(((uint64_t)k[r][e] << 32) | p[r][e].low, base + s + e);
+                // r05: the head leaves its hash and its position in two DENSE arrays (12 B per node, consecutive nodes of a tile
+                // side by side) instead of 16 B inside the 40-byte node (three partly written lines per 128 B); k_finish_nodes
+                // streams over them and writes every node whole, coalesced -- and the edges read the dense hashes directly.
+                node_hash[nid] = ((uint64_t)k[r][e] << 32) | p[r][e].low;
+                node_start[nid] = (uint32_t)(s + e);
             }
         }
         if (BITS) {
@@ -481,45 +483,57 @@ __device__ __forceinline__ uint32_t popc_range(const unsigned long long *__restr
     return c;
 }
 
-// per-node distinct target / non-target assemblies from the two bitmaps + penalty (filter.cpp:89-90, 125-134)
-// (also completes the node: stop = the next node's start, `end` for the last one -- k_nodes writes hash and start only)
-// With node_hash: a dense copy of the hashes for the edges' endpoint look-ups (random 8-byte reads: 16 hashes per line
-// instead of 3 nodes -- 0.64 GB at 79 M nodes, most of it stays in the 256 MB Infinity Cache; k_edges_runs 4.5 -> 3.9 ms).
-__global__ void k_pen_bits(sw_node *__restrict__ nodes, uint64_t n_nodes, uint64_t base, uint64_t end,
-                           const unsigned long long *__restrict__ tbits, const unsigned long long *__restrict__ nbits, double inv_tar,
-                           double inv_neg, uint64_t *__restrict__ node_hash)
+// Completes the nodes (r05; k_pen_bits / k_node_stops before): node i = {hash, start, stop, n_tar, n_neg, penalty} from the dense
+// arrays k_nodes left (hash, position of the node's first occurrence; stop = the next node's start, `end` for the last one) and
+// -- BITS -- the per-node distinct target / non-target assemblies from the two first-of-assembly bitmaps + the penalty
+// (filter.cpp:89-90, 125-134); without BITS the counts are zero (python_bindings.cpp:50-90 hands out n_tar = n_neg = penalty = 0).
+// A workgroup stages its 256 nodes (10 KiB) in LDS and writes them with 16-byte stores, consecutive lanes to consecutive
+// addresses: every line of the node array is written once, whole (one GPU's share of 100 000 iid genomes has 5.4e8 nodes:
+// 21.7 GB of nodes; k_pen_bits wrote 24 of every 40 bytes at a 40-byte stride, 11.3 ms).
+constexpr int FIN_THREADS = 256;
+template <bool BITS>
+__global__ __launch_bounds__(FIN_THREADS) void k_finish_nodes(sw_node *__restrict__ nodes, uint64_t n_nodes, const uint64_t *__restrict__ node_hash,
+                                                              const uint32_t *__restrict__ node_start, uint64_t base, uint64_t end,
+                                                              const unsigned long long *__restrict__ tbits,
+                                                              const unsigned long long *__restrict__ nbits, double inv_tar, double inv_neg)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    if (node_hash) node_hash[i] = nodes[i].hash;
-    const uint64_t stop = i + 1 < n_nodes ? nodes[i + 1].start : end;
-    const uint64_t a = nodes[i].start - base, b = stop - base;
-    const uint32_t n_tar = popc_range(tbits, a, b), n_neg = popc_range(nbits, a, b);
-    nodes[i].stop = stop;
-    nodes[i].n_tar = n_tar;
-    nodes[i].n_neg = n_neg;
-    {
+    static_assert(sizeof(sw_node) == 40, "five 8-byte words per node");
+    __shared__ __align__(16) unsigned long long stage[FIN_THREADS * 5];
+    const uint64_t i0 = (uint64_t)blockIdx.x * FIN_THREADS, i = i0 + threadIdx.x;
+    if (i < n_nodes) {
+        const uint32_t a = node_start[i];
+        const uint64_t b = i + 1 < n_nodes ? (uint64_t)node_start[i + 1] : end - base;
+        uint32_t n_tar = 0, n_neg = 0;
+        double pen = 0.0;
+        if (BITS) {
+            n_tar = popc_range(tbits, a, b);
+            n_neg = popc_range(nbits, a, b);
+            {
 // filter.cpp:132-134 evaluated with separate IEEE multiply / add / sqrt (no FMA contraction)
 #pragma clang fp contract(off)
-        const double ft = (double)n_tar * inv_tar;
-        const double fn = (double)n_neg * inv_neg;
-        const double omf = 1.0 - ft;
-        const double aa = omf * omf;
-        const double bb = fn * fn;
-        const double sum = aa + bb;
-        nodes[i].penalty = __dsqrt_rn(sum);
+                const double ft = (double)n_tar * inv_tar;
+                const double fn = (double)n_neg * inv_neg;
+                const double omf = 1.0 - ft;
+                const double aa = omf * omf;
+                const double bb = fn * fn;
+                const double sum = aa + bb;
+                pen = __dsqrt_rn(sum);
+            }
+        }
+        unsigned long long *w = stage + threadIdx.x * 5;
+        w[0] = node_hash[i];
+        w[1] = base + a;
+        w[2] = base + b;
+        w[3] = ((unsigned long long)n_neg << 32) | n_tar;
+        w[4] = (unsigned long long)__double_as_longlong(pen);
     }
-}
-
-// the same without counts: stop, and the count fields zeroed (python_bindings.cpp:50-90 hands out n_tar = n_neg = penalty = 0)
-__global__ void k_node_stops(sw_node *__restrict__ nodes, uint64_t n_nodes, uint64_t end)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    nodes[i].stop = i + 1 < n_nodes ? nodes[i + 1].start : end;
-    nodes[i].n_tar = 0;
-    nodes[i].n_neg = 0;
-    nodes[i].penalty = 0.0;
+    __syncthreads();
+    const uint64_t cnt = min((uint64_t)FIN_THREADS, n_nodes - i0);          // nodes of this workgroup
+    const uint32_t n16 = (uint32_t)(cnt * 40 / 16), tail8 = (uint32_t)((cnt * 40) % 16) / 8;   // 16-byte pieces (+ one 8-byte word)
+    uint4 *dst = reinterpret_cast<uint4 *>(nodes + i0);                      // (i0 * 40 is a multiple of 16)
+    const uint4 *src = reinterpret_cast<const uint4 *>(stage);
+    for (uint32_t t = threadIdx.x; t < n16; t += FIN_THREADS) dst[t] = src[t];
+    if (tail8 && threadIdx.x == 0) reinterpret_cast<unsigned long long *>(nodes + i0)[n16 * 2] = stage[n16 * 2];
 }
 
 __global__ void k_rec_flag(const uint32_t *__restrict__ rec_asm, const uint8_t *__restrict__ is_target, uint64_t n_records,
@@ -2307,7 +2321,7 @@ void sort_pay(uint64_t n, hipStream_t stream, PaySort &o)
     uint32_t *keys = o.key_a.p, *keys_alt = o.key_b.p;
     OccPay *vals = o.pay_a.p, *vals_alt = o.pay_b.p;
     bool have_low = false;   // the last pass left the low halves in o.low (SEQWIN_AMD_DESC_LOW=0: A/B, the sweeps read the payloads)
-    const bool want_low = bits == 32 && !(getenv("SEQWIN_AMD_DESC_LOW") && atoi(getenv("SEQWIN_AMD_DESC_LOW")) == 0);
+    const bool want_low = bits == 32 && !(SW_AB_GETENV("SEQWIN_AMD_DESC_LOW") && atoi(SW_AB_GETENV("SEQWIN_AMD_DESC_LOW")) == 0);   // (=0: A/B, -DSW_AB)
     if (o.staged) {   // (order_tuples made sure: 32 key bits, radix.hip's pair passes)
         OrderedOcc &occ = *o.staged;
         StageSource S{};
@@ -2444,6 +2458,26 @@ struct UnsortHold {
     DevArray<uint64_t> a, b;
     const uint64_t *sorted = nullptr;
 };
+// what k_nodes leaves of the nodes: dense hashes and first-occurrence positions (relative to the sorted range); k_finish_nodes
+// makes the node array of them (finish_nodes), the edges read the hashes
+struct NodeParts {
+    DevArray<uint64_t> hash;
+    DevArray<uint32_t> start;
+};
+void finish_nodes(sw_index &ix, const NodeParts &np, uint64_t base, uint64_t end, const unsigned long long *tbits,
+                  const unsigned long long *nbits, double inv_tar, double inv_neg, hipStream_t stream)
+{
+    if (!ix.n_nodes) return;
+    const dim3 grid((unsigned)((ix.n_nodes + FIN_THREADS - 1) / FIN_THREADS));
+    if (tbits && nbits)
+        hipLaunchKernelGGL(k_finish_nodes<true>, grid, dim3(FIN_THREADS), 0, stream, ix.nodes.p, ix.n_nodes, (const uint64_t *)np.hash.p,
+                           (const uint32_t *)np.start.p, base, end, tbits, nbits, inv_tar, inv_neg);
+    else
+        hipLaunchKernelGGL(k_finish_nodes<false>, grid, dim3(FIN_THREADS), 0, stream, ix.nodes.p, ix.n_nodes, (const uint64_t *)np.hash.p,
+                           (const uint32_t *)np.start.p, base, end, (const unsigned long long *)nullptr,
+                           (const unsigned long long *)nullptr, 0.0, 0.0);
+    SW_HIP(hipGetLastError());
+}
 
 // ---- recovery when k_nodes' order guard trips (r05) ---------------------------------------------------------------------------
 // The sorted arrays still hold every occurrence with its place in the (record_idx, pos) stream (OccPay::idx), so the stream can
@@ -2493,13 +2527,19 @@ void resort_pay_stable(PaySort &ps, uint64_t n, hipStream_t stream)
     if (nbad) raise(SW_ERR_RUNTIME, "internal error: the node sort lost %u occurrences (not a permutation of its input)", nbad);
     ps.pay = v;
 }
+// parts: the dense hash / start arrays of the nodes, kept for the caller -- who then also completes the nodes (finish_nodes:
+// with the bitmaps, on the stream of its choice); without `parts` the nodes are completed here, counts zero.
 uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_t *rec_flag, hipStream_t stream, sw_index &ix,
                            uint32_t *rank_out, DevArray<unsigned long long> *tbits, DevArray<unsigned long long> *nbits,
-                           bool *rep_marked = nullptr, UnsortHold *hold = nullptr)
+                           bool *rep_marked = nullptr, UnsortHold *hold = nullptr, NodeParts *parts = nullptr)
 {
     sort_pay(n, stream, ps);
     const uint64_t node_cap = settle_sort(ps, stream);   // >= the number of nodes, within ~2 descents of it
     ix.nodes.alloc(node_cap);
+    NodeParts own_parts;
+    NodeParts &np = parts ? *parts : own_parts;
+    np.hash.alloc(node_cap);
+    np.start.alloc(node_cap);
     uint64_t direct_max = UNSORT_DIRECT_MAX;
     if (const char *e = getenv("SEQWIN_AMD_UNSORT_DIRECT")) direct_max = 1ull << std::min(40, std::max(0, atoi(e)));   // A/B, tests
     const bool direct = rank_out && n <= direct_max;
@@ -2523,7 +2563,7 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
         {
             auto launch = [&](auto kern) {
                 hipLaunchKernelGGL(kern, dim3(blocks), dim3(NODES_THREADS), 0, stream, ps.key32, ps.pay, n, base, rec_flag, ix.kmers.p,
-                                   ix.nodes.p, direct ? rank_out : (uint32_t *)nullptr, uv0.p, bits ? tbits->p : (unsigned long long *)nullptr,
+                                   np.hash.p, np.start.p, direct ? rank_out : (uint32_t *)nullptr, uv0.p, bits ? tbits->p : (unsigned long long *)nullptr,
                                    bits ? nbits->p : (unsigned long long *)nullptr, tile_state.p, words.p, words.p + 1, words.p + 3);
             };
             if (bits && rep) launch(k_nodes<true, true>);
@@ -2565,9 +2605,9 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     check_sort_failed(back[1]);
     if (n_nodes > node_cap) raise(SW_ERR_RUNTIME, "internal error: %u nodes exceed the bound %llu", n_nodes, (unsigned long long)node_cap);
     ix.n_nodes = n_nodes;
-    if (!bits && n_nodes) {   // (with the bitmaps the caller runs k_pen_bits, which completes the nodes as well)
-        hipLaunchKernelGGL(k_node_stops, dim3(blocks_for(n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, (uint64_t)n_nodes, base + n);
-        SW_HIP(hipGetLastError());
+    if (!parts) {   // (a caller that takes the parts completes the nodes itself: finish_nodes)
+        finish_nodes(ix, np, base, base + n, nullptr, nullptr, 0.0, 0.0, stream);
+        SW_HIP(hipStreamSynchronize(stream));   // (own_parts goes back to the pool on return)
     }
     if (hold && hold->sorted) {
         hold->a = std::move(uv0);
@@ -3136,7 +3176,7 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
     unsigned long long n_cand = host_n_cand;
     // run lengths by this library's streaming pass (k_rle_keys: ucnt then holds the START of every run, and m behind the last);
     // SEQWIN_AMD_RLE=rocprim: rocprim::run_length_encode (ucnt = the lengths) -- A/B, and what rounds 1-3 ran
-    const char *rle_env = getenv("SEQWIN_AMD_RLE");
+    const char *rle_env = SW_AB_GETENV("SEQWIN_AMD_RLE");   // (-DSW_AB builds only)
     const bool own_rle = !(rle_env && !strcmp(rle_env, "rocprim"));
     bool demoted = false;
     for (int attempt = 0;; ++attempt) {
@@ -3151,12 +3191,14 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
                                ticket.p, ucount.p, ucount.p + 1);
             SW_HIP(hipGetLastError());
         } else {
+#ifdef SW_AB
             hipLaunchKernelGGL(k_check_ascending, dim3(blocks_for(m)), dim3(TPB), 0, stream, (const uint64_t *)keys, m, ucount.p + 1);
             size_t tmp_bytes = 0;
             SW_HIP(rocprim::run_length_encode(nullptr, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
             DevArray<unsigned char> tmp(tmp_bytes);
             SW_HIP(rocprim::run_length_encode(tmp.p, tmp_bytes, keys, m, ukeys.p, ucnt.p, ucount.p, stream));
             SW_HIP(hipStreamSynchronize(stream));   // (tmp is released here)
+#endif
         }
         hipLaunchKernelGGL(k_drop_sentinel_run, dim3(1), dim3(1), 0, stream, ukeys.p, sentinel, ucount.p);
         SW_HIP(hipGetLastError());
@@ -3296,11 +3338,20 @@ void slice_get_penalty(sw_index &ix, uint64_t kmer_base, const uint32_t *d_rec_a
     if (!ix.n_nodes) return;
     hipLaunchKernelGGL(k_rebase_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, (uint64_t)0 - kmer_base);
     SW_HIP(hipGetLastError());
+    struct Restore {   // the resident slice keeps GLOBAL ranges: they are put back on every way out (an exception between the
+                       // two re-basings left the slice corrupted for later calls)
+        sw_index &ix;
+        uint64_t base;
+        hipStream_t st;
+        ~Restore()
+        {
+            hipLaunchKernelGGL(k_rebase_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, st, ix.nodes.p, ix.n_nodes, base);
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(st);
+        }
+    } restore{ix, kmer_base, stream};
     device_get_penalty(ix.kmers.p, ix.n_kmers, ix.nodes.p, ix.n_nodes, d_rec_asm, n_records, d_is_target, n_targets, n_non_targets,
                        stream, err_flags_host);
-    hipLaunchKernelGGL(k_rebase_nodes, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, kmer_base);
-    SW_HIP(hipGetLastError());
-    SW_HIP(hipStreamSynchronize(stream));
 }
 
 void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assemblies, OrderedOcc &occ,
@@ -3327,7 +3378,7 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
     bool rep_marked = false;
     DevArray<uint32_t> rec_flag;
     DevArray<unsigned long long> tbits, nbits;
-    DevArray<uint64_t> node_hash;   // dense copy of the node hashes, written by k_pen_bits on the counts stream
+    NodeParts parts;                // dense node hashes / first-occurrence positions from k_nodes: the edges read the hashes, finish_nodes both
     UnsortHold unsort_hold;         // the unsort's buckets, when the adjacency keys are written straight from them
     // -- nodes: stable radix sort of the occurrences by hash, run-length heads, ranks back in stream order ------
     if (n) {
@@ -3343,8 +3394,11 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
         ps.pay_a = std::move(occ.pay);
         if (occ.staged) ps.staged = &occ;
         group_occurrences(ps, n, 0, rec_flag.p, stream, ix, by_table ? nullptr : rank.p, bits ? &tbits : nullptr,
-                          bits ? &nbits : nullptr, pair_edges ? &rep_marked : nullptr, pair_edges ? &unsort_hold : nullptr);
-        if (by_table) ranks_from_table(ix, occ.hash.p, n, stream, rank.p);
+                          bits ? &nbits : nullptr, pair_edges ? &rep_marked : nullptr, pair_edges ? &unsort_hold : nullptr, &parts);
+        if (!bits || by_table) {   // no bitmaps to wait for (or the table route reads the nodes next): complete the nodes here, counts zero
+            finish_nodes(ix, parts, 0, n, nullptr, nullptr, 0.0, 0.0, stream);
+            if (by_table) ranks_from_table(ix, occ.hash.p, n, stream, rank.p);
+        }
     } else {
         ix.n_nodes = 0;
         ix.nodes.alloc(0);
@@ -3365,10 +3419,8 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
             penalty_launch(ix.kmers.p, n, ix.nodes.p, ix.n_nodes, d_rec_asm, n_records, d_is_target, n_targets, n_non_targets,
                            side, pen);
         } else {
-            if (rep_marked) node_hash.alloc(ix.n_nodes);   // (edges_from_pairs below reads it behind ev[5])
-            hipLaunchKernelGGL(k_pen_bits, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, side, ix.nodes.p, ix.n_nodes, (uint64_t)0, n,
-                               tbits.p, nbits.p, 1.0 / (double)n_targets, 1.0 / (double)n_non_targets, node_hash.p);   // filter.cpp:89-90
-            SW_HIP(hipGetLastError());
+            // (with SEQWIN_AMD_RANKS=table the nodes were completed above with zero counts: this pass writes them again, whole)
+            finish_nodes(ix, parts, 0, n, tbits.p, nbits.p, 1.0 / (double)n_targets, 1.0 / (double)n_non_targets, side);   // filter.cpp:89-90
         }
         SW_HIP(hipEventRecord(ev[5], side));
     }
@@ -3419,14 +3471,14 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
                                    rank.p, d_rec_asm, 0u, n, nb, sentinel, k0.p, ck.p, ca.p, n_cand.p, ehist.p, hbits, hpasses, 2 * nb, iters);
             }
             SW_HIP(hipGetLastError());
-            edges_from_pairs(k0.p, k1.p, m, sentinel, nb, ab, ck.p, ca.p, n_cand.p, 0, node_hash.p, stream, ix,
-                             node_hash.p ? (hipEvent_t)ev[5] : (hipEvent_t) nullptr, ehist.p);
+            edges_from_pairs(k0.p, k1.p, m, sentinel, nb, ab, ck.p, ca.p, n_cand.p, 0, parts.hash.p, stream, ix, (hipEvent_t) nullptr,
+                             ehist.p);   // (the dense hashes are k_nodes' own, on this stream: nothing to wait for)
         } else {
             DevArray<uint32_t> v0(m), v1(m);
             hipLaunchKernelGGL(k_adj_keys, dim3(adj_blocks), dim3(256), 0, stream, occ.rec.p, rank.p, d_rec_asm, n, nb,
                                sentinel, k0.p, v0.p);
             SW_HIP(hipGetLastError());
-            edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, sentinel, nb, nullptr, stream, ix);
+            edges_from_adjacency(k0.p, k1.p, v0.p, v1.p, m, sentinel, nb, parts.hash.p, stream, ix);
         }
     }
     if (ix.n_edges == 0) ix.edges.alloc(0);
@@ -3517,15 +3569,14 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
             SW_HIP(hipGetLastError());
         }
         const bool bits = slice && d_is_target;
-        group_occurrences(ps, n, slice ? kmer_base : 0, rec_flag.p, stream, ix, d_rank_out, bits ? &tbits : nullptr,
-                          bits ? &nbits : nullptr, rec_flag.p ? &marked : nullptr);
+        NodeParts parts;
+        const uint64_t base = slice ? kmer_base : 0;
+        group_occurrences(ps, n, base, rec_flag.p, stream, ix, d_rank_out, bits ? &tbits : nullptr,
+                          bits ? &nbits : nullptr, rec_flag.p ? &marked : nullptr, nullptr, &parts);
         ix.ranks_marked = marked;
-        if (bits && ix.n_nodes) {
-            hipLaunchKernelGGL(k_pen_bits, dim3(blocks_for(ix.n_nodes)), dim3(TPB), 0, stream, ix.nodes.p, ix.n_nodes, kmer_base,
-                               kmer_base + n, tbits.p, nbits.p, 1.0 / (double)n_targets, 1.0 / (double)n_non_targets, (uint64_t *)nullptr);   // filter.cpp:89-90
-            SW_HIP(hipGetLastError());
-        }
-        SW_HIP(hipStreamSynchronize(stream));   // (the bitmaps are released here)
+        if (bits) finish_nodes(ix, parts, base, base + n, tbits.p, nbits.p, 1.0 / (double)n_targets, 1.0 / (double)n_non_targets, stream);   // filter.cpp:89-90
+        else finish_nodes(ix, parts, base, base + n, nullptr, nullptr, 0.0, 0.0, stream);
+        SW_HIP(hipStreamSynchronize(stream));   // (the bitmaps and the parts are released here)
     } else {
         ix.nodes.alloc(0);
         ix.ranks_marked = d_rec_asm && n_records;   // an empty slice returns no rank at all: it must not switch the job's pairs form off

@@ -132,11 +132,90 @@ struct Shared {
     std::vector<const unsigned char *> ans;   // per edge owner
 };
 
-void pull(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t st)
+// How bytes travel between two workers' devices (r05).  Before the workers start, peer access is queried and enabled for every
+// ordered pair of distinct devices (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess): a pair that has it copies directly over
+// xGMI (hipMemcpyPeerAsync on the owner's stream), a pair that has not -- or every pair under SEQWIN_MULTI_NO_P2P=1, which is how
+// the fallback is exercised on one card -- goes through a pinned host buffer of the pulling worker, 32 MiB at a time.  The routes
+// are logged once per build.
+struct Routes {
+    uint32_t P = 0;
+    std::vector<uint8_t> staged;   // [dst worker * P + src worker]: 1 = through the host
+    bool is_staged(uint32_t dst, uint32_t src) const { return staged[(size_t)dst * P + src] != 0; }
+};
+struct HostStage {   // one per worker, allocated on first use
+    static constexpr size_t BYTES = 32u << 20;
+    void *p = nullptr;
+    ~HostStage() { if (p) (void)hipHostFree(p); }
+};
+
+void pull(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hipStream_t st, bool staged, HostStage &hs)
 {
     if (!bytes) return;
-    if (dst_dev == src_dev) SW_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
-    else SW_HIP(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st));
+    if (!staged) {
+        if (dst_dev == src_dev) SW_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+        else SW_HIP(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st));
+        return;
+    }
+    // no peer access: device -> pinned host (on the source's device, blocking) -> device (this worker's stream).  The source's
+    // bytes are complete (every pull follows a rendezvous behind the producer's stream synchronisation).
+    if (!hs.p) SW_HIP(hipHostMalloc(&hs.p, HostStage::BYTES, hipHostMallocDefault));
+    for (size_t o = 0; o < bytes; o += HostStage::BYTES) {
+        const size_t n = std::min(HostStage::BYTES, bytes - o);
+        if (src_dev != dst_dev) SW_HIP(hipSetDevice(src_dev));
+        const hipError_t e = hipMemcpy(hs.p, (const char *)src + o, n, hipMemcpyDeviceToHost);
+        if (src_dev != dst_dev) SW_HIP(hipSetDevice(dst_dev));
+        SW_HIP(e);
+        SW_HIP(hipMemcpyAsync((char *)dst + o, hs.p, n, hipMemcpyHostToDevice, st));
+        SW_HIP(hipStreamSynchronize(st));   // (the one buffer is reused by the next piece)
+    }
+}
+
+Routes make_routes(const std::vector<int> &devs, std::string &summary)
+{
+    Routes R;
+    R.P = (uint32_t)devs.size();
+    R.staged.assign((size_t)R.P * R.P, 0);
+    const bool forced = getenv("SEQWIN_MULTI_NO_P2P") && atoi(getenv("SEQWIN_MULTI_NO_P2P")) != 0;
+    int home = 0;
+    SW_HIP(hipGetDevice(&home));
+    std::map<std::pair<int, int>, int> access;   // (device, peer) -> 1 direct, 0 staged
+    size_t n_pairs = 0, n_direct = 0;
+    for (uint32_t a = 0; a < R.P; ++a)
+        for (uint32_t b = 0; b < R.P; ++b) {
+            const int da = devs[a], db = devs[b];
+            if (da == db) {
+                R.staged[(size_t)a * R.P + b] = forced ? 1 : 0;
+                continue;
+            }
+            auto it = access.find(std::make_pair(da, db));
+            if (it == access.end()) {
+                int can = 0;
+                if (!forced) {
+                    if (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+                    if (can) {
+                        SW_HIP(hipSetDevice(da));
+                        const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+                        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+                        (void)hipGetLastError();
+                    }
+                }
+                it = access.emplace(std::make_pair(da, db), can).first;
+                ++n_pairs;
+                n_direct += can ? 1 : 0;
+            }
+            R.staged[(size_t)a * R.P + b] = it->second ? 0 : 1;
+        }
+    SW_HIP(hipSetDevice(home));
+    char buf[256];
+    if (forced)
+        snprintf(buf, sizeof buf, "every exchange staged through pinned host memory (SEQWIN_MULTI_NO_P2P=1)");
+    else if (n_pairs == 0)
+        snprintf(buf, sizeof buf, "logical shards of one device (device-to-device copies)");
+    else
+        snprintf(buf, sizeof buf, "peer access on %zu of %zu ordered device pairs%s", n_direct, n_pairs,
+                 n_direct == n_pairs ? " (all exchanges direct, hipMemcpyPeerAsync)" : "; the others are staged through pinned host memory");
+    summary = buf;
+    return R;
 }
 
 }  // namespace
@@ -191,13 +270,36 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
     bool by_request = false;
     uint64_t pad = 1;
 
-    auto worker = [&](uint32_t p) {
+    // What a worker holds on its device.  Owned HERE, not by the worker thread: a worker that fails only synchronises
+    // its own stream, while its peers may still have pulls from its buffers in flight until they meet the broken rendezvous -- so
+    // nothing a peer can read is released before every thread has been joined (the cleanup loop below).  On the success path the
+    // workers release their buffers themselves, each behind the rendezvous that makes it safe, to keep the footprint down.
+    struct WorkerState {
         hipStream_t st = nullptr;
         sw_batch *batch = nullptr;
         sw_occ *occ = nullptr;
         sw_index *ix = nullptr;
-        // (declared out here: they go back to the pool only after the stream has been waited for, also when a step throws)
         DevBuf rows, ranks_by_row, keys, cand, r_rows, r_ranks, hashes, table, r_keys, r_cand, req, got, answers, replies;
+        HostStage stage;
+    };
+    std::vector<WorkerState> wstate(P);
+    std::string route_summary;
+    const Routes routes = make_routes(devs, route_summary);
+    {
+        std::string list;
+        for (uint32_t q = 0; q < P; ++q) list += (q ? "," : "") + std::to_string(devs[q]);
+        log_info("multi-device build: %u workers on devices [%s]; %s", P, list.c_str(), route_summary.c_str());
+    }
+
+    auto worker = [&](uint32_t p) {
+        WorkerState &ws = wstate[p];
+        hipStream_t &st = ws.st;
+        sw_batch *&batch = ws.batch;
+        sw_occ *&occ = ws.occ;
+        sw_index *&ix = ws.ix;
+        DevBuf &rows = ws.rows, &ranks_by_row = ws.ranks_by_row, &keys = ws.keys, &cand = ws.cand, &r_rows = ws.r_rows, &r_ranks = ws.r_ranks,
+               &hashes = ws.hashes, &table = ws.table, &r_keys = ws.r_keys, &r_cand = ws.r_cand, &req = ws.req, &got = ws.got,
+               &answers = ws.answers, &replies = ws.replies;
         try {
             const int dev = devs[p];
             SW_HIP(hipSetDevice(dev));
@@ -258,7 +360,7 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
                 for (uint32_t q = 0; q < P; ++q) {
                     size_t off = 0;
                     for (uint32_t o = 0; o < p; ++o) off += sh[q].cnt[o];
-                    pull(r_rows.a.p + at * 16, dev, sh[q].rows + off * 16, devs[q], (size_t)sh[q].cnt[p] * 16, st);
+                    pull(r_rows.a.p + at * 16, dev, sh[q].rows + off * 16, devs[q], (size_t)sh[q].cnt[p] * 16, st, routes.is_staged(p, q), ws.stage);
                     at += sh[q].cnt[p];
                 }
             }
@@ -313,7 +415,7 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
                 for (uint32_t o = 0; o < P; ++o) {
                     size_t off = 0;
                     for (uint32_t q = 0; q < p; ++q) off += sh[q].cnt[o];
-                    pull(ranks_by_row.a.p + at * 4, dev, sh[o].ranks + off * 4, devs[o], (size_t)me.cnt[o] * 4, st);
+                    pull(ranks_by_row.a.p + at * 4, dev, sh[o].ranks + off * 4, devs[o], (size_t)me.cnt[o] * 4, st, routes.is_staged(p, o), ws.stage);
                     at += me.cnt[o];
                 }
             }
@@ -321,7 +423,7 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
                 StreamScope scope(st);
                 table.a.alloc((size_t)P * pad * 8);
                 for (uint32_t o = 0; o < P; ++o)
-                    pull(table.a.p + (size_t)o * pad * 8, dev, sh[o].hashes, devs[o], (size_t)sh[o].n_nodes * 8, st);
+                    pull(table.a.p + (size_t)o * pad * 8, dev, sh[o].hashes, devs[o], (size_t)sh[o].n_nodes * 8, st, routes.is_staged(p, o), ws.stage);
             }
             {
                 StreamScope scope(st);
@@ -359,8 +461,8 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
                         raise(SW_ERR_RUNTIME, "internal error: the sources derived different adjacency key layouts");
                     size_t off = 0, coff = 0;
                     for (uint32_t o = 0; o < p; ++o) off += sh[q].acnt[o], coff += sh[q].ccnt[o];
-                    pull(r_keys.a.p + at * 8, dev, sh[q].keys + off * 8, devs[q], (size_t)sh[q].acnt[p] * 8, st);
-                    pull(r_cand.a.p + cat * 16, dev, sh[q].cand + coff * 16, devs[q], (size_t)sh[q].ccnt[p] * 16, st);
+                    pull(r_keys.a.p + at * 8, dev, sh[q].keys + off * 8, devs[q], (size_t)sh[q].acnt[p] * 8, st, routes.is_staged(p, q), ws.stage);
+                    pull(r_cand.a.p + cat * 16, dev, sh[q].cand + coff * 16, devs[q], (size_t)sh[q].ccnt[p] * 16, st, routes.is_staged(p, q), ws.stage);
                     at += sh[q].acnt[p];
                     cat += sh[q].ccnt[p];
                 }
@@ -405,7 +507,7 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
                     for (uint32_t q = 0; q < P; ++q) {
                         size_t off = 0;
                         for (uint32_t o = 0; o < p; ++o) off += sh[q].req_cnt[o];
-                        pull(got.a.p + at * 4, dev, sh[q].req + off * 4, devs[q], (size_t)sh[q].req_cnt[p] * 4, st);
+                        pull(got.a.p + at * 4, dev, sh[q].req + off * 4, devs[q], (size_t)sh[q].req_cnt[p] * 4, st, routes.is_staged(p, q), ws.stage);
                         me.ans[q] = answers.a.p + at * 8;
                         at += sh[q].req_cnt[p];
                     }
@@ -420,7 +522,7 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
                 {
                     size_t at = 0;
                     for (uint32_t o = 0; o < P; ++o) {
-                        pull(replies.a.p + at * 8, dev, sh[o].ans[p], devs[o], (size_t)me.req_cnt[o] * 8, st);
+                        pull(replies.a.p + at * 8, dev, sh[o].ans[p], devs[o], (size_t)me.req_cnt[o] * 8, st, routes.is_staged(p, o), ws.stage);
                         at += me.req_cnt[o];
                     }
                 }
@@ -448,16 +550,7 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
             }
             meet.fail();
         }
-        if (st) (void)hipStreamSynchronize(st);
-        {
-            StreamScope scope(st);
-            if (ix) sw_index_free(ix);
-            if (occ) sw_occ_free(occ);
-            if (batch) sw_batch_free(batch);
-            for (DevBuf *b : {&rows, &ranks_by_row, &keys, &cand, &r_rows, &r_ranks, &hashes, &table, &r_keys, &r_cand, &req, &got, &answers,
-                              &replies})
-                b->a.release();
-        }
+        if (st) (void)hipStreamSynchronize(st);   // (what is left is released by the caller's cleanup loop, after every thread has joined)
     };
 
     std::vector<std::thread> th;
@@ -471,6 +564,20 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
         meet.fail();
     }
     for (auto &t : th) t.join();
+    // every worker has stopped and synchronised its stream: no copy of any peer is in flight any more
+    for (uint32_t p = 0; p < P; ++p) {
+        WorkerState &ws = wstate[p];
+        if (hipSetDevice(devs[p]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (ws.st) (void)hipStreamSynchronize(ws.st);
+        StreamScope scope(ws.st);
+        if (ws.ix) sw_index_free(ws.ix);
+        if (ws.occ) sw_occ_free(ws.occ);
+        if (ws.batch) sw_batch_free(ws.batch);
+        for (DevBuf *b : {&ws.rows, &ws.ranks_by_row, &ws.keys, &ws.cand, &ws.r_rows, &ws.r_ranks, &ws.hashes, &ws.table, &ws.r_keys,
+                          &ws.r_cand, &ws.req, &ws.got, &ws.answers, &ws.replies})
+            b->a.release();
+        if (ws.stage.p) { (void)hipHostFree(ws.stage.p); ws.stage.p = nullptr; }
+    }
     SW_HIP(hipSetDevice(home));
     if (err) std::rethrow_exception(err);
 
@@ -484,6 +591,7 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
         out.ids_blob += sh[p].ids;
     }
     out.hash_route = by_request ? "requests" : "table";
+    out.copy_route = route_summary;
 }
 
 }  // namespace sw

@@ -101,7 +101,9 @@ template <int BITS> __global__ void k_rs_scan(unsigned long long *__restrict__ h
     if (cursor) cursor[(size_t)threadIdx.x * RS_CURSOR_STRIDE] = s[threadIdx.x] - v;
 }
 
+#ifdef SW_AB   // (records of the one-tile-per-workgroup pass)
 constexpr unsigned long long RS_AGG = 1ull << 62, RS_INC = 2ull << 62, RS_VAL = (1ull << 62) - 1ull;
+#endif
 
 // Lanes of the wave whose digit equals this lane's (among the live ones), as two 32-bit halves: per digit bit one ballot and,
 // per half, one three-input bit operation  m & ~(ballot ^ -bit)  (the compiler's own form of  m &= bit ? bal : ~bal  was nine
@@ -232,6 +234,7 @@ static uint32_t fault_rank()
 // workgroups in index order.  Should a wait ever outlast RS_SPIN_LIMIT polls, the workgroup gives up and raises *fail --
 // the caller then reports an error -- instead of hanging the device.
 constexpr uint32_t RS_SPIN_LIMIT = 1u << 22;
+#ifdef SW_AB
 template <int THREADS, int BITS>
 __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n,
                                                      unsigned shift, unsigned bits, const unsigned long long *__restrict__ digit_base,
@@ -341,6 +344,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_pass(const uint64_t *__restrict_
         }
     }
 }
+#endif   // SW_AB (the one-tile-per-workgroup pass)
 
 // Look-back records of the persistent passes carry a 16-bit epoch (the pass number of their state buffer) above flag and count:
 // a record of an earlier pass -- or of an earlier sort -- reads as "not published", so the buffer is never cleared between passes
@@ -1035,33 +1039,61 @@ __global__ __launch_bounds__(256) void k_rs_stage_prepare(const StageSource S, c
 }
 
 // Look-back state that outlives the sorts: one buffer per (device, stream) -- sorts on one stream follow one another on the
-// device --, cleared when it is made and whenever its 16-bit epoch wraps.
+// device --, cleared when it is made and whenever its 16-bit epoch wraps.  r05: a sort holds the buffer's mutex
+// from its first epoch to its last launch, so two host threads that sort on the same stream (the NULL stream from two Python
+// threads) get disjoint epochs and never see a regrow in between; and the buffers are known to the pool's trim
+// (radix_trim_state, called by dev_pool_trim: sw_pool_trim and the out-of-memory retry of dev_alloc give them back too).
 struct StateBuf {
+    std::mutex mu;
     unsigned long long *p = nullptr;
     size_t words = 0;
     uint32_t epoch = 0;
 };
-StateBuf &state_buf(hipStream_t stream, size_t words)
+std::mutex &state_registry_mu()
 {
     static std::mutex &mu = *new std::mutex;
-    static std::map<std::pair<int, hipStream_t>, StateBuf> &bufs = *new std::map<std::pair<int, hipStream_t>, StateBuf>;
+    return mu;
+}
+std::map<std::pair<int, hipStream_t>, StateBuf *> &state_registry()
+{
+    static auto &bufs = *new std::map<std::pair<int, hipStream_t>, StateBuf *>;   // (leaked on purpose, like the pool)
+    return bufs;
+}
+thread_local int g_state_uses = 0;   // state buffers this thread holds right now (radix_trim_state must not try its own mutex)
+struct StateUse {   // the buffer, locked for the duration of one sort's enqueue
+    StateBuf &b;
+    std::unique_lock<std::mutex> lock;
+    StateUse(StateBuf &buf, std::unique_lock<std::mutex> &&l) : b(buf), lock(std::move(l)) { ++g_state_uses; }
+    StateUse(StateUse &&o) : b(o.b), lock(std::move(o.lock)) { ++g_state_uses; }
+    StateUse(const StateUse &) = delete;
+    StateUse &operator=(const StateUse &) = delete;
+    ~StateUse() { --g_state_uses; }
+};
+StateUse state_buf(hipStream_t stream, size_t words)
+{
     int dev = 0;
     SW_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(mu);
-    StateBuf &b = bufs[std::make_pair(dev, stream)];
-    if (b.words < words) {
-        if (b.p) (void)hipFree(b.p);        // (waits for the device: nothing is reading it any more)
-        b.p = nullptr;
-        b.words = 0;
-        const size_t want = words + words / 4;
-        SW_HIP(hipMalloc(&b.p, want * 8));
-        b.words = want;
-        b.epoch = 0;
-        SW_HIP(hipMemsetAsync(b.p, 0, want * 8, stream));
+    StateBuf *b = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(state_registry_mu());
+        StateBuf *&slot = state_registry()[std::make_pair(dev, stream)];
+        if (!slot) slot = new StateBuf;
+        b = slot;
     }
-    return b;
+    StateUse u(*b, std::unique_lock<std::mutex>(b->mu));
+    if (b->words < words) {
+        if (b->p) (void)hipFree(b->p);        // (waits for the device: nothing is reading it any more)
+        b->p = nullptr;
+        b->words = 0;
+        const size_t want = words + words / 4;
+        SW_HIP(hipMalloc(&b->p, want * 8));
+        b->words = want;
+        b->epoch = 0;
+        SW_HIP(hipMemsetAsync(b->p, 0, want * 8, stream));
+    }
+    return u;
 }
-uint32_t next_epoch(StateBuf &b, hipStream_t stream)
+uint32_t next_epoch(StateBuf &b, hipStream_t stream)   // (b.mu held: StateUse)
 {
     if (++b.epoch >= 0xFFFFu) {             // every record in the buffer could alias a new epoch: start over
         SW_HIP(hipMemsetAsync(b.p, 0, b.words * 8, stream));
@@ -1077,7 +1109,7 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
     constexpr uint32_t RADIX = 1u << BITS, TILE = THREADS * RS_ITEMS;
     const unsigned n_passes = (end_bit - begin_bit + BITS - 1) / BITS;
     const uint64_t n_tiles = (n + TILE - 1) / TILE;
-    const char *kind = getenv("SEQWIN_AMD_RADIX_KERNEL");   // A/B: "classic" = one tile per workgroup
+    const char *kind = SW_AB_GETENV("SEQWIN_AMD_RADIX_KERNEL");   // A/B (-DSW_AB): "classic" = one tile per workgroup
     const bool persistent = !(kind && !strcmp(kind, "classic"));
     uint32_t dbg = 0;
 #ifdef SW_RADIX_ABLATION     // timing experiments only (tests/tools/sort_time.py with SEQWIN_AMD_RADIX_DEBUG; the output is NOT sorted): 1 no look-back, 2 no stores, 4 no loads, 8 no ranking
@@ -1105,9 +1137,10 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
     }
     const bool atomic_rank = persistent && rank_mode() == 1;
     DevArray<unsigned long long> hist_own(d_hist_given ? 0 : (size_t)n_passes * RADIX), state(persistent ? 0 : (size_t)n_tiles * RADIX);
-    StateBuf *sb = persistent ? &state_buf(stream, (size_t)n_tiles * RADIX) : nullptr;   // (epoch-tagged records: never cleared per pass)
+    std::unique_ptr<StateUse> su(persistent ? new StateUse(state_buf(stream, (size_t)n_tiles * RADIX)) : nullptr);   // (epoch-tagged records: never cleared per pass)
+    StateBuf *sb = su ? &su->b : nullptr;
     struct { unsigned long long *p; } hist{d_hist_given ? d_hist_given : hist_own.p};   // ([pass][digit] counts; scanned in place below)
-    const bool unstable = perm_hi32 && persistent && !getenv("SEQWIN_AMD_RADIX_STABLE_UNSORT");   // (A/B: the look-back form)
+    const bool unstable = perm_hi32 && persistent && !SW_AB_GETENV("SEQWIN_AMD_RADIX_STABLE_UNSORT");   // (A/B, -DSW_AB: the look-back form)
     DevArray<unsigned long long> cursor(unstable ? (size_t)RADIX * RS_CURSOR_STRIDE : 0);
     DevArray<uint32_t> tickets(n_passes);
     SW_HIP(hipMemsetAsync(tickets.p, 0, tickets.bytes(), stream));
@@ -1149,9 +1182,12 @@ void sort_passes(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned begin_bit
             // (an unstable pass may rank by atomics on any device: the order inside a digit is free there)
             if (cur ? !ballot_forced() : atomic_rank) launch(k_rs_pass_p<THREADS, BITS, 1>);
             else launch(k_rs_pass_p<THREADS, BITS, 0>);
-        } else
+        } else {
+#ifdef SW_AB
             hipLaunchKernelGGL((k_rs_pass<THREADS, BITS>), dim3((unsigned)n_tiles), dim3(THREADS), 0, stream, keys, alt, n, sh, bits,
                                hist.p + (size_t)p * RADIX, state.p, d_fail);
+#endif
+        }
         SW_HIP(hipGetLastError());
 #ifdef SW_RS_STAMPS
         if (stamps.p) {
@@ -1204,9 +1240,9 @@ bool radix_unsort_perm(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned low
 {
     constexpr int THREADS = 512, BITS = 8;
     constexpr uint32_t RADIX = 1u << BITS, TILE = THREADS * RS_ITEMS;
-    if (n == 0 || nbit <= low_bits + 8 || nbit > low_bits + 16 || getenv("SEQWIN_AMD_RADIX_STABLE_UNSORT")) return false;
+    if (n == 0 || nbit <= low_bits + 8 || nbit > low_bits + 16 || SW_AB_GETENV("SEQWIN_AMD_RADIX_STABLE_UNSORT")) return false;
     if ((1ull << (low_bits + 8)) % TILE) return false;
-    const char *kind = getenv("SEQWIN_AMD_RADIX_KERNEL");
+    const char *kind = SW_AB_GETENV("SEQWIN_AMD_RADIX_KERNEL");
     if (kind && !strcmp(kind, "classic")) return false;
     const unsigned hi_bits = nbit - low_bits - 8;                         // 1 .. 8
     const uint32_t n_groups = (uint32_t)((n + (1ull << (low_bits + 8)) - 1) >> (low_bits + 8));
@@ -1239,6 +1275,31 @@ bool radix_unsort_perm(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned low
 
 bool radix_pairs_available() { return rank_mode() == 1; }   // (the pair passes rank by LDS atomics only)
 int radix_rank_mode() { return rank_mode(); }               // 1: LDS atomics (the device passed the self-check), 0: ballots
+
+// Gives the look-back buffers of idle (device, stream) pairs back to the driver; a buffer whose sort is being enqueued right now
+// (its mutex is held -- possibly by this very thread, whose allocation failed inside a sort) is skipped.  hipFree waits for the
+// device, so passes already enqueued have finished with it.
+uint64_t radix_trim_state()
+{
+    uint64_t freed = 0;
+    if (g_state_uses) return 0;   // (called from inside a sort of this thread: an allocation of the sort failed)
+    std::lock_guard<std::mutex> lock(state_registry_mu());
+    for (auto &kv : state_registry()) {
+        StateBuf &b = *kv.second;
+        std::unique_lock<std::mutex> use(b.mu, std::try_to_lock);
+        if (!use.owns_lock() || !b.p) continue;
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != kv.first.first) (void)hipSetDevice(kv.first.first);
+        (void)hipFree(b.p);
+        if (cur != kv.first.first && cur >= 0) (void)hipSetDevice(cur);
+        freed += b.words * 8;
+        b.p = nullptr;
+        b.words = 0;
+        b.epoch = 0;
+    }
+    return freed;
+}
 
 // The always-on order guards of the consumers (index.hip: k_nodes, k_rle_keys, k_check_ascending) found a result of the
 // LDS-atomic ranking out of order: the current device ranks by ballots from here on (pairs: rocPRIM), for the rest of the process.
@@ -1306,7 +1367,8 @@ void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, Occ
         hipLaunchKernelGGL(k_rs_hist32, dim3((unsigned)((n + 65535) / 65536)), dim3(256), 0, stream, keys, n, n_passes, hist.p);
     }
     SW_HIP(hipGetLastError());
-    StateBuf &sb = state_buf(stream, (size_t)n_tiles * RADIX);
+    StateUse su = state_buf(stream, (size_t)n_tiles * RADIX);
+    StateBuf &sb = su.b;
     const StageSource none{};
     const uint32_t fault = fault_rank();
     for (unsigned p = 0; p < n_passes; ++p) {
@@ -1338,7 +1400,7 @@ static int pick_shape(unsigned bits)
 {
     const char *e = getenv("SEQWIN_AMD_RADIX_BITS");   // A/B: 8 or 9
     const bool nine = e ? atoi(e) == 9 : (bits + 8) / 9 < (bits + 7) / 8;   // 9-bit digits where they save a pass (54 bits: 6 for 7)
-    const char *shape = getenv("SEQWIN_AMD_RADIX_SHAPE");   // A/B
+    const char *shape = SW_AB_GETENV("SEQWIN_AMD_RADIX_SHAPE");   // A/B (-DSW_AB)
     if (shape && !strcmp(shape, "1024x8")) return 2;
     if (shape && !strcmp(shape, "512x9")) return 3;
     if (shape && !strcmp(shape, "256x8")) return 4;
@@ -1365,10 +1427,12 @@ void radix_sort_keys64(uint64_t *&keys, uint64_t *&alt, uint64_t n, unsigned beg
     if (end_bit - begin_bit > 64) raise(SW_ERR_RUNTIME, "radix_sort_keys64: more than 64 key bits");
     // (layout_bits: the upper passes of a radix_layout(layout_bits) sort -- same digit width, begin_bit on a digit boundary)
     switch (pick_shape(layout_bits ? layout_bits : end_bit - begin_bit)) {
+#ifdef SW_AB   // (the shapes that lost: 1024 x 8 bits 28.3 ms, 512 x 9 bits 35.5 ms against 25.1 on 745 M 54-bit keys, NOTES.md)
     case 2: sort_passes<1024, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
     case 3: sort_passes<512, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
-    case 1: sort_passes<1024, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
     case 4: sort_passes<256, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
+#endif
+    case 1: sort_passes<1024, 9>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
     default: sort_passes<512, 8>(keys, alt, n, begin_bit, end_bit, stream, d_fail, perm_hi32, d_hist_given); break;
     }
 }

@@ -1321,7 +1321,11 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
     seg_pos.reserve(R);
     seg_idx.reserve(R);
     uint64_t tiles = 0, tiles_g = 0, tiles0 = 0, tiles1 = 0;
+#ifdef SW_AB
     const bool tails = force && !strcmp(force, "tails");
+#else
+    const bool tails = false;   // (A/B loser: -DSW_AB builds only)
+#endif
     for (size_t r = 0; r < R; ++r) {
         rec_seg_off[r] = (uint32_t)seg_pos.size();
         rec_tile_off[r] = (uint32_t)tiles;

@@ -121,10 +121,8 @@ KNOBS = [
     {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_RADIX_RANK": "ballot"},         # radix.hip's passes ranking by ballots (pairs then go to rocPRIM)
     {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_PAIR_SORT": "rocprim"},         # keys-only sorts own, node pairs by rocPRIM
     {"SEQWIN_AMD_SORT": "rocprim", "SEQWIN_AMD_PAIR_SORT": "own"},         # ... and the other way round
-    {"SEQWIN_AMD_RLE": "rocprim"},                                         # run lengths by rocprim::run_length_encode (default: k_rle_keys)
     {"SEQWIN_AMD_UNSORT_DIRECT": "4", "SEQWIN_AMD_ADJ_SEPARATE": "1"},    # ... with the rank array and k_adj_pairs (default there: keys straight from the buckets, k_unsort_adj)
     {"SEQWIN_AMD_UNSORT_DIRECT": "4", "SEQWIN_AMD_SORT": "rocprim"},      # k_unsort_adj without digit counts
-    {"SEQWIN_AMD_SORT": "own", "SEQWIN_AMD_DESC_LOW": "0"},               # descent sweeps of the node sort on the payloads (default with radix.hip: on the compact low halves its last pass writes)
     {"SEQWIN_AMD_ORDER": "stage"},                                         # node sort's first pass reads the sketch stage (default from 2^20 occurrences on)
     {"SEQWIN_AMD_ORDER": "stage", "SEQWIN_AMD_RC": "3", "SEQWIN_AMD_UNSORT_DIRECT": "4"},   # ... with tiles in the overflow area
     {"SEQWIN_AMD_ORDER": "copy", "SEQWIN_AMD_SORT": "own"},                # ... k_order's copy in front of radix.hip's passes

@@ -1020,6 +1020,30 @@ def test_multi_device_build_on_a_synthetic_job(tmp_path, monkeypatch):
         many = _build(paths, 21, 200, n_cpu=4)
         monkeypatch.delenv("SEQWIN_DEVICES")
         assert all(np.array_equal(a, c) for a, c in zip(one[:4], many[:4])) and one[4] == many[4], devices
+    # r05: the exchanges without peer access -- every pull staged through the pulling worker's pinned host buffer (the route a pair
+    # of GPUs without hipDeviceCanAccessPeer takes; forced here, on logical shards of one card) -- and the route in the log
+    import logging
+    records = []
+
+    class _Grab(logging.Handler):
+        def emit(self, record):
+            records.append(record.getMessage())
+    h = _Grab(level=logging.INFO)
+    root = logging.getLogger()
+    old_level = root.level
+    root.addHandler(h)
+    root.setLevel(logging.INFO)
+    try:
+        for no_p2p, expect in (("1", "staged through pinned host memory (SEQWIN_MULTI_NO_P2P=1)"), ("0", "logical shards of one device")):
+            monkeypatch.setenv("SEQWIN_DEVICES", "0,0,0,0")
+            monkeypatch.setenv("SEQWIN_MULTI_NO_P2P", no_p2p)
+            del records[:]
+            many = _build(paths, 21, 200, n_cpu=4)
+            assert all(np.array_equal(a, c) for a, c in zip(one[:4], many[:4])) and one[4] == many[4], no_p2p
+            assert any("multi-device build: 4 workers on devices [0,0,0,0]" in m and expect in m for m in records), records
+    finally:
+        root.removeHandler(h)
+        root.setLevel(old_level)
 
 
 def test_multi_device_build_without_any_record_or_minimizer(tmp_path, monkeypatch):
