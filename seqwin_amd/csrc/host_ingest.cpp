@@ -23,6 +23,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+
+#include "fast_inflate.hpp"
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
@@ -86,10 +88,69 @@ struct RawBuf {
     }
 };
 
+// The bytes of a file, as they are, + finf::IN_PAD zero bytes behind them (buf.len excludes the padding).
+bool read_raw(const std::string &path, RawBuf &buf)
+{
+    buf.len = 0;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    const size_t expect = (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) ? (size_t)st.st_size : 0;
+    bool ok = true;
+    for (;;) {
+        try {
+            buf.reserve(std::max<size_t>(buf.len + (1u << 20), expect + 1) + finf::IN_PAD);
+        } catch (...) {
+            close(fd);
+            throw;
+        }
+        const ssize_t got = read(fd, buf.p + buf.len, buf.cap - finf::IN_PAD - buf.len);
+        if (got < 0) {
+            if (errno == EINTR) continue;
+            ok = false;
+            break;
+        }
+        if (got == 0) break;
+        buf.len += (size_t)got;
+    }
+    close(fd);
+    if (ok) memset(buf.p + buf.len, 0, finf::IN_PAD);
+    return ok;
+}
+
+// r05: a .gz file that is one or more well-formed gzip members is inflated by fast_inflate.hpp from the whole file in memory
+// (a second per-worker buffer) -- the bytes zlib's gzread loop would deliver, CRC-32 and ISIZE checked; anything else
+// (and SEQWIN_AMD_ZLIB_INFLATE=1) takes the gzread loop below, which is the reference's (fasta_reader.cpp:109-203).
+bool slurp_gz_fast(const std::string &path, RawBuf &buf)
+{
+    static thread_local RawBuf raw;   // the compressed bytes: one buffer per worker thread, reused from file to file
+    static const bool off = getenv("SEQWIN_AMD_ZLIB_INFLATE") != nullptr;
+    if (off || !read_raw(path, raw) || raw.len < 18) return false;
+    const uint8_t *in = (const uint8_t *)raw.p;
+    const uint32_t isize = in[raw.len - 4] | (in[raw.len - 3] << 8) | (in[raw.len - 2] << 16) | ((uint32_t)in[raw.len - 1] << 24);
+    static thread_local finf::Tables tables;
+    size_t cap = std::max<size_t>((size_t)isize, raw.len) + 64;   // (ISIZE of the last member: exact for the one-member files NCBI ships)
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        buf.len = 0;
+        buf.reserve(cap);
+        size_t got = 0;
+        const finf::Result r = finf::gunzip_members(in, raw.len, (uint8_t *)buf.p, cap, &got, tables);
+        if (r == finf::OK) {
+            buf.len = got;
+            return true;
+        }
+        if (r != finf::NEED_OUT) return false;
+        cap *= 2;   // (several members, or more than 4 GiB of text: ISIZE does not say)
+    }
+    return false;
+}
+
 void slurp(const std::string &path, RawBuf &buf)
 {
     buf.len = 0;
     if (ends_with(path, ".gz")) {  // fasta_reader.cpp:209
+        if (slurp_gz_fast(path, buf)) return;
+        buf.len = 0;
         gzFile gz = gzopen(path.c_str(), "rb");
         if (!gz) raise(SW_ERR_RUNTIME, "Unable to open gzip FASTA: %s", path.c_str());
         gzbuffer(gz, 1u << 20);

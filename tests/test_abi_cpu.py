@@ -395,6 +395,63 @@ def test_device_gz_decoder_and_parser_under_sanitizers(tmp_path):
             assert (tmp_path / "m.bin").read_bytes() == o2.astype(np.uint32).tobytes() + b2 + np.array([len(x) for x in s2], np.uint32).tobytes() + b"".join(s2)
 
 
+def test_host_inflate_against_zlib_under_sanitizers(tmp_path):
+    """seqwin_amd/csrc/fast_inflate.hpp -- the whole-buffer gzip / DEFLATE decoder the host ingest uses for .gz files since r05
+    (the gzip branch of fasta_reader.cpp:109-203; zlib's gzread loop stays as the route for everything unusual) -- against zlib,
+    compiled with AddressSanitizer + UBSan (`make -C seqwin_amd/csrc finfsan`, tests/tools/finf_san_driver.cpp).  Contract: what
+    it ACCEPTS is byte for byte what zlib delivers, every well-formed member made by zlib's deflate (levels 0 / 1 / 6 / 9, all
+    strategies, several members, empty members, capacities exact to the byte) is accepted, and on flipped, truncated, extended
+    or overwritten streams it never touches memory outside its buffers; its CRC-32 (PCLMULQDQ folding where the CPU has it)
+    equals zlib's on random spans.  Then the library itself: the same .gz files through the ingest with the fast decoder and with
+    SEQWIN_AMD_ZLIB_INFLATE=1 give the same batch, including members with header fields the fast decoder leaves to zlib."""
+    import os
+    import subprocess
+    import sys
+    import zlib
+    if subprocess.run(["make", "-C", str(ROOT / "seqwin_amd" / "csrc"), "finfsan"], capture_output=True).returncode != 0:
+        pytest.skip("no sanitizer runtime for g++ here")
+    exe = ROOT / "seqwin_amd" / "csrc" / "build" / "finf_san"
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    for seed in (7, 8):
+        r = subprocess.run([str(exe), str(seed), "1500"], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+        assert "cases:" in r.stdout and "crc32: 400 spans equal" in r.stdout
+    # the library: fast route == zlib route on the same files (one thread per route, in child processes: the switch is read once)
+    rng = random.Random(5)
+    files = []
+    for i in range(12):
+        n = rng.choice([0, 1, 50, 4000, 200000])
+        seq = "".join(rng.choice("ACGTNacgtRY") for _ in range(n))
+        text = "".join(f">r{i}_{j} d\n" + "\n".join(seq[a:a + 70] for a in range(j, len(seq), 70 * 3)) + "\n" for j in range(3)).encode()
+        if i % 4 == 3:      # two members
+            data = gzip.compress(text[: len(text) // 2], 6) + gzip.compress(text[len(text) // 2:], 1)
+        elif i % 4 == 2:    # FNAME + FHCRC: the header CRC is zlib's to check
+            head = bytes([0x1F, 0x8B, 8, 2 | 8, 0, 0, 0, 0, 0, 255]) + b"x.fa\0"
+            head += (zlib.crc32(head) & 0xFFFF).to_bytes(2, "little")
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            data = head + co.compress(text) + co.flush() + zlib.crc32(text).to_bytes(4, "little") + (len(text) & 0xFFFFFFFF).to_bytes(4, "little")
+        else:
+            data = gzip.compress(text, rng.choice([0, 1, 6, 9]))
+        p = tmp_path / f"f{i}.fa.gz"
+        p.write_bytes(data)
+        files.append(str(p))
+    code = ("import sys, ctypes, hashlib; sys.path.insert(0, %r); from seqwin_amd._lib import lib, check, c_vp, c_u64\n"
+            "paths = [p.encode() for p in sys.argv[1:]]; arr = (ctypes.c_char_p * len(paths))(*paths); h = c_vp()\n"
+            "check(lib.sw_host_ingest(arr, len(paths), 2, ctypes.byref(h)))\n"
+            "v = [c_u64() for _ in range(5)]; check(lib.sw_hostbatch_info(h, *[ctypes.byref(x) for x in v]))\n"
+            "d = hashlib.sha256()\n"
+            "for r in range(v[1].value):\n"
+            "    n = c_u64(); check(lib.sw_hostbatch_record(h, r, None, 0, ctypes.byref(n)))\n"
+            "    b = ctypes.create_string_buffer(max(n.value, 1)); check(lib.sw_hostbatch_record(h, r, b, n.value, ctypes.byref(n))); d.update(b.raw[:n.value] + b'|')\n"
+            "print([x.value for x in v], d.hexdigest())\n") % str(ROOT)
+    outs = []
+    for extra in ({}, {"SEQWIN_AMD_ZLIB_INFLATE": "1"}):
+        r = subprocess.run([sys.executable, "-c", code] + files, capture_output=True, text=True, env=dict(os.environ, **extra), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and outs[0].strip()
+
+
 def test_half_word_rotate_formulas(tmp_path):
     """The sketch kernel writes srol / sror (hashing_internals.hpp:29-35, 69-74) and their 4-fold forms as funnel shifts
     and bit-field inserts on 32-bit halves (sketch.hip: srol1, sror1, srol4, sror4); tests/tools/rot_check.cpp restates
