@@ -264,7 +264,9 @@ def cpu_baseline_and_parity(batch, k, w, n_genomes_sample, is_targets):
         # T_e2e: the same files through the drop-in boundary.  Reported beside the baseline; never `value`.
         e2e_build(paths[:2], k, w, 2, tar[:2])   # (library warm-up: allocator, module load)
         e2e_runs, e2e_equal = [], True
-        for n_cpu in sorted({min(c, cores) for c in (8, 32, 64, 128)}):
+        quota = cpu_quota()
+        sweep = {min(c, cores) for c in (8, 32, 64, 128)} | ({max(1, min(cores, int(round(quota))))} if quota else set())
+        for n_cpu in sorted(sweep):
             got, wall, split = e2e_build(paths, k, w, n_cpu, tar)
             e2e_runs.append((wall, n_cpu, split))
             e2e_equal = e2e_equal and bool(np.array_equal(got[0], kmers) and np.array_equal(got[1], nodes)
@@ -273,7 +275,7 @@ def cpu_baseline_and_parity(batch, k, w, n_genomes_sample, is_targets):
         e2e_dt, e2e_cpu, e2e_split = min(e2e_runs, key=lambda r: r[0])
         e2e = {"value": round(bp / e2e_dt / 1e9, 3), "unit": "Gbp/s", "n_cpu": e2e_cpu, "equal_to_cpu_baseline": e2e_equal,
                "genomes": n, "Mbp": round(bp / 1e6, 1), "split_ms": e2e_split,
-               "by_n_cpu": {str(c): round(bp / t / 1e9, 2) for t, c, _ in e2e_runs},
+               "by_n_cpu": {str(c): round(bp / t / 1e9, 2) for t, c, _ in e2e_runs}, "cpu_quota_cores": quota,
                "sample": f"the same {n} FASTA files through sw_build + sw_graph_export + sw_get_penalty (ingest + PCIe + device + "
                          "download); wall " + ", ".join(f"{t:.3f} s at n_cpu={c}" for t, c, _ in e2e_runs),
                "vs_cpu_baseline": round(dt / e2e_dt, 1)}
@@ -570,7 +572,8 @@ def main() -> None:
                                                "v_cmp and 64-bit moves measure 4.2-4.9 cycles (scripts/micro/valu_kinds.hip), "
                                                "so this instruction mix cannot reach that peak"}
         parity = {}
-        gold, gold_src = golden_checksums(args.workload, k, w) if scaling == "strong" and not args.genomes else (None, None)
+        # (one rank holds the whole workload whatever the scaling mode is called; with more ranks only "strong" keeps the genomes)
+        gold, gold_src = golden_checksums(args.workload, k, w) if (scaling == "strong" or world == 1) and not args.genomes else (None, None)
         if args.write_golden and world == 1 and not use_dist:
             # (only the file of the HIP path's own results; the reference-derived file is written by scripts/pin_fullsize_ref.py alone)
             allg = json.loads(GOLDEN.read_text()) if GOLDEN.exists() else {}

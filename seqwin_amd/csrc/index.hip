@@ -3163,6 +3163,12 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
         radix_layout(key_bits, &digit_bits, &n_passes);
         const unsigned hb = wide ? wide->hi_bits : nb;
         skip = hb >= digit_bits + 8 ? 1 : 0;
+        // r05: a SECOND digit is left to the repair where few keys repeat -- at most four occurrences per node on average.  With the
+        // thread form of the repair (2^26 descents) the second digit's ~500 x more descents are cheap while the runs that hold them
+        // are short: one GPU's share of 100 000 iid genomes 118 177 descents, no run above 64 keys, -2.3 ms per build; salmonella500 at
+        // w = 10 973 217 descents, -0.7 ms; the 15 000-genome set (9.4 occurrences per node, up to 500) 8.4 M descents in 358 k runs
+        // above 64 keys, +2.1 ms: stays at one (gpurun_out/r5g).  A third digit (4.9e7 descents on the iid share) loses everywhere.
+        if (skip && hb >= 2 * digit_bits + 8 && ix.n_nodes && m <= 4 * ix.n_nodes) skip = 2;
         if (const char *e = getenv("SEQWIN_AMD_EDGE_SKIP_PASSES")) skip = (unsigned)atoi(e);   // A/B, tests (0: all bits by radix passes)
         skip = std::min(skip, n_passes - 1);
         low_bits = skip * digit_bits;
