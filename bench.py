@@ -266,6 +266,8 @@ def cpu_baseline_and_parity(batch, k, w, n_genomes_sample, is_targets):
         e2e_runs, e2e_equal = [], True
         quota = cpu_quota()
         sweep = {min(c, cores) for c in (8, 32, 64, 128)} | ({max(1, min(cores, int(round(quota))))} if quota else set())
+        if os.environ.get("SEQWIN_BENCH_E2E_NCPU"):   # e.g. "16,64,256" with SEQWIN_AMD_INGEST_WORKERS_MAX=256: the ingest's scaling table
+            sweep = {min(int(c), cores) for c in os.environ["SEQWIN_BENCH_E2E_NCPU"].split(",")}
         for n_cpu in sorted(sweep):
             got, wall, split = e2e_build(paths, k, w, n_cpu, tar)
             e2e_runs.append((wall, n_cpu, split))
@@ -342,6 +344,11 @@ def main() -> None:
     ap.add_argument("--write-golden", action="store_true", help="record this run's N=1 checksums in tests/golden/")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: whatever a library prints there (RCCL's version banner when a communicator is
+    # made, for one) goes to stderr -- file descriptor 1 is pointed at stderr for the run, the line is written to the real one
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -593,7 +600,8 @@ def main() -> None:
             parity.update(ref_par)
         if parity:
             out["parity"] = parity
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -169,11 +169,26 @@ struct BitReader {
 
 enum Result { OK = 0, BAD = 1, NEED_OUT = 2 };
 
+// the fixed Huffman code of RFC 1951 section 3.2.6 (built once; a function-local static: thread-safe)
+inline const Tables &fixed_tables()
+{
+    static const Tables fixed = [] {
+        Tables t;
+        uint8_t lens[MAX_LL_SYMS];
+        for (unsigned s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+        uint8_t dl[MAX_D_SYMS];
+        for (unsigned s = 0; s < 32; ++s) dl[s] = 5;
+        (void)build_table(lens, 288, LL_BITS, t.ll, LL_TABLE, ll_entry, false);
+        (void)build_table(dl, 32, D_BITS, t.d, D_TABLE, d_entry, false);
+        t.d_usable = true;
+        return t;
+    }();
+    return fixed;
+}
+
 // One DEFLATE stream: br at its first bit; out_begin..out_cap the output buffer, `out` the write position (history = [out_begin, out)).
 inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, uint8_t *out_cap, Tables &T)
 {
-    static Tables fixed;
-    static bool fixed_ready = false;   // (built by the first caller; racing builders write identical bytes)
     for (;;) {
         br.refill();
         const unsigned final_block = br.peek(1), type = (br.peek(3) >> 1);
@@ -196,17 +211,7 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
             if (final_block) return OK;
             continue;
         } else if (type == 1) {
-            if (!fixed_ready) {
-                uint8_t lens[MAX_LL_SYMS];
-                for (unsigned s = 0; s < 288; ++s) lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-                uint8_t dl[MAX_D_SYMS];
-                for (unsigned s = 0; s < 32; ++s) dl[s] = 5;
-                if (!build_table(lens, 288, LL_BITS, fixed.ll, LL_TABLE, ll_entry, false)) return BAD;
-                if (!build_table(dl, 32, D_BITS, fixed.d, D_TABLE, d_entry, false)) return BAD;
-                fixed.d_usable = true;
-                fixed_ready = true;
-            }
-            tp = &fixed;
+            tp = &fixed_tables();
         } else if (type == 2) {
             const unsigned hlit = br.peek(5) + 257, hdist = (br.peek(10) >> 5) + 1, hclen = (br.peek(14) >> 10) + 4;
             br.drop(14);
@@ -501,34 +506,34 @@ __attribute__((target("pclmul,sse4.1"))) inline uint32_t crc32_pclmul(uint32_t c
 }
 #endif
 
-// 0: not examined yet, 1: the folded form agrees with the tables on this CPU, 2: unavailable / disagrees
-inline int &crc_fold_state()
+// 1: the folded form agrees with the tables on this CPU, 2: unavailable / disagrees (examined once: a function-local static)
+inline int crc_fold_state()
 {
-    static int s = 0;
-    return s;
+#if defined(__x86_64__)
+    static const int state = [] {
+        if (!(__builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1"))) return 2;
+        uint8_t probe[64 * 5 + 16];
+        uint32_t x = 0x2545F491u;
+        for (size_t i = 0; i < sizeof probe; ++i) {
+            x ^= x << 13; x ^= x >> 17; x ^= x << 5;
+            probe[i] = (uint8_t)x;
+        }
+        bool ok = true;
+        for (size_t len : {(size_t)80, (size_t)96, (size_t)128, (size_t)336})
+            ok = ok && crc32_pclmul(0xFFFFFFFFu, probe, len) == crc32_slice8(0xFFFFFFFFu, probe, len) &&
+                 crc32_pclmul(0x12345678u, probe + 3, len - 16) == crc32_slice8(0x12345678u, probe + 3, len - 16);
+        return ok ? 1 : 2;
+    }();
+    return state;
+#else
+    return 2;
+#endif
 }
 inline uint32_t crc32(const uint8_t *p, size_t n)   // the gzip trailer's CRC-32 of p[0, n)
 {
     uint32_t crc = 0xFFFFFFFFu;
 #if defined(__x86_64__)
-    int &st = crc_fold_state();
-    if (st == 0) {
-        st = 2;
-        if (__builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1")) {
-            uint8_t probe[64 * 5 + 16];
-            uint32_t x = 0x2545F491u;
-            for (size_t i = 0; i < sizeof probe; ++i) {
-                x ^= x << 13; x ^= x >> 17; x ^= x << 5;
-                probe[i] = (uint8_t)x;
-            }
-            bool ok = true;
-            for (size_t len : {(size_t)80, (size_t)96, (size_t)128, (size_t)336})
-                ok = ok && crc32_pclmul(0xFFFFFFFFu, probe, len) == crc32_slice8(0xFFFFFFFFu, probe, len) &&
-                     crc32_pclmul(0x12345678u, probe + 3, len - 16) == crc32_slice8(0x12345678u, probe + 3, len - 16);
-            if (ok) st = 1;
-        }
-    }
-    if (st == 1 && n >= 64) {
+    if (n >= 64 && crc_fold_state() == 1) {
         const size_t bulk = n & ~(size_t)15;
         crc = crc32_pclmul(crc, p, bulk);
         p += bulk;

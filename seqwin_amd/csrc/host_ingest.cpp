@@ -22,6 +22,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <sched.h>
 #include <zlib.h>
 
 #include "fast_inflate.hpp"
@@ -522,6 +523,33 @@ struct BufferPool {
 
 }  // namespace
 
+// CPUs this process may run on at once: hardware threads, narrowed by the affinity mask and by the cgroup CPU quota (v2 cpu.max,
+// v1 cfs quota / period), at least 1
+size_t usable_cpus()
+{
+    size_t n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<size_t>(n, (size_t)std::max(1, CPU_COUNT(&set)));
+    auto read_two = [](const char *path, long long &a, long long &b) {
+        FILE *f = fopen(path, "r");
+        if (!f) return false;
+        char x[64] = {0}, y[64] = {0};
+        const int got = fscanf(f, "%63s %63s", x, y);
+        fclose(f);
+        if (got < 1 || !strcmp(x, "max")) return false;
+        a = atoll(x);
+        b = got > 1 ? atoll(y) : 0;
+        return true;
+    };
+    long long q = 0, per = 0;
+    if (read_two("/sys/fs/cgroup/cpu.max", q, per) && q > 0 && per > 0) n = std::min<size_t>(n, (size_t)((q + per - 1) / per));
+    else if (read_two("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", q, per) && q > 0) {
+        long long p2 = 0, dummy = 0;
+        if (read_two("/sys/fs/cgroup/cpu/cpu.cfs_period_us", p2, dummy) && p2 > 0) n = std::min<size_t>(n, (size_t)((q + p2 - 1) / p2));
+    }
+    return std::max<size_t>(n, 1);
+}
+
 void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, HostBatch &out, ChunkSink *sink)
 {
     if (n_paths > UINT32_MAX)  // build.cpp:337-339
@@ -530,10 +558,16 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
     std::vector<std::unique_ptr<Error>> errors(n_paths);
     size_t n_workers = std::max<uint64_t>(1, n_cpu);  // build.cpp:342-347
     if (n_paths > 0) n_workers = std::min(n_workers, n_paths);
-    // Parsing is memory-bound well before 64 threads; beyond that the workers only contend for the address space
-    // (measured on 2 x EPYC 9575F: 19 Gbp/s end to end at 32-64 workers, 5.6 at 256).  The result does not depend
-    // on the worker count.
-    n_workers = std::min<size_t>(n_workers, 64);
+    // r05: the cap follows the CPUs the process may really use.  Round 4 capped at 64 workers "because they contend for the
+    // address space" (19 Gbp/s end to end at 32-64 workers, 5.6 at 256, on 2 x EPYC 9575F) -- the box in fact grants the container
+    // 16 CPUs (cgroup cpu.max), and 256 runnable threads burn a 100 ms period's quota in its first quarter and sit out the rest.
+    // Four workers per usable CPU is where the measured optimum lay (64 on 16); on an unrestricted host that is no cap at all.
+    // SEQWIN_AMD_INGEST_WORKERS_MAX overrides it (scaling tables).  The result does not depend on the worker count.
+    {
+        size_t cap = 4 * usable_cpus();
+        if (const char *e = getenv("SEQWIN_AMD_INGEST_WORKERS_MAX")) cap = (size_t)std::max(1, atoi(e));
+        n_workers = std::min(n_workers, std::max<size_t>(cap, 1));
+    }
 
     const bool timing = getenv("SEQWIN_AMD_DEBUG_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();

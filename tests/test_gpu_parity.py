@@ -624,8 +624,17 @@ def test_bench_line_contract():
                           "--cpu-sample-genomes", "4"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and out.stdout.strip() == lines[0]     # ONE line and nothing else on stdout
     d = json.loads(lines[0])
+    # ... also when RCCL makes a communicator (it prints a version banner to stdout; r05: the bench keeps stdout to itself)
+    import os
+    out2 = subprocess.run([sys.executable, str(root / "bench.py"), "--workload", "tiny", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                          capture_output=True, text=True, timeout=600,
+                          env=dict(os.environ, SEQWIN_DIST_FORCE_COLLECTIVES="1", SEQWIN_BENCH_FORCE_DIST="1", MASTER_PORT="29547"))
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    assert out2.stdout.count("\n") == 1 and out2.stdout.startswith("{"), out2.stdout[:300]
+    d2 = json.loads(out2.stdout)
+    assert d2["dist"]["world"] == 1 and d2["dist"]["distinct_gpus"] == 1 and d2["dist"]["ranks"][0]["rank"] == 0 and d2["dist"]["collectives"] == "issued"
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "plan_ms", "checksums"):
         assert key in d, key
