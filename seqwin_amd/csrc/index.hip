@@ -297,7 +297,7 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
     const uint64_t s0 = (uint64_t)tile * NODES_TILE;
     uint32_t k[NODES_ROWS][2], within[NODES_ROWS], headm = 0, prec[NODES_ROWS];
     OccPay p[NODES_ROWS][2];
-    bool misorder = false;
+    unsigned long long misorder = 0;   // (wave-uniform: lanes that saw (hash, stream index) not ascending)
 #pragma unroll
     for (int r = 0; r < NODES_ROWS; ++r) {
         const uint64_t s = s0 + (uint64_t)r * NODES_ROW + 2 * threadIdx.x;   // occurrences s, s + 1
@@ -330,9 +330,13 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
         // ascending.  The radix passes rank by an LDS atomic whose lane order is checked at start-up but is no architectural
         // promise (radix.hip); a violation is counted here and group_occurrences re-sorts without that ranking.
 #ifndef SW_NO_ORDER_GUARD   // (A/B timing of the guard only: tests/tools/build_variant.sh noguard -DSW_NO_ORDER_GUARD)
-        if (s < n && s && (k[r][0] < pk || (k[r][0] == pk && (p[r][0].low < plow || (!h0 && p[r][0].idx <= pidx))))) misorder = true;
-        if (s + 1 < n && (k[r][1] < k[r][0] || (k[r][1] == k[r][0] && (p[r][1].low < p[r][0].low || (!h1 && p[r][1].idx <= p[r][0].idx)))))
-            misorder = true;
+        {   // (hash, idx) as (key32, low) lexicographic then idx: one 64-bit compare per pair + the equal-hash index test
+            const unsigned long long hp = ((unsigned long long)pk << 32) | plow, h0v = ((unsigned long long)k[r][0] << 32) | p[r][0].low,
+                                     h1v = ((unsigned long long)k[r][1] << 32) | p[r][1].low;
+            const bool bad0 = s < n && s && (h0v < hp || (!h0 && p[r][0].idx <= pidx));
+            const bool bad1 = s + 1 < n && (h1v < h0v || (!h1 && p[r][1].idx <= p[r][0].idx));
+            misorder |= __ballot(bad0 || bad1);
+        }
 #else
         (void)pidx;
 #endif
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
         if (h1) headm |= 2u << (2 * r);
         if (lane == 0) s_row[r * NODES_WAVES + wave] = (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1);
     }
-    if (misorder) atomicAdd(order_bad, 1u);   // (never, on a device whose LDS unit serves the lanes of an atomic in lane order)
+    if (misorder && lane == 0) atomicAdd(order_bad, (uint32_t)__popcll(misorder));   // (never, on a device whose LDS unit serves the lanes of an atomic in lane order)
     __syncthreads();
     if (wave == 0) {
         // exclusive offsets of the (row, wave) groups (two per lane), the tile's total, then the look-back
@@ -1311,7 +1315,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_keys(const uint64_t *__rest
     __syncthreads();
     uint64_t carry = wave ? s_last[wave - 1] : (t0 ? keys[t0 - 1] : 0ull);   // the key before the wave's first (unused at position 0)
     uint32_t cnt[RLE_ITEMS], below[RLE_ITEMS], total_w = 0, headm = 0;
-    bool misorder = false;
+    unsigned long long misorder = 0;   // (wave-uniform: lanes that saw a key below its predecessor)
 #pragma unroll
     for (int j = 0; j < RLE_ITEMS; ++j) {
         const uint64_t i = w0 + (uint64_t)j * 64 + lane;
@@ -1319,7 +1323,9 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_keys(const uint64_t *__rest
         if (lane == 0) prev = carry;
         const bool head = i < m && (i == 0 || k[j] != prev);
 #ifndef SW_NO_ORDER_GUARD
-        if (i < m && i && k[j] < prev) misorder = true;   // always-on order guard (r05): the keys must arrive ascending
+        // always-on order guard (r05): the keys must arrive ascending.  One compare into a scalar mask + one scalar OR per key (the
+        // first form kept a flag per lane: k_rle_keys 2.31 -> 2.65 ms at 745 M keys)
+        misorder |= __ballot(i < m && i && k[j] < prev);
 #endif
         const unsigned long long b = __ballot(head);
         below[j] = total_w + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));   // heads of the wave before this key
@@ -1329,7 +1335,7 @@ __global__ __launch_bounds__(RLE_THREADS) void k_rle_keys(const uint64_t *__rest
         carry = __shfl(k[j], 63, 64);
     }
     if (lane == 0) s_wave[wave] = total_w;
-    if (misorder) atomicAdd(order_bad, 1u);
+    if (misorder && lane == 0) atomicAdd(order_bad, (uint32_t)__popcll(misorder));
     __syncthreads();
     if (wave == 0) {
         const uint32_t wc = lane < RLE_THREADS / 64 ? s_wave[lane] : 0u;
