@@ -592,8 +592,8 @@ _checked_groups = set()
 
 def check_collectives(dev, group=None) -> None:
     """Start-up self-check of the collectives the build relies on, once per process and group: one all_to_all_single whose
-    per-peer messages are ONE ELEMENT LARGER than the round size the exchanges use (SEQWIN_DIST_MSG_LIMIT_MB, capped at
-    SEQWIN_DIST_SELFCHECK_MB, default 64, so that the check costs milliseconds), filled with a position-dependent pattern
+    per-peer messages are ONE ELEMENT LARGER than the round size the exchanges use (SEQWIN_DIST_MSG_LIMIT_MB; capped at
+    SEQWIN_DIST_SELFCHECK_MB, default 64 at world size 1 and the full round size between several ranks), filled with a position-dependent pattern
     and verified element for element on the receiver, plus an all_gather_into_tensor of the same size.  RCCL 2.26 at world
     size 1 silently delivered only the first half of large messages (NOTES.md, round 3): a transport that does so for the
     sizes in use fails HERE, loudly, instead of producing a graph with edges missing.  SEQWIN_DIST_SELFCHECK=0 skips it."""
@@ -603,7 +603,10 @@ def check_collectives(dev, group=None) -> None:
     if key in _checked_groups or os.environ.get("SEQWIN_DIST_SELFCHECK", "1") == "0" or not dist.is_initialized():
         return
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    limit = min(_MSG_LIMIT, int(os.environ.get("SEQWIN_DIST_SELFCHECK_MB", "64")) << 20)
+    # (r05) between distinct GPUs -- never exercised on any box of rounds 1-5 -- the check runs at the FULL round size: a per-peer message
+    # of the size the exchanges really send (256 MiB: ~6 GB of buffers at world 8, some tens of ms once per process); at world size 1,
+    # where the full-size path is covered by tests/test_gpu_fullsize.py, and over gloo (host memory: the CPU suite), it stays at 64 MiB
+    limit = min(_MSG_LIMIT, int(os.environ.get("SEQWIN_DIST_SELFCHECK_MB", "64" if (world == 1 or dist.get_backend(group) != "nccl") else str(max(1, _MSG_LIMIT >> 20)))) << 20)
     n = limit // 8 + 1                                              # int64 elements per peer
     idx = torch.arange(n, dtype=torch.int64, device=dev)
     send = torch.cat([idx * 1000003 + (rank * world + p) * 7919 for p in range(world)])
