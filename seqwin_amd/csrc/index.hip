@@ -235,7 +235,10 @@ __global__ void k_iota(uint32_t *v, uint64_t n)
 // a node are in record order, records are assembly-major, filter.cpp:62-136), so a node's counts are two popcounts.
 // A workgroup takes NODES_TILE consecutive occurrences, NODES_THREADS at a time (lane s of a wave = occurrence s of a
 // 64-aligned group: the bits of a group are one ballot).
-constexpr int NODES_ROWS = 4;                        // rows per tile; a row = NODES_THREADS lanes x 2 consecutive occurrences
+#ifndef SW_NODES_ROWS
+#define SW_NODES_ROWS 4
+#endif
+constexpr int NODES_ROWS = SW_NODES_ROWS;            // rows per tile; a row = NODES_THREADS lanes x 2 consecutive occurrences (-DSW_NODES_ROWS: A/B)
 constexpr int NODES_THREADS = 1024;                  // 16 waves: one workgroup per CU
 constexpr int NODES_WAVES = NODES_THREADS / 64;
 constexpr uint32_t NODES_ROW = NODES_THREADS * 2;
@@ -1402,6 +1405,7 @@ __global__ void k_edges_runs(const uint64_t *__restrict__ ukeys, const uint32_t 
     if (e >= n_edges) return;
     const uint64_t pair = (ukeys[e] >> pshift) & pmask;
     const uint32_t u = (uint32_t)(pair >> nb), v = (uint32_t)(pair & ((1ull << nb) - 1ull));
+    // (r05: the two hashes by non-temporal loads -- random 8-byte reads that are used once -- measured the same, NOTES.md)
     edges[e].first = rank_hash ? rank_hash[u] : nodes[u].hash;
     edges[e].second = rank_hash ? rank_hash[v] : nodes[v].hash;
     edges[e].weight = RUNS ? usum[e + 1] - usum[e] : usum[e];

@@ -229,6 +229,28 @@ def test_config2_full_size_properties(tmp_path):
     assert ids[0][0] == "g100_c0" and sh.record(0) == sub.record(100 * rpg) and sh.record(3 * rpg - 1) == sub.record(103 * rpg - 1)
 
 
+def test_pin_script_reproduces_the_committed_reference_values_on_a_prefix(tmp_path):
+    """scripts/pin_fullsize_ref.py -- the tool that produced tests/golden/bench_checksums_ref.json on the GPU box -- on a prefix of
+    a workload that fits a test: the compiled reference reads the FASTA the device generator wrote, the HIP path builds the same
+    genomes, every array is compared element for element and the checksums computed from the REFERENCE's arrays are written.  For
+    the first 2 500 genomes of random100k at k = 19 those were committed in round 5: a 64-genome prefix here must give `equal`,
+    and the committed entry must still describe a run that was (needs oracle/_ref; skipped where the reference was not built)."""
+    import subprocess
+    if oracle.load_ref() is None:
+        pytest.skip("oracle/_ref has not been built")
+    out = tmp_path / "pin.json"
+    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "pin_fullsize_ref.py"), "--workload", "random100k", "-k", "19", "--genomes", "64",
+                        "--n-cpu", "8", "--out", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    d = json.loads(out.read_text())
+    assert d["equal"] and d["genomes"] == 64 and all(d["hip_vs_reference_elementwise"].values())
+    assert d["counts"]["kmers"] > 3_000_000 and d["checksums_from"].startswith("the compiled reference")
+    ref = json.loads((GOLDEN / "bench_checksums_ref.json").read_text())
+    for key in ("bacteria15k/k21/w200", "random100k/k15/w200", "random100k/k19/w200", "random100k/k31/w200"):
+        e = ref[key]
+        assert e["equal"] and e["genomes"] == e["genomes_of_workload"] and e["reference"]["n_cpu"] >= 64, key
+
+
 def _bench_line(extra_args, env_extra):
     import subprocess
     env = dict(os.environ, **env_extra)
