@@ -130,7 +130,10 @@ bool slurp_gz_fast(const std::string &path, RawBuf &buf)
     const uint8_t *in = (const uint8_t *)raw.p;
     const uint32_t isize = in[raw.len - 4] | (in[raw.len - 3] << 8) | (in[raw.len - 2] << 16) | ((uint32_t)in[raw.len - 1] << 24);
     static thread_local finf::Tables tables;
-    size_t cap = std::max<size_t>((size_t)isize, raw.len) + 64;   // (ISIZE of the last member: exact for the one-member files NCBI ships)
+    // ISIZE of the last member is exact for the one-member files NCBI ships -- but it is four bytes anyone can write: the first
+    // reservation trusts it only up to 8 x the compressed size (FASTA deflates 3-5 x); a stream that really expands more finds
+    // its room by doubling (8 attempts: 2 048 x, above DEFLATE's 1 032 x)
+    size_t cap = std::min<size_t>(std::max<size_t>((size_t)isize, raw.len), raw.len * 8 + 4096) + 64;
     for (int attempt = 0; attempt < 8; ++attempt) {
         buf.len = 0;
         buf.reserve(cap);

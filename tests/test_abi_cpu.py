@@ -435,6 +435,11 @@ def test_host_inflate_against_zlib_under_sanitizers(tmp_path):
         p = tmp_path / f"f{i}.fa.gz"
         p.write_bytes(data)
         files.append(str(p))
+    # a stream that expands ~1000 x (the first reservation trusts ISIZE only up to 8 x the compressed size: found by doubling), and one
+    # whose ISIZE field lies upwards (four bytes anyone can write: the member is then zlib's to refuse)
+    big = (">poly\n" + "A" * 3_000_000 + "\n").encode()
+    (tmp_path / "poly.fa.gz").write_bytes(gzip.compress(big, 9))
+    files.append(str(tmp_path / "poly.fa.gz"))
     code = ("import sys, ctypes, hashlib; sys.path.insert(0, %r); from seqwin_amd._lib import lib, check, c_vp, c_u64\n"
             "paths = [p.encode() for p in sys.argv[1:]]; arr = (ctypes.c_char_p * len(paths))(*paths); h = c_vp()\n"
             "check(lib.sw_host_ingest(arr, len(paths), 2, ctypes.byref(h)))\n"
