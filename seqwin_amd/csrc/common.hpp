@@ -106,5 +106,6 @@ struct ChunkSink {
 // host_ingest.cpp
 void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, HostBatch &out, ChunkSink *sink = nullptr);
 void check_kw(uint64_t k, uint64_t w);
+size_t usable_cpus();   // host_ingest.cpp: hardware threads narrowed by the affinity mask and the cgroup CPU quota
 
 }  // namespace sw

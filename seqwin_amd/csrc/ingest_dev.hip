@@ -143,8 +143,12 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     // A lane inflates ~1.7 MB of text per second whatever the number of files (64 independent decoders run in lockstep, one wave per
     // CU: ~7 500 clocks per symbol, r03), a host thread ~370 MB/s: the device wins from ~320 files per host thread on
     // (measured: 8 192 files of 1 Mbp, 16 threads: 817 ms against 1 404 ms; 1 024 files: 760 against 178 ms).
-    const uint64_t host_threads = std::min<uint64_t>(std::max<uint64_t>(1, n_cpu), 64);
-    if (n_paths == 0 || n_paths >= 0xFFFFFFFFull || (!forced && n_paths < 320 * host_threads)) return false;
+    // r05: the host side got faster (fast_inflate.hpp: ~0.65 GB/s of text per usable CPU, inflate + parse + pack, bench.py e2e.gz) and
+    // is counted in the CPUs the process may really use, not in the threads it was told to start (a 16-CPU quota on a 256-thread
+    // host); the rule is now made from the files' sizes below: device time ~ text of the LARGEST file / 1.27 MB/s (512 files of
+    // 5 Mbp: 3.98 s), host time ~ all text / (0.65 GB/s x CPUs).  15 000 genomes of 5 Mbp on 16 CPUs: 4 s against 7 s -> device;
+    // 512: 4 s against 0.25 s -> host.
+    if (n_paths == 0 || n_paths >= 0xFFFFFFFFull) return false;
     for (size_t i = 0; i < n_paths; ++i)
         if (!ends_with_gz(paths[i])) return false;
     const bool timing = getenv("SEQWIN_AMD_DEBUG_TIMING") != nullptr;
@@ -161,6 +165,17 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
         if (stat(paths[i], &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 18) return decline("not a regular file of 18 bytes or more", i, 0);
         fsize[i] = (uint64_t)st.st_size;
         coff[i + 1] = coff[i] + ((fsize[i] + 15) & ~15ull);
+    }
+    if (!forced) {
+        uint64_t largest = 0, total = 0;
+        for (size_t i = 0; i < n_paths; ++i) {
+            largest = std::max(largest, fsize[i]);
+            total += fsize[i];
+        }
+        const double ratio = 3.3;   // text per compressed byte of level-6 FASTA
+        const double cpus = (double)std::min<uint64_t>(std::max<uint64_t>(1, n_cpu), usable_cpus());
+        const double t_dev = (double)largest * ratio / 1.27e6, t_host = (double)total * ratio / (0.65e9 * cpus);
+        if (t_dev >= t_host) return false;   // (the host route; nothing has been changed)
     }
     size_t free_b = 0, total_b = 0;
     SW_HIP(hipMemGetInfo(&free_b, &total_b));
