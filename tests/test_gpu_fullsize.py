@@ -74,6 +74,25 @@ def test_config1_full_size_equals_reference(tmp_path):
     assert v["weight_sum"] == int(ee["weight"].sum())
 
 
+@pytest.mark.parametrize("w", [200, 10])
+def test_config1_full_size_checksums_of_the_reference(w):
+    """configs[1] at full size in the small-window regime too: 512 genomes at w = 10 are 4.5e8 occurrences, 6.6e7 nodes, 8.1e7 edges --
+    the index stages dominate (54 ms), the compiled reference needs 183 s for it on the GPU box's host.  Counts and checksums were
+    computed from the REFERENCE's arrays there (scripts/pin_fullsize_ref.py, every array also compared element for element;
+    tests/golden/bench_checksums_ref.json), with every other assembly a target."""
+    G, rpg, rl, anc, snp, _ = WORKLOADS["salmonella500"]
+    gold, src = _full_size_golden(f"salmonella500/k21/w{w}")
+    assert src == "reference"
+    b = Batch.synthetic(G, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED)
+    ix = b.build_index(21, w, np.arange(G) % 2 == 0)
+    nk, nn, ne = ix.sizes()
+    assert gold["counts"] == {"kmers": nk, "nodes": nn, "edges": ne}
+    assert [f"{s:016x}" for s in ix.checksums()] == gold["checksums"]
+    v = ix.verify(G)
+    assert all(v[key] == 0 for key in list(v)[:8]), v
+    assert v["weight_sum"] == gold["weight_sum"] and ix.threshold_sums()[0] == gold["n_tar_sum"]
+
+
 def test_config1_multi_device_build_equals_single_device(tmp_path, monkeypatch):
     """configs[1] (512 genomes, 2.46 Gbp, 24.6 M minimizers) as FASTA through ONE sw_build over four and seven logical devices
     (SEQWIN_DEVICES, csrc/multi.hip: worker threads, peer copies, both ways of bringing node hashes to the edge owners) against
