@@ -366,11 +366,7 @@ __global__ __launch_bounds__(NODES_THREADS) void k_nodes(const uint32_t *__restr
         if (lane == 0)
             __hip_atomic_store(&tile_state[tile], (tile == 0 ? TS_INC : TS_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t excl = 0;
-#ifdef SW_NODES_NO_LOOKBACK   // timing ablation only (WRONG node numbers): what the chained look-back costs k_nodes
-        if (false) {
-#else
         if (tile) {
-#endif
             int64_t look = (int64_t)tile - 1;
             for (;;) {
                 const int64_t idx = look - lane;   // lane 0 reads the nearest predecessor
