@@ -412,16 +412,15 @@ struct FileBytes {
     const char *p = nullptr;
     size_t n = 0;
     void *map = nullptr;
-    // use_mmap: only with a single worker -- mapping and unmapping files from many threads of one process
-    // serialises on the address-space lock and its TLB shootdowns and ends up slower than the copy it saves
-    FileBytes(const std::string &path, RawBuf &buf, bool use_mmap)
+    // use_mmap: see ingest_fasta (r05: also with several workers)
+    FileBytes(const std::string &path, RawBuf &buf, int use_mmap)   // 0: read(), 1: mmap, 2: mmap + MAP_POPULATE
     {
         if (use_mmap && !ends_with(path, ".gz")) {
             const int fd = open(path.c_str(), O_RDONLY);
             if (fd < 0) raise(SW_ERR_RUNTIME, "Unable to open FASTA: %s", path.c_str());   // fasta_reader.cpp:100-102
             struct stat st;
             if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) {
-                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE | (use_mmap > 1 ? MAP_POPULATE : 0), fd, 0);
                 if (m != MAP_FAILED) {
                     (void)madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
                     map = m;
@@ -444,7 +443,7 @@ struct FileBytes {
     FileBytes &operator=(const FileBytes &) = delete;
 };
 
-void parse_assembly(const std::string &path, RawBuf &buf, bool use_mmap, std::vector<uint64_t> &&storage,
+void parse_assembly(const std::string &path, RawBuf &buf, int use_mmap, std::vector<uint64_t> &&storage,
                     Assembly &a)
 {
     const FileBytes file(path, buf, use_mmap);
@@ -576,7 +575,16 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
     const auto t_begin = std::chrono::steady_clock::now();
     out = HostBatch();
     const bool threaded = (n_workers > 1 && n_paths > 1) || (sink && n_paths > 0);
-    const bool use_mmap = !threaded && !getenv("SEQWIN_AMD_NO_MMAP");
+    // Plain files are mapped only by a single worker; several workers read() into their buffers.  r05 measured mapping from many
+    // workers again (round 4's "serialises on the address-space lock" had been measured while 256 threads fought over a 16-CPU
+    // quota): 2 048 genomes of 5 Mbp in /dev/shm, FASTA -> numpy at 32 workers (tests/tools/e2e_ingest_ab.py, Gbp/s) -- one box
+    // read() 25.7 / mmap 26.9 / mmap + MAP_POPULATE 30.3, the next box 23.6-26.7 / 22.4-27.1 / 16.7-17.5, and inside bench.py on a
+    // third 15 (all worker counts alike: serialised).  Not robust across boxes: read() stays.  SEQWIN_AMD_MMAP=0 / 1 / 2 forces
+    // read() / mmap / mmap + populate for such measurements, SEQWIN_AMD_NO_MMAP=1 is read() also for a single worker.
+    int mmap_mode = threaded ? 0 : 1;
+    if (const char *e = getenv("SEQWIN_AMD_MMAP")) mmap_mode = atoi(e);
+    if (getenv("SEQWIN_AMD_NO_MMAP")) mmap_mode = 0;
+    const int use_mmap = mmap_mode;
     BufferPool pool;
     std::atomic<size_t> next{0};
     std::atomic<bool> failed{false};
