@@ -393,6 +393,51 @@ __attribute__((target("avx512f,avx512bw"))) const char *pack_line_avx512(Packer 
     return q;
 }
 
+// r05: sequence text 64 bytes at a time ACROSS line ends (AVX-512 VBMI2): a chunk that holds nothing but sequence bytes and '\n' has
+// its line ends squeezed out in the register (vpcompressb on the codes, pext on the validity mask) and goes to the packer as one
+// or two blocks -- no memchr, no per-line tail, no third block per 80-column line.  Stops in front of the first chunk that holds
+// anything else (a blank or control byte other than '\n', or a '>', which may start a header: the line code below takes that
+// line, from where this stopped) or when fewer than 64 bytes are left.
+__attribute__((target("avx512f,avx512bw,avx512vbmi2,bmi2,popcnt"))) const char *pack_chunks_avx512(Packer &pk, const char *p, const char *end)
+{
+    const __m512i exp_lut = _mm512_broadcast_i32x4(_mm_setr_epi8((char)0xFF, 'A', (char)0xFF, 'C', 'T', 'U', (char)0xFF, 'G', (char)0xFF,
+                                                                 (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF,
+                                                                 (char)0xFF));
+    const __m512i code_lut = _mm512_broadcast_i32x4(_mm_setr_epi8(0, 0, 0, 1, 3, 3, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0));
+    while (end - p >= 64) {
+        const __m512i v = _mm512_loadu_si512((const void *)p);
+        const __mmask64 nl = _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('\n'));
+        const __mmask64 stop = (_mm512_cmple_epu8_mask(v, _mm512_set1_epi8(0x20)) & ~nl) | _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('>'));
+        if (stop) break;
+        const __m512i lo = _mm512_and_si512(v, _mm512_set1_epi8(0x0F));
+        const __m512i up = _mm512_and_si512(v, _mm512_set1_epi8((char)0xDF));
+        const __mmask64 ok = _mm512_cmpeq_epi8_mask(up, _mm512_shuffle_epi8(exp_lut, lo));
+        const __mmask64 keep = ~nl;
+        const __m512i code = _mm512_maskz_compress_epi8(keep, _mm512_maskz_shuffle_epi8(ok, code_lut, lo));   // (zero behind the last base)
+        const unsigned nb = (unsigned)__builtin_popcountll((uint64_t)keep);
+        const uint64_t valid = _pext_u64((uint64_t)ok, (uint64_t)keep);
+        const __m512i t16 = _mm512_maddubs_epi16(code, _mm512_set1_epi16(0x0401));
+        const __m512i t32 = _mm512_madd_epi16(t16, _mm512_set1_epi32(0x00100001));
+        const __m128i packed = _mm512_cvtepi32_epi8(t32);   // byte j = the codes of bases 4 j .. 4 j + 3
+        if (nb >= 32) {
+            pk.push_block((uint64_t)_mm_extract_epi64(packed, 0), 32, (uint32_t)valid);
+            if (nb > 32) pk.push_block((uint64_t)_mm_extract_epi64(packed, 1), nb - 32, (uint32_t)(valid >> 32));
+        } else if (nb) {
+            pk.push_block((uint64_t)_mm_extract_epi64(packed, 0), nb, (uint32_t)valid);
+        }
+        p += 64;
+    }
+    return p;
+}
+
+bool have_chunk_packer()
+{
+    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi2") &&
+                           __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt") && !getenv("SEQWIN_AMD_SCALAR_INGEST") &&
+                           !getenv("SEQWIN_AMD_NO_AVX512") && !getenv("SEQWIN_AMD_LINE_PACKER");
+    return ok;
+}
+
 bool have_avx512_packer()
 {
     static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
@@ -456,10 +501,23 @@ void parse_assembly(const std::string &path, RawBuf &buf, int use_mmap, std::vec
     std::string cur_id;
     words.reserve(file.n / 32 + 64);
 #ifdef SW_HAVE_AVX2_PACKER
-    const bool simd512 = have_avx512_packer(), simd = !simd512 && have_avx2_packer();
+    const bool simd512 = have_avx512_packer(), simd = !simd512 && have_avx2_packer(), chunks = have_chunk_packer();
 #endif
+    bool midline = false;   // p is inside a sequence line whose head pack_chunks_avx512 has taken
 
     while (p < end) {
+#ifdef SW_HAVE_AVX2_PACKER
+        if (chunks && have && end - p >= 64) {
+            const char *q = pack_chunks_avx512(pk, p, end);
+            if (q != p) {
+                midline = q[-1] != '\n';
+                p = q;
+                if (p >= end) break;
+            }
+        }
+#endif
+        const bool rest_of_line = midline;   // (then a '>' at its front is a sequence byte, not a header's)
+        midline = false;
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
         const char *ls = p, *le = nl ? nl : end;
         p = nl ? nl + 1 : end;
@@ -471,7 +529,7 @@ void parse_assembly(const std::string &path, RawBuf &buf, int use_mmap, std::vec
             while (q < le && kChar.t[(unsigned char)*q] == 5) ++q;
             if (q == le) continue;
         }
-        if (*ls == '>') {  // :58-67
+        if (*ls == '>' && !rest_of_line) {  // :58-67
             if (have) pk.close_record(path, cur_id);
             const char *ie = ls + 1;  // extract_id :26-33
             while (ie < le && kChar.t[(unsigned char)*ie] != 5) ++ie;

@@ -992,6 +992,30 @@ __global__ __launch_bounds__(1024, 8) void k_unsort_adj(const uint64_t *__restri
 {
     __shared__ uint32_t sr[UNSORT_RANGE];
     extern __shared__ uint32_t sh_hist[];   // (hpasses << hbits counters, dynamic: 12 KB at 15 000 genomes lets two workgroups share a CU)
+    // r05: the candidates of a bucket are staged in LDS and take their place in the list with ONE global atomic per workgroup and
+    // bucket.  One atomic per wave that had any (r02-r04) is rare on the pan-genome sets, but on 12 500 iid genomes at k = 15 --
+    // 2e7 nodes for 6e8 occurrences: 0.24 % of the pairs touch a node that recurs in its assembly -- it was 1.1e6 atomics on one
+    // address, serialised across the XCDs: 23 ms for a 5 ms kernel (profiles/r05_random100k_k15_kernel_stats.txt).  128 entries
+    // (1.5 KB: two workgroups still share a CU with seven digit histograms); what does not fit goes to the list directly.
+    constexpr uint32_t CAND_STAGE = 128;
+    __shared__ uint32_t s_cn;
+    __shared__ unsigned long long s_cbase;
+    __shared__ uint64_t s_ck[CAND_STAGE];
+    __shared__ uint32_t s_ca[CAND_STAGE];
+    if (threadIdx.x == 0) s_cn = 0;
+    auto flush_candidates = [&]() {   // (all threads, behind a barrier that follows the last staging)
+        const uint32_t cn = min(s_cn, CAND_STAGE);   // (workgroup-uniform)
+        if (cn) {
+            if (threadIdx.x == 0) s_cbase = atomicAdd(n_cand, (unsigned long long)cn);
+            __syncthreads();
+            if (threadIdx.x < cn) {
+                cand_key[s_cbase + threadIdx.x] = s_ck[threadIdx.x];
+                cand_asm[s_cbase + threadIdx.x] = s_ca[threadIdx.x];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_cn = 0;   // (the next staging lies behind the bucket's own barrier)
+        }
+    };
     if (hist)
         for (uint32_t i = threadIdx.x; i < (hpasses << hbits); i += 1024) sh_hist[i] = 0;
     const uint32_t lane = threadIdx.x & 63u;
@@ -1000,6 +1024,7 @@ __global__ __launch_bounds__(1024, 8) void k_unsort_adj(const uint64_t *__restri
         if (b0 >= n) break;   // (workgroup-uniform)
         const uint32_t cnt = (uint32_t)min((uint64_t)UNSORT_RANGE, n - b0);
         __syncthreads();      // the previous bucket's ranks have been read (first round: the counters are zero)
+        flush_candidates();   // ... and its candidates staged
         // the bucket's words and the records of its occurrences are requested in batches (as a plain loop the compiler waits
         // for every word before it requests the next: 16 + 4 serialized round trips per bucket, 5.0 ms of the kernel's 5.8)
         constexpr uint32_t ITERS = UNSORT_RANGE / 4096u;
@@ -1085,21 +1110,29 @@ __global__ __launch_bounds__(1024, 8) void k_unsort_adj(const uint64_t *__restri
                     if (lane >= d) incl += up;
                 }
                 const uint32_t total = __shfl(incl, 63, 64);
-                unsigned long long base = 0;
-                if (lane == 63) base = atomicAdd(n_cand, (unsigned long long)total);
-                base = __shfl(base, 63, 64) + (incl - c);
+                uint32_t slot = 0;
+                if (lane == 63) slot = atomicAdd(&s_cn, total);   // (LDS: the workgroup's staging area)
+                slot = __shfl(slot, 63, 64) + (incl - c);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if ((cm >> j) & 1u) {
-                        cand_key[base] = out[j];
-                        cand_asm[base] = asm_base + rec_asm[r[j]];
-                        ++base;
+                        const uint32_t ca = asm_base + rec_asm[r[j]];
+                        if (slot < CAND_STAGE) {
+                            s_ck[slot] = out[j];
+                            s_ca[slot] = ca;
+                        } else {   // the staging area is full: straight to the list
+                            const unsigned long long at = atomicAdd(n_cand, 1ull);
+                            cand_key[at] = out[j];
+                            cand_asm[at] = ca;
+                        }
+                        ++slot;
                     }
             }
         }
     }
+    __syncthreads();
+    flush_candidates();   // the last bucket's
     if (hist) {
-        __syncthreads();
         for (uint32_t i = threadIdx.x; i < (hpasses << hbits); i += 1024)
             if (sh_hist[i]) atomicAdd(&hist[i], (unsigned long long)sh_hist[i]);
     }

@@ -197,7 +197,7 @@ def _byte_soup_files(tmp_path, seed=7, n_files=12):
     length around the packer's 32-byte step, records shorter than a step, '>' inside sequence lines."""
     rng = np.random.default_rng(seed)
     refused = {1, 3, 4, 5, 7}
-    any_byte = np.array([b for b in range(1, 256) if b not in refused and b not in (10, 62)], np.uint8)   # (the oracle wrapper returns NUL-terminated strings)
+    any_byte = np.array([b for b in range(1, 256) if b not in refused and b != 10], np.uint8)   # (the oracle wrapper returns NUL-terminated strings)
     files = []
     for f in range(n_files):
         parts = []
@@ -245,6 +245,46 @@ def test_host_ingest_random_bytes_match_oracle_reader(tmp_path):
         assert bp == sum(len(s) for s in exp_seqs)
 
 
+def test_host_ingest_across_line_ends_matches_oracle_reader(tmp_path):
+    """The 64-bytes-per-step packer that squeezes line ends out in the register (r05, AVX-512 VBMI2 hosts; elsewhere this runs the
+    line packer) against the oracle's reader: mostly clean sequence text in lines of every width, so that its steps start at
+    every offset inside a line, with the bytes that end a run of steps -- '>', blanks, CR, tabs -- and the ones that do not --
+    lower case, N, IUPAC, bytes >= 0x80 -- sprinkled in, blank lines, headers right behind a full step, no final newline."""
+    rng = np.random.default_rng(23)
+    rare = np.frombuffer(b">> \r\tNnacgtuURYK-*\x7f\x80\xff\x0b", np.uint8)
+    files = []
+    for f in range(160):
+        parts = []
+        for r in range(int(rng.integers(1, 5))):
+            parts.append(b">r%d d\n" % r if rng.random() < 0.8 else b">r%d\r\n" % r)
+            n = int(rng.choice([0, 63, 64, 65, 127, 128, 129, 300, 1000, 3000]))
+            seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), n)
+            if n and rng.random() < 0.7:
+                k = int(rng.integers(1, 2 + n // 100))
+                seq[rng.integers(0, n, k)] = rng.choice(rare, k)
+            width = int(rng.integers(1, 150)) if rng.random() < 0.7 else int(rng.choice([60, 64, 70, 80, 128]))
+            raw = seq.tobytes()
+            for i in range(0, len(raw), width):
+                line = raw[i:i + width]
+                if line[:1] == b">":
+                    line = b"A" + line
+                parts.append(line + (b"\n" if rng.random() < 0.97 else b"\n\n" if rng.random() < 0.5 else b"\r\n"))
+        blob = b"".join(parts)
+        if rng.random() < 0.3:
+            blob = blob.rstrip(b"\r\n")
+        p = tmp_path / f"chunk_{f}.fa"
+        p.write_bytes(blob)
+        files.append(p)
+    offs, ids, seqs, bp = _host_ingest(files, 3)
+    exp_ids, exp_seqs, exp_offs = [], [], [0]
+    for f in files:
+        recs = oracle.read_fasta(f)
+        exp_ids += [r[0] for r in recs]; exp_seqs += [_canon(r[1]) for r in recs]
+        exp_offs.append(len(exp_ids))
+    assert ids == exp_ids and offs.tolist() == exp_offs
+    assert seqs == exp_seqs
+
+
 def test_host_ingest_under_sanitizers(tmp_path):
     """host_ingest.cpp (hand-written SIMD over hostile bytes, threads, zlib streams) rebuilt with AddressSanitizer + UBSan
     (`make -C seqwin_amd/csrc asan`) and run on the byte soup, gzip members, truncated gzip, blank / header-only files and
@@ -266,7 +306,8 @@ def test_host_ingest_under_sanitizers(tmp_path):
     env = dict(__import__("os").environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     files.append(_line_length_file(tmp_path))
     # the packer a host offers by default (64 bytes per step with AVX-512 BW, else 32 with AVX2), the 32-byte one, the byte loop
-    for n_cpu, scalar in ((1, ""), (3, ""), (2, "SEQWIN_AMD_NO_AVX512"), (2, "SEQWIN_AMD_SCALAR_INGEST")):
+    # (r05: by default, with AVX-512 VBMI2, 64 bytes per step across line ends; SEQWIN_AMD_LINE_PACKER keeps the line-by-line form)
+    for n_cpu, scalar in ((1, ""), (3, ""), (2, "SEQWIN_AMD_LINE_PACKER"), (2, "SEQWIN_AMD_NO_AVX512"), (2, "SEQWIN_AMD_SCALAR_INGEST")):
         e = dict(env, **({scalar: "1"} if scalar else {}))
         dump = tmp_path / f"dump_{n_cpu}_{scalar}.bin"
         out = subprocess.run([str(exe), str(n_cpu), str(dump)] + [str(f) for f in files], capture_output=True, text=True, env=e)
