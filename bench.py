@@ -114,9 +114,10 @@ def e2e_build(paths, k, w, n_cpu, tar):
     from seqwin_amd._lib import c_u64, c_vp, check, lib
     arr = (ctypes.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
     g = c_vp()
+    thr0, c0 = cgroup_throttled_ms(), time.process_time()
     t0 = time.perf_counter()
     check(lib.sw_build(arr, ctypes.c_size_t(len(paths)), c_u64(k), c_u64(w), c_u64(n_cpu), ctypes.c_int(0), ctypes.byref(g)))
-    t1 = time.perf_counter()
+    t1, c1 = time.perf_counter(), time.process_time()
     try:
         sz = [c_u64() for _ in range(6)]
         check(lib.sw_graph_sizes(g, *[ctypes.byref(x) for x in sz]))
@@ -125,7 +126,7 @@ def e2e_build(paths, k, w, n_cpu, tar):
         ro = np.empty(na + 1, np.uint32)
         blob = ctypes.create_string_buffer(max(nb, 1))
         check(lib.sw_graph_export(g, _core._ptr(kmers), _core._ptr(nodes), _core._ptr(edges), _core._ptr(ro), blob))
-        t2 = time.perf_counter()
+        t2, c2 = time.perf_counter(), time.process_time()
         st = (ctypes.c_double * 8)()
         check(lib.sw_graph_stats(g, st))
     finally:
@@ -133,11 +134,27 @@ def e2e_build(paths, k, w, n_cpu, tar):
     t3 = time.perf_counter()
     _core._get_penalty_native(kmers, nodes, ro, tar, n_cpu)
     t4 = time.perf_counter()
+    c4, thr4 = time.process_time(), cgroup_throttled_ms()
     split = graph_stats_of_last_build(list(st))
+    # CPU seconds of this process (all threads) over the call, and how long the container's CPU quota held its threads back
+    split.update(cpu_s=round(c4 - c0, 3), cpu_s_build_export_penalty=[round(c1 - c0, 3), round(c2 - c1, 3), round(c4 - c2, 3)], quota_throttled_ms=None if thr0 is None or thr4 is None else round(thr4 - thr0, 1))
     split.update(sw_build_wall_ms=round((t1 - t0) * 1e3, 2), alloc_and_export_wall_ms=round((t2 - t1) * 1e3, 2),
                  get_penalty_wall_ms=round((t4 - t3) * 1e3, 2), total_wall_ms=round((t4 - t0) * 1e3, 2),
                  output_MB=round((kmers.nbytes + nodes.nbytes + edges.nbytes) / 1e6, 1))
     return (kmers, nodes, edges, ro), t4 - t0, split
+
+
+def cgroup_throttled_ms():
+    """Total time the container's threads have been held back by its CPU quota so far (cgroup v2 cpu.stat throttled_usec), or None."""
+    for path, key, scale in (("/sys/fs/cgroup/cpu.stat", "throttled_usec", 1e-3), ("/sys/fs/cgroup/cpu/cpu.stat", "throttled_time", 1e-6)):
+        try:
+            for line in open(path):
+                f = line.split()
+                if len(f) == 2 and f[0] == key:
+                    return int(f[1]) * scale
+        except Exception:
+            continue
+    return None
 
 
 def cpu_quota():

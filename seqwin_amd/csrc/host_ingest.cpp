@@ -488,77 +488,144 @@ struct FileBytes {
     FileBytes &operator=(const FileBytes &) = delete;
 };
 
-void parse_assembly(const std::string &path, RawBuf &buf, int use_mmap, std::vector<uint64_t> &&storage,
-                    Assembly &a)
-{
-    const FileBytes file(path, buf, use_mmap);
-    const char *p = file.p;
-    const char *end = p + file.n;
-    std::vector<uint64_t> words(std::move(storage));
-    words.clear();
-    Packer pk(a, words);
+// The reader's line loop (fasta_reader.cpp:41-95) + the packer, fed with the text of one assembly in one piece or in several:
+// every piece ends behind a '\n', except the last one of the file.
+struct TextParser {
+    const std::string &path;
+    Assembly &a;
+    std::vector<uint64_t> words;
+    Packer pk;
     bool have = false;
     std::string cur_id;
-    words.reserve(file.n / 32 + 64);
 #ifdef SW_HAVE_AVX2_PACKER
     const bool simd512 = have_avx512_packer(), simd = !simd512 && have_avx2_packer(), chunks = have_chunk_packer();
 #endif
-    bool midline = false;   // p is inside a sequence line whose head pack_chunks_avx512 has taken
+    TextParser(const std::string &path_, Assembly &a_, std::vector<uint64_t> &&storage) : path(path_), a(a_), words(std::move(storage)), pk(a_, words)
+    {
+        words.clear();
+    }
+    void expect_bytes(size_t n) { words.reserve(n / 32 + 64); }
 
-    while (p < end) {
+    void feed(const char *p, const char *end)
+    {
+        bool midline = false;   // p is inside a sequence line whose head pack_chunks_avx512 has taken
+        while (p < end) {
 #ifdef SW_HAVE_AVX2_PACKER
-        if (chunks && have && end - p >= 64) {
-            const char *q = pack_chunks_avx512(pk, p, end);
-            if (q != p) {
-                midline = q[-1] != '\n';
-                p = q;
-                if (p >= end) break;
+            if (chunks && have && end - p >= 64) {
+                const char *q = pack_chunks_avx512(pk, p, end);
+                if (q != p) {
+                    midline = q[-1] != '\n';
+                    p = q;
+                    if (p >= end) break;
+                }
+            }
+#endif
+            const bool rest_of_line = midline;   // (then a '>' at its front is a sequence byte, not a header's)
+            midline = false;
+            const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+            const char *ls = p, *le = nl ? nl : end;
+            p = nl ? nl + 1 : end;
+            if (le > ls && le[-1] == '\r') --le;  // fasta_reader.cpp:51-53
+            // empty or whitespace-only (:55-57): cheap test on the first byte, full scan only if it is ws
+            if (le == ls) continue;
+            if (kChar.t[(unsigned char)*ls] == 5) {
+                const char *q = ls;
+                while (q < le && kChar.t[(unsigned char)*q] == 5) ++q;
+                if (q == le) continue;
+            }
+            if (*ls == '>' && !rest_of_line) {  // :58-67
+                if (have) pk.close_record(path, cur_id);
+                const char *ie = ls + 1;  // extract_id :26-33
+                while (ie < le && kChar.t[(unsigned char)*ie] != 5) ++ie;
+                cur_id.assign(ls + 1, ie);
+                a.ids.append(cur_id);
+                a.ids.push_back('\0');
+                pk.open_record();
+                have = true;
+                continue;
+            }
+            if (!have) raise(SW_ERR_RUNTIME, "Invalid FASTA: sequence encountered before header");  // :69-71
+            const char *q = ls;
+#ifdef SW_HAVE_AVX2_PACKER
+            if (simd512) q = pack_line_avx512(pk, ls, le);   // (both stop early at a chunk with whitespace / control bytes)
+            else if (simd) q = pack_line_avx2(pk, ls, le);
+#endif
+            for (; q < le; ++q) {  // :73-88
+                const unsigned code = kChar.t[(unsigned char)*q];
+                if (code == 5) continue;
+                if (code == 6)
+                    raise(SW_ERR_VALUE, "unsupported control byte 0x%02x in sequence of record %s in assembly %s",
+                          (unsigned)(unsigned char)*q, cur_id.c_str(), path.c_str());
+                pk.push(code);
             }
         }
-#endif
-        const bool rest_of_line = midline;   // (then a '>' at its front is a sequence byte, not a header's)
-        midline = false;
-        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-        const char *ls = p, *le = nl ? nl : end;
-        p = nl ? nl + 1 : end;
-        if (le > ls && le[-1] == '\r') --le;  // fasta_reader.cpp:51-53
-        // empty or whitespace-only (:55-57): cheap test on the first byte, full scan only if it is ws
-        if (le == ls) continue;
-        if (kChar.t[(unsigned char)*ls] == 5) {
-            const char *q = ls;
-            while (q < le && kChar.t[(unsigned char)*q] == 5) ++q;
-            if (q == le) continue;
-        }
-        if (*ls == '>' && !rest_of_line) {  // :58-67
-            if (have) pk.close_record(path, cur_id);
-            const char *ie = ls + 1;  // extract_id :26-33
-            while (ie < le && kChar.t[(unsigned char)*ie] != 5) ++ie;
-            cur_id.assign(ls + 1, ie);
-            a.ids.append(cur_id);
-            a.ids.push_back('\0');
-            pk.open_record();
-            have = true;
-            continue;
-        }
-        if (!have) raise(SW_ERR_RUNTIME, "Invalid FASTA: sequence encountered before header");  // :69-71
-        const char *q = ls;
-#ifdef SW_HAVE_AVX2_PACKER
-        if (simd512) q = pack_line_avx512(pk, ls, le);   // (both stop early at a chunk with whitespace / control bytes)
-        else if (simd) q = pack_line_avx2(pk, ls, le);
-#endif
-        for (; q < le; ++q) {  // :73-88
-            const unsigned code = kChar.t[(unsigned char)*q];
-            if (code == 5) continue;
-            if (code == 6)
-                raise(SW_ERR_VALUE, "unsupported control byte 0x%02x in sequence of record %s in assembly %s",
-                      (unsigned)(unsigned char)*q, cur_id.c_str(), path.c_str());
-            pk.push(code);
-        }
     }
-    if (have) pk.close_record(path, cur_id);
-    a.rec_run_off.push_back((uint32_t)a.run_pos.size());
-    a.packed = std::move(words);
-    a.n_words = a.packed.size();
+    void finish()
+    {
+        if (have) pk.close_record(path, cur_id);
+        a.rec_run_off.push_back((uint32_t)a.run_pos.size());
+        a.packed = std::move(words);
+        a.n_words = a.packed.size();
+    }
+};
+
+// r05: a plain file read by read() goes through the parser block by block (256 KiB: the block the kernel has just copied is
+// parsed out of the core's L2, and the buffer it lands in stays there from block to block, instead of 5 MB written to memory and
+// read back); the rest of a block behind its last '\n' moves to the front of the next.  A line longer than a block makes the
+// buffer grow until its end is in.  SEQWIN_AMD_READ_BLOCK_KB=0: the whole file first (r01-r04).
+size_t read_block_bytes()
+{
+    static const size_t n = [] {
+        const char *e = getenv("SEQWIN_AMD_READ_BLOCK_KB");
+        return (size_t)(e ? std::max(0, atoi(e)) : 256) << 10;
+    }();
+    return n;
+}
+
+void stream_plain_file(const std::string &path, RawBuf &buf, size_t block, TextParser &tp)
+{
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) raise(SW_ERR_RUNTIME, "Unable to open FASTA: %s", path.c_str());   // fasta_reader.cpp:100-102
+    struct Close {
+        int fd;
+        ~Close() { close(fd); }
+    } closer{fd};
+    struct stat st;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0) tp.expect_bytes((size_t)st.st_size);
+    size_t fill = 0;   // bytes of a line whose end has not been read yet, at the front of the buffer
+    for (;;) {
+        buf.reserve(fill + block);
+        const ssize_t got = read(fd, buf.p + fill, block);
+        if (got < 0) {
+            if (errno == EINTR) continue;
+            raise(SW_ERR_RUNTIME, "Unable to read FASTA: %s", path.c_str());
+        }
+        if (got == 0) break;
+        const char *nl = (const char *)memrchr(buf.p + fill, '\n', (size_t)got);
+        fill += (size_t)got;
+        if (!nl) continue;
+        tp.feed(buf.p, nl + 1);
+        const size_t rest = fill - (size_t)(nl + 1 - buf.p);
+        memmove(buf.p, nl + 1, rest);
+        fill = rest;
+    }
+    tp.feed(buf.p, buf.p + fill);   // the last line, if the file does not end with '\n'
+    buf.len = 0;
+}
+
+void parse_assembly(const std::string &path, RawBuf &buf, int use_mmap, std::vector<uint64_t> &&storage,
+                    Assembly &a)
+{
+    TextParser tp(path, a, std::move(storage));
+    const size_t block = read_block_bytes();
+    if (!use_mmap && block && !ends_with(path, ".gz")) {
+        stream_plain_file(path, buf, block, tp);
+    } else {
+        const FileBytes file(path, buf, use_mmap);
+        tp.expect_bytes(file.n);
+        tp.feed(file.p, file.p + file.n);
+    }
+    tp.finish();
 }
 
 // Recycles the packed-word buffers of assemblies that have been handed to the sink, so that a streaming ingest

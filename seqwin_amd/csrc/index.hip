@@ -992,30 +992,14 @@ __global__ __launch_bounds__(1024, 8) void k_unsort_adj(const uint64_t *__restri
 {
     __shared__ uint32_t sr[UNSORT_RANGE];
     extern __shared__ uint32_t sh_hist[];   // (hpasses << hbits counters, dynamic: 12 KB at 15 000 genomes lets two workgroups share a CU)
-    // r05: the candidates of a bucket are staged in LDS and take their place in the list with ONE global atomic per workgroup and
-    // bucket.  One atomic per wave that had any (r02-r04) is rare on the pan-genome sets, but on 12 500 iid genomes at k = 15 --
-    // 2e7 nodes for 6e8 occurrences: 0.24 % of the pairs touch a node that recurs in its assembly -- it was 1.1e6 atomics on one
-    // address, serialised across the XCDs: 23 ms for a 5 ms kernel (profiles/r05_random100k_k15_kernel_stats.txt).  128 entries
-    // (1.5 KB: two workgroups still share a CU with seven digit histograms); what does not fit goes to the list directly.
-    constexpr uint32_t CAND_STAGE = 128;
-    __shared__ uint32_t s_cn;
+    // r05: a bucket's candidates take their place in the list with ONE global atomic per workgroup and bucket: the pair loop only
+    // notes which of a thread's pairs are candidates (16 bits), the waves' counts meet in LDS behind a barrier, and the threads
+    // that have any form those keys again from the ranks still in LDS.  One atomic per wave that had any (r02-r04) is rare on the
+    // pan-genome sets; on 12 500 iid genomes at k = 15 -- 2e7 nodes for 6e8 occurrences, 0.5-1 % of the pairs touch a node that
+    // recurs in its assembly -- it was over a million atomics on one address, serialised across the XCDs: 18 of the kernel's
+    // 21 ms (profiles/r05_random100k_k15_kernel_stats.txt; a 128-entry staging area in LDS overflowed on that set and gained 2 ms).
+    __shared__ uint32_t s_wtot[16];
     __shared__ unsigned long long s_cbase;
-    __shared__ uint64_t s_ck[CAND_STAGE];
-    __shared__ uint32_t s_ca[CAND_STAGE];
-    if (threadIdx.x == 0) s_cn = 0;
-    auto flush_candidates = [&]() {   // (all threads, behind a barrier that follows the last staging)
-        const uint32_t cn = min(s_cn, CAND_STAGE);   // (workgroup-uniform)
-        if (cn) {
-            if (threadIdx.x == 0) s_cbase = atomicAdd(n_cand, (unsigned long long)cn);
-            __syncthreads();
-            if (threadIdx.x < cn) {
-                cand_key[s_cbase + threadIdx.x] = s_ck[threadIdx.x];
-                cand_asm[s_cbase + threadIdx.x] = s_ca[threadIdx.x];
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) s_cn = 0;   // (the next staging lies behind the bucket's own barrier)
-        }
-    };
     if (hist)
         for (uint32_t i = threadIdx.x; i < (hpasses << hbits); i += 1024) sh_hist[i] = 0;
     const uint32_t lane = threadIdx.x & 63u;
@@ -1024,7 +1008,6 @@ __global__ __launch_bounds__(1024, 8) void k_unsort_adj(const uint64_t *__restri
         if (b0 >= n) break;   // (workgroup-uniform)
         const uint32_t cnt = (uint32_t)min((uint64_t)UNSORT_RANGE, n - b0);
         __syncthreads();      // the previous bucket's ranks have been read (first round: the counters are zero)
-        flush_candidates();   // ... and its candidates staged
         // the bucket's words and the records of its occurrences are requested in batches (as a plain loop the compiler waits
         // for every word before it requests the next: 16 + 4 serialized round trips per bucket, 5.0 ms of the kernel's 5.8)
         constexpr uint32_t ITERS = UNSORT_RANGE / 4096u;
@@ -1059,6 +1042,7 @@ __global__ __launch_bounds__(1024, 8) void k_unsort_adj(const uint64_t *__restri
             edge_rank[2 * bkt] = sr[0];
             edge_rank[2 * bkt + 1] = sr[cnt - 1];
         }
+        uint32_t cmask = 0;   // bit 4 it + j: the pair (t0 + j, t0 + j + 1) of iteration `it` is a candidate
 #pragma unroll
         for (uint32_t it = 0; it < ITERS; ++it) {
             const uint32_t t0 = (it * 1024u + threadIdx.x) * 4u;   // pairs (t0 + j, t0 + j + 1), j < 4, that lie inside the bucket
@@ -1102,37 +1086,48 @@ __global__ __launch_bounds__(1024, 8) void k_unsort_adj(const uint64_t *__restri
                             }
                 }
             }
-            if (__any(cm != 0)) {   // rare: one atomic per wave that has candidates
-                const uint32_t c = (uint32_t)__popc(cm);
-                uint32_t incl = c;
-                for (uint32_t d = 1; d < 64; d <<= 1) {
-                    const uint32_t up = __shfl_up(incl, d, 64);
-                    if (lane >= d) incl += up;
-                }
-                const uint32_t total = __shfl(incl, 63, 64);
-                uint32_t slot = 0;
-                if (lane == 63) slot = atomicAdd(&s_cn, total);   // (LDS: the workgroup's staging area)
-                slot = __shfl(slot, 63, 64) + (incl - c);
+            cmask |= cm << (4u * it);
+        }
+        // the bucket's candidates
+        const uint32_t c = (uint32_t)__popc(cmask);
+        uint32_t incl = c;
+        if (__any(cmask != 0)) {
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+                const uint32_t up = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += up;
+            }
+        }
+        if (lane == 63) s_wtot[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t wg_total = 0, before = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if ((cm >> j) & 1u) {
-                        const uint32_t ca = asm_base + rec_asm[r[j]];
-                        if (slot < CAND_STAGE) {
-                            s_ck[slot] = out[j];
-                            s_ca[slot] = ca;
-                        } else {   // the staging area is full: straight to the list
-                            const unsigned long long at = atomicAdd(n_cand, 1ull);
-                            cand_key[at] = out[j];
-                            cand_asm[at] = ca;
+        for (uint32_t w = 0; w < 16; ++w) {
+            const uint32_t t = s_wtot[w];
+            wg_total += t;
+            before += w < (threadIdx.x >> 6) ? t : 0u;
+        }
+        if (wg_total) {   // (workgroup-uniform)
+            if (threadIdx.x == 0) s_cbase = atomicAdd(n_cand, (unsigned long long)wg_total);
+            __syncthreads();
+            if (cmask) {
+                unsigned long long at = s_cbase + before + (incl - c);
+#pragma unroll
+                for (uint32_t it = 0; it < ITERS; ++it)
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j)
+                        if ((cmask >> (4u * it + j)) & 1u) {
+                            const uint32_t t = (it * 1024u + threadIdx.x) * 4u + j;
+                            uint32_t u = sr[t] & ~RANK_REP, v = sr[t + 1] & ~RANK_REP;
+                            if (v < u) { const uint32_t x = u; u = v; v = x; }
+                            cand_key[at] = ((uint64_t)u << nb) | v;
+                            cand_asm[at] = asm_base + rec_asm[rr[it][j]];
+                            ++at;
                         }
-                        ++slot;
-                    }
             }
         }
     }
-    __syncthreads();
-    flush_candidates();   // the last bucket's
     if (hist) {
+        __syncthreads();
         for (uint32_t i = threadIdx.x; i < (hpasses << hbits); i += 1024)
             if (sh_hist[i]) atomicAdd(&hist[i], (unsigned long long)sh_hist[i]);
     }
@@ -3496,7 +3491,7 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
             DevArray<unsigned long long> ehist;
             unsigned hbits = 0, hpasses = 0;
             uint32_t iters = 1;
-            if (sort_keys64_is_own(m)) {
+            if (sort_keys64_is_own(m) && !SW_AB_GETENV("SEQWIN_AMD_NO_ADJ_HIST")) {
                 radix_layout(2 * nb, &hbits, &hpasses);
                 ehist.alloc((size_t)hpasses << hbits);
                 SW_HIP(hipMemsetAsync(ehist.p, 0, ehist.bytes(), stream));

@@ -275,6 +275,14 @@ def test_host_ingest_across_line_ends_matches_oracle_reader(tmp_path):
         p = tmp_path / f"chunk_{f}.fa"
         p.write_bytes(blob)
         files.append(p)
+    # several read blocks (256 KiB each) with the block ends at every offset inside a line, one line longer than a block
+    big = [b">big\n"]
+    for width in (79, 80, 61, 300_000, 1):
+        raw = rng.choice(np.frombuffer(b"ACGTN", np.uint8), 300_007 if width > 1 else 500, p=[.24, .24, .24, .24, .04]).tobytes()
+        big += [raw[i:i + width] + b"\n" for i in range(0, len(raw), width)] + [b">next %d\n" % width]
+    p = tmp_path / "blocks.fa"
+    p.write_bytes(b"".join(big))
+    files.append(p)
     offs, ids, seqs, bp = _host_ingest(files, 3)
     exp_ids, exp_seqs, exp_offs = [], [], [0]
     for f in files:
@@ -307,7 +315,9 @@ def test_host_ingest_under_sanitizers(tmp_path):
     files.append(_line_length_file(tmp_path))
     # the packer a host offers by default (64 bytes per step with AVX-512 BW, else 32 with AVX2), the 32-byte one, the byte loop
     # (r05: by default, with AVX-512 VBMI2, 64 bytes per step across line ends; SEQWIN_AMD_LINE_PACKER keeps the line-by-line form)
-    for n_cpu, scalar in ((1, ""), (3, ""), (2, "SEQWIN_AMD_LINE_PACKER"), (2, "SEQWIN_AMD_NO_AVX512"), (2, "SEQWIN_AMD_SCALAR_INGEST")):
+    # SEQWIN_AMD_READ_BLOCK_KB=1: plain files go through the parser in 1 KiB blocks (default 256 KiB: most of these files are one block)
+    for n_cpu, scalar in ((1, ""), (3, ""), (3, "SEQWIN_AMD_READ_BLOCK_KB"), (2, "SEQWIN_AMD_LINE_PACKER"), (2, "SEQWIN_AMD_NO_AVX512"),
+                          (2, "SEQWIN_AMD_SCALAR_INGEST")):
         e = dict(env, **({scalar: "1"} if scalar else {}))
         dump = tmp_path / f"dump_{n_cpu}_{scalar}.bin"
         out = subprocess.run([str(exe), str(n_cpu), str(dump)] + [str(f) for f in files], capture_output=True, text=True, env=e)
