@@ -427,7 +427,7 @@ void upload_batch(sw_batch &b)
             SW_HIP(hipMemcpyAsync(b.d_packed.p + 2 * h.chunk_word0[c], h.chunks[c].data(), h.chunks[c].size() * 8,
                                   hipMemcpyHostToDevice, nullptr));
     SW_HIP(hipStreamSynchronize(nullptr));
-    std::vector<std::vector<uint64_t>>().swap(h.chunks);
+    std::vector<WordBuf>().swap(h.chunks);
     upload_tables(b);
 }
 
@@ -442,6 +442,18 @@ struct PinnedRing {
     hipEvent_t ev[SLOTS];
     hipStream_t st = nullptr;
     std::mutex in_use;
+    std::vector<hipEvent_t> spare;   // events for copies that do not go through a slot (DeviceSink::in_flight); under in_use
+    hipEvent_t take_event()
+    {
+        if (!spare.empty()) {
+            hipEvent_t e = spare.back();
+            spare.pop_back();
+            return e;
+        }
+        hipEvent_t e = nullptr;
+        SW_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return e;
+    }
 };
 PinnedRing &pinned_ring(int device)
 {
@@ -459,6 +471,91 @@ PinnedRing &pinned_ring(int device)
     return *r;
 }
 
+// r05: the parsers' word buffers are page-locked blocks, so a finished assembly goes to HBM by DMA from where the packer wrote it --
+// the sink thread no longer copies every packed word into the ring first (2.6 GB at 20 GB/s = 130 ms of one thread for 2 048
+// genomes, the longest serial piece of the ingest; gpurun_out/r5z: with 64 parsers on the 16-CPU quota that thread fell behind
+// to 450 ms).  One pool per process, leaked like the rings: slabs of 64 MiB cut into blocks of a multiple of 256 KiB, freed blocks
+// handed out best-fit, at most SEQWIN_AMD_PINNED_POOL_MB (default 1024) in total -- beyond that get() declines, the parser
+// mallocs and the sink takes the ring for that assembly.  SEQWIN_AMD_PINNED_POOL_MB=0: the ring for everything (r01-r05a).
+struct PinnedArena : WordArena {
+    static constexpr size_t SLAB = 64u << 20, GRAIN = 256u << 10;
+    std::mutex mu;        // free list, bump pointer, totals
+    std::mutex grow_mu;   // one thread page-locks a new slab at a time (the others wait for it rather than lock more memory)
+    std::vector<std::pair<uint64_t *, size_t>> free_blocks;   // (block, capacity in words)
+    char *slab = nullptr;
+    size_t slab_left = 0;
+    size_t total_bytes = 0, limit_bytes = (size_t)1024 << 20;
+    void read_limit()   // (per ingest, so that one process can compare settings)
+    {
+        const char *e = getenv("SEQWIN_AMD_PINNED_POOL_MB");
+        std::lock_guard<std::mutex> lock(mu);
+        limit_bytes = e ? (size_t)std::max(0, atoi(e)) << 20 : (size_t)1024 << 20;
+    }
+    // under mu: a block of the free list (best fit) or of the current slab
+    uint64_t *take(size_t min_words, size_t bytes, size_t *cap_words)
+    {
+        size_t best = free_blocks.size();
+        for (size_t i = 0; i < free_blocks.size(); ++i)
+            if (free_blocks[i].second >= min_words && (best == free_blocks.size() || free_blocks[i].second < free_blocks[best].second)) best = i;
+        if (best != free_blocks.size()) {
+            const auto blk = free_blocks[best];
+            free_blocks[best] = free_blocks.back();
+            free_blocks.pop_back();
+            *cap_words = blk.second;
+            return blk.first;
+        }
+        if (bytes <= slab_left) {
+            uint64_t *p = (uint64_t *)slab;
+            slab += bytes;
+            slab_left -= bytes;
+            *cap_words = bytes / 8;
+            return p;
+        }
+        return nullptr;
+    }
+    uint64_t *get(size_t min_words, size_t *cap_words) override
+    {
+        const size_t bytes = (min_words * 8 + GRAIN - 1) / GRAIN * GRAIN;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (uint64_t *p = take(min_words, bytes, cap_words)) return p;
+        }
+        // Page-locking costs 0.25 ms per MiB in one large call and ten times that in 2 MiB calls from many threads at once
+        // (gpurun_out/r5aa: the first streaming ingest of a process took 0.4-0.7 s longer): whole slabs, one thread at a time.
+        std::lock_guard<std::mutex> grow(grow_mu);
+        const size_t want = std::max(bytes, SLAB);
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (uint64_t *p = take(min_words, bytes, cap_words)) return p;   // (another thread has grown the pool meanwhile)
+            if (total_bytes + want > limit_bytes) return nullptr;
+            total_bytes += want;
+        }
+        void *fresh = nullptr;
+        if (hipHostMalloc(&fresh, want, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            std::lock_guard<std::mutex> lock(mu);
+            total_bytes -= want;
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> lock(mu);
+        if (slab_left >= GRAIN) free_blocks.emplace_back((uint64_t *)slab, slab_left / 8);   // the old slab's tail stays usable
+        slab = (char *)fresh + bytes;
+        slab_left = want - bytes;
+        *cap_words = bytes / 8;
+        return (uint64_t *)fresh;
+    }
+    void put(uint64_t *p, size_t cap_words) override
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        free_blocks.emplace_back(p, cap_words);
+    }
+};
+PinnedArena &pinned_arena()
+{
+    static PinnedArena *a = new PinnedArena;   // leaked on purpose (see pool())
+    return *a;
+}
+
 struct DeviceSink : ChunkSink {
     sw_batch &b;
     PinnedRing &ring;
@@ -466,7 +563,29 @@ struct DeviceSink : ChunkSink {
     uint64_t cap32 = 0;     // capacity of b.d_packed in 32-bit words
     uint64_t used32 = 0;    // words written so far (a prefix)
     unsigned next_slot = 0;
-    DeviceSink(sw_batch &batch, PinnedRing &r) : b(batch), ring(r), hold(r.in_use) {}
+    struct InFlight {
+        WordBuf words;
+        hipEvent_t ev;
+    };
+    std::deque<InFlight> in_flight;   // page-locked buffers whose copies are on their way, oldest first
+    static constexpr size_t IN_FLIGHT_MAX = 48;
+    DeviceSink(sw_batch &batch, PinnedRing &r) : b(batch), ring(r), hold(r.in_use) { pinned_arena().read_limit(); }
+    WordArena *arena() override { return pinned_arena().limit_bytes ? &pinned_arena() : nullptr; }
+    void reap(bool all)
+    {
+        while (!in_flight.empty()) {
+            InFlight &f = in_flight.front();
+            if (all || in_flight.size() >= IN_FLIGHT_MAX) {
+                SW_HIP(hipEventSynchronize(f.ev));
+            } else {
+                const hipError_t q = hipEventQuery(f.ev);
+                if (q == hipErrorNotReady) break;
+                SW_HIP(q);
+            }
+            ring.spare.push_back(f.ev);
+            in_flight.pop_front();   // (the block goes back to the arena)
+        }
+    }
     void reserve(uint64_t words32)
     {
         if (words32 <= cap32) return;
@@ -478,12 +597,22 @@ struct DeviceSink : ChunkSink {
         cap32 = ncap;
     }
     void begin(uint64_t expected_words64) override { reserve(expected_words64 * 2 + 8); }
-    void chunk(const uint64_t *data, uint64_t n_words64, uint64_t word_off) override
+    void chunk(WordBuf &words, uint64_t word_off) override
     {
+        const uint64_t n_words64 = words.size();
         reserve((word_off + n_words64) * 2 + 8);
-        const char *src = (const char *)data;
+        const char *src = (const char *)words.data();
         size_t left = n_words64 * 8;
         char *dst = (char *)(b.d_packed.p + 2 * word_off);
+        if (words.in_arena()) {   // DMA from the parser's own buffer; it returns to the arena when the copy has left the host
+            reap(false);
+            hipEvent_t ev = ring.take_event();
+            SW_HIP(hipMemcpyAsync(dst, src, left, hipMemcpyHostToDevice, ring.st));
+            SW_HIP(hipEventRecord(ev, ring.st));
+            in_flight.push_back(InFlight{std::move(words), ev});
+            used32 = (word_off + n_words64) * 2;
+            return;
+        }
         while (left) {
             const size_t n = std::min(left, PinnedRing::SLOT);
             const unsigned s = next_slot++ % PinnedRing::SLOTS;
@@ -503,9 +632,14 @@ struct DeviceSink : ChunkSink {
         reserve(n_words64 * 2 + 8);
         SW_HIP(hipMemsetAsync(b.d_packed.p + 2 * n_words64, 0, 8 * 4, ring.st));   // the read slack
         SW_HIP(hipStreamSynchronize(ring.st));
+        reap(true);
         b.packed_words = n_words64 * 2 + 8;
     }
-    ~DeviceSink() { (void)hipStreamSynchronize(ring.st); }   // nothing may still read the ring / write the buffer
+    ~DeviceSink()   // nothing may still read the ring or the parsers' buffers / write the device buffer
+    {
+        (void)hipStreamSynchronize(ring.st);
+        for (InFlight &f : in_flight) ring.spare.push_back(f.ev);
+    }
 };
 
 // FASTA files -> device-resident batch

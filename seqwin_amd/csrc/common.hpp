@@ -4,7 +4,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -67,6 +69,83 @@ template <class F> int guarded(F &&f)
     }
 }
 
+// ---- packed words of one assembly ------------------------------------------------------------
+// Where the parsers' word buffers come from when the ingest streams to the device (r05): page-locked blocks that the DMA engine
+// reads where the packer wrote them (api.hip: PinnedArena).  get() may decline (nullptr: the limit of pinned memory is reached).
+struct WordArena {
+    virtual uint64_t *get(size_t min_words, size_t *cap_words) = 0;
+    virtual void put(uint64_t *p, size_t cap_words) = 0;
+    virtual ~WordArena() {}
+};
+
+// A growing array of 64-bit words (what std::vector<uint64_t> was until r05) whose storage is malloc'd or an arena's.
+class WordBuf {
+    uint64_t *p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+    WordArena *home_ = nullptr;    // owner of p_ (nullptr: malloc)
+    WordArena *arena_ = nullptr;   // where to ask first when growing
+    void drop()
+    {
+        if (p_) {
+            if (home_) home_->put(p_, cap_);
+            else free(p_);
+        }
+        p_ = nullptr;
+        n_ = cap_ = 0;
+        home_ = nullptr;
+    }
+    void grow(size_t want)
+    {
+        size_t ncap = std::max<size_t>(std::max(want, cap_ + cap_ / 2), 1024), got = 0;
+        uint64_t *q = arena_ ? arena_->get(ncap, &got) : nullptr;
+        WordArena *home = q ? arena_ : nullptr;
+        if (!q) {
+            q = (uint64_t *)malloc(ncap * 8);
+            got = ncap;
+            if (!q) throw std::bad_alloc();
+        }
+        if (n_) memcpy(q, p_, n_ * 8);
+        const size_t n = n_;
+        drop();
+        p_ = q;
+        n_ = n;
+        cap_ = got;
+        home_ = home;
+    }
+
+public:
+    WordBuf() = default;
+    explicit WordBuf(WordArena *arena) : arena_(arena) {}
+    WordBuf(WordBuf &&o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_), home_(o.home_), arena_(o.arena_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; o.home_ = nullptr; }
+    WordBuf &operator=(WordBuf &&o) noexcept
+    {
+        if (this != &o) {
+            drop();
+            p_ = o.p_; n_ = o.n_; cap_ = o.cap_; home_ = o.home_; arena_ = o.arena_;
+            o.p_ = nullptr; o.n_ = o.cap_ = 0; o.home_ = nullptr;
+        }
+        return *this;
+    }
+    WordBuf(const WordBuf &) = delete;
+    WordBuf &operator=(const WordBuf &) = delete;
+    ~WordBuf() { drop(); }
+    void push_back(uint64_t x)
+    {
+        if (n_ == cap_) grow(n_ + 1);
+        p_[n_++] = x;
+    }
+    void reserve(size_t c) { if (c > cap_) grow(c); }
+    void clear() { n_ = 0; }
+    void set_arena(WordArena *a) { arena_ = a; }
+    size_t size() const { return n_; }
+    size_t capacity() const { return cap_; }
+    bool empty() const { return n_ == 0; }
+    bool has_storage() const { return p_ != nullptr; }
+    bool in_arena() const { return home_ != nullptr; }
+    const uint64_t *data() const { return p_; }
+    uint64_t operator[](size_t i) const { return p_[i]; }
+};
+
 // ---- host-side result of FASTA ingest (k-independent) ---------------------------------------
 // Bases are packed 2 bits each (A0 C1 G2 T/U3; invalid bases are stored as 0 and described by
 // the run table), 16 per uint32 word, base i of the stream in bits [2*(i%16), 2*(i%16)+2) of word
@@ -82,7 +161,7 @@ struct HostBatch {
     std::vector<uint32_t> run_pos, run_len; // maximal runs of valid bases, in (record, pos) order
     // 2-bit stream: one chunk per assembly, never concatenated on the host.  When the ingest streams to a ChunkSink
     // the chunks are gone by the time it returns (chunks[i] empty); chunk_word0 always describes the layout.
-    std::vector<std::vector<uint64_t>> chunks;   // [n_assemblies]
+    std::vector<WordBuf> chunks;                 // [n_assemblies]
     std::vector<uint64_t> chunk_word0;           // [n_assemblies + 1] index of the chunk's first 64-bit word in the stream
     uint64_t packed_words32() const { return (chunk_word0.empty() ? 0 : chunk_word0.back()) * 2 + 8; }   // + read slack
     uint32_t word32(uint64_t i) const            // test / debug accessor (non-streamed batches)
@@ -97,7 +176,10 @@ struct HostBatch {
 // Receives the packed chunks in assembly order while later files are still being parsed (pipelined upload).
 struct ChunkSink {
     virtual void begin(uint64_t expected_words64) = 0;                                   // estimate, before the first chunk
-    virtual void chunk(const uint64_t *data, uint64_t n_words64, uint64_t word_off) = 0; // word_off: place in the stream
+    // word_off: the chunk's place in the stream.  The sink may keep the buffer (an arena's, until its copy has left the host)
+    // or leave it to the caller, who recycles it.
+    virtual void chunk(WordBuf &words, uint64_t word_off) = 0;
+    virtual WordArena *arena() { return nullptr; }                                       // where the parsers' buffers should come from
     virtual ~ChunkSink() {}
 };
 

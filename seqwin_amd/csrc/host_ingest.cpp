@@ -208,7 +208,7 @@ struct alignas(128) Assembly {   // neighbours are filled by different workers: 
     std::vector<uint64_t> rec_base;  // local (within this assembly's packed stream)
     std::vector<uint32_t> rec_run_off;
     std::vector<uint32_t> run_pos, run_len;
-    std::vector<uint64_t> packed;    // 32 bases per word; private to the worker until the assembly is published
+    WordBuf packed;                  // 32 bases per word; private to the worker until the assembly is published
     uint64_t n_words = 0;            // packed.size() at publication (packed itself may have gone to the sink)
     std::string ids;
     uint64_t total_bp = 0;
@@ -216,12 +216,12 @@ struct alignas(128) Assembly {   // neighbours are filled by different workers: 
 
 struct Packer {
     Assembly &a;
-    std::vector<uint64_t> &words;   // a local of the parsing function while packing (moved into a.packed at the end)
+    WordBuf &words;                 // a local of the parsing function while packing (moved into a.packed at the end)
     uint64_t acc = 0;
     unsigned nacc = 0;     // bases in acc
     uint64_t len = 0;      // bases in the current record
     int64_t run_start = -1;
-    Packer(Assembly &as, std::vector<uint64_t> &w) : a(as), words(w) {}
+    Packer(Assembly &as, WordBuf &w) : a(as), words(w) {}
 
     void open_record()
     {
@@ -493,14 +493,14 @@ struct FileBytes {
 struct TextParser {
     const std::string &path;
     Assembly &a;
-    std::vector<uint64_t> words;
+    WordBuf words;
     Packer pk;
     bool have = false;
     std::string cur_id;
 #ifdef SW_HAVE_AVX2_PACKER
     const bool simd512 = have_avx512_packer(), simd = !simd512 && have_avx2_packer(), chunks = have_chunk_packer();
 #endif
-    TextParser(const std::string &path_, Assembly &a_, std::vector<uint64_t> &&storage) : path(path_), a(a_), words(std::move(storage)), pk(a_, words)
+    TextParser(const std::string &path_, Assembly &a_, WordBuf &&storage) : path(path_), a(a_), words(std::move(storage)), pk(a_, words)
     {
         words.clear();
     }
@@ -613,8 +613,7 @@ void stream_plain_file(const std::string &path, RawBuf &buf, size_t block, TextP
     buf.len = 0;
 }
 
-void parse_assembly(const std::string &path, RawBuf &buf, int use_mmap, std::vector<uint64_t> &&storage,
-                    Assembly &a)
+void parse_assembly(const std::string &path, RawBuf &buf, int use_mmap, WordBuf &&storage, Assembly &a)
 {
     TextParser tp(path, a, std::move(storage));
     const size_t block = read_block_bytes();
@@ -632,16 +631,17 @@ void parse_assembly(const std::string &path, RawBuf &buf, int use_mmap, std::vec
 // keeps only ~n_workers buffers alive (and does not unmap / fault in fresh memory for every file).
 struct BufferPool {
     std::mutex mu;
-    std::vector<std::vector<uint64_t>> free_list;
-    std::vector<uint64_t> get()
+    std::vector<WordBuf> free_list;
+    WordArena *arena = nullptr;   // fresh buffers ask it first (the sink's page-locked blocks)
+    WordBuf get()
     {
         std::lock_guard<std::mutex> lock(mu);
-        if (free_list.empty()) return {};
-        std::vector<uint64_t> v = std::move(free_list.back());
+        if (free_list.empty()) return WordBuf(arena);
+        WordBuf v = std::move(free_list.back());
         free_list.pop_back();
         return v;
     }
-    void put(std::vector<uint64_t> &&v)
+    void put(WordBuf &&v)
     {
         std::lock_guard<std::mutex> lock(mu);
         free_list.push_back(std::move(v));
@@ -688,10 +688,12 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
     // r05: the cap follows the CPUs the process may really use.  Round 4 capped at 64 workers "because they contend for the
     // address space" (19 Gbp/s end to end at 32-64 workers, 5.6 at 256, on 2 x EPYC 9575F) -- the box in fact grants the container
     // 16 CPUs (cgroup cpu.max), and 256 runnable threads burn a 100 ms period's quota in its first quarter and sit out the rest.
-    // Four workers per usable CPU is where the measured optimum lay (64 on 16); on an unrestricted host that is no cap at all.
+    // Four workers per usable CPU is where the measured optimum lay then (64 on 16); with the faster packer, the block-wise read and
+    // the page-locked word buffers of the end of r05 it is two (FASTA -> numpy at n_cpu 16 / 32 / 64 / 128: 38 / 44 / 29 / 27 Gbp/s
+    // with four, gpurun_out/r5aa); on an unrestricted host that is no cap at all.
     // SEQWIN_AMD_INGEST_WORKERS_MAX overrides it (scaling tables).  The result does not depend on the worker count.
     {
-        size_t cap = 4 * usable_cpus();
+        size_t cap = 2 * usable_cpus();
         if (const char *e = getenv("SEQWIN_AMD_INGEST_WORKERS_MAX")) cap = (size_t)std::max(1, atoi(e));
         n_workers = std::min(n_workers, std::max<size_t>(cap, 1));
     }
@@ -711,16 +713,29 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
     if (getenv("SEQWIN_AMD_NO_MMAP")) mmap_mode = 0;
     const int use_mmap = mmap_mode;
     BufferPool pool;
+    if (sink) pool.arena = sink->arena();
     std::atomic<size_t> next{0};
     std::atomic<bool> failed{false};
     std::mutex done_mu;
     std::condition_variable done_cv;
     std::vector<char> done(n_paths, 0);
+    // r05: with a sink, the parsers stay within a window of assemblies ahead of the one the sink is at.  Unbounded (r01-r05a) they ran
+    // as far ahead as the CPUs let them -- 2 048 genomes parsed while the sink thread was at the 500th: 2.6 GB of word buffers
+    // faulted in fresh instead of ~n_workers buffers going round (page faults and zeroing on the parsers' CPU time, 95-220 ms of
+    // munmap when ingest_fasta returned: SEQWIN_AMD_DEBUG_TIMING, gpurun_out/r5z).
+    size_t sunk = 0;   // assemblies the sink thread is done with (under done_mu)
+    std::condition_variable sunk_cv;
+    size_t window = 2 * n_workers + 8;
+    if (const char *e = getenv("SEQWIN_AMD_INGEST_WINDOW")) window = (size_t)std::max(1, atoi(e));
     auto worker = [&]() {
         RawBuf buf;
         for (;;) {
             size_t i = next.fetch_add(1);
             if (i >= n_paths) break;
+            if (sink) {
+                std::unique_lock<std::mutex> lock(done_mu);
+                sunk_cv.wait(lock, [&] { return i < sunk + window; });
+            }
             try {
                 parse_assembly(paths[i], buf, use_mmap, pool.get(), asms[i]);
             } catch (const Error &e) {
@@ -767,22 +782,30 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
                 {
                     const auto w0 = std::chrono::steady_clock::now();
                     std::unique_lock<std::mutex> lock(done_mu);
+                    sunk = i;   // (assembly i itself is inside every window)
+                    sunk_cv.notify_all();
                     done_cv.wait(lock, [&] { return done[i] != 0; });
                     wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
                 }
                 if (failed.load() || !sink_ok) continue;   // keep draining the flags; the error is raised below
                 out.chunk_word0[i] = word_off;
+                const size_t n_words = asms[i].packed.size();
                 try {
-                    if (!asms[i].packed.empty()) sink->chunk(asms[i].packed.data(), asms[i].packed.size(), word_off);
+                    if (n_words) sink->chunk(asms[i].packed, word_off);
                 } catch (const Error &e) {
                     sink_ok = false;
                     sink_error.reset(new Error(e));
                     continue;
                 }
-                word_off += asms[i].packed.size();
-                pool.put(std::move(asms[i].packed));
-                asms[i].packed = std::vector<uint64_t>();
+                word_off += n_words;
+                if (asms[i].packed.has_storage()) pool.put(std::move(asms[i].packed));   // (the sink has copied it: next file's buffer)
+                asms[i].packed = WordBuf();
             }
+            {
+                std::lock_guard<std::mutex> lock(done_mu);
+                sunk = n_paths;
+            }
+            sunk_cv.notify_all();
             out.chunk_word0[n_paths] = word_off;
             if (timing) fprintf(stderr, "[seqwin_amd] ingest: sink thread waited %.1f ms for the parsers\n", wait_ms);
             for (auto &t : th) t.join();

@@ -30,8 +30,12 @@ if os.environ.get("AB_REF"):          # as bench.py: the compiled reference has 
         print(f"reference on 512 files at {nc} threads: {time.perf_counter() - t0:.1f} s", flush=True)
 e2e_build(paths[:2], 21, 200, 2, tar[:2])
 try:
-    for rep in range(2):
-        for name, env in (("mmap", {"SEQWIN_AMD_MMAP": "1"}), ("read()", {"SEQWIN_AMD_MMAP": "0"}), ("mmap+populate", {"SEQWIN_AMD_MMAP": "2"})):
+    for rep in range(int(os.environ.get("AB_REPS", "2"))):
+        modes = (("mmap", {"SEQWIN_AMD_MMAP": "1"}), ("read()", {"SEQWIN_AMD_MMAP": "0"}), ("mmap+populate", {"SEQWIN_AMD_MMAP": "2"}))
+        if os.environ.get("AB_MODES") == "pinned":   # r05: the parsers' buffers page-locked (default) / the ring for every copy / no window either
+            modes = (("pinned+window", {}), ("ring+window", {"SEQWIN_AMD_PINNED_POOL_MB": "0"}),
+                     ("ring, no window", {"SEQWIN_AMD_PINNED_POOL_MB": "0", "SEQWIN_AMD_INGEST_WINDOW": "1000000"}))
+        for name, env in modes:
             for k_, v in env.items():
                 os.environ[k_] = v
             _, wall, split = e2e_build(paths, 21, 200, n_cpu, tar)
