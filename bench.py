@@ -285,6 +285,11 @@ def cpu_baseline_and_parity(batch, k, w, n_genomes_sample, is_targets):
         sweep = {min(c, cores) for c in (8, 32, 64, 128)} | ({max(1, min(cores, int(round(quota))))} if quota else set())
         if os.environ.get("SEQWIN_BENCH_E2E_NCPU"):   # e.g. "16,64,256" with SEQWIN_AMD_INGEST_WORKERS_MAX=256: the ingest's scaling table
             sweep = {min(int(c), cores) for c in os.environ["SEQWIN_BENCH_E2E_NCPU"].split(",")}
+        # the first full call of the process pays once for what later calls reuse (page-locked buffers of the streaming ingest,
+        # pool blocks, the download ring): timed and reported on its own, outside the sweep
+        first_cpu = 32 if 32 in sweep else max(sweep)
+        got, first_wall, first_split = e2e_build(paths, k, w, first_cpu, tar)
+        del got
         for n_cpu in sorted(sweep):
             got, wall, split = e2e_build(paths, k, w, n_cpu, tar)
             e2e_runs.append((wall, n_cpu, split))
@@ -295,6 +300,8 @@ def cpu_baseline_and_parity(batch, k, w, n_genomes_sample, is_targets):
         e2e = {"value": round(bp / e2e_dt / 1e9, 3), "unit": "Gbp/s", "n_cpu": e2e_cpu, "equal_to_cpu_baseline": e2e_equal,
                "genomes": n, "Mbp": round(bp / 1e6, 1), "split_ms": e2e_split,
                "by_n_cpu": {str(c): round(bp / t / 1e9, 2) for t, c, _ in e2e_runs}, "cpu_quota_cores": quota,
+               "first_call": {"Gbp_per_s": round(bp / first_wall / 1e9, 2), "wall_s": round(first_wall, 3), "n_cpu": first_cpu,
+                              "ingest_upload_ms": first_split["ingest_upload_ms"]},
                "sample": f"the same {n} FASTA files through sw_build + sw_graph_export + sw_get_penalty (ingest + PCIe + device + "
                          "download); wall " + ", ".join(f"{t:.3f} s at n_cpu={c}" for t, c, _ in e2e_runs),
                "vs_cpu_baseline": round(dt / e2e_dt, 1)}

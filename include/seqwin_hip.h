@@ -116,7 +116,9 @@ void sw_graph_free(sw_graph *g);
 void sw_release_resident(void);
 /* Device memory comes from a caching pool (steady-state builds do no hipMalloc).  sw_pool_trim() hands every cached, unused
  * block back to the driver -- for a host program that shares the GPU's memory with another allocator (torch's, in the
- * multi-GPU choreography); the pool trims itself when one of its own hipMalloc calls fails. */
+ * multi-GPU choreography); the pool trims itself when one of its own hipMalloc calls fails.  HOST memory the library keeps for
+ * the life of the process: the page-locked rings of the up- and download (32 + 64 MiB per device) and the page-locked blocks the
+ * streaming ingest packs into (grown on demand to at most SEQWIN_AMD_PINNED_POOL_MB, default 1024; 0 disables them). */
 void sw_pool_trim(void);
 /* out[3] = { occurrences of the resident index (0: none), sw_get_penalty calls served from it, sw_filter_kmers calls served from it } */
 void sw_resident_stats(uint64_t *out);

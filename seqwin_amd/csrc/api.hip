@@ -474,11 +474,11 @@ PinnedRing &pinned_ring(int device)
 // r05: the parsers' word buffers are page-locked blocks, so a finished assembly goes to HBM by DMA from where the packer wrote it --
 // the sink thread no longer copies every packed word into the ring first (2.6 GB at 20 GB/s = 130 ms of one thread for 2 048
 // genomes, the longest serial piece of the ingest; gpurun_out/r5z: with 64 parsers on the 16-CPU quota that thread fell behind
-// to 450 ms).  One pool per process, leaked like the rings: slabs of 64 MiB cut into blocks of a multiple of 256 KiB, freed blocks
+// to 450 ms).  One pool per process, leaked like the rings: slabs of 32 MiB cut into blocks of a multiple of 256 KiB, freed blocks
 // handed out best-fit, at most SEQWIN_AMD_PINNED_POOL_MB (default 1024) in total -- beyond that get() declines, the parser
 // mallocs and the sink takes the ring for that assembly.  SEQWIN_AMD_PINNED_POOL_MB=0: the ring for everything (r01-r05a).
 struct PinnedArena : WordArena {
-    static constexpr size_t SLAB = 64u << 20, GRAIN = 256u << 10;
+    static constexpr size_t SLAB = 32u << 20, GRAIN = 256u << 10;
     std::mutex mu;        // free list, bump pointer, totals
     std::mutex grow_mu;   // one thread page-locks a new slab at a time (the others wait for it rather than lock more memory)
     std::vector<std::pair<uint64_t *, size_t>> free_blocks;   // (block, capacity in words)
@@ -520,9 +520,12 @@ struct PinnedArena : WordArena {
             std::lock_guard<std::mutex> lock(mu);
             if (uint64_t *p = take(min_words, bytes, cap_words)) return p;
         }
-        // Page-locking costs 0.25 ms per MiB in one large call and ten times that in 2 MiB calls from many threads at once
-        // (gpurun_out/r5aa: the first streaming ingest of a process took 0.4-0.7 s longer): whole slabs, one thread at a time.
-        std::lock_guard<std::mutex> grow(grow_mu);
+        // Page-locking fresh memory costs 2-4 ms per MiB on the target host while the parsers keep its CPUs busy, in 2 MiB calls
+        // from many threads as in one 64 MiB call (gpurun_out/r5aa, r5ab: the first streaming ingest of a process took 0.15-0.6 s
+        // longer): whole slabs, by one thread at a time, and nobody waits for it -- while a slab is being locked the other parsers
+        // get nullptr (malloc + the ring for that assembly, as before r05) and find blocks at their next file.
+        std::unique_lock<std::mutex> grow(grow_mu, std::try_to_lock);
+        if (!grow.owns_lock()) return nullptr;
         const size_t want = std::max(bytes, SLAB);
         {
             std::lock_guard<std::mutex> lock(mu);

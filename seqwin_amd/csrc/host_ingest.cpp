@@ -725,7 +725,7 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
     // munmap when ingest_fasta returned: SEQWIN_AMD_DEBUG_TIMING, gpurun_out/r5z).
     size_t sunk = 0;   // assemblies the sink thread is done with (under done_mu)
     std::condition_variable sunk_cv;
-    size_t window = 2 * n_workers + 8;
+    size_t window = n_workers + n_workers / 2 + 4;
     if (const char *e = getenv("SEQWIN_AMD_INGEST_WINDOW")) window = (size_t)std::max(1, atoi(e));
     auto worker = [&]() {
         RawBuf buf;
@@ -798,7 +798,9 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
                     continue;
                 }
                 word_off += n_words;
-                if (asms[i].packed.has_storage()) pool.put(std::move(asms[i].packed));   // (the sink has copied it: next file's buffer)
+                // (the sink has copied it: the next file's buffer -- unless the sink offers page-locked ones, which a recycled
+                // malloc'd buffer would keep its parser from ever getting)
+                if (asms[i].packed.has_storage() && !pool.arena) pool.put(std::move(asms[i].packed));
                 asms[i].packed = WordBuf();
             }
             {
