@@ -478,7 +478,8 @@ PinnedRing &pinned_ring(int device)
 // handed out best-fit, at most SEQWIN_AMD_PINNED_POOL_MB (default 1024) in total -- beyond that get() declines, the parser
 // mallocs and the sink takes the ring for that assembly.  SEQWIN_AMD_PINNED_POOL_MB=0: the ring for everything (r01-r05a).
 struct PinnedArena : WordArena {
-    static constexpr size_t SLAB = 32u << 20, GRAIN = 256u << 10;
+    static constexpr size_t GRAIN = 256u << 10;
+    size_t SLAB = 32u << 20;   // (SEQWIN_AMD_PINNED_SLAB_MB: tests make blocks outgrow it)
     std::mutex mu;        // free list, bump pointer, totals
     std::mutex grow_mu;   // one thread page-locks a new slab at a time (the others wait for it rather than lock more memory)
     std::vector<std::pair<uint64_t *, size_t>> free_blocks;   // (block, capacity in words)
@@ -487,9 +488,10 @@ struct PinnedArena : WordArena {
     size_t total_bytes = 0, limit_bytes = (size_t)1024 << 20;
     void read_limit()   // (per ingest, so that one process can compare settings)
     {
-        const char *e = getenv("SEQWIN_AMD_PINNED_POOL_MB");
+        const char *e = getenv("SEQWIN_AMD_PINNED_POOL_MB"), *sl = getenv("SEQWIN_AMD_PINNED_SLAB_MB");
         std::lock_guard<std::mutex> lock(mu);
         limit_bytes = e ? (size_t)std::max(0, atoi(e)) << 20 : (size_t)1024 << 20;
+        SLAB = sl ? (size_t)std::max(1, atoi(sl)) << 20 : (size_t)32 << 20;
     }
     // under mu: a block of the free list (best fit) or of the current slab
     uint64_t *take(size_t min_words, size_t bytes, size_t *cap_words)

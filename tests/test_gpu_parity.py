@@ -879,6 +879,52 @@ def _device_gz_batches() -> int:
     return int(lib.sw_device_gz_batches())
 
 
+_INGEST_ROUTE_CHILD = """
+import sys, numpy as np
+from seqwin_amd import KmerGraph
+paths = open(sys.argv[1]).read().split()
+g = KmerGraph(paths, kmerlen=17, windowsize=30, n_cpu=5)
+np.savez(sys.argv[2], kmers=g.kmers, nodes=g.nodes, edges=g.edges, record_offsets=g.record_offsets)
+"""
+
+
+def test_streaming_ingest_buffer_routes_give_one_batch(tmp_path):
+    """sw_build's streaming ingest (r05: the parsers pack into page-locked blocks that the DMA engine reads in place, and stay
+    within a window of the assembly the sink thread is at): the default, every copy through the ring (pool of 0 MB), a pool
+    that runs out after a few blocks with slabs smaller than the largest assembly's block, a window of one assembly, and files
+    read 1 KiB at a time -- each in a process of its own (the pool lives as long as the process) -- give the oracle's graph."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    rng = random.Random(17)
+    paths = []
+    for a in range(48):
+        txt = ""
+        for r in range(rng.randrange(1, 4)):
+            s = _randseq(rng, rng.choice([0, 40, 3000, 20000, 60000]))
+            txt += f">r{r}_{a} d\n" + "\n".join(s[i:i + 80] for i in range(0, len(s), 80)) + "\n"
+        if a == 7:   # 1.25 MB of packed words: more than a 1 MiB slab
+            big = np.random.default_rng(3).choice(np.frombuffer(b"ACGT", np.uint8), 5_000_000).tobytes().decode()
+            txt += ">big\n" + "\n".join(big[i:i + 70] for i in range(0, len(big), 70)) + "\n"
+        p = tmp_path / f"s{a}.fa"
+        p.write_text(txt)
+        paths.append(str(p))
+    (tmp_path / "paths.txt").write_text("\n".join(paths))
+    exp = oracle.build(paths, 17, 30)
+    for i, extra in enumerate(({}, {"SEQWIN_AMD_PINNED_POOL_MB": "0"}, {"SEQWIN_AMD_PINNED_POOL_MB": "3", "SEQWIN_AMD_PINNED_SLAB_MB": "1"},
+                               {"SEQWIN_AMD_INGEST_WINDOW": "1"}, {"SEQWIN_AMD_READ_BLOCK_KB": "1"})):
+        out = tmp_path / f"g{i}.npz"
+        env = dict(os.environ, PYTHONPATH=str(ROOT), **extra)
+        r = subprocess.run([sys.executable, "-c", _INGEST_ROUTE_CHILD, str(tmp_path / "paths.txt"), str(out)], capture_output=True, text=True,
+                           timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = np.load(out)
+        for name, want in zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4]):
+            assert np.array_equal(got[name], want), (extra, name)
+
+
 def test_device_gz_ingest_matches_host_route(tmp_path, monkeypatch):
     """.gz inputs inflated, parsed and packed ON THE DEVICE (csrc/ingest_dev.hip: the gzip branch of fasta_reader.cpp:109-203
     and the parse of :41-95, one file per lane) give the batch the host route gives: records, ids, graph -- and the oracle's
