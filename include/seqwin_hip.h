@@ -100,7 +100,8 @@ int sw_graph_sizes(const sw_graph *g, uint64_t *n_kmers, uint64_t *n_nodes, uint
 /* Copy the graph into caller-owned buffers (numpy arrays allocated by the Python glue):
  * kmers[n_kmers], nodes[n_nodes] (n_tar = n_neg = 0, penalty = 0.0), edges[n_edges],
  * record_offsets[n_assemblies + 1], ids_blob[ids_bytes].  Replaces array_to_numpy
- * (python_bindings.cpp:21-39, 69-83) without foreign-owned memory outliving the call. */
+ * (python_bindings.cpp:21-39, 69-83) without foreign-owned memory outliving the call.  (Large results cross PCIe through a
+ * ring of pinned slots, nodes and edges in a packed form that host threads expand into these buffers: same bytes.) */
 int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *edges,
                     uint32_t *record_offsets, char *ids_blob);
 /* Where the time of the sw_build that made g (and of its sw_graph_export) went, in ms: out[0] ingest + upload (host parse and

@@ -254,7 +254,16 @@ void require_current_device(int device, const char *what)
 struct HostSpan {
     void *p;
     size_t n;
+    // expand != 0 (download only, r05): the source is a packed form that the copiers expand on the way to p --
+    //   EXPAND_NODES: {hash u64, stop - start u32} (12 bytes) -> sw_node with start / stop from a running sum that begins at
+    //                 chunk_base[chunk] (one entry per NODES_PER_CHUNK nodes) and zero n_tar / n_neg / penalty;
+    //   EXPAND_EDGES: {first u64, second u64, weight u32} (20 bytes) -> sw_edge.
+    // n stays the number of SOURCE bytes.
+    int expand = 0;
+    const uint64_t *chunk_base = nullptr;
 };
+enum { EXPAND_NODES = 1, EXPAND_EDGES = 2 };
+constexpr size_t PACKED_NODE = 12, PACKED_EDGE = 20;
 void prefault(const HostSpan *spans, int n_spans)
 {
     size_t total = 0;
@@ -304,13 +313,31 @@ DownloadRing &download_ring(int device)
 
 // dst[i] (host, pageable) <- src[i] (current device), dst[i].n bytes each.  The device data must be complete (every producing
 // stream synchronised) when this is called; it returns when the host arrays are.
-void download(const HostSpan *dst, const void *const *src, int n_spans)
+// bytes of a slot that a chunk may fill (tests: SEQWIN_AMD_DOWNLOAD_SLOT_KB makes small graphs span many chunks)
+size_t download_slot_bytes()
+{
+    size_t b = DownloadRing::SLOT;
+    if (const char *e = getenv("SEQWIN_AMD_DOWNLOAD_SLOT_KB")) b = std::min(b, (size_t)std::max(1, atoi(e)) << 10);
+    return b;
+}
+size_t download_pipeline_min()
 {
     size_t pipeline_min = 256u << 20;   // below: not worth the ring's one-off 16 ms of pinned allocation
     if (const char *e = getenv("SEQWIN_AMD_DOWNLOAD_PIPELINE_MB")) pipeline_min = (size_t)std::max(0, atoi(e)) << 20;   // (tests: 0)
+    return pipeline_min;
+}
+// whether download() of `total` bytes goes through the ring (what a caller that offers packed sources has to know beforehand)
+bool download_is_pipelined(size_t total) { return total > 0 && total >= download_pipeline_min() && !getenv("SEQWIN_AMD_PLAIN_DOWNLOAD"); }
+
+void download(const HostSpan *dst, const void *const *src, int n_spans)
+{
+    const size_t pipeline_min = download_pipeline_min();
     size_t total = 0;
     for (int i = 0; i < n_spans; ++i) total += (dst[i].p && src[i]) ? dst[i].n : 0;
     if (total == 0) return;
+    for (int i = 0; i < n_spans; ++i)
+        if (dst[i].p && src[i] && dst[i].expand && !download_is_pipelined(total))
+            raise(SW_ERR_RUNTIME, "download: a packed source outside the pipelined route");   // (a caller's mistake)
     if (total < pipeline_min || getenv("SEQWIN_AMD_PLAIN_DOWNLOAD")) {
         prefault(dst, n_spans);
         for (int i = 0; i < n_spans; ++i)
@@ -325,12 +352,24 @@ void download(const HostSpan *dst, const void *const *src, int n_spans)
         char *dst;
         const char *src;
         size_t n;
+        int expand;
+        uint64_t base;
     };
     std::vector<Chunk> chunks;
+    const size_t slot_bytes = download_slot_bytes();
     for (int i = 0; i < n_spans; ++i) {
         if (!dst[i].p || !src[i]) continue;
-        for (size_t o = 0; o < dst[i].n; o += DownloadRing::SLOT)
-            chunks.push_back({(char *)dst[i].p + o, (const char *)src[i] + o, std::min(DownloadRing::SLOT, dst[i].n - o)});
+        if (dst[i].expand) {   // whole packed records per slot
+            const size_t rec = dst[i].expand == EXPAND_NODES ? PACKED_NODE : PACKED_EDGE;
+            const size_t out = dst[i].expand == EXPAND_NODES ? sizeof(sw_node) : sizeof(sw_edge);
+            const size_t per = slot_bytes / rec * rec;
+            for (size_t o = 0, c = 0; o < dst[i].n; o += per, ++c)
+                chunks.push_back({(char *)dst[i].p + o / rec * out, (const char *)src[i] + o, std::min(per, dst[i].n - o), dst[i].expand,
+                                  dst[i].expand == EXPAND_NODES ? dst[i].chunk_base[c] : 0});
+            continue;
+        }
+        for (size_t o = 0; o < dst[i].n; o += slot_bytes)
+            chunks.push_back({(char *)dst[i].p + o, (const char *)src[i] + o, std::min(slot_bytes, dst[i].n - o), 0, 0});
     }
     std::mutex mu;
     std::condition_variable cv;
@@ -354,7 +393,36 @@ void download(const HostSpan *dst, const void *const *src, int n_spans)
             }
             const hipError_t e = hipEventSynchronize(ring.ev[job.first]);   // the slot holds the chunk
             const Chunk &c = chunks[job.second];
-            if (e == hipSuccess) memcpy(c.dst, ring.base + (size_t)job.first * DownloadRing::SLOT, c.n);
+            if (e == hipSuccess) {
+                const char *slot = ring.base + (size_t)job.first * DownloadRing::SLOT;
+                if (c.expand == EXPAND_NODES) {
+                    uint64_t start = c.base;
+                    sw_node nd;
+                    nd.n_tar = 0;
+                    nd.n_neg = 0;
+                    nd.penalty = 0.0;
+                    for (size_t r = 0; r < c.n / PACKED_NODE; ++r) {
+                        uint32_t cnt;
+                        memcpy(&nd.hash, slot + r * PACKED_NODE, 8);
+                        memcpy(&cnt, slot + r * PACKED_NODE + 8, 4);
+                        nd.start = start;
+                        start += cnt;
+                        nd.stop = start;
+                        memcpy(c.dst + r * sizeof(sw_node), &nd, sizeof(sw_node));
+                    }
+                } else if (c.expand == EXPAND_EDGES) {
+                    for (size_t r = 0; r < c.n / PACKED_EDGE; ++r) {
+                        sw_edge e;
+                        uint32_t wgt;
+                        memcpy(&e, slot + r * PACKED_EDGE, 16);
+                        memcpy(&wgt, slot + r * PACKED_EDGE + 16, 4);
+                        e.weight = wgt;
+                        memcpy(c.dst + r * sizeof(sw_edge), &e, sizeof(sw_edge));
+                    }
+                } else {
+                    memcpy(c.dst, slot, c.n);
+                }
+            }
             {
                 std::lock_guard<std::mutex> lock(mu);
                 if (e != hipSuccess && !failure)
@@ -1879,7 +1947,35 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
             if (!h.ids_blob.empty()) memcpy(ids_blob, h.ids_blob.data(), h.ids_blob.size());
             return;
         }
-        {
+        // r05: nodes and edges cross PCIe in a packed form when the result is large enough for the ring -- a node as {hash, number of
+        // occurrences} (12 of its 40 bytes: start / stop are the running sum, the counts are zero in a graph sw_build made), an edge
+        // with a 32-bit weight (20 of 24) -- and the copiers write the arrays out in full: 2 048 genomes 2.28 -> 1.67 GB, 15 000
+        // genomes 13.1 -> 10.3 GB over a link that carries 31-34 GB/s.  Declined (device flag) if any node has counts, a range that
+        // does not start where its predecessor's stops, or an edge weight above 2^32 - 1; SEQWIN_AMD_EXPORT_WHOLE=1 forces the plain form.
+        bool packed = false;
+        const size_t packed_total = ix.n_kmers * sizeof(sw_kmer) + ix.n_nodes * PACKED_NODE + ix.n_edges * PACKED_EDGE;
+        if (kmers && nodes && edges && ix.n_nodes && ix.n_edges && ix.n_kmers < (1ull << 32) && download_is_pipelined(packed_total) &&
+            !getenv("SEQWIN_AMD_EXPORT_WHOLE")) {
+            const uint64_t per = download_slot_bytes() / PACKED_NODE, n_chunks = (ix.n_nodes + per - 1) / per;
+            DevArray<uint32_t> pn(ix.n_nodes * 3), pe(ix.n_edges * 5), flag(1);
+            DevArray<uint64_t> bases(n_chunks);
+            SW_HIP(hipMemsetAsync(flag.p, 0, 4, nullptr));
+            pack_export(ix.nodes.p, ix.n_nodes, ix.n_kmers, ix.edges.p, ix.n_edges, per, pn.p, bases.p, pe.p, flag.p, nullptr);
+            uint32_t declined = 0;
+            std::vector<uint64_t> h_bases(n_chunks);
+            SW_HIP(hipMemcpy(&declined, flag.p, 4, hipMemcpyDeviceToHost));
+            if (!declined) {
+                SW_HIP(hipMemcpy(h_bases.data(), bases.p, n_chunks * 8, hipMemcpyDeviceToHost));
+                HostSpan ps[3] = {{kmers, ix.n_kmers * sizeof(sw_kmer)}, {nodes, ix.n_nodes * PACKED_NODE}, {edges, ix.n_edges * PACKED_EDGE}};
+                ps[1].expand = EXPAND_NODES;
+                ps[1].chunk_base = h_bases.data();
+                ps[2].expand = EXPAND_EDGES;
+                const void *const from[3] = {ix.kmers.p, pn.p, pe.p};
+                download(ps, from, 3);
+                packed = true;
+            }
+        }
+        if (!packed) {
             const void *const from[3] = {ix.kmers.p, ix.nodes.p, ix.edges.p};
             download(spans, from, 3);
         }
@@ -2083,6 +2179,9 @@ int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint6
         if (err & 1) raise(SW_ERR_VALUE, "node range is outside kmers");
         if (err & 2) raise(SW_ERR_VALUE, "record_idx is outside record_offsets range");                    // filter.cpp:104-106,120-122
         if (err & 4) raise(SW_ERR_VALUE, "record_idx must be nondecreasing within each node range");        // filter.cpp:113-115
+        // (measured at the end of r05: sending back only the 16 bytes per node that changed -- packed on the device, put into place
+        // by the download's copiers -- saves 60 % of the PCIe bytes and no time: 28.6 against 24.4 ms on 17.3 M nodes; the strided
+        // writes cost the host what the link saves, and the host-side identity check is half of the call.  Not kept.)
         const HostSpan span[1] = {{nodes, n_nodes * sizeof(sw_node)}};
         const void *const from[1] = {dn};
         download(span, from, 1);

@@ -315,6 +315,8 @@ void concat_occ(std::vector<OrderedOcc> &chunks, const std::vector<uint64_t> &re
 // occ: index form (key32 / pay / rec); d_rec_asm[n_records] = assembly of every record of the stream
 void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assemblies, OrderedOcc &occ,
                  const uint8_t *d_is_target, uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, sw_index &ix);
+void pack_export(const sw_node *nodes, uint64_t n_nodes, uint64_t n_kmers, const sw_edge *edges, uint64_t n_edges, uint64_t per, uint32_t *pn,
+                 uint64_t *bases, uint32_t *pe, uint32_t *flag, hipStream_t stream);
 void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
                         const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,
                         uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, uint64_t *err_flags_host);

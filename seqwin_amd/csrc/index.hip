@@ -3363,6 +3363,45 @@ void edges_from_adjacency(uint64_t *keys, uint64_t *keys_alt, uint32_t *vals, ui
 }
 }  // namespace
 
+// sw_graph_export's packed forms (api.hip): a node as {hash, stop - start}, the start of every `per`-th node, an edge with a 32-bit
+// weight; *flag becomes non-zero if the forms cannot carry the arrays (see there).
+__global__ void k_pack_export_nodes(const sw_node *__restrict__ nodes, uint64_t n, uint64_t n_kmers, uint64_t per, uint32_t *__restrict__ out,
+                                    uint64_t *__restrict__ bases, uint32_t *__restrict__ flag)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const sw_node nd = nodes[i];
+    const uint64_t cnt = nd.stop - nd.start, next = i + 1 < n ? nodes[i + 1].start : n_kmers;
+    uint64_t pen;
+    memcpy(&pen, &nd.penalty, 8);
+    if (nd.stop < nd.start || cnt > 0xFFFFFFFFull || next != nd.stop || (i == 0 && nd.start != 0) || nd.n_tar || nd.n_neg || pen) atomicOr(flag, 1u);
+    out[3 * i] = (uint32_t)nd.hash;
+    out[3 * i + 1] = (uint32_t)(nd.hash >> 32);
+    out[3 * i + 2] = (uint32_t)cnt;
+    if (i % per == 0) bases[i / per] = nd.start;
+}
+__global__ void k_pack_export_edges(const sw_edge *__restrict__ edges, uint64_t n, uint32_t *__restrict__ out, uint32_t *__restrict__ flag)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const sw_edge e = edges[i];
+    if (e.weight > 0xFFFFFFFFull) atomicOr(flag, 1u);
+    out[5 * i] = (uint32_t)e.first;
+    out[5 * i + 1] = (uint32_t)(e.first >> 32);
+    out[5 * i + 2] = (uint32_t)e.second;
+    out[5 * i + 3] = (uint32_t)(e.second >> 32);
+    out[5 * i + 4] = (uint32_t)e.weight;
+}
+void pack_export(const sw_node *nodes, uint64_t n_nodes, uint64_t n_kmers, const sw_edge *edges, uint64_t n_edges, uint64_t per, uint32_t *pn,
+                 uint64_t *bases, uint32_t *pe, uint32_t *flag, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_pack_export_nodes, dim3(blocks_for(n_nodes)), dim3(TPB), 0, stream, nodes, n_nodes, n_kmers, per, pn, bases, flag);
+    SW_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_pack_export_edges, dim3(blocks_for(n_edges)), dim3(TPB), 0, stream, edges, n_edges, pe, flag);
+    SW_HIP(hipGetLastError());
+    SW_HIP(hipStreamSynchronize(stream));
+}
+
 void device_get_penalty(const sw_kmer *d_kmers, uint64_t n_kmers, sw_node *d_nodes, uint64_t n_nodes,
                         const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target,
                         uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, uint64_t *err_flags_host)

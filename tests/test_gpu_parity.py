@@ -1149,9 +1149,30 @@ def test_pipelined_download_equals_plain_copy(tmp_path, smoke_paths, monkeypatch
         monkeypatch.delenv("SEQWIN_AMD_PLAIN_DOWNLOAD")
         monkeypatch.setenv("SEQWIN_AMD_DOWNLOAD_PIPELINE_MB", "0")
         ring = _build(paths, k, w, n_cpu=2)
+        monkeypatch.setenv("SEQWIN_AMD_DOWNLOAD_SLOT_KB", "1")      # many chunks: 85 packed nodes / 51 packed edges / 128 kmers each
+        small_slots = _build(paths, k, w, n_cpu=2)
+        monkeypatch.setenv("SEQWIN_AMD_EXPORT_WHOLE", "1")          # ... and nodes / edges as they are (until r05a) instead of packed
+        whole = _build(paths, k, w, n_cpu=2)
+        monkeypatch.delenv("SEQWIN_AMD_EXPORT_WHOLE")
+        monkeypatch.delenv("SEQWIN_AMD_DOWNLOAD_SLOT_KB")
         monkeypatch.delenv("SEQWIN_AMD_DOWNLOAD_PIPELINE_MB")
-        for a, b in zip(plain[:4], ring[:4]):
-            assert a.dtype == b.dtype and np.array_equal(a, b), (k, w)
+        for other in (ring, small_slots, whole):
+            for a, b in zip(plain[:4], other[:4]):
+                assert a.dtype == b.dtype and np.array_equal(a, b), (k, w)
+        # sw_get_penalty's nodes come back by the same routes (resident index or uploaded arrays): one result, and the oracle's
+        if len(plain[1]) and len(paths) >= 2:
+            tar = np.array([i % 2 == 0 for i in range(len(paths))], np.bool_)
+            exp = oracle.build(paths, k, w)
+            oracle.get_penalty(exp[0], exp[1], exp[3], list(tar))
+            for env in ({}, {"SEQWIN_AMD_DOWNLOAD_PIPELINE_MB": "0"}, {"SEQWIN_AMD_DOWNLOAD_PIPELINE_MB": "0", "SEQWIN_AMD_DOWNLOAD_SLOT_KB": "1"},
+                        {"SEQWIN_AMD_NO_RESIDENT": "1"}):
+                for key, val in env.items():
+                    monkeypatch.setenv(key, val)
+                g = _build(paths, k, w, n_cpu=2)
+                _get_penalty(g[0], g[1], g[3], tar, 2)
+                for key in env:
+                    monkeypatch.delenv(key)
+                assert np.array_equal(g[1], exp[1]), (k, w, env)
     if devices:
         return
     from seqwin_amd.device import Batch
