@@ -554,6 +554,9 @@ struct PinnedArena : WordArena {
     char *slab = nullptr;
     size_t slab_left = 0;
     size_t total_bytes = 0, limit_bytes = (size_t)1024 << 20;
+    // The parsers are plain threads whose current device is 0: a slab is page-locked from the device of a sink that is at work (the
+    // memory is portable, any of them will do) -- never a context on a GPU this process does not use.
+    std::atomic<int> grow_device{0};
     void read_limit()   // (per ingest, so that one process can compare settings)
     {
         const char *e = getenv("SEQWIN_AMD_PINNED_POOL_MB"), *sl = getenv("SEQWIN_AMD_PINNED_SLAB_MB");
@@ -604,6 +607,7 @@ struct PinnedArena : WordArena {
             total_bytes += want;
         }
         void *fresh = nullptr;
+        (void)hipSetDevice(grow_device.load());
         if (hipHostMalloc(&fresh, want, hipHostMallocPortable) != hipSuccess) {
             (void)hipGetLastError();
             std::lock_guard<std::mutex> lock(mu);
@@ -642,7 +646,11 @@ struct DeviceSink : ChunkSink {
     };
     std::deque<InFlight> in_flight;   // page-locked buffers whose copies are on their way, oldest first
     static constexpr size_t IN_FLIGHT_MAX = 48;
-    DeviceSink(sw_batch &batch, PinnedRing &r) : b(batch), ring(r), hold(r.in_use) { pinned_arena().read_limit(); }
+    DeviceSink(sw_batch &batch, PinnedRing &r) : b(batch), ring(r), hold(r.in_use)
+    {
+        pinned_arena().read_limit();
+        pinned_arena().grow_device.store(batch.device);
+    }
     WordArena *arena() override { return pinned_arena().limit_bytes ? &pinned_arena() : nullptr; }
     void reap(bool all)
     {
