@@ -327,6 +327,23 @@ def test_host_ingest_under_sanitizers(tmp_path):
         lens = np.array([len(x) for x in seqs], np.uint32)
         assert dump.read_bytes() == offs.astype(np.uint32).tobytes() + blob + lens.tobytes() + b"".join(seqs)
         assert f"{len(files)} assemblies {len(seqs)} records {bp} bp" in out.stdout
+    # the streaming form sw_build uses (r05: word buffers from an arena, chunks to a sink in order, the parsers inside their window of
+    # the sink) with a host-memory sink, under ASan / UBSan and -- where the runtime is there -- ThreadSanitizer: the same dump
+    ref = tmp_path / "dump_1_.bin"
+    for n_cpu, extra in ((4, {}), (3, {"SEQWIN_AMD_INGEST_WINDOW": "1"}), (2, {"SEQWIN_AMD_READ_BLOCK_KB": "1"})):
+        dump = tmp_path / f"dump_sink_{n_cpu}.bin"
+        out = subprocess.run([str(exe), str(n_cpu), str(dump)] + [str(f) for f in files], capture_output=True, text=True,
+                             env=dict(env, INGEST_SAN_SINK="1", **extra))
+        assert out.returncode == 0 and "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
+        assert dump.read_bytes() == ref.read_bytes()
+    if subprocess.run(["make", "-C", str(ROOT / "seqwin_amd" / "csrc"), "tsan"], capture_output=True).returncode == 0:
+        texe = ROOT / "seqwin_amd" / "csrc" / "build" / "ingest_tsan"
+        for n_cpu, extra in ((6, {}), (5, {"SEQWIN_AMD_INGEST_WINDOW": "2"})):
+            dump = tmp_path / f"dump_tsan_{n_cpu}.bin"
+            out = subprocess.run([str(texe), str(n_cpu), str(dump)] + [str(f) for f in files], capture_output=True, text=True,
+                                 env=dict(__import__("os").environ, INGEST_SAN_SINK="1", TSAN_OPTIONS="halt_on_error=0", **extra))
+            assert out.returncode == 0 and "ThreadSanitizer" not in out.stderr, out.stderr[-3000:]
+            assert dump.read_bytes() == ref.read_bytes()
     # refused / broken inputs must fail cleanly under the sanitizers too (exit code 3, no report)
     ctl = tmp_path / "ctl.fa"; ctl.write_bytes(b">r\nACGT\x01ACGT\n")
     nohdr = tmp_path / "nohdr.fa"; nohdr.write_bytes(b"ACGT\n>r\nAC\n")
