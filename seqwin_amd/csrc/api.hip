@@ -332,8 +332,15 @@ bool download_is_pipelined(size_t total) { return total > 0 && total >= download
 void download(const HostSpan *dst, const void *const *src, int n_spans)
 {
     const size_t pipeline_min = download_pipeline_min();
-    size_t total = 0;
-    for (int i = 0; i < n_spans; ++i) total += (dst[i].p && src[i]) ? dst[i].n : 0;
+    size_t total = 0;   // bytes that arrive in the destination arrays (a packed source counts as what it expands to)
+    for (int i = 0; i < n_spans; ++i) {
+        if (!dst[i].p || !src[i]) continue;
+        switch (dst[i].expand) {
+        case EXPAND_NODES: total += dst[i].n / PACKED_NODE * sizeof(sw_node); break;
+        case EXPAND_EDGES: total += dst[i].n / PACKED_EDGE * sizeof(sw_edge); break;
+        default: total += dst[i].n;
+        }
+    }
     if (total == 0) return;
     for (int i = 0; i < n_spans; ++i)
         if (dst[i].p && src[i] && dst[i].expand && !download_is_pipelined(total))
@@ -1961,8 +1968,8 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
         // genomes 13.1 -> 10.3 GB over a link that carries 31-34 GB/s.  Declined (device flag) if any node has counts, a range that
         // does not start where its predecessor's stops, or an edge weight above 2^32 - 1; SEQWIN_AMD_EXPORT_WHOLE=1 forces the plain form.
         bool packed = false;
-        const size_t packed_total = ix.n_kmers * sizeof(sw_kmer) + ix.n_nodes * PACKED_NODE + ix.n_edges * PACKED_EDGE;
-        if (kmers && nodes && edges && ix.n_nodes && ix.n_edges && ix.n_kmers < (1ull << 32) && download_is_pipelined(packed_total) &&
+        const size_t whole_total = ix.n_kmers * sizeof(sw_kmer) + ix.n_nodes * sizeof(sw_node) + ix.n_edges * sizeof(sw_edge);
+        if (kmers && nodes && edges && ix.n_nodes && ix.n_edges && ix.n_kmers < (1ull << 32) && download_is_pipelined(whole_total) &&
             !getenv("SEQWIN_AMD_EXPORT_WHOLE")) {
             const uint64_t per = download_slot_bytes() / PACKED_NODE, n_chunks = (ix.n_nodes + per - 1) / per;
             DevArray<uint32_t> pn(ix.n_nodes * 3), pe(ix.n_edges * 5), flag(1);
