@@ -2167,10 +2167,28 @@ int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint6
         int dev = -1;
         SW_HIP(hipGetDevice(&dev));
         bool use_resident = false;
+        uint64_t err = 0;
         if (res.ix && res.ix->device == dev && res.ix->n_kmers == n_kmers && res.ix->n_nodes == n_nodes) {
-            uint64_t id[2];
-            host_identity(kmers, n_kmers, nodes, n_nodes, (unsigned)std::min<uint64_t>(std::max<uint64_t>(n_cpu, 1), 64), id);
+            // r05: while host threads verify that the caller's arrays are the resident ones (1.5 GB read for 2 048 genomes: half of this
+            // call), the device already scores the resident arrays; if the check fails, the counts it wrote there are never read
+            uint64_t id[2] = {0, 0}, spec_err = 0;
+            std::exception_ptr id_fail;
+            std::thread checker([&] {
+                try {
+                    host_identity(kmers, n_kmers, nodes, n_nodes, (unsigned)std::min<uint64_t>(std::max<uint64_t>(n_cpu, 1), 64), id);
+                } catch (...) {
+                    id_fail = std::current_exception();
+                }
+            });
+            struct Join {
+                std::thread &t;
+                ~Join() { if (t.joinable()) t.join(); }
+            } join{checker};
+            device_get_penalty(res.ix->kmers.p, n_kmers, res.ix->nodes.p, n_nodes, d_rec_asm.p, n_records, d_tar.p, n_tar, n_neg, 0, &spec_err);
+            checker.join();
+            if (id_fail) std::rethrow_exception(id_fail);
             use_resident = id[0] == res.kmer_sum && id[1] == res.node_sum;
+            if (use_resident) err = spec_err;
         }
         DevArray<sw_kmer> d_kmers;
         DevArray<sw_node> d_nodes;
@@ -2188,9 +2206,8 @@ int sw_get_penalty(const sw_kmer *kmers, uint64_t n_kmers, sw_node *nodes, uint6
             SW_HIP(hipMemcpy(d_nodes.p, nodes, n_nodes * sizeof(sw_node), hipMemcpyHostToDevice));
             dk = d_kmers.p;
             dn = d_nodes.p;
+            device_get_penalty(dk, n_kmers, dn, n_nodes, d_rec_asm.p, n_records, d_tar.p, n_tar, n_neg, 0, &err);
         }
-        uint64_t err = 0;
-        device_get_penalty(dk, n_kmers, dn, n_nodes, d_rec_asm.p, n_records, d_tar.p, n_tar, n_neg, 0, &err);
         if (err & 1) raise(SW_ERR_VALUE, "node range is outside kmers");
         if (err & 2) raise(SW_ERR_VALUE, "record_idx is outside record_offsets range");                    // filter.cpp:104-106,120-122
         if (err & 4) raise(SW_ERR_VALUE, "record_idx must be nondecreasing within each node range");        // filter.cpp:113-115
