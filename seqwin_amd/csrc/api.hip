@@ -121,10 +121,28 @@ void *dev_alloc(size_t bytes)
             p.live[blk.ptr] = it->first;
             p.free_blocks.erase(it);
             bool ok = true;
-            if (blk.main != T) {   // released under another stream: fence on that stream's work up to now
+            if (blk.main != T) {
+                // Released under ANOTHER main stream -- another worker thread of a SEQWIN_DEVICES build, whose queued kernels may
+                // still read the block.  Until r05 only T was made to wait for them; but the new owner also touches the block from
+                // streams that are not T (the upload ring's DMA into a fresh d_packed, synchronous copies on the NULL stream), and
+                // one multi-device fuzz campaign of r05 ended in a GPU memory fault with four processes sharing the card
+                // (gpurun_out/r5al; not reproduced).  The hand-over between threads is now ordered on the HOST: the releasing
+                // stream's work up to now, and that of its forked streams, has finished before the block is returned.  (Within one
+                // thread -- every single-device build -- blk.main == T and nothing changes.)
                 hipEvent_t e = take_event(p, dev);
-                ok = e && hipEventRecord(e, blk.main) == hipSuccess && hipStreamWaitEvent(T, e, 0) == hipSuccess;
+                ok = e && hipEventRecord(e, blk.main) == hipSuccess;
+                lock.unlock();
+                if (ok) ok = hipEventSynchronize(e) == hipSuccess;
+                for (auto &se : blk.side)
+                    if (ok) ok = hipEventSynchronize(se.second) == hipSuccess;
+                if (!ok) {
+                    (void)hipGetLastError();
+                    (void)hipDeviceSynchronize();
+                }
+                lock.lock();
                 if (e) p.spare_events[dev].push_back(e);
+                for (auto &se : blk.side) p.spare_events[dev].push_back(se.second);
+                return blk.ptr;
             }
             for (auto &se : blk.side) {   // (a block's events belong to its device = dev: blocks are keyed by device)
                 if (se.first != T && ok) ok = hipStreamWaitEvent(T, se.second, 0) == hipSuccess;

@@ -20,7 +20,7 @@ if DIST:
 tmp = tempfile.mkdtemp(prefix="fuzz_")
 t_end = time.time() + budget
 n_cases = n_bad = 0
-it = 0
+it = int(os.environ.get("FUZZ_START", "0"))   # (continue a campaign's seed sequence from its it-th case)
 while time.time() < t_end and (not replay or it < len(replay)):
     seed = replay[it] if replay else seed0 * 1000003 + it
     it += 1
@@ -64,6 +64,9 @@ while time.time() < t_end and (not replay or it < len(replay)):
         ps.append(p)
     k = rng.choice([3, 4, 5, 7, 11, 15, 16, 17, 19, 21, 31, 32, 33, 47, 64, 65, 100, 255, 256, 257])
     w = rng.choice([1, 2, 3, 5, 10, 15, 16, 17, 25, 31, 32, 33, 34, 50, 63, 64, 65, 100, 200, 201, 500, 1000, 4096, 4097, 5000, 20000])
+    if os.environ.get("FUZZ_TRACE"):   # the case that is about to run, for a process that does not come back
+        with open(os.environ["FUZZ_TRACE"] + f".{os.getpid()}", "a") as tf:
+            tf.write(f"{it} seed={seed} k={k} w={w} files={[os.path.getsize(p) for p in ps]}\n")
     try:
         t_a = time.time()
         got = _core._build_native(ps, k, w, rng.choice([1, 3]), LOWMEM)
