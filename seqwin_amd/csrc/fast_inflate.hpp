@@ -275,15 +275,22 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
             br.refill();
             uint32_t e = tb.ll[br.peek(LL_BITS)];
             if (e & K_LIT) {
-                // literals straight from the first-level table while whole codes are left in the buffer (the bits behind the
-                // valid ones are zero: an entry found through them is only taken if its code fits what is really there)
-                do {
+                // up to three literals straight from the first-level table (3 x 11 bits of the >= 56 in the buffer: every entry is
+                // found through valid bits, and a non-literal entry behind them is still good after the refill below)
+                br.drop(e & 0xFFu);
+                *out++ = (uint8_t)(e >> 16);
+                e = tb.ll[br.peek(LL_BITS)];
+                if (e & K_LIT) {
                     br.drop(e & 0xFFu);
                     *out++ = (uint8_t)(e >> 16);
                     e = tb.ll[br.peek(LL_BITS)];
-                } while ((e & K_LIT) && (e & 0xFFu) <= br.cnt);
-                if (br.cnt < 48) continue;   // a length / distance pair may need 48 bits: refill first
-                if (e & K_LIT) continue;
+                    if (e & K_LIT) {
+                        br.drop(e & 0xFFu);
+                        *out++ = (uint8_t)(e >> 16);
+                        continue;
+                    }
+                }
+                br.refill();   // a length / distance pair may need 48 bits (the bits `e` was found through stay where they are)
             }
             if (e & K_SUB) {
                 br.drop(LL_BITS);
@@ -294,15 +301,16 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
                     continue;
                 }
             }
-            br.drop(e & 0xFFu);
             if (e & (K_EOB | K_BAD)) {
+                br.drop(e & 0xFFu);
                 if (e & K_BAD) return BAD;
                 block_done = true;
                 break;
             }
-            const unsigned lx = (e >> 8) & 0xFu;
-            const unsigned len = (e >> 16) + br.peek(lx);
-            br.drop(lx);
+            // length: code + extra bits in one step
+            const unsigned lc = e & 0xFFu, lx = (e >> 8) & 0xFu;
+            const unsigned len = (e >> 16) + ((uint32_t)(br.buf >> lc) & ((1u << lx) - 1u));
+            br.drop(lc + lx);
             if (!tb.d_usable) return BAD;
             uint32_t de = tb.d[br.peek(D_BITS)];
             if (de & K_SUB) {
@@ -310,22 +318,29 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
                 de = tb.d[(de >> 16) + br.peek((de >> 8) & 0xFu)];
             }
             if (de & K_BAD) return BAD;
-            br.drop(de & 0xFFu);
-            const unsigned dx = (de >> 8) & 0xFu;
-            const size_t dist = (de >> 16) + br.peek(dx);
-            br.drop(dx);
+            const unsigned dc = de & 0xFFu, dx = (de >> 8) & 0xFu;
+            const size_t dist = (de >> 16) + ((uint32_t)(br.buf >> dc) & ((1u << dx) - 1u));
+            br.drop(dc + dx);
             if (dist > (size_t)(out - out_begin)) return BAD;
             const uint8_t *src = out - dist;
             uint8_t *dst = out;
             out += len;
             if (dist >= 8) {
-                do {
-                    uint64_t w;
-                    memcpy(&w, src, 8);
-                    memcpy(dst, &w, 8);
-                    src += 8;
-                    dst += 8;
-                } while (dst < out);
+                uint64_t w;   // (most matches of DNA text are 3 ... 16 bytes: two moves without a loop; 320 spare bytes behind `out`)
+                memcpy(&w, src, 8);
+                memcpy(dst, &w, 8);
+                memcpy(&w, src + 8, 8);
+                memcpy(dst + 8, &w, 8);
+                if (len > 16) {
+                    src += 16;
+                    dst += 16;
+                    do {
+                        memcpy(&w, src, 8);
+                        memcpy(dst, &w, 8);
+                        src += 8;
+                        dst += 8;
+                    } while (dst < out);
+                }
             } else if (dist == 1) {
                 memset(dst, *src, len);
             } else {
