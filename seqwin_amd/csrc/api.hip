@@ -774,14 +774,6 @@ void ingest_to_device(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     }
 }
 
-__host__ __device__ inline uint64_t mix64(uint64_t x)
-{
-    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
-    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
-    x ^= x >> 31;
-    return x;
-}
-
 // One thread = one packed word (16 bases) of one record.
 __global__ void k_synth(uint32_t *packed, uint64_t words_per_record, uint64_t n_words, uint64_t records_per_genome,
                         uint64_t record_len, uint64_t n_ancestors, uint64_t snp_ppm, uint64_t seed, uint64_t word_base,
@@ -875,16 +867,15 @@ void release_resident_if_idle()
 namespace {
 void host_identity(const sw_kmer *kmers, uint64_t nk, const sw_node *nodes, uint64_t nn, unsigned n_threads, uint64_t *sums2)
 {
-    const uint64_t G = 0x9E3779B97F4A7C15ULL;
     n_threads = std::max(1u, std::min(n_threads, 64u));
     if (nk + nn < (1u << 20)) n_threads = 1;
     std::vector<uint64_t> pa(n_threads, 0), pb(n_threads, 0);
     auto work = [&](unsigned t) {
         uint64_t a = 0, b = 0;
         for (uint64_t i = nk * t / n_threads, e = nk * (t + 1) / n_threads; i < e; ++i)
-            a += mix64(i * G + ((uint64_t)kmers[i].pos | ((uint64_t)kmers[i].record_idx << 32)));
+            a += ck_kmer(i, kmers[i]);
         for (uint64_t i = nn * t / n_threads, e = nn * (t + 1) / n_threads; i < e; ++i)
-            b += mix64(i * G + nodes[i].hash) + mix64(nodes[i].start * 3 + 1) + mix64(nodes[i].stop * 5 + 2);
+            b += ck_node_identity(i, nodes[i]);
         pa[t] = a;
         pb[t] = b;
     };

@@ -19,6 +19,46 @@ namespace sw {
                         __FILE__, __LINE__, #expr);                                                    \
     } while (0)
 
+// ---- position-dependent checksums of the output arrays (r06: EVERY field of an element enters together with the element's index) ----
+// Element i of array X contributes  sum over its fields f of  mix64(((base + i) * G ^ K_f) + value_f)  (mod 2^64), so two
+// elements that swap ANY field -- a node's start / stop / counts / penalty, an edge's second / weight -- change the sum (until r05
+// only kmers, nodes.hash and edges.first carried the index).  `base` = the element's index in the whole array
+// when the array at hand is a slice of it: the shares of the slices of a sharded index add up modulo 2^64.  One definition for
+// the device kernels (index.hip: k_checksum, k_identity), the host threads of sw_get_penalty's identity test (api.hip:
+// host_identity) and -- restated in numpy -- seqwin_amd/device.py: host_checksums.  Whole node rows compared: tests/smoke/test_graph.py:281-291.
+__host__ __device__ inline uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+constexpr uint64_t CK_G = 0x9E3779B97F4A7C15ULL;
+constexpr uint64_t CK_K1 = 0xA0761D6478BD642FULL, CK_K2 = 0xE7037ED1A0B428DBULL, CK_K3 = 0x8EBC6AF09C88C6E3ULL,
+                   CK_K4 = 0x589965CC75374CC3ULL;
+__host__ __device__ inline uint64_t ck_kmer(uint64_t i, const sw_kmer &k)
+{
+    return mix64(i * CK_G + ((uint64_t)k.pos | ((uint64_t)k.record_idx << 32)));
+}
+// the immutable part of a node (what sw_get_penalty's identity test compares): hash, start, stop
+__host__ __device__ inline uint64_t ck_node_identity(uint64_t i, const sw_node &n)
+{
+    const uint64_t x = i * CK_G;
+    return mix64(x + n.hash) + mix64((x ^ CK_K1) + n.start) + mix64((x ^ CK_K2) + n.stop);
+}
+__host__ __device__ inline uint64_t ck_node(uint64_t i, const sw_node &n)
+{
+    const uint64_t x = i * CK_G;
+    uint64_t pbits;
+    memcpy(&pbits, &n.penalty, 8);   // the f64 by bit pattern (-0.0 and 0.0 differ, a NaN's payload counts)
+    return ck_node_identity(i, n) + mix64((x ^ CK_K3) + ((uint64_t)n.n_tar << 32 | n.n_neg)) + mix64((x ^ CK_K4) + pbits);
+}
+__host__ __device__ inline uint64_t ck_edge(uint64_t i, const sw_edge &e)
+{
+    const uint64_t x = i * CK_G;
+    return mix64(x + e.first) + mix64((x ^ CK_K1) + e.second) + mix64((x ^ CK_K2) + e.weight);
+}
+
 // ---- caching device allocator (steady-state index builds do no hipMalloc), stream-aware: api.hip ----------
 void *dev_alloc(size_t bytes);
 void dev_free(void *p);

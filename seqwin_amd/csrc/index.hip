@@ -1608,28 +1608,17 @@ __global__ void k_filter_kmers(const sw_kmer *__restrict__ kmers, const uint64_t
     out[j] = kmers[src_start[lo] + (j - dst_start[lo])];
 }
 
-// ---- checksums ------------------------------------------------------------------------------------------
-__host__ __device__ inline uint64_t mix64(uint64_t x)
-{
-    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
-    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
-    x ^= x >> 31;
-    return x;
-}
-
+// ---- checksums (the per-element terms: device.hpp) ------------------------------------------------------
 // element i of a slice is element base + i of the whole (concatenated) array: the sums of the slices of a sharded
 // index add up (mod 2^64) to the checksums of the unsharded one
 __global__ void k_checksum(const sw_kmer *kmers, uint64_t nk, const sw_node *nodes, uint64_t nn, const sw_edge *edges,
                            uint64_t ne, uint64_t kbase, uint64_t nbase, uint64_t ebase, unsigned long long *sums)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t G = 0x9E3779B97F4A7C15ULL;
     uint64_t a = 0, b = 0, c = 0;
-    if (i < nk) a = mix64((kbase + i) * G + ((uint64_t)kmers[i].pos | ((uint64_t)kmers[i].record_idx << 32)));
-    if (i < nn)
-        b = mix64((nbase + i) * G + nodes[i].hash) + mix64(nodes[i].start * 3 + 1) + mix64(nodes[i].stop * 5 + 2) +
-            mix64(((uint64_t)nodes[i].n_tar << 32 | nodes[i].n_neg) + 7);
-    if (i < ne) c = mix64((ebase + i) * G + edges[i].first) + mix64(edges[i].second * 3 + 1) + mix64(edges[i].weight * 5 + 2);
+    if (i < nk) a = ck_kmer(kbase + i, kmers[i]);
+    if (i < nn) b = ck_node(nbase + i, nodes[i]);
+    if (i < ne) c = ck_edge(ebase + i, edges[i]);
     for (int d = 32; d; d >>= 1) {
         a += __shfl_down(a, d, 64);
         b += __shfl_down(b, d, 64);
@@ -4407,10 +4396,9 @@ __global__ void k_identity(const sw_kmer *kmers, uint64_t nk, const sw_node *nod
                            uint64_t kbase, uint64_t nbase)   // (bases: the slice's place in the whole, multi-device graphs)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t G = 0x9E3779B97F4A7C15ULL;
     uint64_t a = 0, b = 0;
-    if (i < nk) a = mix64((kbase + i) * G + ((uint64_t)kmers[i].pos | ((uint64_t)kmers[i].record_idx << 32)));
-    if (i < nn) b = mix64((nbase + i) * G + nodes[i].hash) + mix64(nodes[i].start * 3 + 1) + mix64(nodes[i].stop * 5 + 2);
+    if (i < nk) a = ck_kmer(kbase + i, kmers[i]);
+    if (i < nn) b = ck_node_identity(nbase + i, nodes[i]);
     for (int d = 32; d; d >>= 1) {
         a += __shfl_down(a, d, 64);
         b += __shfl_down(b, d, 64);

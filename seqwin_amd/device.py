@@ -202,16 +202,23 @@ def _mix64(x: np.ndarray) -> np.ndarray:
     return x
 
 
+_K1, _K2, _K3, _K4 = (np.uint64(0xA0761D6478BD642F), np.uint64(0xE7037ED1A0B428DB), np.uint64(0x8EBC6AF09C88C6E3),
+                      np.uint64(0x589965CC75374CC3))
+
+
 def host_checksums(kmers, nodes, edges, kmer_base: int = 0, node_base: int = 0, edge_base: int = 0):
-    """numpy restatement of sw_index_checksums / sw_index_checksums_at (index.hip:k_checksum) for host arrays."""
+    """numpy restatement of sw_index_checksums / sw_index_checksums_at (csrc/device.hpp: ck_kmer / ck_node / ck_edge) for host
+    arrays.  Every field of an element is mixed with the element's index (r06): kmers; nodes' hash, start, stop, (n_tar, n_neg) and
+    the penalty's bit pattern; edges' first, second, weight -- whole rows, as tests/smoke/test_graph.py:281-291 compares them."""
     with np.errstate(over="ignore"):
-        i = np.arange(len(kmers), dtype=np.uint64) + np.uint64(kmer_base)
-        a = _mix64(i * _G + (kmers["pos"].astype(np.uint64) | (kmers["record_idx"].astype(np.uint64) << np.uint64(32)))).sum(dtype=np.uint64)
-        i = np.arange(len(nodes), dtype=np.uint64) + np.uint64(node_base)
-        b = (_mix64(i * _G + nodes["hash"]) + _mix64(nodes["start"].astype(np.uint64) * np.uint64(3) + np.uint64(1)) +
-             _mix64(nodes["stop"].astype(np.uint64) * np.uint64(5) + np.uint64(2)) +
-             _mix64(((nodes["n_tar"].astype(np.uint64) << np.uint64(32)) | nodes["n_neg"].astype(np.uint64)) + np.uint64(7))).sum(dtype=np.uint64)
-        i = np.arange(len(edges), dtype=np.uint64) + np.uint64(edge_base)
-        c = (_mix64(i * _G + edges["first"]) + _mix64(edges["second"] * np.uint64(3) + np.uint64(1)) +
-             _mix64(edges["weight"].astype(np.uint64) * np.uint64(5) + np.uint64(2))).sum(dtype=np.uint64)
+        x = (np.arange(len(kmers), dtype=np.uint64) + np.uint64(kmer_base)) * _G
+        a = _mix64(x + (kmers["pos"].astype(np.uint64) | (kmers["record_idx"].astype(np.uint64) << np.uint64(32)))).sum(dtype=np.uint64)
+        x = (np.arange(len(nodes), dtype=np.uint64) + np.uint64(node_base)) * _G
+        b = (_mix64(x + nodes["hash"]) + _mix64((x ^ _K1) + nodes["start"].astype(np.uint64)) +
+             _mix64((x ^ _K2) + nodes["stop"].astype(np.uint64)) +
+             _mix64((x ^ _K3) + ((nodes["n_tar"].astype(np.uint64) << np.uint64(32)) | nodes["n_neg"].astype(np.uint64))) +
+             _mix64((x ^ _K4) + np.ascontiguousarray(nodes["penalty"]).view(np.uint64))).sum(dtype=np.uint64)
+        x = (np.arange(len(edges), dtype=np.uint64) + np.uint64(edge_base)) * _G
+        c = (_mix64(x + edges["first"]) + _mix64((x ^ _K1) + edges["second"].astype(np.uint64)) +
+             _mix64((x ^ _K2) + edges["weight"].astype(np.uint64))).sum(dtype=np.uint64)
     return int(a), int(b), int(c)

@@ -693,6 +693,43 @@ def _resident_stats():
     return [int(x) for x in v]
 
 
+def test_identity_test_of_the_resident_route_sees_permuted_node_ranges():
+    """sw_get_penalty scores the index still resident in HBM only when the caller's arrays ARE the exported ones.  Until r05 the
+    identity sums mixed the element index into kmers and nodes.hash only, so caller nodes whose start / stop had been permuted
+    among nodes passed for the exported ones and were scored from HBM -- a silent divergence from filter.cpp:92-136, which
+    walks kmers[start:stop) of the arrays it is GIVEN.  Now every term carries the index: such arrays are
+    uploaded and give what the reference gives for them; the device checksums equal the numpy restatement on scored nodes
+    (counts and penalty bits in the sum)."""
+    paths = sorted((GOLDEN / "synth").glob("pan_*.fa"))
+    tar = [i % 2 == 0 for i in range(len(paths))]
+    ek, en, ee, eo, _ = oracle.build(paths, 15, 20)
+    g = KmerGraph(paths, kmerlen=15, windowsize=20, n_cpu=2)
+    hits = _resident_stats()[1]
+    # two nodes with the same number of occurrences exchange their ranges: sizes, multisets of start and of stop unchanged
+    size = (en["stop"] - en["start"]).astype(np.int64)
+    i = int(np.flatnonzero(size == size[0])[1]) if np.count_nonzero(size == size[0]) > 1 else None
+    assert i is not None
+    nodes = g.nodes.copy()
+    for f in ("start", "stop"):
+        nodes[f][[0, i]] = g.nodes[f][[i, 0]]
+    want = en.copy()
+    for f in ("start", "stop"):
+        want[f][[0, i]] = en[f][[i, 0]]
+    oracle.get_penalty(ek, want, eo, tar)
+    _get_penalty(g.kmers, nodes, g.record_offsets, tar)
+    assert _resident_stats()[1] == hits, "permuted node ranges were taken for the exported arrays"
+    assert np.array_equal(nodes, want)
+    _get_penalty(g.kmers, g.nodes, g.record_offsets, tar)                    # the exported arrays themselves: resident
+    assert _resident_stats()[1] == hits + 1
+    b = Batch.from_fasta(paths, n_cpu=2)
+    ix = b.build_index(15, 20, tar)
+    K, N, E = ix.export()
+    assert np.any(N["penalty"] != 0) and ix.checksums() == host_checksums(K, N, E)
+    N2 = N.copy()
+    N2["penalty"][[0, 1]] = N2["penalty"][[1, 0]]
+    assert N["penalty"][0] == N["penalty"][1] or host_checksums(K, N2, E)[1] != ix.checksums()[1]
+
+
 def test_resident_index_serves_get_penalty_and_filter_kmers(tmp_path, monkeypatch):
     """The index of the last build stays in HBM; get_penalty / filter_kmers use it instead of uploading the caller's arrays
     when -- and only when -- those still are the exported ones (host checksums); the size phase of filter_kmers keeps its

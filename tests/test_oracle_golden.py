@@ -160,3 +160,42 @@ print("SAN_OK")
     out = subprocess.run([sys.executable, "-c", script, str(root), str(tmp_path)], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "SAN_OK" in out.stdout, out.stderr[-3000:]
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
+
+
+def test_checksums_change_when_any_field_moves_between_elements():
+    """seqwin_amd.device.host_checksums (= csrc/device.hpp ck_kmer / ck_node / ck_edge, what the full-size tests pin the 75 Gbp
+    arrays with): EVERY field of a node / edge enters with the element's index, the penalty by bit pattern -- swapping two nodes'
+    counts, starts, stops or penalties, or two edges' seconds or weights, changes the sum (until r05 those
+    terms were index-free sums, so the full-size arrays were pinned only up to permutation in them).  Whole rows are what the
+    reference's own tests compare (tests/smoke/test_graph.py:281-291).  The shares of slices still add up modulo 2^64."""
+    from seqwin_amd.device import host_checksums
+    paths = sorted((GOLDEN / "synth").glob("pan_*.fa"))
+    k, n, e, ro, _ = oracle.build(paths, 15, 20)
+    oracle.get_penalty(k, n, ro, [i % 2 == 0 for i in range(len(paths))])
+    base = host_checksums(k, n, e)
+    differing = lambda arr, f: next((i, j) for i in range(len(arr)) for j in range(i + 1, min(i + 50, len(arr))) if arr[f][i] != arr[f][j])
+    for field in ("hash", "start", "stop", "n_tar", "n_neg", "penalty"):
+        i, j = differing(n, field)
+        m = n.copy()
+        m[field][[i, j]] = m[field][[j, i]]
+        got = host_checksums(k, m, e)
+        assert got[1] != base[1] and got[0] == base[0] and got[2] == base[2], field
+    for field in ("first", "second", "weight"):
+        i, j = differing(e, field)
+        m = e.copy()
+        m[field][[i, j]] = m[field][[j, i]]
+        assert host_checksums(k, n, m)[2] != base[2], field
+    m = k.copy()
+    m[[3, 4]] = m[[4, 3]]
+    assert host_checksums(m, n, e)[0] != base[0]
+    # the penalty enters by bit pattern: -0.0 is not 0.0
+    m = n.copy()
+    z = int(np.flatnonzero(m["penalty"] == 0.0)[0]) if np.any(m["penalty"] == 0.0) else 0
+    m["penalty"][z] = 0.0
+    b0 = host_checksums(k, m, e)[1]
+    m["penalty"][z] = -0.0
+    assert host_checksums(k, m, e)[1] != b0
+    # shares of slices add up
+    ck, cn, ce = len(k) // 3, len(n) // 2, len(e) // 4
+    parts = [host_checksums(k[:ck], n[:cn], e[:ce]), host_checksums(k[ck:], n[cn:], e[ce:], ck, cn, ce)]
+    assert tuple(sum(p[i] for p in parts) % 2**64 for i in range(3)) == base
