@@ -340,13 +340,15 @@ def cpu_baseline_and_parity(batch, k, w, n_genomes_sample, is_targets):
 
 def golden_checksums(workload, k, w):
     """(entry, "reference" | "self"): the reference-derived full-size values where they exist, else the HIP path's own."""
+    from seqwin_amd.device import CHECKSUM_SCHEME
     key = f"{workload}/k{k}/w{w}"
     for path, src in ((GOLDEN_REF, "reference"), (GOLDEN, "self")):
         try:
             e = json.loads(path.read_text()).get(key)
         except Exception:
             e = None
-        if e is not None and e.get("genomes", e.get("genomes_of_workload")) == e.get("genomes_of_workload"):
+        if e is not None and e.get("genomes", e.get("genomes_of_workload")) == e.get("genomes_of_workload") \
+                and e.get("checksum_scheme") == CHECKSUM_SCHEME:   # (entries of an older checksum definition do not count)
             return e, src
     return None, None
 
@@ -608,7 +610,8 @@ def main() -> None:
         if args.write_golden and world == 1 and not use_dist:
             # (only the file of the HIP path's own results; the reference-derived file is written by scripts/pin_fullsize_ref.py alone)
             allg = json.loads(GOLDEN.read_text()) if GOLDEN.exists() else {}
-            allg[f"{args.workload}/k{k}/w{w}"] = {"checksums": out["checksums"], "counts": out["counts"]}
+            from seqwin_amd.device import CHECKSUM_SCHEME
+            allg[f"{args.workload}/k{k}/w{w}"] = {"checksums": out["checksums"], "counts": out["counts"], "checksum_scheme": CHECKSUM_SCHEME}
             GOLDEN.write_text(json.dumps(allg, indent=1, sort_keys=True) + "\n")
         if gold is not None:
             # full-size parity: counts + position-dependent checksums of kmers / nodes (all fields but the f64) / edges against the

@@ -114,7 +114,7 @@ def main():
 
     import oracle
     from bench import SEED, WORKLOADS, write_fasta_fast
-    from seqwin_amd.device import Batch, set_device
+    from seqwin_amd.device import CHECKSUM_SCHEME, Batch, set_device
 
     ref = oracle.load_ref()
     if ref is None:
@@ -192,6 +192,7 @@ def main():
         result["counts"] = {"kmers": int(len(rk)), "nodes": int(len(rn)), "edges": int(len(re_))}
         result["checksums"] = [f"{s:016x}" for s in sums]
         result["checksums_from"] = "the compiled reference's arrays (numpy, seqwin_amd.device.host_checksums)"
+        result["checksum_scheme"] = CHECKSUM_SCHEME
         result["weight_sum"] = int(re_["weight"].sum(dtype=np.uint64))
         result["n_tar_sum"] = int(rn["n_tar"].sum(dtype=np.uint64))
         result["n_neg_sum"] = int(rn["n_neg"].sum(dtype=np.uint64))

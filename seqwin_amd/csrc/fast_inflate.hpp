@@ -189,8 +189,13 @@ inline const Tables &fixed_tables()
 // One DEFLATE stream: br at its first bit; out_begin..out_cap the output buffer, `out` the write position (history = [out_begin, out)).
 inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, uint8_t *out_cap, Tables &T)
 {
+    // Every refill outside the fast loop is followed by an overrun() test before the next one: a refill moves `in` by at most 7
+    // bytes and leaves >= 56 bits, so "not overrun" means in <= in_end + 7 and the NEXT refill's 8-byte load ends at or before
+    // in_end + 15 < in_end + IN_PAD (the block header and the code-length-code loop refilled without that test, and a
+    // stream truncated inside a dynamic header read up to 6 bytes behind the pad).
     for (;;) {
         br.refill();
+        if (br.overrun()) return BAD;
         const unsigned final_block = br.peek(1), type = (br.peek(3) >> 1);
         br.drop(3);
         const Tables *tp = &T;
@@ -219,11 +224,16 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
             static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
             uint8_t cl[19] = {0};
             br.refill();
-            for (unsigned i = 0; i < hclen; ++i) {
-                if (br.cnt < 3) br.refill();
+            if (br.overrun()) return BAD;
+            for (unsigned i = 0; i < hclen; ++i) {   // (19 x 3 = 57 bits: at most one more refill)
+                if (br.cnt < 3) {
+                    br.refill();
+                    if (br.overrun()) return BAD;
+                }
                 cl[order[i]] = (uint8_t)br.peek(3);
                 br.drop(3);
             }
+            if (br.overrun()) return BAD;   // (the header's last bits were padding: truncated)
             uint32_t clt[128 + 8];
             if (!build_table(cl, 19, 7, clt, 128, [](unsigned s) { return (uint32_t)s << 16; }, false)) return BAD;
             uint8_t lens[MAX_LL_SYMS + MAX_D_SYMS];

@@ -134,9 +134,36 @@ bool slurp_gz_fast(const std::string &path, RawBuf &buf)
     // reservation trusts it only up to 8 x the compressed size (FASTA deflates 3-5 x); a stream that really expands more finds
     // its room by doubling (8 attempts: 2 048 x, above DEFLATE's 1 032 x)
     size_t cap = std::min<size_t>(std::max<size_t>((size_t)isize, raw.len), raw.len * 8 + 4096) + 64;
+    // BGZF (bgzip: many members, each with its block size in a 'BC' extra subfield; the last one is empty, so its ISIZE says 0):
+    // the members' ISIZEs are summed by hopping from block to block -- the exact size, one attempt (sized from the
+    // last member alone such a file was inflated three or four times over)
+    {
+        size_t off = 0, total = 0;
+        bool bgzf = raw.len >= 28;
+        while (bgzf && off < raw.len) {
+            if (raw.len - off < 18 || in[off] != 0x1f || in[off + 1] != 0x8b || in[off + 2] != 8 || !(in[off + 3] & 4)) { bgzf = false; break; }
+            const size_t xlen = in[off + 10] | (in[off + 11] << 8);
+            if (raw.len - off < 12 + xlen + 8) { bgzf = false; break; }
+            size_t bsize = 0;
+            for (size_t x = off + 12, xe = off + 12 + xlen; x + 4 <= xe;) {
+                const size_t slen = in[x + 2] | (in[x + 3] << 8);
+                if (in[x] == 'B' && in[x + 1] == 'C' && slen == 2 && x + 6 <= xe) bsize = (size_t)(in[x + 4] | (in[x + 5] << 8)) + 1;
+                x += 4 + slen;
+            }
+            if (bsize < 12 + xlen + 8 || bsize > raw.len - off) { bgzf = false; break; }
+            const uint8_t *t = in + off + bsize - 4;
+            total += (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+            off += bsize;
+        }
+        if (bgzf && total <= raw.len * 1040 + 4096) cap = total + 64;   // (DEFLATE expands at most 1 032 x: a larger claim is a lie)
+    }
     for (int attempt = 0; attempt < 8; ++attempt) {
         buf.len = 0;
-        buf.reserve(cap);
+        try {
+            buf.reserve(cap);
+        } catch (...) {
+            return false;   // (a stream that claims more room than the host has: the gzread loop grows with the REAL output and raises what it raises)
+        }
         size_t got = 0;
         const finf::Result r = finf::gunzip_members(in, raw.len, (uint8_t *)buf.p, cap, &got, tables);
         if (r == finf::OK) {
@@ -693,7 +720,7 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
     // with four, gpurun_out/r5aa); on an unrestricted host that is no cap at all.
     // SEQWIN_AMD_INGEST_WORKERS_MAX overrides it (scaling tables).  The result does not depend on the worker count.
     {
-        size_t cap = 2 * usable_cpus();
+        size_t cap = std::min<size_t>(2 * usable_cpus(), 128);   // (128: an absolute ceiling until a host without a quota has been measured -- ADVICE r5)
         if (const char *e = getenv("SEQWIN_AMD_INGEST_WORKERS_MAX")) cap = (size_t)std::max(1, atoi(e));
         n_workers = std::min(n_workers, std::max<size_t>(cap, 1));
     }

@@ -202,6 +202,7 @@ def _mix64(x: np.ndarray) -> np.ndarray:
     return x
 
 
+CHECKSUM_SCHEME = 2   # r06: every field carries the element index (1: kmers, nodes.hash and edges.first only)
 _K1, _K2, _K3, _K4 = (np.uint64(0xA0761D6478BD642F), np.uint64(0xE7037ED1A0B428DB), np.uint64(0x8EBC6AF09C88C6E3),
                       np.uint64(0x589965CC75374CC3))
 

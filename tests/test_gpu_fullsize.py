@@ -20,7 +20,7 @@ import pytest
 import oracle
 from conftest import GOLDEN, ROOT, assert_graph_equal
 from seqwin_amd import KmerGraph, _get_penalty
-from seqwin_amd.device import Batch, host_checksums
+from seqwin_amd.device import CHECKSUM_SCHEME, Batch, host_checksums
 
 sys.path.insert(0, str(ROOT))
 from bench import SEED, WORKLOADS, write_fasta_sample  # noqa: E402
@@ -36,6 +36,7 @@ def _full_size_golden(key):
     if key in ref:
         e = ref[key]
         assert e["equal"] and e["genomes"] == e["genomes_of_workload"] and all(e["hip_vs_reference_elementwise"].values())
+        assert e.get("checksum_scheme") == CHECKSUM_SCHEME, "tests/golden/bench_checksums_ref.json predates the checksum definition"
         return e, "reference"
     return json.loads((GOLDEN / "bench_checksums.json").read_text())[key], "self"
 

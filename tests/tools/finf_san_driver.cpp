@@ -143,6 +143,42 @@ int main(int argc, char **argv)
         }
         printf("crc32: 400 spans equal to zlib's (folded form %s)\n", sw::finf::crc_fold_state() == 1 ? "in use" : "not in use");
     }
+    // Streams that END inside a dynamic block's header (the header loops refilled without an overrun test and read
+    // behind IN_PAD): 0-8 empty fixed blocks in front (every bit alignment), then BTYPE=2 with HCLEN=19 and j of the 19 code-length
+    // codes present, cut there -- and every such stream cut again at each earlier byte.  Exact-size input allocations.
+    {
+        long n_hdr = 0;
+        for (int nf = 0; nf < 9 * 4; ++nf)
+            for (int j = 0; j <= 19; ++j)
+                for (int fill = 0; fill < 2; ++fill) {
+                    const int nfixed = nf % 9, nlit = nf / 9;   // nlit fixed blocks of one 9-bit literal (19 bits each: odd alignments too)
+                    std::vector<uint8_t> gz = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+                    uint64_t acc = 0;
+                    unsigned nb = 0;
+                    auto put = [&](uint32_t v, unsigned n) {
+                        acc |= (uint64_t)v << nb;
+                        nb += n;
+                        while (nb >= 8) { gz.push_back((uint8_t)acc); acc >>= 8; nb -= 8; }
+                    };
+                    for (int b = 0; b < nfixed; ++b) { put(0, 1); put(1, 2); put(0, 7); }   // BFINAL=0, fixed, end-of-block
+                    for (int b = 0; b < nlit; ++b) { put(0, 1); put(1, 2); put(0x13, 9); put(0, 7); }   // ... with literal 144 (code 110010000, MSB first)
+                    put(0, 1); put(2, 2); put(fill ? 29 : 0, 5); put(fill ? 29 : 0, 5); put(15, 4);
+                    for (int c = 0; c < j; ++c) put(fill ? 7 : 1, 3);
+                    if (nb) gz.push_back((uint8_t)(acc | (fill ? 0xFFu << nb : 0)));
+                    for (size_t len = gz.size(); len >= 10; --len) {
+                        std::vector<uint8_t> in(len + sw::finf::IN_PAD, 0);
+                        memcpy(in.data(), gz.data(), len);
+                        std::vector<uint8_t> out(64);
+                        size_t got = 0;
+                        if (sw::finf::gunzip_members(in.data(), len, out.data(), out.size(), &got, T) == sw::finf::OK) {
+                            fprintf(stderr, "a stream cut inside a dynamic header was accepted (nfixed %d, j %d, len %zu)\n", nfixed, j, len);
+                            return 1;
+                        }
+                        ++n_hdr;
+                    }
+                }
+        printf("%ld streams ending inside a dynamic block header: all declined, no access outside the buffers\n", n_hdr);
+    }
     for (long c = 0; c < cases; ++c) {
         const int kind = (int)(rnd() % 6);
         static const size_t sizes[] = {0, 1, 2, 17, 300, 5000, 70000, 300000};
