@@ -572,13 +572,16 @@ PinnedRing &pinned_ring(int device)
 // mallocs and the sink takes the ring for that assembly.  SEQWIN_AMD_PINNED_POOL_MB=0: the ring for everything (r01-r05a).
 struct PinnedArena : WordArena {
     static constexpr size_t GRAIN = 256u << 10;
-    size_t SLAB = 32u << 20;   // (SEQWIN_AMD_PINNED_SLAB_MB: tests make blocks outgrow it)
+    std::atomic<size_t> SLAB{32u << 20};   // (SEQWIN_AMD_PINNED_SLAB_MB: tests make blocks outgrow it)
     std::mutex mu;        // free list, bump pointer, totals
     std::mutex grow_mu;   // one thread page-locks a new slab at a time (the others wait for it rather than lock more memory)
     std::vector<std::pair<uint64_t *, size_t>> free_blocks;   // (block, capacity in words)
     char *slab = nullptr;
     size_t slab_left = 0;
-    size_t total_bytes = 0, limit_bytes = (size_t)1024 << 20;
+    size_t total_bytes = 0;
+    // (atomic: every ingest re-reads the settings while the sinks of other worker threads consult them -- found by ThreadSanitizer on
+    //  the mock runtime, tests/tools/hip_mock, r06)
+    std::atomic<size_t> limit_bytes{(size_t)1024 << 20};
     // The parsers are plain threads whose current device is 0: a slab is page-locked from the device of a sink that is at work (the
     // memory is portable, any of them will do) -- never a context on a GPU this process does not use.
     std::atomic<int> grow_device{0};
@@ -624,7 +627,7 @@ struct PinnedArena : WordArena {
         // get nullptr (malloc + the ring for that assembly, as before r05) and find blocks at their next file.
         std::unique_lock<std::mutex> grow(grow_mu, std::try_to_lock);
         if (!grow.owns_lock()) return nullptr;
-        const size_t want = std::max(bytes, SLAB);
+        const size_t want = std::max(bytes, SLAB.load());
         {
             std::lock_guard<std::mutex> lock(mu);
             if (uint64_t *p = take(min_words, bytes, cap_words)) return p;   // (another thread has grown the pool meanwhile)
