@@ -121,6 +121,10 @@ void sw_release_resident(void);
  * the life of the process: the page-locked rings of the up- and download (32 + 64 MiB per device) and the page-locked blocks the
  * streaming ingest packs into (grown on demand to at most SEQWIN_AMD_PINNED_POOL_MB, default 1024; 0 disables them). */
 void sw_pool_trim(void);
+/* out[3] = { 1 if SEQWIN_AMD_POOL_DEBUG is on (every release waits for the device and poisons the block, every reuse waits and
+ * checks the poison: a soak mode for the multi-device path), blocks found written after their release, host-side hand-overs of
+ * a block between threads / streams so far (0 in single-stream builds) } */
+void sw_pool_debug_stats(uint64_t *out);
 /* out[3] = { occurrences of the resident index (0: none), sw_get_penalty calls served from it, sw_filter_kmers calls served from it } */
 void sw_resident_stats(uint64_t *out);
 

@@ -106,6 +106,56 @@ void alloc_join(hipStream_t side)
 }
 
 void release_resident_if_idle();   // (below: drops the parked index of the last sw_build unless a call is using it)
+
+// ---- SEQWIN_AMD_POOL_DEBUG=1 (r06) ---------------------------------------------------------------------
+// A debugging mode of the pool for soak runs of the multi-device path: EVERY release waits on the host for the whole device,
+// fills the block with a poison pattern and caches it; EVERY reuse of a cached block waits for the device again and checks that
+// the poison is intact.  A block written after its release -- by a kernel or copy that was still queued on some stream, of any
+// thread -- is reported (stderr + the log callback, counted in sw_pool_debug_violations) with the first damaged offset, and the
+// allocation fails.  Stream-order bugs cannot survive the device-wide waits, so: a fault that shows only WITHOUT this mode
+// convicts the hand-over; a violation WITH it names a kernel that writes outside its buffers or after its stream was waited for.
+namespace {
+constexpr uint32_t POOL_POISON = 0xA5C3A5C3u;
+std::atomic<uint64_t> g_pool_debug_violations{0}, g_pool_handover_syncs{0};
+bool pool_debug()
+{
+    static const bool on = [] { const char *e = getenv("SEQWIN_AMD_POOL_DEBUG"); return e && atoi(e) != 0; }();
+    return on;
+}
+__global__ void k_pool_check(const uint32_t *p, uint64_t n_words, uint32_t poison, unsigned long long *first_bad)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride)
+        if (p[i] != poison) atomicMin(first_bad, (unsigned long long)i);
+}
+void pool_debug_poison(void *ptr, size_t sz)
+{
+    (void)hipDeviceSynchronize();
+    if (hipMemsetD32Async((hipDeviceptr_t)ptr, (int)POOL_POISON, sz / 4, nullptr) != hipSuccess) (void)hipGetLastError();
+    (void)hipStreamSynchronize(nullptr);
+}
+void pool_debug_check(void *ptr, size_t sz)   // raises if the block was written after pool_debug_poison
+{
+    (void)hipDeviceSynchronize();
+    unsigned long long *d_bad = nullptr, bad = ~0ull;
+    if (hipMalloc((void **)&d_bad, 8) != hipSuccess) { (void)hipGetLastError(); return; }
+    (void)hipMemcpy(d_bad, &bad, 8, hipMemcpyHostToDevice);
+    const uint64_t n_words = sz / 4;
+    hipLaunchKernelGGL(k_pool_check, dim3((unsigned)std::min<uint64_t>((n_words + 255) / 256, 4096)), dim3(256), 0, nullptr, (const uint32_t *)ptr,
+                       n_words, POOL_POISON, d_bad);
+    (void)hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    if (bad != ~0ull) {
+        ++g_pool_debug_violations;
+        fprintf(stderr, "[seqwin_amd] POOL_DEBUG: block %p of %zu bytes was written AFTER its release (first damaged byte offset %llu)\n", ptr, sz,
+                bad * 4);
+        raise(SW_ERR_RUNTIME, "POOL_DEBUG: a cached device block of %zu bytes was written after its release (offset %llu)", sz, bad * 4);
+    }
+}
+}  // namespace
+uint64_t pool_debug_violations() { return g_pool_debug_violations.load(); }
+uint64_t pool_handover_syncs() { return g_pool_handover_syncs.load(); }
+
 void *dev_alloc(size_t bytes)
 {
     Pool &p = pool();
@@ -118,10 +168,23 @@ void *dev_alloc(size_t bytes)
         auto it = p.free_blocks.lower_bound(std::make_pair(dev, sz));
         if (it != p.free_blocks.end() && it->first.first == dev && it->first.second <= sz + sz / 4 + (1u << 20)) {
             FreeBlock blk = std::move(it->second);
+            const size_t blk_size = it->first.second;
             p.live[blk.ptr] = it->first;
             p.free_blocks.erase(it);
             bool ok = true;
+            if (pool_debug()) {   // (the block was poisoned behind a device-wide wait when it was released: no fence to carry over)
+                for (auto &se : blk.side) p.spare_events[dev].push_back(se.second);
+                lock.unlock();
+                try {
+                    pool_debug_check(blk.ptr, blk_size);
+                } catch (...) {
+                    dev_free(blk.ptr);
+                    throw;
+                }
+                return blk.ptr;
+            }
             if (blk.main != T) {
+                ++g_pool_handover_syncs;   // (host-side hand-overs of this process: sw_pool_debug_stats; zero in single-stream builds)
                 // Released under ANOTHER main stream -- another worker thread of a SEQWIN_DEVICES build, whose queued kernels may
                 // still read the block.  Until r05 only T was made to wait for them; but the new owner also touches the block from
                 // streams that are not T (the upload ring's DMA into a fresh d_packed, synchronous copies on the NULL stream), and
@@ -132,9 +195,16 @@ void *dev_alloc(size_t bytes)
                 hipEvent_t e = take_event(p, dev);
                 ok = e && hipEventRecord(e, blk.main) == hipSuccess;
                 lock.unlock();
+#ifdef SW_POOL_TEST_R04_HANDOVER   // (tests/tools/hip_mock: the hand-over as it was until r05 -- only T waits, on the device -- must
+                                   //  show up as a data race in the choreography harness; never defined in a library build)
+                if (ok) ok = hipStreamWaitEvent(T, e, 0) == hipSuccess;
+                for (auto &se : blk.side)
+                    if (ok && se.first != T) ok = hipStreamWaitEvent(T, se.second, 0) == hipSuccess;
+#else
                 if (ok) ok = hipEventSynchronize(e) == hipSuccess;
                 for (auto &se : blk.side)
                     if (ok) ok = hipEventSynchronize(se.second) == hipSuccess;
+#endif
                 if (!ok) {
                     (void)hipGetLastError();
                     (void)hipDeviceSynchronize();
@@ -210,6 +280,11 @@ void dev_free(void *ptr)
         lock.unlock();
         (void)hipFree(ptr);
         return;
+    }
+    if (pool_debug()) {
+        lock.unlock();
+        pool_debug_poison(ptr, key.second);
+        lock.lock();
     }
     p.free_blocks.emplace(key, std::move(blk));
 }
@@ -2080,6 +2155,12 @@ void sw_resident_stats(uint64_t *out)
 }
 
 void sw_pool_trim(void) { dev_pool_trim(); }
+void sw_pool_debug_stats(uint64_t *out)
+{
+    out[0] = pool_debug() ? 1 : 0;
+    out[1] = pool_debug_violations();
+    out[2] = pool_handover_syncs();
+}
 
 void sw_release_resident(void)
 {

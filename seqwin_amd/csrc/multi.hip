@@ -343,7 +343,9 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
             me.cnt.assign(P, 0);
             ck(sw_occ_partition(occ, nb.data(), nb.size(), rec_base[p], rows.p(), nullptr, me.cnt.data(), st));
             me.rows = rows.a.p;
+#ifndef SW_MULTI_TEST_SKIP_SYNC   // (tests/tools/hip_mock builds one variant without it: the harness must notice)
             SW_HIP(hipStreamSynchronize(st));
+#endif
             meet.arrive();                                   // (C) every source's rows and counts are ready
             // ---- 2: this device's hash range: pull the rows, build the slice ------------------------------------------------
             uint64_t n_mine = 0, kmer_base = 0;

@@ -28,6 +28,7 @@
 #include <deque>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <thread>
@@ -148,11 +149,39 @@ constexpr size_t TOTAL_MEM = 288ull << 30;
 }  // namespace
 
 // ---- events ---------------------------------------------------------------------------------------------------------
+// Every hipEventRecord makes a record of its own; the event points at its latest one.  A wait / synchronize / query refers to the
+// record that was the latest WHEN IT WAS ISSUED, as in the real runtime -- an event that goes back to a pool and is recorded again
+// on another stream must not release an earlier waiter.
+struct EventRecord {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    void complete()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        done = true;
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return done; });
+    }
+    bool is_done()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        return done;
+    }
+};
 struct ihipEvent_t {
     int device = 0;
     std::mutex mu;
-    std::condition_variable cv;
-    uint64_t recorded = 0, completed = 0;
+    std::shared_ptr<EventRecord> last;   // null: never recorded (complete)
+    std::shared_ptr<EventRecord> latest()
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        return last;
+    }
 };
 
 extern "C" {
@@ -397,12 +426,7 @@ hipError_t hipEventCreate(hipEvent_t *e) { return hipEventCreateWithFlags(e, 0);
 hipError_t hipEventDestroy(hipEvent_t e)
 {
     if (!e) return fail(hipErrorInvalidHandle);
-    // (a marker of this event may still sit in a queue: wait for it, as the runtime keeps the event alive until then)
-    {
-        std::unique_lock<std::mutex> lock(e->mu);
-        e->cv.wait(lock, [&] { return e->completed >= e->recorded; });
-    }
-    delete e;
+    delete e;   // (queued markers and waiters hold their record by shared_ptr)
     return hipSuccess;
 }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
@@ -410,31 +434,25 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
     if (!e) return fail(hipErrorInvalidHandle);
     ihipStream_t *st = resolve(s);
     if (st->device != e->device) return fail(hipErrorInvalidHandle);   // (as the real runtime: ADVICE r4)
-    uint64_t gen;
+    auto rec = std::make_shared<EventRecord>();
     {
         std::lock_guard<std::mutex> lock(e->mu);
-        gen = ++e->recorded;
+        e->last = rec;
     }
-    st->push([e, gen] {
-        std::lock_guard<std::mutex> lock(e->mu);
-        if (e->completed < gen) e->completed = gen;
-        e->cv.notify_all();
-    });
+    st->push([rec] { rec->complete(); });
     return hipSuccess;
 }
 hipError_t hipEventSynchronize(hipEvent_t e)
 {
     if (!e) return fail(hipErrorInvalidHandle);
-    std::unique_lock<std::mutex> lock(e->mu);
-    const uint64_t gen = e->recorded;
-    e->cv.wait(lock, [&] { return e->completed >= gen; });
+    if (auto rec = e->latest()) rec->wait();
     return hipSuccess;
 }
 hipError_t hipEventQuery(hipEvent_t e)
 {
     if (!e) return fail(hipErrorInvalidHandle);
-    std::lock_guard<std::mutex> lock(e->mu);
-    return e->completed >= e->recorded ? hipSuccess : hipErrorNotReady;
+    auto rec = e->latest();
+    return (!rec || rec->is_done()) ? hipSuccess : hipErrorNotReady;
 }
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 {
@@ -445,15 +463,7 @@ hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
 {
     if (!e) return fail(hipErrorInvalidHandle);
-    uint64_t gen;
-    {
-        std::lock_guard<std::mutex> lock(e->mu);
-        gen = e->recorded;
-    }
-    resolve(s)->push([e, gen] {
-        std::unique_lock<std::mutex> lock(e->mu);
-        e->cv.wait(lock, [&] { return e->completed >= gen; });
-    });
+    if (auto rec = e->latest()) resolve(s)->push([rec] { rec->wait(); });
     return hipSuccess;
 }
 
