@@ -353,6 +353,74 @@ def golden_checksums(workload, k, w):
     return None, None
 
 
+def preflight(world, rank, local_rank, dev):
+    """Before anything is timed at N > 1: the N ranks must drive N DISTINCT GPUs, every ordered pair of them
+    must have peer access (a pair without it would be staged through host memory: a different, slower experiment), and the
+    collectives must deliver messages of the size the exchanges really send (dist.check_collectives: one element more than a
+    256 MiB round, verified element for element -- RCCL 2.26 at world size 1 silently dropped half of such a message, NOTES.md r03).
+    Returns (info, reason): reason is None, or why this run must not be timed -- every rank gets the same answer.
+    SEQWIN_BENCH_ALLOW_SHARED_GPU=1 / SEQWIN_BENCH_ALLOW_STAGED=1 lift the first two refusals (rehearsals on one card);
+    SEQWIN_BENCH_PREFLIGHT_FORCE=distinct|peer|collectives makes that probe fail (tests)."""
+    import torch
+    import torch.distributed as dist
+
+    from seqwin_amd import dist as swdist
+    force = os.environ.get("SEQWIN_BENCH_PREFLIGHT_FORCE", "")
+    try:
+        prop = torch.cuda.get_device_properties(local_rank)
+        me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": prop.name,
+              "uuid": str(getattr(prop, "uuid", "")), "pci_bus_id": getattr(prop, "pci_bus_id", None), "host": os.uname().nodename,
+              "pid": os.getpid(), "visible_devices": torch.cuda.device_count()}
+    except Exception as e:
+        me = {"rank": rank, "error": str(e)}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+    distinct = len({(r.get("host"), r.get("uuid") or r.get("pci_bus_id") or r.get("device")) for r in ranks})
+    if force == "distinct":
+        distinct = 1
+    info = {"ranks": ranks, "distinct_gpus": distinct}
+    if world == 1:
+        return info, None
+    # peer access from this rank's device to every other rank's (where this process can see it)
+    mine = []
+    for r in ranks:
+        if r.get("rank") == rank:
+            continue
+        d, ok = r.get("device"), None
+        try:
+            if r.get("host") == me.get("host") and isinstance(d, int) and d < torch.cuda.device_count() and d != torch.cuda.current_device():
+                ok = bool(torch.cuda.can_device_access_peer(torch.cuda.current_device(), d))
+        except Exception:
+            ok = None
+        mine.append(ok)
+    if force == "peer":
+        mine = [False] * len(mine)
+    allp = [None] * world
+    dist.all_gather_object(allp, mine)
+    flat = [x for row in allp for x in row]
+    info["peer_access"] = {"ordered_pairs": len(flat), "direct": sum(1 for x in flat if x is True), "not_direct": sum(1 for x in flat if x is False),
+                           "unknown": sum(1 for x in flat if x is None)}
+    reason = None
+    if distinct != world and os.environ.get("SEQWIN_BENCH_ALLOW_SHARED_GPU") != "1":
+        reason = (f"{world} ranks drive {distinct} distinct GPU(s): a scaling point needs one GPU per rank "
+                  "(SEQWIN_BENCH_ALLOW_SHARED_GPU=1 times it anyway, as a rehearsal)")
+    elif info["peer_access"]["not_direct"] and os.environ.get("SEQWIN_BENCH_ALLOW_STAGED") != "1":
+        reason = (f"{info['peer_access']['not_direct']} of {len(flat)} ordered GPU pairs have no peer access: the exchanges would be staged "
+                  "through host memory (SEQWIN_BENCH_ALLOW_STAGED=1 times that anyway)")
+    else:
+        try:
+            if force == "collectives":
+                raise RuntimeError("collective self-check failed: forced by SEQWIN_BENCH_PREFLIGHT_FORCE")
+            swdist.check_collectives(dev)
+            info["collectives_checked"] = f"per-peer messages of one element more than a round of {swdist._MSG_LIMIT >> 20} MiB" \
+                if dist.get_backend() == "nccl" else "64 MiB messages (not RCCL)"
+        except RuntimeError as e:
+            reason = str(e)
+    return info, reason
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -434,6 +502,17 @@ def main() -> None:
         def step():
             return batch.build_index(k, w, my_targets)
 
+    pre_info, refused = preflight(world, rank, local_rank, engine.device if use_dist and world > 1 else torch.device("cuda", local_rank))
+    if refused is not None:
+        if rank == 0:
+            sys.stderr.write(f"bench.py: NOT TIMED -- {refused}\n")
+            os.write(real_stdout, (json.dumps({"metric": "Gbp/s minimizer-indexed", "value": None, "unit": "Gbp/s", "n_gpus": world,
+                                               "refused": refused, "preflight": pre_info}) + "\n").encode())
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        raise SystemExit(3)
+
     def fence():
         torch.cuda.synchronize()
         if world > 1:
@@ -488,18 +567,8 @@ def main() -> None:
                          collectives="issued" if (world > 1 or force_coll) else "skipped (one rank, SEQWIN_BENCH_FORCE_DIST)")
 
     # who ran: one entry per rank -- device index, UUID and PCI bus id of the GPU it drove -- gathered over the job's own process
-    # group, so that a SCALE record can show N ranks on N distinct GPUs over RCCL
-    try:
-        prop = torch.cuda.get_device_properties(local_rank)
-        me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": prop.name,
-              "uuid": str(getattr(prop, "uuid", "")), "pci_bus_id": getattr(prop, "pci_bus_id", None), "host": os.uname().nodename,
-              "pid": os.getpid()}
-    except Exception as e:
-        me = {"rank": rank, "error": str(e)}
-    ranks_info = [me]
-    if world > 1:
-        ranks_info = [None] * world
-        dist.all_gather_object(ranks_info, me)
+    # group by the pre-flight, so that a SCALE record can show N ranks on N distinct GPUs over RCCL
+    ranks_info = pre_info["ranks"]
 
     nk, nn, ne = ix.sizes()
     tm = ix.timings()
@@ -587,8 +656,8 @@ def main() -> None:
             dist_info = {}
         dist_info.update(world=world, backend=(dist.get_backend() if dist.is_initialized() else None),
                          process_group_size=(dist.get_world_size() if dist.is_initialized() else 1),
-                         distinct_gpus=len({(r.get("host"), r.get("uuid") or r.get("pci_bus_id") or r.get("device")) for r in ranks_info}),
-                         ranks=ranks_info)
+                         distinct_gpus=pre_info["distinct_gpus"], peer_access=pre_info.get("peer_access"),
+                         collectives_checked=pre_info.get("collectives_checked"), ranks=ranks_info)
         try:
             dist_info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:

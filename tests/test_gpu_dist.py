@@ -477,9 +477,44 @@ def test_bench_strong_scaling_reproduces_n1_checksums(workload, extra):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     import os
-    env = dict(os.environ, SEQWIN_BENCH_BACKEND="gloo")
+    env = dict(os.environ, SEQWIN_BENCH_BACKEND="gloo", SEQWIN_BENCH_ALLOW_SHARED_GPU="1")   # (two ranks on the one card: a rehearsal)
     two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", str(port)] + base + ["--gpus", "2"], env)
+    assert two["dist"]["distinct_gpus"] == 1 and two["dist"]["collectives_checked"]
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
     assert two["config"]["genomes"] == one["config"]["genomes"] and two["config"]["genomes_per_gpu"] * 2 == one["config"]["genomes"]
     assert two["counts"] == one["counts"] and two["checksums"] == one["checksums"]
+
+
+@pytest.mark.parametrize("force,allow,needle", [("", "", "distinct GPU"), ("peer", "SEQWIN_BENCH_ALLOW_SHARED_GPU", "no peer access"),
+                                                 ("collectives", "SEQWIN_BENCH_ALLOW_SHARED_GPU", "collective self-check failed")])
+def test_bench_preflight_refuses_to_time_a_run_that_is_not_a_scaling_point(force, allow, needle):
+    """bench.py --gpus N times nothing unless the N ranks drive N distinct GPUs, every ordered pair has peer access and the
+    collectives deliver messages of the real round size (the day a multi-GPU node appears, SCALE is one shot).
+    Each refusal is forced here on the one card: two ranks share it (refused unless allowed), then the peer probe and the
+    collective check are made to fail.  A refused run prints ONE JSON line with value null and the reason, and exits with 3."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SEQWIN_BENCH_BACKEND="gloo")
+    env.pop("SEQWIN_BENCH_ALLOW_SHARED_GPU", None)
+    if force:
+        env["SEQWIN_BENCH_PREFLIGHT_FORCE"] = force
+    if allow:
+        env[allow] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(root / "bench.py"), "--workload", "tiny", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--gpus", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (out.stdout[-2000:], out.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and needle in d["refused"] and d["n_gpus"] == 2 and len(d["preflight"]["ranks"]) == 2
+    assert "NOT TIMED" in out.stderr
