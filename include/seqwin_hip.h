@@ -301,6 +301,11 @@ int sw_index_merge(const void *occ_rows_dev, uint64_t n_occ, const void *edge_ro
 typedef struct sw_occ sw_occ; /* device-resident (out_hash, pos|record) stream of one shard in (record_idx, pos) order */
 int sw_occ_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *stream, sw_occ **out);
 int sw_occ_size(const sw_occ *o, uint64_t *n, double *sketch_ms);
+/* A shard's tuple stream straight from its FASTA files, the files streamed through HBM in chunks of ~chunk_bp bases (0: one
+ * chunk) -- low_memory inside a multi-device build (build.cpp:264-325 keeps the peak down by a second pass; here only 16 B per
+ * minimizer of a finished chunk stay resident).  *batch_out holds the shard's record tables only (no packed bases). */
+int sw_occ_sketch_paths(const char *const *assembly_paths, size_t n_assemblies, uint64_t kmerlen, uint64_t windowsize, uint64_t n_cpu,
+                        uint64_t chunk_bp, void *stream, sw_batch **batch_out, sw_occ **occ_out);
 void sw_occ_free(sw_occ *o);
 /* Stable partition by owner = number of ascending bounds <= out_hash.  DEVICE outputs: rows[n][2] =
  * {out_hash, pos | (record_idx + rec_offset) << 32} grouped by owner, perm[n] (u32: original index of row j; may be

@@ -15,7 +15,23 @@
 namespace sw {
 
 static thread_local std::string g_last_error;
-void set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
+static thread_local uint64_t g_last_occ_cap = 0;
+void set_last_error(const char *msg) { g_last_error = msg ? msg : ""; g_last_occ_cap = 0; }
+void note_occ_cap(uint64_t n) { g_last_occ_cap = n; }
+uint64_t last_occ_cap_n() { return g_last_occ_cap; }
+uint64_t occ_cap()
+{
+    const char *e = getenv("SEQWIN_AMD_OCC_CAP");   // (read per call: a handful of times per build)
+    const long long v = e ? atoll(e) : 0;
+    return v > 0 && (uint64_t)v < 0xFFFFFFFEull ? (uint64_t)v : 0xFFFFFFFEull;
+}
+void raise_occ_cap(uint64_t n, const char *what)
+{
+    char buf[256];
+    snprintf(buf, sizeof buf, "more than %s %s on one device (%llu): use more devices (SEQWIN_DEVICES)", occ_cap() == 0xFFFFFFFEull ? "2^32-2" : "SEQWIN_AMD_OCC_CAP",
+             what, (unsigned long long)n);
+    throw OccCapError(n, buf);
+}
 
 // ---- caching allocator, stream-aware -----------------------------------------------------------------
 // Blocks go back to the pool while work that uses them may still be queued, so every cached block remembers the stream
@@ -1467,6 +1483,100 @@ int sw_occ_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void
     });
 }
 
+namespace sw {
+namespace {
+__global__ void k_rebase_records(uint64_t *kmer, uint64_t n, uint64_t rec_base)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) kmer[i] += rec_base << 32;
+}
+}  // namespace
+}  // namespace sw
+
+static size_t chunk_end(const char *const *paths, size_t n_paths, size_t a0, uint64_t chunk_bp);
+int sw_occ_sketch_paths(const char *const *assembly_paths, size_t n_assemblies, uint64_t kmerlen, uint64_t windowsize, uint64_t n_cpu,
+                        uint64_t chunk_bp, void *stream, sw_batch **batch_out, sw_occ **occ_out)
+{
+    return guarded([&] {
+        check_kw(kmerlen, windowsize);
+        require_device();
+        hipStream_t st = (hipStream_t)stream;
+        std::unique_ptr<sw_batch> tables(new sw_batch);   // record tables only: no packed bases stay behind
+        SW_HIP(hipGetDevice(&tables->device));
+        HostBatch &H = tables->host;
+        H.record_offsets.assign(1, 0);
+        std::vector<OrderedOcc> chunks;
+        std::vector<uint32_t> rec_asm;
+        uint64_t n_records = 0, n_total = 0;
+        float sk_ms_total = 0.f;
+        size_t a0 = 0;
+        while (a0 < n_assemblies) {
+            const size_t a1 = chunk_bp ? chunk_end(assembly_paths, n_assemblies, a0, chunk_bp) : n_assemblies;
+            sw_batch b;
+            b.device = tables->device;
+            ingest_to_device(assembly_paths + a0, a1 - a0, n_cpu, b);
+            StreamScope scope(st);
+            Plan &plan = get_plan(b, kmerlen, windowsize);
+            SketchOut sk;
+            float sk_ms = 0.f;
+            run_sketch(b, plan, st, sk, &sk_ms);
+            sk_ms_total += sk_ms;
+            chunks.emplace_back();
+            OrderedOcc &c = chunks.back();
+            order_tuples(sk, plan, st, c);                       // exchange form: (out_hash, pos | record << 32), chunk-local records
+            if (c.n && n_records)
+                hipLaunchKernelGGL(k_rebase_records, dim3((unsigned)((c.n + 255) / 256)), dim3(256), 0, st, c.kmer.p, c.n, n_records);
+            SW_HIP(hipGetLastError());
+            SW_HIP(hipStreamSynchronize(st));                    // the chunk's batch, plan and stage go out of scope
+            n_total += c.n;
+            const HostBatch &h = b.host;
+            for (uint64_t a = 0; a < h.n_assemblies; ++a) {
+                const uint64_t nr = h.record_offsets[a + 1] - h.record_offsets[a];
+                if (n_records + nr > UINT32_MAX) raise(SW_ERR_RUNTIME, "Total number of FASTA records exceeds uint32 range");   // build.cpp:136-147
+                rec_asm.insert(rec_asm.end(), nr, (uint32_t)(a0 + a));
+                n_records += nr;
+                H.record_offsets.push_back((uint32_t)n_records);
+            }
+            H.ids_blob += h.ids_blob;
+            H.total_bp += h.total_bp;
+            a0 = a1;
+        }
+        H.n_assemblies = n_assemblies;
+        tables->n_records = n_records;
+        if (n_total > occ_cap()) raise_occ_cap(n_total, "minimizer occurrences");
+        StreamScope scope(st);
+        tables->d_rec_asm.alloc(n_records);
+        if (n_records) {
+            SW_HIP(hipMemcpyAsync(tables->d_rec_asm.p, rec_asm.data(), n_records * 4, hipMemcpyHostToDevice, st));
+            SW_HIP(hipStreamSynchronize(st));                    // (rec_asm is a local)
+        }
+        std::unique_ptr<sw_occ> o(new sw_occ);
+        o->last_stream = st;
+        o->batch = tables.get();
+        o->sketch_ms = sk_ms_total;
+        o->occ = new OrderedOcc;
+        if (chunks.size() == 1) {
+            *o->occ = std::move(chunks[0]);
+        } else {
+            OrderedOcc &out = *o->occ;
+            out.n = n_total;
+            out.hash.alloc(n_total);
+            out.kmer.alloc(n_total);
+            uint64_t at = 0;
+            for (OrderedOcc &c : chunks) {
+                if (c.n) {
+                    SW_HIP(hipMemcpyAsync(out.hash.p + at, c.hash.p, c.n * 8, hipMemcpyDeviceToDevice, st));
+                    SW_HIP(hipMemcpyAsync(out.kmer.p + at, c.kmer.p, c.n * 8, hipMemcpyDeviceToDevice, st));
+                }
+                at += c.n;
+                c = OrderedOcc();                                // (released under st: stream-ordered behind its copies)
+            }
+        }
+        *batch_out = tables.release();
+        *occ_out = o.release();
+    });
+}
+
 int sw_occ_size(const sw_occ *o, uint64_t *n, double *sketch_ms)
 {
     return guarded([&] {
@@ -1813,6 +1923,26 @@ int sw_sketch(const sw_batch *b, uint64_t kmerlen, uint64_t windowsize, void *st
 // stream through HBM in consecutive chunks -- ingest, upload, sketch and order one chunk, keep only its 24 B per
 // minimizer, release its packed bases / stage slots / host buffers -- and the index is built once from the concatenated
 // tuple stream.  That stream is exactly what the one-shot build sorts, so the result is identical by construction.
+// consecutive assemblies [a0, a1) of up to ~chunk_bp bases, estimated from the file sizes (gz: x4), at least one
+static size_t chunk_end(const char *const *paths, size_t n_paths, size_t a0, uint64_t chunk_bp)
+{
+    size_t a1 = a0;
+    uint64_t est = 0;
+    while (a1 < n_paths && (a1 == a0 || est < chunk_bp)) {
+        uint64_t sz = 0;
+        if (FILE *f = fopen(paths[a1], "rb")) {
+            if (fseek(f, 0, SEEK_END) == 0) { const long t = ftell(f); sz = t > 0 ? (uint64_t)t : 0; }
+            fclose(f);
+        }
+        const size_t len = strlen(paths[a1]);
+        if (len > 3 && !strcmp(paths[a1] + len - 3, ".gz")) sz *= 4;
+        if (a1 > a0 && est + sz > chunk_bp) break;
+        est += sz;
+        ++a1;
+    }
+    return a1;
+}
+
 static void build_chunked(const char *const *paths, size_t n_paths, uint64_t k, uint64_t w, uint64_t n_cpu, uint64_t chunk_bp,
                           GraphHost &g, double *ingest_ms, double *device_ms)
 {
@@ -1828,21 +1958,7 @@ static void build_chunked(const char *const *paths, size_t n_paths, uint64_t k, 
     uint64_t n_records = 0;
     size_t a0 = 0;
     while (a0 < n_paths) {
-        // consecutive assemblies up to ~chunk_bp bases, estimated from the file sizes (gz: x4), at least one
-        size_t a1 = a0;
-        uint64_t est = 0;
-        while (a1 < n_paths && (a1 == a0 || est < chunk_bp)) {
-            uint64_t sz = 0;
-            if (FILE *f = fopen(paths[a1], "rb")) {
-                if (fseek(f, 0, SEEK_END) == 0) { const long t = ftell(f); sz = t > 0 ? (uint64_t)t : 0; }
-                fclose(f);
-            }
-            const size_t len = strlen(paths[a1]);
-            if (len > 3 && !strcmp(paths[a1] + len - 3, ".gz")) sz *= 4;
-            if (a1 > a0 && est + sz > chunk_bp) break;
-            est += sz;
-            ++a1;
-        }
+        const size_t a1 = chunk_end(paths, n_paths, a0, chunk_bp);
         const auto t0 = now();
         sw_batch b;
         SW_HIP(hipGetDevice(&b.device));
@@ -1925,41 +2041,67 @@ int sw_build(const char *const *assembly_paths, size_t n_assemblies, uint64_t km
             }
         }
         const auto t0 = now();
-        const std::vector<int> devs = devices_from_env();
-        if (devs.size() > 1 && n_assemblies > 1) {
-            // one worker per listed device, the reference's partition of the assemblies, peer-to-peer exchanges (multi.hip)
-            g->g.multi.reset(new MultiGraph);
-            build_multi_device(assembly_paths, n_assemblies, kmerlen, windowsize, n_cpu, devs, *g->g.multi);
-            MultiGraph &m = *g->g.multi;
-            device_ms = ms(t0, now());
-            g->g.record_offsets = m.record_offsets;
-            g->g.ids_blob = m.ids_blob;
-            g->g.n_assemblies = m.n_assemblies;
-            g->g.total_bp = m.total_bp;
-            for (auto &sl : m.slices) {   // (sizes of the whole; the arrays stay per device until sw_graph_export)
-                g->g.ix.n_kmers += sl->n_kmers;
-                g->g.ix.n_nodes += sl->n_nodes;
-                g->g.ix.n_edges += sl->n_edges;
+        // r06: never fail where the reference succeeds (its indices are size_t, graph.hpp:28-41).  A build whose occurrences -- of the
+        // whole job on one device, of a shard, or the rows of a slice -- exceed what 32-bit indices address ends in OccCapError;
+        // the job is then split into more shards: the listed devices (SEQWIN_DEVICES), or the current one, taken round robin as
+        // LOGICAL workers of multi.hip until every shard and slice fits (at most 16 owners, at most one per assembly).  On one card
+        // the shards share its HBM, so a job of that size needs real devices to fit; the split itself is exercised by lowering the
+        // bound (SEQWIN_AMD_OCC_CAP, tests).
+        std::vector<int> devs = devices_from_env();
+        int cur_dev = 0;
+        SW_HIP(hipGetDevice(&cur_dev));
+        const std::vector<int> base_devs = devs.size() > 1 ? devs : std::vector<int>(1, cur_dev);
+        for (int attempt = 0;; ++attempt) {
+            try {
+                if (devs.size() > 1 && n_assemblies > 1) {
+                    // one worker per listed device, the reference's partition of the assemblies, peer-to-peer exchanges (multi.hip)
+                    g->g.multi.reset(new MultiGraph);
+                    build_multi_device(assembly_paths, n_assemblies, kmerlen, windowsize, n_cpu, devs, *g->g.multi, chunked ? chunk_bp : 0);
+                    MultiGraph &m = *g->g.multi;
+                    device_ms = ms(t0, now());
+                    g->g.record_offsets = m.record_offsets;
+                    g->g.ids_blob = m.ids_blob;
+                    g->g.n_assemblies = m.n_assemblies;
+                    g->g.total_bp = m.total_bp;
+                    g->g.ix.n_kmers = g->g.ix.n_nodes = g->g.ix.n_edges = 0;
+                    for (auto &sl : m.slices) {   // (sizes of the whole; the arrays stay per device until sw_graph_export)
+                        g->g.ix.n_kmers += sl->n_kmers;
+                        g->g.ix.n_nodes += sl->n_nodes;
+                        g->g.ix.n_edges += sl->n_edges;
+                    }
+                    log_message("info", "MI355X build over %zu %s (%s), node hashes to the edge owners by %s; %s%s", m.slices.size(),
+                                attempt ? "shards" : "devices", attempt ? "split automatically: more occurrences than 32-bit indices address" : "SEQWIN_DEVICES",
+                                m.hash_route, m.copy_route.c_str(), chunked ? "; every worker streams its shard through HBM in chunks (low_memory)" : "");
+                } else if (chunked) {
+                    build_chunked(assembly_paths, n_assemblies, kmerlen, windowsize, n_cpu, chunk_bp, g->g, &ingest_ms, &device_ms);
+                } else {
+                    std::unique_ptr<sw_batch> b(new sw_batch);
+                    SW_HIP(hipGetDevice(&b->device));
+                    ingest_to_device(assembly_paths, n_assemblies, n_cpu, *b);
+                    const auto t1 = now();
+                    do_index_build(*b, kmerlen, windowsize, nullptr, 0, 0, g->g.ix);
+                    ingest_ms = ms(t0, t1);
+                    device_ms = ms(t1, now());
+                    g->g.record_offsets = b->host.record_offsets;
+                    g->g.ids_blob = b->host.ids_blob;
+                    g->g.n_assemblies = b->host.n_assemblies;
+                    g->g.total_bp = b->host.total_bp;
+                }
+                break;
+            } catch (const OccCapError &e) {
+                const size_t have = devs.size() > 1 ? std::min(devs.size(), n_assemblies) : 1;
+                const size_t limit = std::min<size_t>(16, n_assemblies);   // (occ_partition: at most 16 owners; a shard is whole assemblies)
+                if (have >= limit) throw;
+                // what overflowed was one of `have` parts: aim at 3/4 of the bound per part
+                const double parts = (double)e.n / (0.75 * (double)occ_cap());
+                size_t want = std::max(have + 1, (size_t)std::ceil(parts * (double)have));
+                want = std::min(want, limit);
+                log_message("info", "MI355X build: %s -- splitting the job into %zu shards (was %zu)", e.what(), want, have);
+                devs.clear();
+                for (size_t i = 0; i < want; ++i) devs.push_back(base_devs[i % base_devs.size()]);
+                g.reset(new sw_graph);
+                ingest_ms = device_ms = 0;
             }
-            log_message("info", "MI355X build over %zu devices (SEQWIN_DEVICES), node hashes to the edge owners by %s; %s", m.slices.size(),
-                        m.hash_route, m.copy_route.c_str());
-            if (chunked)   // (a shard per device is the memory bound of this route: the request is not an error, but it is not honoured)
-                log_message("warning", "low_memory / SEQWIN_AMD_HBM_BUDGET_GB are not applied under SEQWIN_DEVICES: every device holds its "
-                                       "whole shard (1 / %zu of the job)", m.slices.size());
-        } else if (chunked) {
-            build_chunked(assembly_paths, n_assemblies, kmerlen, windowsize, n_cpu, chunk_bp, g->g, &ingest_ms, &device_ms);
-        } else {
-            std::unique_ptr<sw_batch> b(new sw_batch);
-            SW_HIP(hipGetDevice(&b->device));
-            ingest_to_device(assembly_paths, n_assemblies, n_cpu, *b);
-            const auto t1 = now();
-            do_index_build(*b, kmerlen, windowsize, nullptr, 0, 0, g->g.ix);
-            ingest_ms = ms(t0, t1);
-            device_ms = ms(t1, now());
-            g->g.record_offsets = b->host.record_offsets;
-            g->g.ids_blob = b->host.ids_blob;
-            g->g.n_assemblies = b->host.n_assemblies;
-            g->g.total_bp = b->host.total_bp;
         }
         // the reference logs its stages from native code (build.cpp:358-392 through log_python); two lines here
         log_message("info", "MI355X sketch + index: %llu assemblies, %.1f Mbp%s (ingest + upload %.1f ms, device %.1f ms)",

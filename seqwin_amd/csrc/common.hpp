@@ -46,7 +46,20 @@ struct Error : std::runtime_error {
     throw Error(code, buf);
 }
 
+// More items than 32-bit indices address on one device (2^32 - 2 minimizer occurrences of a shard, or rows of a slice: the
+// permutation words of the sorts are 32-bit).  sw_build catches it and splits the job into more (logical) shards instead of failing
+// where the reference succeeds (its indices are size_t, cpp/include/seqwin/graph.hpp:28-41); every other caller sees a RuntimeError.
+// SEQWIN_AMD_OCC_CAP lowers the bound so that a unit-sized input takes that route (tests).
+struct OccCapError : Error {
+    uint64_t n;
+    OccCapError(uint64_t n_, const std::string &m) : Error(SW_ERR_RUNTIME, m), n(n_) {}
+};
+uint64_t occ_cap();                                             // api.hip
+[[noreturn]] void raise_occ_cap(uint64_t n, const char *what);  // api.hip
+uint64_t last_occ_cap_n();   // api.hip: n of the OccCapError the calling thread's last failed C-ABI call ended with (0: none)
+
 void set_last_error(const char *msg);
+void note_occ_cap(uint64_t n);   // api.hip
 // api.hip: an always-on order guard of the index build tripped (which: 0 node sort, 1 edge-key sort); counted (sw_order_guard_trips),
 // logged as a WARNING through the log callback and on stderr.  The caller then re-sorts without the LDS-atomic ranking.
 void order_guard_tripped(int which, uint32_t places);
@@ -57,6 +70,10 @@ template <class F> int guarded(F &&f)
     try {
         f();
         return SW_OK;
+    } catch (const OccCapError &e) {
+        set_last_error(e.what());
+        note_occ_cap(e.n);
+        return e.code;
     } catch (const Error &e) {
         set_last_error(e.what());
         return e.code;

@@ -236,8 +236,9 @@ struct MultiGraph {
     std::string copy_route;   // how the exchanges travelled: peer access per device pair, or staged through the host (multi.hip: Routes)
 };
 std::vector<int> devices_from_env();   // SEQWIN_DEVICES: "all" or a list of device indices (repeats allowed); empty: one device
+// chunk_bp > 0: every worker streams its shard through HBM in chunks of about that many bases (low_memory / the HBM budget per shard)
 void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, uint64_t w, uint64_t n_cpu, std::vector<int> devs,
-                        MultiGraph &out);
+                        MultiGraph &out, uint64_t chunk_bp = 0);
 
 Plan &get_plan(sw_batch &b, uint64_t k, uint64_t w, bool *cached = nullptr);
 

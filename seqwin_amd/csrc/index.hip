@@ -2683,7 +2683,7 @@ void concat_occ(std::vector<OrderedOcc> &chunks, const std::vector<uint64_t> &re
 {
     uint64_t n = 0;
     for (const OrderedOcc &c : chunks) n += c.n;
-    if (n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
+    if (n > occ_cap()) raise_occ_cap(n, "minimizer occurrences");
     out.n = n;
     out.key32.alloc(n);
     out.pay.alloc(n);
@@ -2924,7 +2924,7 @@ void order_tuples(SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOc
     const bool large = plan.w_full > plan.w;   // the stage holds a superset: the minimizers of plan.w (see above)
     out.n = sk.n_occ;
     out.staged = false;
-    if (!large && out.n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
+    if (!large && out.n > occ_cap()) raise_occ_cap(out.n, "minimizer occurrences");
     const bool table_ranks = index_form && ranks_by_table();
     if (take_stage && index_form && !large && !table_ranks && plan.n_tiles && stage_fits_sort(sk.n_occ, plan.n_tiles)) {
         out.rec.alloc(out.n);
@@ -2961,7 +2961,7 @@ void order_tuples(SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOc
     const uint64_t threads = (uint64_t)plan.n_tiles * 64;
     if (large) {
         const uint64_t c = sk.n_occ;
-        if (c >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 window candidates on one device");
+        if (c > occ_cap()) raise_occ_cap(c, "window candidates");
         DevArray<uint64_t> canon(c), kmer(c), keep_off(c);
         DevArray<uint32_t> g(c), keep(c);
         DevArray<unsigned long long> total(1);
@@ -3012,7 +3012,7 @@ void order_tuples(SketchOut &sk, const Plan &plan, hipStream_t stream, OrderedOc
         SW_HIP(hipMemcpyAsync(&n_keep, total.p, 8, hipMemcpyDeviceToHost, stream));
         SW_HIP(hipStreamSynchronize(stream));   // (the side arrays are released on return)
         out.n = n_keep;
-        if (out.n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
+        if (out.n > occ_cap()) raise_occ_cap(out.n, "minimizer occurrences");
         return;
     }
     if (index_form)
@@ -3430,7 +3430,7 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
                  const uint8_t *d_is_target, uint64_t n_targets, uint64_t n_non_targets, hipStream_t stream, sw_index &ix)
 {
     const uint64_t n = occ.n;
-    if (n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 minimizer occurrences on one device");
+    if (n > occ_cap()) raise_occ_cap(n, "minimizer occurrences");
     Event ev[6];
     SW_HIP(hipEventRecord(ev[0], stream));
 
@@ -3608,7 +3608,7 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
                  const uint32_t *d_rec_asm, uint64_t n_records, const uint8_t *d_is_target, uint64_t n_targets,
                  uint64_t n_non_targets, hipStream_t stream, sw_index &ix, uint32_t *d_rank_out)
 {
-    if (n >= 0xFFFFFFFFull || m >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 rows on one device");
+    if (n > occ_cap() || m > occ_cap()) raise_occ_cap(std::max<uint64_t>(n, m), "rows");
     ix.n_kmers = n;
     ix.kmers.alloc(n);
     ix.n_nodes = 0;
@@ -3873,7 +3873,7 @@ void stable_partition(const Src &src, uint64_t n, const uint64_t *bounds, uint32
 {
     if (n_bounds > 15) raise(SW_ERR_VALUE, "at most 16 owners are supported");
     for (uint32_t j = 0; j < n_bounds + 2; ++j) counts_host[j] = 0;
-    if (n >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 rows on one device");
+    if (n > occ_cap()) raise_occ_cap(n, "rows");
     PartArgs P{};
     P.n = n;
     P.n_bounds = n_bounds;
@@ -3972,7 +3972,7 @@ void slice_edges(sw_index &ix, const uint64_t *d_adj_rows, uint64_t m, unsigned 
                  hipStream_t stream)
 {
     ix.n_edges = 0;
-    if (m >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 adjacency rows on one device");
+    if (m > occ_cap()) raise_occ_cap(m, "adjacency rows");
     if (m && ab) {
         DevArray<uint64_t> k0(m), k1(m);
         SW_HIP(hipMemcpyAsync(k0.p, d_adj_rows, m * 8, hipMemcpyDeviceToDevice, stream));
@@ -4072,7 +4072,7 @@ void slice_edges_pairs(sw_index &ix, uint64_t *d_keys, uint64_t m, const uint64_
 {
     ix.n_edges = 0;
     ix.edges_hold_ranks = d_rank_hash == nullptr;   // (null table: first / second stay global ranks for now)
-    if (m >= 0xFFFFFFFFull || c >= 0xFFFFFFFFull) raise(SW_ERR_RUNTIME, "more than 2^32-2 adjacency rows on one device");
+    if (m > occ_cap() || c > occ_cap()) raise_occ_cap(std::max<uint64_t>(m, c), "adjacency rows");
     if (n_owners == 0 || n_owners > 16) raise(SW_ERR_VALUE, "1 .. 16 owners are supported");
     if (lo_bits + hi_bits > 64 || lo_bits == 0 || hi_bits == 0) raise(SW_ERR_VALUE, "edge keys: 1 <= lo_bits, hi_bits and lo_bits + hi_bits <= 64");
     if (m) {

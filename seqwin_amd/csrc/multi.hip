@@ -100,7 +100,9 @@ struct Rendezvous {
 
 void ck(int rc)   // a C-ABI call made from a worker: its message lives in this thread's sw_last_error
 {
-    if (rc != SW_OK) raise(rc, "%s", sw_last_error());
+    if (rc == SW_OK) return;
+    if (const uint64_t n = last_occ_cap_n()) throw OccCapError(n, sw_last_error());   // (sw_build splits the job further)
+    raise(rc, "%s", sw_last_error());
 }
 
 struct DevBuf {   // a plain device buffer of one worker (the pool is per device; released under the worker's stream scope)
@@ -246,7 +248,7 @@ std::vector<int> devices_from_env()
 }
 
 void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, uint64_t w, uint64_t n_cpu, std::vector<int> devs,
-                        MultiGraph &out)
+                        MultiGraph &out, uint64_t chunk_bp)
 {
     if (devs.size() > n_paths) devs.resize(std::max<size_t>(1, n_paths));   // (build.cpp:344-346: no more workers than assemblies)
     const uint32_t P = (uint32_t)devs.size();
@@ -307,7 +309,8 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
             Shared &me = sh[p];
             // ---- 1: ingest, sketch, partition by hash range ------------------------------------------------------------
             const uint64_t cpu_share = std::max<uint64_t>(1, n_cpu / P);
-            ck(sw_batch_from_fasta(paths + first[p], first[p + 1] - first[p], cpu_share, &batch));
+            if (chunk_bp) ck(sw_occ_sketch_paths(paths + first[p], first[p + 1] - first[p], k, w, cpu_share, chunk_bp, st, &batch, &occ));
+            else ck(sw_batch_from_fasta(paths + first[p], first[p + 1] - first[p], cpu_share, &batch));
             {
                 uint64_t na = 0, nr = 0, bp = 0, bytes = 0, idb = 0;
                 ck(sw_batch_info(batch, &na, &nr, &bp, &bytes));
@@ -317,7 +320,7 @@ void build_multi_device(const char *const *paths, size_t n_paths, uint64_t k, ui
                 me.ids.resize(idb);
                 if (idb) ck(sw_batch_records(batch, me.offs.data(), &me.ids[0], idb, &idb));
             }
-            ck(sw_occ_sketch(batch, k, w, st, &occ));
+            if (!chunk_bp) ck(sw_occ_sketch(batch, k, w, st, &occ));
             double sk_ms = 0;
             ck(sw_occ_size(occ, &me.n_occ, &sk_ms));
             meet.arrive();                                   // (A) every shard's record count is known

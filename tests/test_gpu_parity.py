@@ -1138,6 +1138,71 @@ def test_multi_device_build_on_a_synthetic_job(tmp_path, monkeypatch):
         root.setLevel(old_level)
 
 
+def test_build_splits_itself_when_the_occurrences_outgrow_32_bit_indices(tmp_path, monkeypatch):
+    """The reference indexes occurrences with size_t (cpp/include/seqwin/graph.hpp:28-41); here a device addresses 2^32 - 2 of
+    them.  Until r05 a larger job was a RuntimeError; now sw_build splits it into logical shards by itself
+    -- the SEQWIN_DEVICES machinery on the current card, or the listed devices taken round robin -- until every shard and slice
+    fits, and says so in the log.  SEQWIN_AMD_OCC_CAP lowers the bound so that a 58 k-minimizer job takes that route: plain build
+    (1 -> several shards), a build that was already sharded (SEQWIN_DEVICES=0,0 -> more), low_memory on top; the arrays are the
+    single-device build's.  A job that cannot be split further (one assembly) still fails, with the reference-free message."""
+    import logging
+    from test_gpu_fullsize import write_fasta_sample
+    b = Batch.synthetic(24, 4, 60_000, n_ancestors=3, snp_ppm=20_000, seed=11)
+    paths, _ = write_fasta_sample(b, 24, str(tmp_path))
+    b.close()
+    one = _build(paths, 21, 200, n_cpu=4)
+    n_occ = len(one[0])
+    records = []
+
+    class _Grab(logging.Handler):
+        def emit(self, record):
+            records.append(record.getMessage())
+    h = _Grab(level=logging.INFO)
+    root = logging.getLogger()
+    old_level = root.level
+    root.addHandler(h)
+    root.setLevel(logging.INFO)
+    try:
+        for cap, devices, low in ((n_occ // 3, None, False), (n_occ // 5, "0,0", False), (n_occ // 3, None, True), (n_occ // 2 + 1, "0,0,0", True)):
+            monkeypatch.setenv("SEQWIN_AMD_OCC_CAP", str(cap))
+            if devices:
+                monkeypatch.setenv("SEQWIN_DEVICES", devices)
+            else:
+                monkeypatch.delenv("SEQWIN_DEVICES", raising=False)
+            if low:
+                monkeypatch.setenv("SEQWIN_AMD_LOWMEM_CHUNK_MBP", "1")
+            del records[:]
+            many = _build(paths, 21, 200, n_cpu=4, low_memory=low)
+            assert all(np.array_equal(a, c) for a, c in zip(one[:4], many[:4])) and one[4] == many[4], (cap, devices, low)
+            if cap < n_occ // 2 or not devices:
+                assert any("splitting the job into" in m for m in records), records
+            assert any("split automatically" in m or "SEQWIN_DEVICES" in m for m in records), records
+            if low:
+                assert any("streams its shard through HBM in chunks" in m for m in records), records
+            monkeypatch.delenv("SEQWIN_AMD_LOWMEM_CHUNK_MBP", raising=False)
+        monkeypatch.delenv("SEQWIN_DEVICES", raising=False)
+        monkeypatch.setenv("SEQWIN_AMD_OCC_CAP", "100")
+        with pytest.raises(RuntimeError, match="SEQWIN_AMD_OCC_CAP minimizer occurrences on one device"):
+            KmerGraph(paths[:1], kmerlen=21, windowsize=200, n_cpu=1)
+    finally:
+        root.removeHandler(h)
+        root.setLevel(old_level)
+
+
+def test_low_memory_is_honoured_under_seqwin_devices(tmp_path, monkeypatch):
+    """low_memory / SEQWIN_AMD_HBM_BUDGET_GB under SEQWIN_DEVICES: every worker streams ITS shard through HBM in chunks
+    (sw_occ_sketch_paths; until r05 the request was answered with a warning) -- chunk boundaries inside a shard, gz files, shards of
+    one assembly -- and the arrays are the standard build's and the oracle's (build.cpp:264-325: the low-memory second pass changes
+    the peak, never the result)."""
+    synth = sorted((GOLDEN / "synth").glob("pan_*.fa")) + sorted((GOLDEN / "synth").glob("edge_*"))
+    exp = oracle.build(synth, 15, 20)
+    for devices, chunk in (("0,0", "0"), ("0,0,0", "1"), ("0,0,0,0,0,0,0,0", "0")):
+        monkeypatch.setenv("SEQWIN_DEVICES", devices)
+        monkeypatch.setenv("SEQWIN_AMD_LOWMEM_CHUNK_MBP", chunk)     # 0: one assembly per chunk
+        many = _build(synth, 15, 20, n_cpu=3, low_memory=True)
+        assert_graph_equal(many, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])), [list(t) for t in exp[4]])
+
+
 def test_multi_device_build_without_any_record_or_minimizer(tmp_path, monkeypatch):
     """Assemblies without a record, or without a k-mer: every slice of the multi-device build is empty (found by the SEQWIN_DEVICES
     fuzz campaign: a slice that received nothing reports no rank marks, which must not be taken for "2^31 nodes")."""

@@ -172,6 +172,11 @@ int sw_occ_sketch(const sw_batch *b_, uint64_t, uint64_t, void *st, sw_occ **out
     *out = (sw_occ *)o;
     return SW_OK;
 }
+int sw_occ_sketch_paths(const char *const *paths, size_t n, uint64_t k, uint64_t w, uint64_t n_cpu, uint64_t, void *st, sw_batch **b, sw_occ **o)
+{
+    const int rc = sw_batch_from_fasta(paths, n, n_cpu, b);
+    return rc != SW_OK ? rc : sw_occ_sketch(*b, k, w, st, o);
+}
 int sw_occ_size(const sw_occ *o, uint64_t *n, double *ms)
 {
     *n = ((const FakeOcc *)o)->n_occ;
@@ -327,7 +332,7 @@ int main(int argc, char **argv)
         else setenv("SEQWIN_DIST_HASH_ROUTE", "table", 1);
         sw::MultiGraph mg;
         try {
-            sw::build_multi_device(paths.data(), n_paths, 21, 200, 8, devs, mg);
+            sw::build_multi_device(paths.data(), n_paths, 21, 200, 8, devs, mg, rnd() % 4 == 0 ? 1000 : 0);
             ++ok;
             // the result: every slice's arrays carry this job's stamps (read on the NULL stream of the slice's device)
             if (mg.slices.size() != std::min<size_t>(P, n_paths) || mg.record_offsets.size() != n_paths + 1 || mg.n_assemblies != n_paths) ++wrong;

@@ -8,6 +8,7 @@
 #define sw_batch_free mock_batch_free
 #define sw_occ_sketch mock_occ_sketch
 #define sw_occ_size mock_occ_size
+#define sw_occ_sketch_paths mock_occ_sketch_paths
 #define sw_occ_free mock_occ_free
 #define sw_occ_partition mock_occ_partition
 #define sw_slice_build mock_slice_build
