@@ -5,6 +5,11 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O; cd $R; T=${2:-240}
 if [ "$3" = "gz" ]; then
 FUZZ_GZ=1 SEQWIN_AMD_DEVICE_INFLATE=1 python3 tests/tools/fuzz_gpu.py $T 26 > $O/fuzz_device_gz.log 2>&1 &
 FUZZ_GZ=1 SEQWIN_AMD_DEVICE_INFLATE=1 SEQWIN_AMD_RC=3 SEQWIN_AMD_SLOT_CAP=3 python3 tests/tools/fuzz_gpu.py $T 27 > $O/fuzz_device_gz_rc3.log 2>&1 &
+elif [ "$3" = "multi2" ]; then   # r06 soak of the multi-device path: 2 and 4 logical devices, with POOL_DEBUG=$POOL_DEBUG (export it: 0 / 1)
+SEQWIN_AMD_POOL_DEBUG=${POOL_DEBUG:-0} SEQWIN_DEVICES=0,0 python3 tests/tools/fuzz_gpu.py $T 51 > $O/fuzz_devices2_a.log 2>&1 &
+SEQWIN_AMD_POOL_DEBUG=${POOL_DEBUG:-0} SEQWIN_DEVICES=0,0 python3 tests/tools/fuzz_gpu.py $T 52 > $O/fuzz_devices2_b.log 2>&1 &
+SEQWIN_AMD_POOL_DEBUG=${POOL_DEBUG:-0} SEQWIN_DEVICES=0,0,0,0 python3 tests/tools/fuzz_gpu.py $T 53 > $O/fuzz_devices4_a.log 2>&1 &
+SEQWIN_AMD_POOL_DEBUG=${POOL_DEBUG:-0} SEQWIN_DEVICES=0,0,0,0 SEQWIN_DIST_HASH_ROUTE=requests python3 tests/tools/fuzz_gpu.py $T 54 > $O/fuzz_devices4_requests.log 2>&1 &
 elif [ "$3" = "multi" ]; then
 SEQWIN_DEVICES=0,0 python3 tests/tools/fuzz_gpu.py $T 31 > $O/fuzz_devices2.log 2>&1 &
 SEQWIN_DEVICES=0,0,0 SEQWIN_DIST_HASH_ROUTE=requests SEQWIN_AMD_SORT=own python3 tests/tools/fuzz_gpu.py $T 32 > $O/fuzz_devices3_requests_own.log 2>&1 &
@@ -24,4 +29,4 @@ FUZZ_LOWMEM=1 SEQWIN_AMD_LOWMEM_CHUNK_MBP=0 SEQWIN_AMD_RANKS=table SEQWIN_AMD_RC
 fi
 for i in $(seq 1 40); do sleep 30; echo "t=$((i*30))s"; kill -0 $! 2>/dev/null || break; done
 wait
-tail -n 1 $O/fuzz_*.log
+tail -n 2 $O/fuzz_*.log

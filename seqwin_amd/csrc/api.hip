@@ -242,9 +242,12 @@ void *dev_alloc(size_t bytes)
             return blk.ptr;
         }
     }
-    if (getenv("SEQWIN_AMD_DEBUG_ALLOC") && sz >= (1ull << 28)) fprintf(stderr, "[seqwin_amd] hipMalloc %.3f GiB\n", sz / 1073741824.0);
     void *ptr = nullptr;
     hipError_t e = hipMalloc(&ptr, sz);
+    // (r06: with the address -- the bimodal nodes stage is decided by where a process's first large blocks land, NOTES.md)
+    if (getenv("SEQWIN_AMD_DEBUG_ALLOC") && sz >= (1ull << 28))
+        fprintf(stderr, "[seqwin_amd] hipMalloc %.3f GiB at %p (offset in 2 MiB %llu KiB, in 1 GiB %llu MiB)\n", sz / 1073741824.0, ptr,
+                (unsigned long long)(((uintptr_t)ptr >> 10) & 2047), (unsigned long long)(((uintptr_t)ptr >> 20) & 1023));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         dev_pool_trim();  // give cached blocks back and retry once

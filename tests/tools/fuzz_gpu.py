@@ -122,5 +122,13 @@ while time.time() < t_end and (not replay or it < len(replay)):
             print("   only in expected:", sorted(set(oh) - set(gh))[:10], " only in got:", sorted(set(gh) - set(oh))[:10])
     for p in ps:
         os.unlink(p)
+try:   # SEQWIN_AMD_POOL_DEBUG soaks: what the pool saw
+    import ctypes
+    from seqwin_amd._lib import lib as _lib
+    _st = (ctypes.c_uint64 * 3)()
+    _lib.sw_pool_debug_stats(_st)
+    print(f"pool: debug mode {'on' if _st[0] else 'off'}, {_st[1]} blocks written after their release, {_st[2]} host-side hand-overs between threads / streams")
+except Exception as e:
+    print("pool stats unavailable:", e)
 print(f"fuzz: {n_cases} cases, {n_bad} mismatches, seed0={seed0}")
 sys.exit(1 if n_bad else 0)
