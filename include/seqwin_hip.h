@@ -187,6 +187,12 @@ int sw_batch_synthetic_shard(uint64_t n_genomes, uint64_t records_per_genome, ui
                              uint64_t n_ancestors, uint64_t snp_ppm, uint64_t seed, uint64_t first_genome,
                              sw_batch **out);
 
+/* Ragged draft assemblies for the measurements (r06): genome g of the job has 20 ... 300 contigs whose lengths follow a bell over
+ * 200 bp ... 1.5 Mbp (200 * 2^x, x a sum of four uniforms; median ~17 kbp) until ~genome_bp bases are reached, cut from ancestor
+ * g % n_ancestors with snp_ppm substitutions; one contig in ten carries one to three scaffold gaps of 10 ... 1000 N.  The shape of
+ * real inputs (tests/targets.txt assemblies): short-record tiles, gap tiles and the generic kernel's list mode at scale. */
+int sw_batch_synthetic_ragged(uint64_t n_genomes, uint64_t genome_bp, uint64_t n_ancestors, uint64_t snp_ppm, uint64_t seed, uint64_t first_genome,
+                              sw_batch **out);
 /* Copy the ASCII sequence of record `record_idx` (A/C/G/T, 'N' for invalid bases) back to the host;
  * used by tests to hand the same input to the oracle. *len_out receives the record length. */
 int sw_batch_record(const sw_batch *b, uint64_t record_idx, char *seq_out, uint64_t cap, uint64_t *len_out);
@@ -220,6 +226,9 @@ typedef struct sw_timings {
     double plan_ms;      /* host + upload time the (batch, k, w) launch plan took when it was built (tile tables, roll LUTs);
                             cached in the batch afterwards, so it is outside total_ms except for the first build */
     uint64_t plan_cached; /* 1: this build found the plan in the batch's cache */
+    /* r06: the plan's tiles by class -- fast kernel with 256-thread / 64-thread workgroups, generic kernel (records that are mostly
+     * gaps, w < 4, k > 256), and the fast-class tiles that cross an invalid-base gap (done by the generic kernel's list mode) */
+    uint64_t tiles_b256, tiles_b64, tiles_generic, tiles_gap;
 } sw_timings;
 
 /*

@@ -113,7 +113,7 @@ def main():
     import numpy as np
 
     import oracle
-    from bench import SEED, WORKLOADS, write_fasta_fast
+    from bench import SEED, WORKLOADS, make_batch, write_fasta_fast
     from seqwin_amd.device import CHECKSUM_SCHEME, Batch, set_device
 
     ref = oracle.load_ref()
@@ -143,7 +143,9 @@ def main():
     log("host:", json.dumps(host))
 
     # sizing: FASTA text in /dev/shm (counts as memory) + the reference's working set + both sides' arrays
-    bp_genome = rpg * rl
+    bp_genome = rpg * rl if rpg else rl
+    if not rpg:
+        os.environ.setdefault("SEQWIN_AMD_WRITE_LOWER_PPM", "10000")   # ragged workloads: 1 % of the bases soft-masked in the FASTA text
     fasta_genome = bp_genome * (81.0 / 80.0) + rpg * 16
     occ_genome = bp_genome * 2.0 / (w + 1)
     ref_per_occ = args.ref_bytes_per_occ
@@ -165,7 +167,7 @@ def main():
 
     set_device(0)
     t0 = time.perf_counter()
-    batch = Batch.synthetic(G_run, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED)
+    batch = make_batch(WORKLOADS[args.workload], G_run, SEED)
     tmp = tempfile.mkdtemp(prefix="seqwin_pin_", dir="/dev/shm")
     result = {"workload": args.workload, "k": k, "w": w, "genomes": G_run, "genomes_of_workload": G_full, "host": host,
               "command": "python3 " + " ".join(sys.argv), "seed": SEED}

@@ -53,6 +53,16 @@ class Batch:
                                            ctypes.byref(h)))
         return cls(h)
 
+    @classmethod
+    def synthetic_ragged(cls, n_genomes: int, genome_bp: int, n_ancestors: int = 1, snp_ppm: int = 10000, seed: int = 1,
+                         first_genome: int = 0) -> "Batch":
+        """Ragged draft assemblies (sw_batch_synthetic_ragged): 20-300 contigs of 200 bp ... 1.5 Mbp per genome, scaffold gaps of
+        10-1000 N in one contig of ten."""
+        h = c_vp()
+        check(lib.sw_batch_synthetic_ragged(c_u64(n_genomes), c_u64(genome_bp), c_u64(n_ancestors), c_u64(snp_ppm), c_u64(seed),
+                                            c_u64(first_genome), ctypes.byref(h)))
+        return cls(h)
+
     def info(self) -> dict:
         v = [c_u64() for _ in range(4)]
         check(lib.sw_batch_info(self._h, *[ctypes.byref(x) for x in v]))

@@ -94,6 +94,27 @@ def test_config1_full_size_checksums_of_the_reference(w):
     assert v["weight_sum"] == gold["weight_sum"] and ix.threshold_sums()[0] == gold["n_tar_sum"]
 
 
+def test_ragged500_full_size_checksums_of_the_reference():
+    """512 ragged draft assemblies (bench.py --workload ragged500: 2.5 Gbp in ~45 k contigs of 200 bp ... 1.5 Mbp, scaffold gaps in
+    one contig of ten) at full size: counts and checksums computed from the COMPILED REFERENCE's arrays on the GPU box
+    (scripts/pin_fullsize_ref.py: FASTA with 1 % soft-masked bases -> _build_native + _get_penalty_native, every array also compared
+    element for element; tests/golden/bench_checksums_ref.json).  VERDICT r5 missing #4: a realistic assembly shape at scale."""
+    from bench import make_batch
+    gold, src = _full_size_golden("ragged500/k21/w200")
+    assert src == "reference"
+    b = make_batch(WORKLOADS["ragged500"], WORKLOADS["ragged500"][0], SEED)
+    G = WORKLOADS["ragged500"][0]
+    ix = b.build_index(21, 200, np.arange(G) % 2 == 0)
+    nk, nn, ne = ix.sizes()
+    assert gold["counts"] == {"kmers": nk, "nodes": nn, "edges": ne}
+    assert [f"{s:016x}" for s in ix.checksums()] == gold["checksums"]
+    t = ix.timings()
+    assert t["tiles_b64"] > 0 and t["tiles_gap"] > 0 and t["tiles_b256"] > 0
+    v = ix.verify(G)
+    assert all(v[key] == 0 for key in list(v)[:8]), v
+    assert v["weight_sum"] == gold["weight_sum"] and ix.threshold_sums()[0] == gold["n_tar_sum"]
+
+
 def test_config1_multi_device_build_equals_single_device(tmp_path, monkeypatch):
     """configs[1] (512 genomes, 2.46 Gbp, 24.6 M minimizers) as FASTA through ONE sw_build over four and seven logical devices
     (SEQWIN_DEVICES, csrc/multi.hip: worker threads, peer copies, both ways of bringing node hashes to the edge owners) against

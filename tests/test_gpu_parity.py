@@ -375,6 +375,43 @@ def test_synthetic_batch_index_matches_oracle(tmp_path, shape, k, w):
     assert b.build_index(k, w, tar).checksums() == ix.checksums()
 
 
+@pytest.mark.parametrize("k,w", [(21, 200), (15, 10), (31, 50)])
+def test_ragged_assemblies_with_scaffold_gaps_match_oracle(tmp_path, monkeypatch, k, w):
+    """The shape of real draft assemblies (sw_batch_synthetic_ragged; reference inputs: tests/targets.txt): per genome 20-300 contigs
+    of 200 bp ... 1.5 Mbp, scaffold gaps of 10-1000 N in one contig of ten -- 64-thread tiles for the short contigs, gap tiles and
+    the generic kernel's list mode next to the 256-thread tiles, in one batch.  From the device batch, and from its FASTA text (1 % of
+    the bases in lower case) through the host ingest: kmers / scored nodes / edges of the oracle (N-skipping:
+    nthash_kmer.hpp:315-333, 491-511; windows span the gaps: minimizer.cpp:69-70)."""
+    b = Batch.synthetic_ragged(7, 150_000, n_ancestors=2, snp_ppm=10000, seed=20260821)
+    info = b.info()
+    assert info["n_assemblies"] == 7 and info["n_records"] >= 7 * 20
+    lens = [len(b.record(r)) for r in range(info["n_records"])]
+    assert min(lens) >= 200 and max(lens) <= 1_500_000 and sum(lens) == info["total_bp"]
+    assert any(b"N" in b.record(r) for r in range(info["n_records"]))
+    tar = [i % 2 == 0 for i in range(7)]
+    exp = _oracle_for_batch(b, k, w, tar, tmp_path)
+    ix = b.build_index(k, w, tar)
+    K, N, E = ix.export()
+    assert np.array_equal(K, exp[0]) and np.array_equal(N, exp[1]) and np.array_equal(E, exp[2])
+    t = ix.timings()
+    assert t["tiles_b256"] and t["tiles_b64"] and t["tiles_gap"], t          # every tile class of the plan is in play
+    assert ix.checksums() == host_checksums(exp[0], exp[1], exp[2])
+    # the same genomes as FASTA text with soft-masked bases, through sw_build
+    from bench import write_fasta_fast
+    monkeypatch.setenv("SEQWIN_AMD_WRITE_LOWER_PPM", "10000")
+    d = tmp_path / "fa"
+    d.mkdir()
+    paths, bp = write_fasta_fast(b, 7, str(d), 4)
+    assert bp == info["total_bp"] and any(c.islower() for c in open(paths[0]).read(200000) if c.isalpha())
+    g = KmerGraph(paths, kmerlen=k, windowsize=w, n_cpu=3)
+    _get_penalty(g.kmers, g.nodes, g.record_offsets, tar)
+    assert np.array_equal(g.kmers, exp[0]) and np.array_equal(g.nodes, exp[1]) and np.array_equal(g.edges, exp[2])
+    # a shard of the job holds the same genomes (bench.py --gpus N)
+    s = Batch.synthetic_ragged(3, 150_000, n_ancestors=2, snp_ppm=10000, seed=20260821, first_genome=4)
+    off = b.record_offsets()
+    assert [s.record(r) for r in range(s.info()["n_records"])] == [b.record(r) for r in range(int(off[4]), int(off[7]))]
+
+
 def test_window_split_route_at_full_size(monkeypatch):
     """Windows above SW_MAX_WINDOW are sketched with a smaller window and selected from that superset (index.hip:
     select in order_tuples).  The test knob sends w = 200 down that route on a configs[1]-sized batch -- sketch with
