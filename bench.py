@@ -625,7 +625,7 @@ def main() -> None:
         path_bytes = 0.25 * total_bp + 80.0 * tot[0] + 40.0 * tot[1] + 24.0 * tot[2]
         # HBM bytes per launch of the dominant kernel from the committed PMC profile of this same command
         # (profiles/traffic.json, written by scripts/summarize_profiles.py); null for other workloads
-        traffic, traffic_src, valu_insts = None, None, None
+        traffic, traffic_src, valu_insts, valu_busy = None, None, None, (None, None)
         try:
             tj = json.loads((ROOT / "profiles" / "traffic.json").read_text())
             tj = tj.get("entries", {}).get(f"{args.workload}/k{k}/w{w}", tj if "entries" not in tj else {})   # one entry per (workload, k, w)
@@ -636,6 +636,7 @@ def main() -> None:
                     and not args.genomes and same_kernel:
                 traffic, traffic_src = int(tj["hbm_bytes_per_launch"]), tj.get("source")
                 valu_insts = tj.get("valu_wave_insts_per_launch")
+                valu_busy = (tj.get("valu_busy_frac"), tj.get("valu_busy_source"))
         except Exception:
             pass
         out = {
@@ -693,6 +694,8 @@ def main() -> None:
             out["roofline"]["valu"] = {"lane_ops_per_bp": round(lane_ops / bp_rank, 1),
                                        "achieved_Tlaneops_per_s": round(lane_ops / (stage["sketch_ms"] * 1e-3) / 1e12, 2),
                                        "peak_Tlaneops_per_s": 78.64, "frac": round(lane_ops / (stage["sketch_ms"] * 1e-3) / 78.64e12, 3),
+                                       "busy_frac": valu_busy[0],   # MEASURED: SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / GRBM_GUI_ACTIVE (gfx94x VALUBusy)
+                                       "busy_source": valu_busy[1],
                                        "source": "SQ_INSTS_VALU of the committed PMC profile (profiles/*_pmc_sketch.txt)",
                                        "note": "peak = 32 lanes/clk/SIMD (2 cycles per wave64 VOP2); three-operand VOP3, v_cndmask, "
                                                "v_cmp and 64-bit moves measure 4.2-4.9 cycles (scripts/micro/valu_kinds.hip), "

@@ -6,6 +6,10 @@ SEQWIN_BENCH_FORCE_DIST=1 python3 bench.py --steps 4 --warmup 1 --no-cpu-baselin
 cd /tmp &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/stats -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_stats.log 2>&1 &&
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $O/prof/pmc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_pmc.log 2>&1 &&
+AVAIL=$(rocprofv3 -L 2>/dev/null | tr -c 'A-Za-z0-9_' '\n' | sort -u) &&
+PMC2=$(for c in SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE; do echo "$AVAIL" | grep -qx $c && echo -n "$c "; done) &&
+echo "pmc2 counters: $PMC2" > $O/prof_pmc2.log &&
+rocprofv3 --pmc $PMC2 --output-format csv -d $O/prof/pmc2 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline >> $O/prof_pmc2.log 2>&1 &&
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof/fetch -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_fetch.log 2>&1 &&
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof/write -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/prof_write.log 2>&1 &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_w10/stats -- python3 $R/bench.py --workload salmonella500 -w 10 --steps 4 --warmup 1 --no-cpu-baseline > $O/prof_w10.log 2>&1 &&
