@@ -88,7 +88,7 @@ def main():
         with open(a.out_prefix + "_kernel_stats.txt", "w") as f:
             f.write(f"rocprofv3 --kernel-trace --stats -- {a.title}   ({a.workload}; {a.steps} passes incl. warm-up)\n")
             f.write(f"{'kernel':56s} {'calls/pass':>10s} {'avg_us':>10s} {'ms/pass':>9s} {'pct':>6s}\n")
-            outside = ("k_synth", "k_checksum")   # input generation / result checksums: not in a pass of the hot path
+            outside = ("k_synth", "k_synth_ragged", "k_checksum")   # input generation / result checksums: not in a pass of the hot path
             total = sum(v[1] for s, v in merged.items() if s not in outside)
             for s, (calls, ns) in sorted(merged.items(), key=lambda kv: -kv[1][1]):
                 if ns / 1e6 / a.steps < 0.004 or s in outside:
