@@ -636,7 +636,7 @@ def main() -> None:
                     and not args.genomes and same_kernel:
                 traffic, traffic_src = int(tj["hbm_bytes_per_launch"]), tj.get("source")
                 valu_insts = tj.get("valu_wave_insts_per_launch")
-                valu_busy = (tj.get("valu_busy_frac"), tj.get("valu_busy_source"))
+                valu_busy = (tj.get("valu_insts_per_simd_cycle"), tj.get("valu_busy_source"))
         except Exception:
             pass
         out = {
@@ -694,7 +694,11 @@ def main() -> None:
             out["roofline"]["valu"] = {"lane_ops_per_bp": round(lane_ops / bp_rank, 1),
                                        "achieved_Tlaneops_per_s": round(lane_ops / (stage["sketch_ms"] * 1e-3) / 1e12, 2),
                                        "peak_Tlaneops_per_s": 78.64, "frac": round(lane_ops / (stage["sketch_ms"] * 1e-3) / 78.64e12, 3),
-                                       "busy_frac": valu_busy[0],   # MEASURED: SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / GRBM_GUI_ACTIVE (gfx94x VALUBusy)
+                                       # MEASURED (r06): VALU wave-instructions per SIMD and kernel cycle (GRBM_GUI_ACTIVE / 8 XCDs); with the mix's
+                                       # measured issue costs (2.05-4.9 cycles, mean ~3.6) the VALU port is occupied ~0.97 of the time.  gfx950 exposes
+                                       # no VALU-cycle counter: SQ_ACTIVE_INST_VALU equals SQ_INSTS_VALU (profiles/*_pmc_valu_busy.txt)
+                                       "insts_per_simd_cycle": valu_busy[0],
+                                       "issue_interval_cycles": round(1.0 / valu_busy[0], 2) if valu_busy[0] else None,
                                        "busy_source": valu_busy[1],
                                        "source": "SQ_INSTS_VALU of the committed PMC profile (profiles/*_pmc_sketch.txt)",
                                        "note": "peak = 32 lanes/clk/SIMD (2 cycles per wave64 VOP2); three-operand VOP3, v_cndmask, "

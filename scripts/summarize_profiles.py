@@ -141,13 +141,26 @@ def main():
                 for c, x in avg.items():
                     f.write(f"   {c:22s} {x:18.0f}\n")
                 if "fast" in k and "256" in k and "SQ_ACTIVE_INST_VALU" in avg and "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"]:
-                    valu_busy = avg["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / avg["GRBM_GUI_ACTIVE"]
-                    f.write(f"   => VALUBusy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs) / GRBM_GUI_ACTIVE = {valu_busy:.3f}\n")
+                    # What these counters are on gfx950 / ROCm 7.2 (r06): SQ_ACTIVE_INST_VALU comes out EQUAL to SQ_INSTS_VALU of the other
+                    # pass (52 757 731 017 both at 15 000 genomes) -- it counts issued instructions (one unit each), not busy cycles, and
+                    # SQ_INST_CYCLES_VALU / SQ_THREAD_CYCLES_VALU are not listed by the device.  So no counter gives "VALU busy cycles"
+                    # directly; what IS measured: the kernel's cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs), hence VALU instructions
+                    # per SIMD and cycle -- to be held against the issue costs of this instruction mix (scripts/micro/valu_kinds.hip:
+                    # 2.05-4.9 cycles per wave64 instruction) -- and the split of a wave's cycles (ACTIVE + WAIT + WAIT_INST = WAVE_CYCLES).
+                    cyc = avg["GRBM_GUI_ACTIVE"] / 8.0
+                    per_simd_cycle = avg["SQ_ACTIVE_INST_VALU"] / 1024.0 / cyc
+                    valu_busy = per_simd_cycle
+                    f.write(f"   => kernel cycles (GRBM_GUI_ACTIVE / 8 XCDs) = {cyc:.0f}; VALU wave-instructions per SIMD and cycle = {per_simd_cycle:.3f} "
+                            f"= one every {1 / per_simd_cycle:.2f} cycles\n")
+                    f.write("      (issue cost of this mix, measured per instruction kind: 2.05-4.9 cycles, scripts/micro/valu_kinds.hip -- the VALU port is\n"
+                            "       occupied for count x cost cycles: with the mix's mean of ~3.6 that is ~0.97 of the kernel's cycles.  SQ_ACTIVE_INST_VALU\n"
+                            "       equals SQ_INSTS_VALU on this stack: an instruction count, not a cycle count; no VALU-cycle counter is exposed)\n")
                     if "SQ_ACTIVE_INST_ANY" in avg and avg.get("SQ_WAVE_CYCLES"):
-                        f.write(f"   => a wave has an instruction in flight in {avg['SQ_ACTIVE_INST_ANY'] / avg['SQ_WAVE_CYCLES']:.3f} of its cycles, "
-                                f"a VALU instruction in {avg['SQ_ACTIVE_INST_VALU'] / avg['SQ_WAVE_CYCLES']:.3f}\n")
+                        f.write(f"   => of a wave's cycles: an instruction issued in {avg['SQ_ACTIVE_INST_ANY'] / avg['SQ_WAVE_CYCLES']:.3f} "
+                                f"(VALU {avg['SQ_ACTIVE_INST_VALU'] / avg['SQ_WAVE_CYCLES']:.3f}, scalar {avg.get('SQ_ACTIVE_INST_SCA', 0) / avg['SQ_WAVE_CYCLES']:.3f}, "
+                                f"LDS {avg.get('SQ_ACTIVE_INST_LDS', 0) / avg['SQ_WAVE_CYCLES']:.3f}); the rest is SQ_WAIT_ANY + SQ_WAIT_INST_ANY (pmc_sketch.txt)\n")
                     if "SQ_BUSY_CU_CYCLES" in avg and avg["SQ_BUSY_CU_CYCLES"]:
-                        f.write(f"   => SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES = {avg['SQ_ACTIVE_INST_VALU'] / avg['SQ_BUSY_CU_CYCLES']:.3f}\n")
+                        f.write(f"   => SQ_BUSY_CU_CYCLES / (256 CUs x kernel cycles) = {avg['SQ_BUSY_CU_CYCLES'] / 256.0 / cyc:.3f}\n")
         print(open(a.out_prefix + "_pmc_valu_busy.txt").read())
 
     fe_p, wr_p = one(f"{a.run_dir}/fetch/**/*counter_collection.csv"), one(f"{a.run_dir}/write/**/*counter_collection.csv")
@@ -180,7 +193,7 @@ def main():
         if fast and traffic and fast[0].get("SQ_INSTS_VALU"):
             traffic["valu_wave_insts_per_launch"] = sum(fast[0]["SQ_INSTS_VALU"]) / len(fast[0]["SQ_INSTS_VALU"])
         if traffic and valu_busy is not None:
-            traffic["valu_busy_frac"] = round(valu_busy, 4)
+            traffic["valu_insts_per_simd_cycle"] = round(valu_busy, 4)
             traffic["valu_busy_source"] = a.out_prefix + "_pmc_valu_busy.txt"
         if traffic:
             # stamp with the kernel's source: bench.py reports `traffic` only while sketch.hip still is what was profiled

@@ -2355,13 +2355,23 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
         if (kmers && nodes && edges && ix.n_nodes && ix.n_edges && ix.n_kmers < (1ull << 32) && download_is_pipelined(whole_total) &&
             !getenv("SEQWIN_AMD_EXPORT_WHOLE")) {
             const uint64_t per = download_slot_bytes() / PACKED_NODE, n_chunks = (ix.n_nodes + per - 1) / per;
-            DevArray<uint32_t> pn(ix.n_nodes * 3), pe(ix.n_edges * 5), flag(1);
+            DevArray<uint32_t> pn, pe, flag(1);
             DevArray<uint64_t> bases(n_chunks);
+            bool room = true;
+            try {   // (the packed copies need 12 B per node + 20 B per edge of HBM next to the index: without it the arrays go whole -- ADVICE r5)
+                pn.alloc(ix.n_nodes * 3);
+                pe.alloc(ix.n_edges * 5);
+            } catch (const Error &e) {
+                if (e.code != SW_ERR_DEVICE) throw;
+                room = false;
+                log_message("info", "sw_graph_export: no room in HBM for the packed form of nodes and edges: whole arrays");
+            }
             SW_HIP(hipMemsetAsync(flag.p, 0, 4, nullptr));
+            if (room)
             pack_export(ix.nodes.p, ix.n_nodes, ix.n_kmers, ix.edges.p, ix.n_edges, per, pn.p, bases.p, pe.p, flag.p, nullptr);
-            uint32_t declined = 0;
+            uint32_t declined = room ? 0 : 1;
             std::vector<uint64_t> h_bases(n_chunks);
-            SW_HIP(hipMemcpy(&declined, flag.p, 4, hipMemcpyDeviceToHost));
+            if (room) SW_HIP(hipMemcpy(&declined, flag.p, 4, hipMemcpyDeviceToHost));
             if (!declined) {
                 SW_HIP(hipMemcpy(h_bases.data(), bases.p, n_chunks * 8, hipMemcpyDeviceToHost));
                 HostSpan ps[3] = {{kmers, ix.n_kmers * sizeof(sw_kmer)}, {nodes, ix.n_nodes * PACKED_NODE}, {edges, ix.n_edges * PACKED_EDGE}};
