@@ -2,6 +2,7 @@
 # usage (through gpurun): bash scripts/gpu/fuzz.sh <tag> [seconds] [gz|multi|stage]      gz: the two device-gzip-ingest campaigns instead;
 #                                                                                 multi: sw_build over logical devices (SEQWIN_DEVICES) instead; stage: the node sort reading the sketch stage (SEQWIN_AMD_ORDER=stage)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O; cd $R; T=${2:-240}
+export SEQWIN_AMD_LIB=${SEQWIN_AMD_LIB:-$R/seqwin_amd/libseqwin_hip_test.so}   # (the knobs of the campaigns are test hooks: the test library)
 if [ "$3" = "gz" ]; then
 FUZZ_GZ=1 SEQWIN_AMD_DEVICE_INFLATE=1 python3 tests/tools/fuzz_gpu.py $T 26 > $O/fuzz_device_gz.log 2>&1 &
 FUZZ_GZ=1 SEQWIN_AMD_DEVICE_INFLATE=1 SEQWIN_AMD_RC=3 SEQWIN_AMD_SLOT_CAP=3 python3 tests/tools/fuzz_gpu.py $T 27 > $O/fuzz_device_gz_rc3.log 2>&1 &

@@ -21,7 +21,7 @@ void note_occ_cap(uint64_t n) { g_last_occ_cap = n; }
 uint64_t last_occ_cap_n() { return g_last_occ_cap; }
 uint64_t occ_cap()
 {
-    const char *e = getenv("SEQWIN_AMD_OCC_CAP");   // (read per call: a handful of times per build)
+    const char *e = SW_TEST_GETENV("SEQWIN_AMD_OCC_CAP");   // (read per call: a handful of times per build)
     const long long v = e ? atoll(e) : 0;
     return v > 0 && (uint64_t)v < 0xFFFFFFFEull ? (uint64_t)v : 0xFFFFFFFEull;
 }
@@ -429,17 +429,17 @@ DownloadRing &download_ring(int device)
 size_t download_slot_bytes()
 {
     size_t b = DownloadRing::SLOT;
-    if (const char *e = getenv("SEQWIN_AMD_DOWNLOAD_SLOT_KB")) b = std::min(b, (size_t)std::max(1, atoi(e)) << 10);
+    if (const char *e = SW_TEST_GETENV("SEQWIN_AMD_DOWNLOAD_SLOT_KB")) b = std::min(b, (size_t)std::max(1, atoi(e)) << 10);
     return b;
 }
 size_t download_pipeline_min()
 {
     size_t pipeline_min = 256u << 20;   // below: not worth the ring's one-off 16 ms of pinned allocation
-    if (const char *e = getenv("SEQWIN_AMD_DOWNLOAD_PIPELINE_MB")) pipeline_min = (size_t)std::max(0, atoi(e)) << 20;   // (tests: 0)
+    if (const char *e = SW_TEST_GETENV("SEQWIN_AMD_DOWNLOAD_PIPELINE_MB")) pipeline_min = (size_t)std::max(0, atoi(e)) << 20;   // (tests: 0)
     return pipeline_min;
 }
 // whether download() of `total` bytes goes through the ring (what a caller that offers packed sources has to know beforehand)
-bool download_is_pipelined(size_t total) { return total > 0 && total >= download_pipeline_min() && !getenv("SEQWIN_AMD_PLAIN_DOWNLOAD"); }
+bool download_is_pipelined(size_t total) { return total > 0 && total >= download_pipeline_min() && !SW_TEST_GETENV("SEQWIN_AMD_PLAIN_DOWNLOAD"); }
 
 void download(const HostSpan *dst, const void *const *src, int n_spans)
 {
@@ -457,7 +457,7 @@ void download(const HostSpan *dst, const void *const *src, int n_spans)
     for (int i = 0; i < n_spans; ++i)
         if (dst[i].p && src[i] && dst[i].expand && !download_is_pipelined(total))
             raise(SW_ERR_RUNTIME, "download: a packed source outside the pipelined route");   // (a caller's mistake)
-    if (total < pipeline_min || getenv("SEQWIN_AMD_PLAIN_DOWNLOAD")) {
+    if (total < pipeline_min || SW_TEST_GETENV("SEQWIN_AMD_PLAIN_DOWNLOAD")) {
         prefault(dst, n_spans);
         for (int i = 0; i < n_spans; ++i)
             if (dst[i].p && src[i] && dst[i].n) SW_HIP(hipMemcpy(dst[i].p, src[i], dst[i].n, hipMemcpyDeviceToHost));
@@ -681,7 +681,7 @@ struct PinnedArena : WordArena {
     std::atomic<int> grow_device{0};
     void read_limit()   // (per ingest, so that one process can compare settings)
     {
-        const char *e = getenv("SEQWIN_AMD_PINNED_POOL_MB"), *sl = getenv("SEQWIN_AMD_PINNED_SLAB_MB");
+        const char *e = getenv("SEQWIN_AMD_PINNED_POOL_MB"), *sl = SW_TEST_GETENV("SEQWIN_AMD_PINNED_SLAB_MB");
         std::lock_guard<std::mutex> lock(mu);
         limit_bytes = e ? (size_t)std::max(0, atoi(e)) << 20 : (size_t)1024 << 20;
         SLAB = sl ? (size_t)std::max(1, atoi(sl)) << 20 : (size_t)32 << 20;
@@ -852,7 +852,7 @@ void ingest_to_device(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
         upload_tables(b);
         return;
     }
-    if (n_paths >= 2 && !getenv("SEQWIN_AMD_NO_STREAM_UPLOAD")) {
+    if (n_paths >= 2 && !SW_TEST_GETENV("SEQWIN_AMD_NO_STREAM_UPLOAD")) {
         const auto t0 = std::chrono::steady_clock::now();
         DeviceSink sink(b, pinned_ring(b.device));
         const auto t1 = std::chrono::steady_clock::now();
@@ -2353,7 +2353,7 @@ int sw_graph_export(const sw_graph *g, sw_kmer *kmers, sw_node *nodes, sw_edge *
         bool packed = false;
         const size_t whole_total = ix.n_kmers * sizeof(sw_kmer) + ix.n_nodes * sizeof(sw_node) + ix.n_edges * sizeof(sw_edge);
         if (kmers && nodes && edges && ix.n_nodes && ix.n_edges && ix.n_kmers < (1ull << 32) && download_is_pipelined(whole_total) &&
-            !getenv("SEQWIN_AMD_EXPORT_WHOLE")) {
+            !SW_TEST_GETENV("SEQWIN_AMD_EXPORT_WHOLE")) {
             const uint64_t per = download_slot_bytes() / PACKED_NODE, n_chunks = (ix.n_nodes + per - 1) / per;
             DevArray<uint32_t> pn, pe, flag(1);
             DevArray<uint64_t> bases(n_chunks);

@@ -28,6 +28,18 @@
 #define SW_AB_GETENV(name) ((const char *)nullptr)
 #endif
 
+// Test hooks (r06): switches that force a path which is the DEFAULT only at sizes no unit test has (how the
+// suite and the fuzzer reach the 15 000-genome branches), the safe alternatives the guards fall back to, the host packer's narrower
+// forms, the fault injection and the lowered index bound.  They are live in the TEST library (`make -C seqwin_amd/csrc test` ->
+// seqwin_amd/libseqwin_hip_test.so, -DSW_TEST_HOOKS: what tests/conftest.py and the fuzzer load) and in the A/B build; in the
+// release library they read as unset -- same kernels, same code, the switches' strings are not even in the binary
+// (tests/test_abi_cpu.py checks that) -- which leaves a deployment the "use" switches of DESIGN.md section 8a only.
+#if defined(SW_TEST_HOOKS) || defined(SW_AB)
+#define SW_TEST_GETENV(name) getenv(name)
+#else
+#define SW_TEST_GETENV(name) ((const char *)nullptr)
+#endif
+
 namespace sw {
 
 // ---- error plumbing: C++ exceptions inside, int codes at the C ABI -------------------------

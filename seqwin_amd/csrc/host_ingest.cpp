@@ -460,21 +460,21 @@ __attribute__((target("avx512f,avx512bw,avx512vbmi2,bmi2,popcnt"))) const char *
 bool have_chunk_packer()
 {
     static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi2") &&
-                           __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt") && !getenv("SEQWIN_AMD_SCALAR_INGEST") &&
-                           !getenv("SEQWIN_AMD_NO_AVX512") && !getenv("SEQWIN_AMD_LINE_PACKER");
+                           __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt") && !SW_TEST_GETENV("SEQWIN_AMD_SCALAR_INGEST") &&
+                           !SW_TEST_GETENV("SEQWIN_AMD_NO_AVX512") && !SW_TEST_GETENV("SEQWIN_AMD_LINE_PACKER");
     return ok;
 }
 
 bool have_avx512_packer()
 {
     static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") &&
-                           !getenv("SEQWIN_AMD_SCALAR_INGEST") && !getenv("SEQWIN_AMD_NO_AVX512");
+                           !SW_TEST_GETENV("SEQWIN_AMD_SCALAR_INGEST") && !SW_TEST_GETENV("SEQWIN_AMD_NO_AVX512");
     return ok;
 }
 
 bool have_avx2_packer()
 {
-    static const bool ok = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !getenv("SEQWIN_AMD_SCALAR_INGEST");
+    static const bool ok = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && !SW_TEST_GETENV("SEQWIN_AMD_SCALAR_INGEST");
     return ok;
 }
 #endif
@@ -603,7 +603,7 @@ struct TextParser {
 size_t read_block_bytes()
 {
     static const size_t n = [] {
-        const char *e = getenv("SEQWIN_AMD_READ_BLOCK_KB");
+        const char *e = SW_TEST_GETENV("SEQWIN_AMD_READ_BLOCK_KB");
         return (size_t)(e ? std::max(0, atoi(e)) : 256) << 10;
     }();
     return n;
@@ -736,8 +736,8 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
     // third 15 (all worker counts alike: serialised).  Not robust across boxes: read() stays.  SEQWIN_AMD_MMAP=0 / 1 / 2 forces
     // read() / mmap / mmap + populate for such measurements, SEQWIN_AMD_NO_MMAP=1 is read() also for a single worker.
     int mmap_mode = threaded ? 0 : 1;
-    if (const char *e = getenv("SEQWIN_AMD_MMAP")) mmap_mode = atoi(e);
-    if (getenv("SEQWIN_AMD_NO_MMAP")) mmap_mode = 0;
+    if (const char *e = SW_TEST_GETENV("SEQWIN_AMD_MMAP")) mmap_mode = atoi(e);
+    if (SW_TEST_GETENV("SEQWIN_AMD_NO_MMAP")) mmap_mode = 0;
     const int use_mmap = mmap_mode;
     BufferPool pool;
     if (sink) pool.arena = sink->arena();
@@ -753,7 +753,7 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
     size_t sunk = 0;   // assemblies the sink thread is done with (under done_mu)
     std::condition_variable sunk_cv;
     size_t window = n_workers + n_workers / 2 + 4;
-    if (const char *e = getenv("SEQWIN_AMD_INGEST_WINDOW")) window = (size_t)std::max(1, atoi(e));
+    if (const char *e = SW_TEST_GETENV("SEQWIN_AMD_INGEST_WINDOW")) window = (size_t)std::max(1, atoi(e));
     auto worker = [&]() {
         RawBuf buf;
         for (;;) {

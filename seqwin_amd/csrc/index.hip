@@ -30,7 +30,7 @@ constexpr int TPB = 256;
 inline unsigned blocks_for(uint64_t n, int per = TPB) { return (unsigned)((n + per - 1) / per); }
 inline bool ranks_by_table()
 {
-    const char *e = getenv("SEQWIN_AMD_RANKS");
+    const char *e = SW_TEST_GETENV("SEQWIN_AMD_RANKS");
     return e && !strcmp(e, "table");
 }
 
@@ -63,7 +63,7 @@ bool sort_keys64_is_own(size_t n)
     // measured per build, edges stage (r04d, gpurun_out/r4v; keys = occurrences): 0.38 M keys 0.30 against 0.23 ms with rocPRIM,
     // 3 M 0.41 / 0.37, 6 M 0.53 / 0.55, 12 M 0.76 / 0.81, 24 M 1.22 / 1.47 (the launches and the look-back of few tiles weigh
     // more on small inputs) -> the own passes from 2^23 keys on (r03, with ballot ranking and state resets: from 2^26)
-    const char *e = getenv("SEQWIN_AMD_SORT");
+    const char *e = SW_TEST_GETENV("SEQWIN_AMD_SORT");
     const bool own = e ? !strcmp(e, "own") : n >= (1ull << 23);
     return own && !(e && !strcmp(e, "rocprim"));
 }
@@ -93,7 +93,7 @@ void sort_keys64(uint64_t *&keys, uint64_t *&keys_alt, size_t n, unsigned begin_
 // with the first pass reading the sketch stage, which comes with these passes; at 0.38 M the whole build is the same either way).
 bool sort_pairs_is_own(size_t n, unsigned bits)
 {
-    const char *e = getenv("SEQWIN_AMD_PAIR_SORT"), *all = getenv("SEQWIN_AMD_SORT");
+    const char *e = SW_TEST_GETENV("SEQWIN_AMD_PAIR_SORT"), *all = SW_TEST_GETENV("SEQWIN_AMD_SORT");
     if (e && !strcmp(e, "rocprim")) return false;
     if (bits % 8 != 0 || bits > 32 || n >= 0xFFFFFFFFull) return false;
     bool own = n >= (1ull << 20);
@@ -2337,7 +2337,7 @@ struct PaySort {
 void sort_pay(uint64_t n, hipStream_t stream, PaySort &o)
 {
     unsigned bits = 32;
-    if (const char *e = getenv("SEQWIN_AMD_SORT_KEYBITS")) {
+    if (const char *e = SW_TEST_GETENV("SEQWIN_AMD_SORT_KEYBITS")) {
         const int b = atoi(e);
         if (b >= 1 && b <= 32) bits = (unsigned)b;
     }
@@ -2568,7 +2568,7 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
     np.hash.alloc(node_cap);
     np.start.alloc(node_cap);
     uint64_t direct_max = UNSORT_DIRECT_MAX;
-    if (const char *e = getenv("SEQWIN_AMD_UNSORT_DIRECT")) direct_max = 1ull << std::min(40, std::max(0, atoi(e)));   // A/B, tests
+    if (const char *e = SW_TEST_GETENV("SEQWIN_AMD_UNSORT_DIRECT")) direct_max = 1ull << std::min(40, std::max(0, atoi(e)));   // A/B, tests
     const bool direct = rank_out && n <= direct_max;
     DevArray<uint64_t> uv0, uv1;
     if (rank_out && !direct) uv0.alloc(n);
@@ -2609,7 +2609,7 @@ uint32_t group_occurrences(PaySort &ps, uint64_t n, uint64_t base, const uint32_
                 if (!(sort_keys64_is_own(n) && radix_unsort_perm(v, v_alt, n, UNSORT_BITS, nbit, stream, words.p + 2)))
                     sort_keys64(v, v_alt, n, 32 + UNSORT_BITS, 32 + nbit, stream, words.p + 2, true);   // (the indices are a permutation)
             }
-            if (hold && rep && nbit > UNSORT_BITS && !getenv("SEQWIN_AMD_ADJ_SEPARATE")) {
+            if (hold && rep && nbit > UNSORT_BITS && !SW_TEST_GETENV("SEQWIN_AMD_ADJ_SEPARATE")) {
                 hold->sorted = v;
             } else {
                 hipLaunchKernelGGL(k_unsort_bucket, dim3((unsigned)((n + UNSORT_RANGE - 1) / UNSORT_RANGE)), dim3(1024), 0, stream, v, n,
@@ -2907,11 +2907,11 @@ __global__ void k_lw_emit(const uint64_t *__restrict__ canon, const uint64_t *__
 // SEQWIN_AMD_ORDER=copy keeps k_order (A/B, tests).
 static bool stage_fits_sort(uint64_t n, uint32_t n_tiles)
 {
-    if (const char *e = getenv("SEQWIN_AMD_ORDER")) {
+    if (const char *e = SW_TEST_GETENV("SEQWIN_AMD_ORDER")) {
         if (!strcmp(e, "copy")) return false;
-        if (!strcmp(e, "stage")) return n > 0 && radix_pairs_available() && !getenv("SEQWIN_AMD_SORT_KEYBITS");
+        if (!strcmp(e, "stage")) return n > 0 && radix_pairs_available() && !SW_TEST_GETENV("SEQWIN_AMD_SORT_KEYBITS");
     }
-    return n > 0 && sort_pairs_is_own(n, 32) && !getenv("SEQWIN_AMD_SORT_KEYBITS") && n / 16 >= n_tiles;
+    return n > 0 && sort_pairs_is_own(n, 32) && !SW_TEST_GETENV("SEQWIN_AMD_SORT_KEYBITS") && n / 16 >= n_tiles;
 }
 
 __global__ void k_fill_u64(uint64_t *p, uint32_t n, uint64_t v)
@@ -3196,7 +3196,7 @@ void edges_from_pairs(uint64_t *keys, uint64_t *keys_alt, uint64_t m, uint64_t s
         // w = 10 973 217 descents, -0.7 ms; the 15 000-genome set (9.4 occurrences per node, up to 500) 8.4 M descents in 358 k runs
         // above 64 keys, +2.1 ms: stays at one (gpurun_out/r5g).  A third digit (4.9e7 descents on the iid share) loses everywhere.
         if (skip && hb >= 2 * digit_bits + 8 && ix.n_nodes && m <= 4 * ix.n_nodes) skip = 2;
-        if (const char *e = getenv("SEQWIN_AMD_EDGE_SKIP_PASSES")) skip = (unsigned)atoi(e);   // A/B, tests (0: all bits by radix passes)
+        if (const char *e = SW_TEST_GETENV("SEQWIN_AMD_EDGE_SKIP_PASSES")) skip = (unsigned)atoi(e);   // A/B, tests (0: all bits by radix passes)
         skip = std::min(skip, n_passes - 1);
         low_bits = skip * digit_bits;
     }
@@ -3441,12 +3441,12 @@ void build_index(const uint32_t *d_rec_asm, uint64_t n_records, uint64_t n_assem
     // occurrence order is this library's own stable sort, so the validation flags of filter.cpp:103-123 are only produced
     // under SEQWIN_AMD_CHECK_ORDER=1 (then the C-ABI get_penalty's flag / prefix-sum form runs instead).
     const bool want_counts = d_is_target != nullptr;
-    const bool check_order = want_counts && getenv("SEQWIN_AMD_CHECK_ORDER") != nullptr;
+    const bool check_order = want_counts && SW_TEST_GETENV("SEQWIN_AMD_CHECK_ORDER") != nullptr;
     // The edges are counted without assemblies (keys-only pair sort + a side list of the records that can repeat a pair
     // inside one assembly, k_adj_pairs) unless SEQWIN_AMD_NO_PACKED_EDGES=1 asks for the (pair, assembly) sort that the
     // multi-GPU slices use, or the rank words have no spare bit (2^31 nodes or more).
     const bool by_table = occ.hash.p != nullptr;   // SEQWIN_AMD_RANKS=table (order_tuples then kept the hashes)
-    const bool pair_edges = !getenv("SEQWIN_AMD_NO_PACKED_EDGES") && !by_table;
+    const bool pair_edges = !SW_TEST_GETENV("SEQWIN_AMD_NO_PACKED_EDGES") && !by_table;
     bool rep_marked = false;
     DevArray<uint32_t> rec_flag;
     DevArray<unsigned long long> tbits, nbits;
@@ -3617,11 +3617,11 @@ void merge_build(const uint64_t *d_occ_rows, uint64_t n, const uint64_t *d_edge_
     // concatenated in source-rank = (record, pos) order, so the counts come from k_nodes' bitmaps as in the single-GPU build
     // (no flag arrays, no prefix sums, nothing left running) and the ranks carry the repeat marks.  SEQWIN_AMD_CHECK_ORDER=1
     // keeps the validating form below.
-    const bool slice = d_rank_out && m == 0 && d_rec_asm && n_records && !getenv("SEQWIN_AMD_CHECK_ORDER");
+    const bool slice = d_rank_out && m == 0 && d_rec_asm && n_records && !SW_TEST_GETENV("SEQWIN_AMD_CHECK_ORDER");
     if (n) {
         PaySort ps;
-        const char *order = getenv("SEQWIN_AMD_ORDER");   // ("copy": A/B, as for the sketch stage of the single-GPU build)
-        if (sort_pairs_is_own(n, 32) && !getenv("SEQWIN_AMD_SORT_KEYBITS") && !(order && !strcmp(order, "copy"))) {
+        const char *order = SW_TEST_GETENV("SEQWIN_AMD_ORDER");   // ("copy": A/B, as for the sketch stage of the single-GPU build)
+        if (sort_pairs_is_own(n, 32) && !SW_TEST_GETENV("SEQWIN_AMD_SORT_KEYBITS") && !(order && !strcmp(order, "copy"))) {
             ps.rows_src = d_occ_rows;   // the sort's first pass reads the rows
         } else {
             ps.key_a.alloc(n);

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(1024) void k_rs_rank_selftest(uint32_t *__restrict_
 // fails loudly if the device does not pass it).
 bool ballot_forced()
 {
-    const char *e = getenv("SEQWIN_AMD_RADIX_RANK");
+    const char *e = SW_TEST_GETENV("SEQWIN_AMD_RADIX_RANK");
     return e && !strcmp(e, "ballot");
 }
 std::mutex &rank_mu()
@@ -195,7 +195,7 @@ int rank_mode()
 {
     std::mutex &mu = rank_mu();
     std::map<int, int> &modes = rank_modes();
-    const char *e = getenv("SEQWIN_AMD_RADIX_RANK");
+    const char *e = SW_TEST_GETENV("SEQWIN_AMD_RADIX_RANK");
     if (e && !strcmp(e, "ballot")) return 0;
     int dev = 0;
     SW_HIP(hipGetDevice(&dev));
@@ -222,7 +222,7 @@ int rank_mode()
 // passes and rocPRIM's have no such hook, so a build recovers once the guards have demoted the device.
 static uint32_t fault_rank()
 {
-    const char *e = getenv("SEQWIN_AMD_FAULT_INJECT");
+    const char *e = SW_TEST_GETENV("SEQWIN_AMD_FAULT_INJECT");
     return (e && !strcmp(e, "rank")) ? 1u : 0u;
 }
 
@@ -1398,7 +1398,7 @@ void radix_sort_pairs32(uint32_t *&keys, uint32_t *&keys_alt, OccPay *&vals, Occ
 // which shape a sort of `bits` key bits takes: 0 = 512 threads x 8 bits, 1 = 1024 x 9, 2 = 1024 x 8, 3 = 512 x 9, 4 = 256 x 8 (the last three: A/B)
 static int pick_shape(unsigned bits)
 {
-    const char *e = getenv("SEQWIN_AMD_RADIX_BITS");   // A/B: 8 or 9
+    const char *e = SW_TEST_GETENV("SEQWIN_AMD_RADIX_BITS");   // A/B: 8 or 9
     const bool nine = e ? atoi(e) == 9 : (bits + 8) / 9 < (bits + 7) / 8;   // 9-bit digits where they save a pass (54 bits: 6 for 7)
     const char *shape = SW_AB_GETENV("SEQWIN_AMD_RADIX_SHAPE");   // A/B (-DSW_AB)
     if (shape && !strcmp(shape, "1024x8")) return 2;

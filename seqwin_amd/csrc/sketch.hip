@@ -1263,7 +1263,7 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
     // whole build, direct / two-step: w = 1500 5.6 / 6.0 ms, 2048 7.1 / 5.9, 3000 7.3 / 5.8, 4096 10.0 / 5.7.
     // SEQWIN_AMD_WINDOW_SPLIT="T,B" (tests, A/B): windows above T <= SW_MAX_WINDOW go through base B <= T.
     uint32_t split_at = SW_WINDOW_SPLIT, split_base = 1024;
-    if (const char *e = getenv("SEQWIN_AMD_WINDOW_SPLIT")) {
+    if (const char *e = SW_TEST_GETENV("SEQWIN_AMD_WINDOW_SPLIT")) {
         unsigned t = 0, bs = 0;
         if (sscanf(e, "%u,%u", &t, &bs) == 2 && bs >= 1 && bs <= t && t <= SW_MAX_WINDOW) {
             split_at = t;
@@ -1291,7 +1291,7 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
     p.TW = p.NE - w;
     p.lds_bytes = lds_bytes_for(L);
     // fast class: single-segment records, k <= KF, power-of-two run length
-    const char *force = getenv("SEQWIN_AMD_SKETCH");   // "generic" disables the fast path (debug / A-B)
+    const char *force = SW_TEST_GETENV("SEQWIN_AMD_SKETCH");   // "generic" disables the fast path (debug / A-B)
     // (r04: runs of 8 and 4 for windows below 16 -- the fast kernel needs w >= L; SEQWIN_AMD_SKETCH=nosmall: the generic kernel, as before)
     const bool small_ok = !(force && !strcmp(force, "nosmall"));
     p.Lf = (k <= KF && !(force && !strcmp(force, "generic")))
@@ -1406,7 +1406,7 @@ Plan &get_plan(sw_batch &b, uint64_t k64, uint64_t w64, bool *cached)
     {   // a tile's own stage slot: 1.5 x the expected 2 / (w + 1) minimizers per window end, + 16
         const uint64_t tw = std::max<uint64_t>(p.TW, p.fc[0].TW);
         p.slot_cap = (uint32_t)std::min<uint64_t>(tw + w, (3 * tw / (w + 1) + 16 + 7) / 8 * 8);
-        if (const char *e = getenv("SEQWIN_AMD_SLOT_CAP")) p.slot_cap = (uint32_t)std::max(1, atoi(e));   // test hook
+        if (const char *e = SW_TEST_GETENV("SEQWIN_AMD_SLOT_CAP")) p.slot_cap = (uint32_t)std::max(1, atoi(e));   // test hook
     }
 
     auto up32 = [](DevArray<uint32_t> &d, const std::vector<uint32_t> &v) {
@@ -1605,7 +1605,7 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         a.ovf_list = nullptr;
         a.halo = plan.halo_f;
         {
-            const char *rc = getenv("SEQWIN_AMD_RC");   // test hook: force the overflow (list-mode) path
+            const char *rc = SW_TEST_GETENV("SEQWIN_AMD_RC");   // test hook: force the overflow (list-mode) path
             a.rc_limit = rc ? std::min<uint32_t>(RC, (uint32_t)atoi(rc)) : RC;
         }
         // the lists start with the plan's gap tiles; the fast kernels append

@@ -11,6 +11,18 @@ if str(ROOT) not in sys.path:
 
 GOLDEN = ROOT / "tests" / "golden"
 
+# The suite drives the library through switches that force size-dependent paths on small inputs, inject faults, lower bounds ...
+# Those test hooks are compiled OUT of the release library (csrc/common.hpp: SW_TEST_GETENV); the suite loads the TEST library --
+# same sources, hooks live -- unless told otherwise.  SEQWIN_AMD_RELEASE_LIB=1 keeps the release library (tests/test_release_library.py
+# runs the parity tests that need no hook on it); an explicit SEQWIN_AMD_LIB wins over both.
+import os  # noqa: E402
+
+_TEST_LIB = ROOT / "seqwin_amd" / "libseqwin_hip_test.so"
+if "SEQWIN_AMD_LIB" not in os.environ and os.environ.get("SEQWIN_AMD_RELEASE_LIB") != "1":
+    if not _TEST_LIB.exists():
+        raise RuntimeError(f"{_TEST_LIB} is missing: make -C seqwin_amd/csrc test (or python -c 'import __graft_entry__ as g; g.build()')")
+    os.environ["SEQWIN_AMD_LIB"] = str(_TEST_LIB)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")

@@ -568,3 +568,30 @@ def test_multi_device_host_side_under_thread_sanitizer(tmp_path):
         assert f"{jobs} jobs:" in r.stdout and " 0 wrong results, 0 stamp mismatches" in r.stdout, r.stdout
         if "MOCK_FAIL" not in extra:
             assert f"{jobs} built, 0 failed" in r.stdout, r.stdout
+
+
+def test_release_library_carries_no_test_hooks():
+    """The switches that force size-dependent paths, inject faults or lower bounds are live in the TEST library only
+    (csrc/common.hpp: SW_TEST_GETENV; `make test`): the release library reads them as unset -- their names are not even in the
+    binary -- so a deployment is left with the "use" switches of DESIGN.md section 8a.  Both libraries are built from the same
+    sources; this suite runs on the test library (tests/conftest.py), tests/test_release_library.py on the release one."""
+    import os
+    import subprocess
+    rel, tst = ROOT / "seqwin_amd" / "libseqwin_hip.so", ROOT / "seqwin_amd" / "libseqwin_hip_test.so"
+    assert rel.exists() and tst.exists()
+    hooks = ["SORT_KEYBITS", "FAULT_INJECT", "SLOT_CAP", "WINDOW_SPLIT", "RADIX_RANK", "EDGE_SKIP_PASSES", "UNSORT_DIRECT", "NO_PACKED_EDGES",
+             "SCALAR_INGEST", "LINE_PACKER", "READ_BLOCK_KB", "EXPORT_WHOLE", "PLAIN_DOWNLOAD", "PINNED_SLAB_MB", "INGEST_WINDOW"]
+    use = ["SEQWIN_DEVICES", "SEQWIN_AMD_HBM_BUDGET_GB", "SEQWIN_AMD_LOWMEM_CHUNK_MBP", "SEQWIN_AMD_NO_RESIDENT", "SEQWIN_AMD_DEVICE_INFLATE",
+           "SEQWIN_AMD_POOL_DEBUG"]
+    blob_rel, blob_tst = rel.read_bytes(), tst.read_bytes()
+    for h in hooks:
+        name = b'SEQWIN_AMD_' + h.encode() + b'\0'
+        assert name not in blob_rel, f"{h} is readable in the release library"
+        assert name in blob_tst, f"{h} is missing from the test library"
+    for u in use:
+        assert u.encode() + b'\0' in blob_rel, u
+    assert os.path.samefile(os.environ["SEQWIN_AMD_LIB"], tst) or os.environ.get("SEQWIN_AMD_RELEASE_LIB") == "1"
+    # the suite really runs on the test library, a fresh interpreter without the suite's environment on the release one
+    r = subprocess.run([__import__("sys").executable, "-c", "from seqwin_amd._lib import LIB_PATH; print(LIB_PATH)"], capture_output=True, text=True,
+                       cwd=str(ROOT), env={k: v for k, v in os.environ.items() if k not in ("SEQWIN_AMD_LIB",)})
+    assert r.returncode == 0 and r.stdout.strip().endswith("libseqwin_hip.so"), (r.stdout, r.stderr)
