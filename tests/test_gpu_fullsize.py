@@ -294,6 +294,16 @@ def test_pin_script_reproduces_the_committed_reference_values_on_a_prefix(tmp_pa
 
 def _bench_line(extra_args, env_extra):
     import subprocess
+    # The child builds the 75 Gbp set in its own process next to this one on the ONE card: what this process still caches -- the pool's
+    # blocks of the tests before (~130 GB after a 15 000-genome build), a resident index, torch's cached blocks -- goes back to the
+    # driver first (r06: with it the child had 4 GiB to spare or not, depending on the day).
+    from seqwin_amd._lib import lib as _l
+    from seqwin_amd.device import pool_trim
+    _l.sw_release_resident.restype = None
+    _l.sw_release_resident()
+    pool_trim()
+    if "torch" in sys.modules:
+        sys.modules["torch"].cuda.empty_cache()
     env = dict(os.environ, **env_extra)
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--no-cpu-baseline"] + extra_args, capture_output=True, text=True,
                          timeout=900, env=env)
