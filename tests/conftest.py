@@ -19,8 +19,11 @@ import os  # noqa: E402
 
 _TEST_LIB = ROOT / "seqwin_amd" / "libseqwin_hip_test.so"
 if "SEQWIN_AMD_LIB" not in os.environ and os.environ.get("SEQWIN_AMD_RELEASE_LIB") != "1":
-    if not _TEST_LIB.exists():
-        raise RuntimeError(f"{_TEST_LIB} is missing: make -C seqwin_amd/csrc test (or python -c 'import __graft_entry__ as g; g.build()')")
+    if not _TEST_LIB.exists():   # (a fresh checkout: the libraries are build products, __graft_entry__.build() makes both)
+        import subprocess
+        r = subprocess.run(["make", "-C", str(ROOT / "seqwin_amd" / "csrc"), "-j6", "all", "test"], capture_output=True, text=True)
+        if r.returncode != 0 or not _TEST_LIB.exists():
+            raise RuntimeError(f"{_TEST_LIB} is missing and `make -C seqwin_amd/csrc all test` failed:\n{r.stderr[-2000:]}")
     os.environ["SEQWIN_AMD_LIB"] = str(_TEST_LIB)
 
 
