@@ -1670,18 +1670,22 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         // their class).  The list length is only known on the device: a first batch of LIST_GRID workgroups per class is
         // enqueued blind (surplus workgroups exit at once), the rest -- rare -- after the counts have come back.
         constexpr uint32_t LIST_GRID = 2048;
+        // (r06: the gap tiles of a class are known to the plan -- ragged assemblies with scaffold gaps list thousands of them --, so the
+        //  blind launch covers them + LIST_GRID overflow tiles: no read-back and second launch for what the host already knows)
+        uint32_t list_grid[2] = {LIST_GRID, LIST_GRID};
         SketchArgs al[2] = {a, a};
         for (int c = 0; c < 2; ++c) {
             const Plan::FastClass &fc = plan.fc[c];
             if (!fc.n_tiles) continue;
+            list_grid[c] = (uint32_t)std::min<uint64_t>((uint64_t)fc.n_gap + LIST_GRID, MAX_TILES_PER_LAUNCH);
             al[c].cls_desc = fc.desc.p;
             al[c].ovf_count = ovf_count.p + c;
             al[c].L = plan.Lg_list;
             al[c].TW = fc.TW;
             al[c].list = ovf_list[c];
             al[c].tile_base = 0;
-            al[c].n_tiles = LIST_GRID;
-            hipLaunchKernelGGL(sketch_generic_kernel, dim3(std::min(LIST_GRID, fc.n_tiles)), dim3(BLOCK),
+            al[c].n_tiles = list_grid[c];
+            hipLaunchKernelGGL(sketch_generic_kernel, dim3(std::min(list_grid[c], fc.n_tiles)), dim3(BLOCK),
                                lds_bytes_for(plan.Lg_list), stream, al[c]);
             SW_HIP(hipGetLastError());
         }
@@ -1702,10 +1706,10 @@ void run_sketch(const sw_batch &b, const Plan &plan, hipStream_t stream, SketchO
         if (sketch_ms) *sketch_ms += ms;
         ++out.launches;
         out.n_ovf_tiles += (uint64_t)n_ovf[0] + n_ovf[1];
-        if (n_ovf[0] > LIST_GRID || n_ovf[1] > LIST_GRID) {
+        if (n_ovf[0] > list_grid[0] || n_ovf[1] > list_grid[1]) {
             SW_HIP(hipEventRecord(ev0, stream));
             for (int c = 0; c < 2; ++c)
-                for (uint32_t tb = LIST_GRID; tb < n_ovf[c]; tb += MAX_TILES_PER_LAUNCH) {
+                for (uint32_t tb = list_grid[c]; tb < n_ovf[c]; tb += MAX_TILES_PER_LAUNCH) {
                     al[c].tile_base = tb;
                     hipLaunchKernelGGL(sketch_generic_kernel, dim3(std::min(n_ovf[c] - tb, MAX_TILES_PER_LAUNCH)), dim3(BLOCK),
                                        lds_bytes_for(plan.Lg_list), stream, al[c]);
