@@ -160,7 +160,8 @@ void pull(void *dst, int dst_dev, const void *src, int src_dev, size_t bytes, hi
     }
     // no peer access: device -> pinned host (on the source's device, blocking) -> device (this worker's stream).  The source's
     // bytes are complete (every pull follows a rendezvous behind the producer's stream synchronisation).
-    if (!hs.p) SW_HIP(hipHostMalloc(&hs.p, HostStage::BYTES, hipHostMallocDefault));
+    // (portable: the source device's copy engine writes it, the pulling device's reads it -- two different devices on a real node)
+    if (!hs.p) SW_HIP(hipHostMalloc(&hs.p, HostStage::BYTES, hipHostMallocPortable));
     for (size_t o = 0; o < bytes; o += HostStage::BYTES) {
         const size_t n = std::min(HostStage::BYTES, bytes - o);
         if (src_dev != dst_dev) SW_HIP(hipSetDevice(src_dev));
