@@ -1226,6 +1226,34 @@ def test_build_splits_itself_when_the_occurrences_outgrow_32_bit_indices(tmp_pat
         root.setLevel(old_level)
 
 
+@pytest.mark.parametrize("chunk_mbp", ["0", "1", "4096"])
+def test_pipelined_build_matches_standard(tmp_path, monkeypatch, chunk_mbp):
+    """SEQWIN_AMD_PIPELINE=1: the host threads parse the files in consecutive chunks while a second host thread drives the device
+    through the previous chunk (plan, sketch, ordered tuples); the index is built from the concatenated tuple stream.  The
+    reference interleaves reading and minimizing per assembly (build.cpp:98-256); the result must not depend on it: one assembly
+    per chunk, a few per chunk, everything in one chunk -- gz files, empty records, low complexity -- against the oracle."""
+    from test_gpu_fullsize import write_fasta_sample
+    monkeypatch.setenv("SEQWIN_AMD_PIPELINE", "1")
+    monkeypatch.setenv("SEQWIN_AMD_PIPELINE_CHUNK_MBP", chunk_mbp)
+    synth = sorted((GOLDEN / "synth").glob("pan_*.fa")) + sorted((GOLDEN / "synth").glob("edge_*"))
+    lc = tmp_path / "lc.fa"
+    lc.write_text(">at\n" + "AT" * 4000 + "\n>rep7\n" + "ACGGTCA" * 2000 + "\n>mix\n" + "A" * 500 + "N" + "C" * 700 + "ACGT" * 300 + "\n")
+    for paths, k, w in ((synth, 15, 20), (synth + [lc, lc], 11, 5)):
+        exp = oracle.build(paths, k, w)
+        many = _build(paths, k, w, n_cpu=3)
+        assert_graph_equal(many, dict(zip(("kmers", "nodes", "edges", "record_offsets"), exp[:4])), [list(t) for t in exp[4]])
+    b = Batch.synthetic(24, 4, 60_000, n_ancestors=3, snp_ppm=20_000, seed=11)
+    paths, _ = write_fasta_sample(b, 24, str(tmp_path))
+    b.close()
+    got = _build(paths, 21, 200, n_cpu=4)
+    monkeypatch.delenv("SEQWIN_AMD_PIPELINE")
+    one = _build(paths, 21, 200, n_cpu=4)
+    assert all(np.array_equal(a, c) for a, c in zip(one[:4], got[:4])) and one[4] == got[4]
+    with pytest.raises(RuntimeError, match="Unable to open FASTA"):
+        monkeypatch.setenv("SEQWIN_AMD_PIPELINE", "1")
+        _build(paths[:6] + [tmp_path / "missing.fa"] + paths[6:], 21, 200, n_cpu=2)
+
+
 def test_low_memory_is_honoured_under_seqwin_devices(tmp_path, monkeypatch):
     """low_memory / SEQWIN_AMD_HBM_BUDGET_GB under SEQWIN_DEVICES: every worker streams ITS shard through HBM in chunks
     (sw_occ_sketch_paths; until r05 the request was answered with a warning) -- chunk boundaries inside a shard, gz files, shards of

@@ -83,6 +83,12 @@ int main(int argc, char **argv)
         else unsetenv("SEQWIN_DEVICES");
         if (r % 3 == 2) setenv("SEQWIN_MULTI_NO_P2P", "1", 1);
         else unsetenv("SEQWIN_MULTI_NO_P2P");
+        if (r % 7 == 0 && r % 5 != 4) {   // the single-device rounds: ingest and sketch overlapped (a second host thread drives the device)
+            setenv("SEQWIN_AMD_PIPELINE", "1", 1);
+            setenv("SEQWIN_AMD_PIPELINE_CHUNK_MBP", "0", 1);
+        } else {
+            unsetenv("SEQWIN_AMD_PIPELINE");
+        }
         const auto paths = write_files(dir, 3 + (int)(rnd() % 9), r);
         const int rc = one_build(paths, 15 + rnd() % 10, 10 + rnd() % 200, 1 + rnd() % 8, r % 5 == 4);
         printf("round %d devices=[%s]%s files=%zu rc=%d\n", r, devs, r % 3 == 2 ? " no-p2p" : "", paths.size(), rc);
