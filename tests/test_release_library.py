@@ -19,7 +19,7 @@ def test_parity_tests_pass_on_the_release_library():
     env = {k: v for k, v in os.environ.items() if k != "SEQWIN_AMD_LIB"}
     env["SEQWIN_AMD_RELEASE_LIB"] = "1"
     sel = ("smoke or golden or fuzz_build or synthetic_batch or ragged or penalty_f64 or identity_test or reference_vectors or "
-           "full_size_properties or low_complexity or multi_device_build_on_a_synthetic_job or pipelined or low_memory_is_honoured")
+           "full_size_properties or low_complexity or multi_device_build_on_a_synthetic_job or pipelined_build or low_memory_is_honoured")
     r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k", sel,
                         "-p", "no:cacheprovider"], capture_output=True, text=True, cwd=str(ROOT), env=env, timeout=900)
     tail = r.stdout[-1500:]
