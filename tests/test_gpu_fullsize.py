@@ -115,6 +115,47 @@ def test_ragged500_full_size_checksums_of_the_reference():
     assert v["weight_sum"] == gold["weight_sum"] and ix.threshold_sums()[0] == gold["n_tar_sum"]
 
 
+def test_automatic_split_at_the_scale_of_configs1_w10(tmp_path, monkeypatch):
+    """The automatic split of a job that outgrows a device's 32-bit indices (sw_build catches OccCapError and rebuilds the job over
+    logical shards: csrc/multi.hip on one card) at a size where the shards are real: configs[1] at w = 10 -- 4.5e8 occurrences,
+    6.6e7 nodes, 8.1e7 edges -- with the bound lowered to 2e8 (SEQWIN_AMD_OCC_CAP, test library): FASTA -> sw_build (one shard fails,
+    three or four succeed) -> numpy; counts and checksums must be the compiled reference's (tests/golden/bench_checksums_ref.json).
+    The reference indexes with size_t and has no such bound (cpp/include/seqwin/graph.hpp:28-41)."""
+    import logging
+
+    from bench import write_fasta_fast
+    from seqwin_amd import KmerGraph
+    sys.path.insert(0, str(ROOT / "scripts"))
+    from pin_fullsize_ref import chunked_checksums
+    G, rpg, rl, anc, snp, _ = WORKLOADS["salmonella500"]
+    gold, src = _full_size_golden("salmonella500/k21/w10")
+    b = Batch.synthetic(G, rpg, rl, n_ancestors=anc, snp_ppm=snp, seed=SEED)
+    paths, bp = write_fasta_fast(b, G, str(tmp_path), 16)
+    b.close()
+    records = []
+
+    class _Grab(logging.Handler):
+        def emit(self, record):
+            records.append(record.getMessage())
+    h = _Grab(level=logging.INFO)
+    root = logging.getLogger()
+    old_level = root.level
+    root.addHandler(h)
+    root.setLevel(logging.INFO)
+    try:
+        monkeypatch.setenv("SEQWIN_AMD_OCC_CAP", "200000000")
+        g = KmerGraph(paths, kmerlen=21, windowsize=10, n_cpu=16)
+    finally:
+        root.removeHandler(h)
+        root.setLevel(old_level)
+    assert any("splitting the job into" in m for m in records), records
+    assert gold["counts"] == {"kmers": len(g.kmers), "nodes": len(g.nodes), "edges": len(g.edges)}
+    nodes = g.nodes.copy()
+    from seqwin_amd import _get_penalty
+    _get_penalty(g.kmers, nodes, g.record_offsets, list(np.arange(G) % 2 == 0))
+    assert [f"{v:016x}" for v in chunked_checksums(g.kmers, nodes, g.edges)] == gold["checksums"]
+
+
 def test_config1_multi_device_build_equals_single_device(tmp_path, monkeypatch):
     """configs[1] (512 genomes, 2.46 Gbp, 24.6 M minimizers) as FASTA through ONE sw_build over four and seven logical devices
     (SEQWIN_DEVICES, csrc/multi.hip: worker threads, peer copies, both ways of bringing node hashes to the edge owners) against
