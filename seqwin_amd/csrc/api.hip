@@ -149,6 +149,14 @@ void pool_debug_poison(void *ptr, size_t sz)
     (void)hipDeviceSynchronize();
     if (hipMemsetD32Async((hipDeviceptr_t)ptr, (int)POOL_POISON, sz / 4, nullptr) != hipSuccess) (void)hipGetLastError();
     (void)hipStreamSynchronize(nullptr);
+    // test hook: SEQWIN_AMD_FAULT_INJECT=pool writes one word into every 64th released block AFTER it was poisoned -- what a kernel
+    // still queued at the release would do -- so that the suite can see the detector detect (tests/test_gpu_parity.py)
+    static std::atomic<uint64_t> n_released{0};
+    const char *inj = SW_TEST_GETENV("SEQWIN_AMD_FAULT_INJECT");
+    if (inj && !strcmp(inj, "pool") && sz >= 4096 && n_released.fetch_add(1) % 64 == 63) {
+        const uint32_t stray = 0xDEADBEEFu;
+        (void)hipMemcpy((char *)ptr + 1024, &stray, 4, hipMemcpyHostToDevice);
+    }
 }
 void pool_debug_check(void *ptr, size_t sz)   // raises if the block was written after pool_debug_poison
 {

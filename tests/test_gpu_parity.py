@@ -7,6 +7,7 @@ bit-identical (tolerance 0) because the reference's own thread-invariance test c
 rows with np.array_equal (test_graph.py:281-291).
 """
 import gzip
+import os
 import random
 from pathlib import Path
 
@@ -1252,6 +1253,44 @@ def test_pipelined_build_matches_standard(tmp_path, monkeypatch, chunk_mbp):
     with pytest.raises(RuntimeError, match="Unable to open FASTA"):
         monkeypatch.setenv("SEQWIN_AMD_PIPELINE", "1")
         _build(paths[:6] + [tmp_path / "missing.fa"] + paths[6:], 21, 200, n_cpu=2)
+
+
+def test_pool_debug_mode_detects_a_block_written_after_its_release(tmp_path):
+    """SEQWIN_AMD_POOL_DEBUG=1 (the soak mode of the device pool: releases wait for the device and poison, reuses wait and check) must
+    DETECT -- a soak that reports "0 blocks written after their release" only means something if a block that IS written after its
+    release is reported.  The test hook SEQWIN_AMD_FAULT_INJECT=pool writes one word into every 64th released block behind the
+    poison, as a kernel still queued at the release would: builds then fail with the offset of the damage and sw_pool_debug_stats
+    counts the blocks; without the injection the same builds under the debug mode give the oracle's arrays."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys, numpy as np\n"
+        "from seqwin_amd import KmerGraph\n"
+        "from seqwin_amd._lib import lib\n"
+        "paths = sys.argv[1:]\n"
+        "errors, g = 0, None\n"
+        "for rep in range(12):\n"
+        "    try:\n"
+        "        g = KmerGraph(paths, kmerlen=15, windowsize=20, n_cpu=2)\n"
+        "    except RuntimeError as e:\n"
+        "        assert 'POOL_DEBUG' in str(e) and 'offset 1024' in str(e), e\n"
+        "        errors += 1\n"
+        "st = (ctypes.c_uint64 * 3)()\n"
+        "lib.sw_pool_debug_stats(st)\n"
+        "print('debug', st[0], 'violations', st[1], 'errors', errors, 'kmers', len(g.kmers) if g is not None else -1)\n")
+    paths = [str(p) for p in sorted((GOLDEN / "synth").glob("pan_*.fa"))]
+    env = dict(os.environ, SEQWIN_AMD_POOL_DEBUG="1")
+    r = subprocess.run([sys.executable, "-c", code] + paths, capture_output=True, text=True, env=dict(env, SEQWIN_AMD_FAULT_INJECT="pool"), timeout=300,
+                       cwd=str(Path(__file__).resolve().parent.parent))
+    assert r.returncode == 0, r.stderr[-2000:]
+    f = r.stdout.split()
+    assert f[1] == "1" and int(f[3]) >= 1 and int(f[5]) >= 1, r.stdout
+    assert "was written AFTER its release" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code] + paths, capture_output=True, text=True, env=env, timeout=300, cwd=str(Path(__file__).resolve().parent.parent))
+    assert r.returncode == 0, r.stderr[-2000:]
+    f = r.stdout.split()
+    ek = oracle.build(paths, 15, 20)[0]
+    assert f[1] == "1" and f[3] == "0" and f[5] == "0" and int(f[7]) == len(ek), r.stdout
 
 
 def test_low_memory_is_honoured_under_seqwin_devices(tmp_path, monkeypatch):
