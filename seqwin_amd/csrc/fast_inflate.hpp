@@ -284,6 +284,7 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
         while (br.in + 8 <= br.in_end && (size_t)(out_cap - out) >= 320) {
             br.refill();
             uint32_t e = tb.ll[br.peek(LL_BITS)];
+        have_entry:   // (r06: behind a match, the next symbol's entry is looked up BEFORE the match is copied -- see below)
             if (e & K_LIT) {
                 // up to three literals straight from the first-level table (3 x 11 bits of the >= 56 in the buffer: every entry is
                 // found through valid bits, and a non-literal entry behind them is still good after the refill below)
@@ -335,6 +336,14 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
             const uint8_t *src = out - dist;
             uint8_t *dst = out;
             out += len;
+            // The loop is one dependent chain -- refill -> table -> bits -> table -- of ~23 cycles per length / distance pair, and three of
+            // four symbols of level-6 DNA text are such pairs.  The next symbol's table entry does not depend on the bytes the match copies:
+            // refill and look it up now (while the loop's conditions still hold), so that its load overlaps the copy.
+            const bool ahead = br.in + 8 <= br.in_end && (size_t)(out_cap - out) >= 320;
+            if (ahead) {
+                br.refill();
+                e = tb.ll[br.peek(LL_BITS)];
+            }
             if (dist >= 8) {
                 uint64_t w;   // (most matches of DNA text are 3 ... 16 bytes: two moves without a loop; 320 spare bytes behind `out`)
                 memcpy(&w, src, 8);
@@ -356,6 +365,7 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
             } else {
                 do *dst++ = *src++; while (dst < out);
             }
+            if (ahead) goto have_entry;
         }
         // ---- ... and the careful loop for the ends of the buffers ----
         while (!block_done) {
