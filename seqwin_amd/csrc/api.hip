@@ -687,6 +687,8 @@ struct PinnedArena : WordArena {
     // The parsers are plain threads whose current device is 0: a slab is page-locked from the device of a sink that is at work (the
     // memory is portable, any of them will do) -- never a context on a GPU this process does not use.
     std::atomic<int> grow_device{0};
+    // (SEQWIN_AMD_DEBUG_TIMING: what an ingest got from the arena)
+    std::atomic<uint64_t> n_served{0}, n_declined_busy{0}, n_declined_limit{0}, n_slabs{0}, lock_us{0};
     void read_limit()   // (per ingest, so that one process can compare settings)
     {
         const char *e = getenv("SEQWIN_AMD_PINNED_POOL_MB"), *sl = SW_TEST_GETENV("SEQWIN_AMD_PINNED_SLAB_MB");
@@ -721,24 +723,29 @@ struct PinnedArena : WordArena {
         const size_t bytes = (min_words * 8 + GRAIN - 1) / GRAIN * GRAIN;
         {
             std::lock_guard<std::mutex> lock(mu);
-            if (uint64_t *p = take(min_words, bytes, cap_words)) return p;
+            if (uint64_t *p = take(min_words, bytes, cap_words)) { ++n_served; return p; }
         }
         // Page-locking fresh memory costs 2-4 ms per MiB on the target host while the parsers keep its CPUs busy, in 2 MiB calls
         // from many threads as in one 64 MiB call (gpurun_out/r5aa, r5ab: the first streaming ingest of a process took 0.15-0.6 s
         // longer): whole slabs, by one thread at a time, and nobody waits for it -- while a slab is being locked the other parsers
         // get nullptr (malloc + the ring for that assembly, as before r05) and find blocks at their next file.
         std::unique_lock<std::mutex> grow(grow_mu, std::try_to_lock);
-        if (!grow.owns_lock()) return nullptr;
+        if (!grow.owns_lock()) { ++n_declined_busy; return nullptr; }
         const size_t want = std::max(bytes, SLAB.load());
         {
             std::lock_guard<std::mutex> lock(mu);
-            if (uint64_t *p = take(min_words, bytes, cap_words)) return p;   // (another thread has grown the pool meanwhile)
-            if (total_bytes + want > limit_bytes) return nullptr;
+            if (uint64_t *p = take(min_words, bytes, cap_words)) { ++n_served; return p; }   // (another thread has grown the pool meanwhile)
+            if (total_bytes + want > limit_bytes) { ++n_declined_limit; return nullptr; }
             total_bytes += want;
         }
         void *fresh = nullptr;
         (void)hipSetDevice(grow_device.load());
-        if (hipHostMalloc(&fresh, want, hipHostMallocPortable) != hipSuccess) {
+        const auto t_lock = std::chrono::steady_clock::now();
+        const hipError_t lock_err = hipHostMalloc(&fresh, want, hipHostMallocPortable);
+        lock_us += (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_lock).count();
+        ++n_slabs;
+        ++n_served;
+        if (lock_err != hipSuccess) {
             (void)hipGetLastError();
             std::lock_guard<std::mutex> lock(mu);
             total_bytes -= want;
@@ -775,6 +782,7 @@ struct DeviceSink : ChunkSink {
         hipEvent_t ev;
     };
     std::deque<InFlight> in_flight;   // page-locked buffers whose copies are on their way, oldest first
+    uint64_t n_direct = 0, n_ring = 0;
     static constexpr size_t IN_FLIGHT_MAX = 48;
     DeviceSink(sw_batch &batch, PinnedRing &r) : b(batch), ring(r), hold(r.in_use)
     {
@@ -816,6 +824,7 @@ struct DeviceSink : ChunkSink {
         size_t left = n_words64 * 8;
         char *dst = (char *)(b.d_packed.p + 2 * word_off);
         if (words.in_arena()) {   // DMA from the parser's own buffer; it returns to the arena when the copy has left the host
+            ++n_direct;
             reap(false);
             hipEvent_t ev = ring.take_event();
             SW_HIP(hipMemcpyAsync(dst, src, left, hipMemcpyHostToDevice, ring.st));
@@ -824,6 +833,7 @@ struct DeviceSink : ChunkSink {
             used32 = (word_off + n_words64) * 2;
             return;
         }
+        ++n_ring;
         while (left) {
             const size_t n = std::min(left, PinnedRing::SLOT);
             const unsigned s = next_slot++ % PinnedRing::SLOTS;
@@ -868,11 +878,18 @@ void ingest_to_device(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
         const auto t2 = std::chrono::steady_clock::now();
         sink.finish();
         upload_tables(b);
-        if (getenv("SEQWIN_AMD_DEBUG_TIMING"))
+        if (getenv("SEQWIN_AMD_DEBUG_TIMING")) {
             fprintf(stderr, "[seqwin_amd] ingest_to_device: ring %.1f ms, ingest %.1f ms, finish + tables %.1f ms\n",
                     std::chrono::duration<double, std::milli>(t1 - t0).count(),
                     std::chrono::duration<double, std::milli>(t2 - t1).count(),
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t2).count());
+            PinnedArena &pa = pinned_arena();
+            fprintf(stderr, "[seqwin_amd] pinned arena (process totals): %.0f MiB in %llu slabs, %.0f ms of page-locking; requests served %llu, declined %llu while a slab "
+                            "was being locked + %llu at the limit; chunks by DMA from the parsers' buffers %llu, through the ring %llu\n",
+                    pa.total_bytes / 1048576.0, (unsigned long long)pa.n_slabs.load(), pa.lock_us.load() / 1e3, (unsigned long long)pa.n_served.load(),
+                    (unsigned long long)pa.n_declined_busy.load(), (unsigned long long)pa.n_declined_limit.load(), (unsigned long long)sink.n_direct,
+                    (unsigned long long)sink.n_ring);
+        }
     } else {
         ingest_fasta(paths, n_paths, n_cpu, b.host);
         upload_batch(b);

@@ -43,6 +43,11 @@ def main():
         open(lst, "w").write("\n".join(paths) + "\n")
         variants = [("default", {}), ("default again", {}), ("pinned pool 128 MB", {"SEQWIN_AMD_PINNED_POOL_MB": "128"}),
                     ("pinned pool 0 (ring only)", {"SEQWIN_AMD_PINNED_POOL_MB": "0"}), ("default, third", {})]
+        if os.environ.get("FIRST_CALL_VARIANTS"):   # "name=ENV=VAL,ENV2=VAL2;name2=..."
+            variants = []
+            for item in os.environ["FIRST_CALL_VARIANTS"].split(";"):
+                name, _, envs = item.partition("=")
+                variants.append((name, dict(kv.split("=", 1) for kv in envs.split(",") if kv)))
         for name, env in variants:
             e = dict(os.environ, SEQWIN_AMD_DEBUG_TIMING="1", **env)
             r = subprocess.run([sys.executable, "-c", CHILD, str(ROOT), lst, str(n_cpu)], capture_output=True, text=True, env=e, timeout=600)
