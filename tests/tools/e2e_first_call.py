@@ -66,7 +66,8 @@ def main():
             d = json.loads(line[-1])
             s = d["split"]
             print(f"{name:28s} prewarm {d.get('prewarm_s')} wall {d['wall_s']:6.2f} s = {bp / d['wall_s'] / 1e9:5.1f} Gbp/s  ingest+upload {s['ingest_upload_ms']:7.0f} ms  device {s['device_ms']:6.0f}  export {s['export_ms']:6.0f}  "
-                  f"penalty {s['get_penalty_wall_ms']:5.0f}  cpu_s {s['cpu_s']:6.1f}  throttled {s['quota_throttled_ms']:8.0f} ms", flush=True)
+                  f"penalty {s['get_penalty_wall_ms']:5.0f}  cpu_s {s['cpu_s']:6.1f}  throttled {s['quota_throttled_ms']:8.0f} ms | on the device: plan {s['plan_ms']:.0f} sketch {s['sketch_ms']:.0f} "
+                  f"nodes {s['nodes_ms']:.0f} edges {s['edges_ms']:.0f}", flush=True)
             dbg = [ln for ln in r.stderr.splitlines() if "seqwin_amd" in ln]
             for ln in dbg[:12]:
                 print("      ", ln[:200])
