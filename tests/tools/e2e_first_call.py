@@ -56,7 +56,9 @@ def main():
             for item in os.environ["FIRST_CALL_VARIANTS"].split(";"):
                 name, _, envs = item.partition("=")
                 variants.append((name, dict(kv.split("=", 1) for kv in envs.split(",") if kv)))
+        import time
         for name, env in variants:
+            time.sleep(float(os.environ.get("FIRST_CALL_PAUSE", "0")))   # (let whatever the previous process left behind settle)
             e = dict(os.environ, SEQWIN_AMD_DEBUG_TIMING="1", **env)
             r = subprocess.run([sys.executable, "-c", CHILD, str(ROOT), lst, str(n_cpu)], capture_output=True, text=True, env=e, timeout=600)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
