@@ -163,6 +163,13 @@ public:
         if (n_ == cap_) grow(n_ + 1);
         p_[n_++] = x;
     }
+    void push_back2(uint64_t x, uint64_t y)
+    {
+        if (n_ + 2 > cap_) grow(n_ + 2);
+        p_[n_] = x;
+        p_[n_ + 1] = y;
+        n_ += 2;
+    }
     void reserve(size_t c) { if (c > cap_) grow(c); }
     void clear() { n_ = 0; }
     void set_arena(WordArena *a) { arena_ = a; }

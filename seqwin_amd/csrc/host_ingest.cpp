@@ -312,6 +312,48 @@ struct Packer {
             nacc = total;
         }
     }
+    // nb <= 64 bases at once (r06; the 64-byte chunks of pack_chunks_avx512): lo / hi = 2 bits per base of bases 0..31 / 32..63, zero
+    // above 2 nb bits.  A chunk of valid bases only -- the rule -- is appended to the accumulator in one step and leaves as up to two
+    // words; anything else takes the 32-base blocks above.
+    inline void push_chunk(uint64_t lo, uint64_t hi, unsigned nb, uint64_t valid)
+    {
+        const uint64_t full = nb == 64 ? ~0ull : ((1ull << nb) - 1ull);
+        if (nb == 0 || (valid & full) != full) {
+            if (nb >= 32) {
+                push_block(lo, 32, (uint32_t)valid);
+                if (nb > 32) push_block(hi, nb - 32, (uint32_t)(valid >> 32));
+            } else if (nb) {
+                push_block(lo, nb, (uint32_t)valid);
+            }
+            return;
+        }
+        if (run_start < 0) run_start = (int64_t)len;
+        len += nb;
+        const unsigned s = 2 * nacc;   // 0 .. 62
+        uint64_t w0, w1, w2;
+        if (s == 0) {
+            w0 = lo;
+            w1 = hi;
+            w2 = 0;
+        } else {
+            w0 = acc | (lo << s);
+            w1 = (lo >> (64 - s)) | (hi << s);
+            w2 = hi >> (64 - s);
+        }
+        const unsigned total = nacc + nb;   // < 96
+        if (total >= 64) {
+            words.push_back2(w0, w1);
+            acc = w2;
+            nacc = total - 64;
+        } else if (total >= 32) {
+            words.push_back(w0);
+            acc = w1;
+            nacc = total - 32;
+        } else {
+            acc = w0;
+            nacc = total;
+        }
+    }
     inline void push(unsigned code)
     {
         if (code < 4) {
@@ -425,7 +467,7 @@ __attribute__((target("avx512f,avx512bw"))) const char *pack_line_avx512(Packer 
 // or two blocks -- no memchr, no per-line tail, no third block per 80-column line.  Stops in front of the first chunk that holds
 // anything else (a blank or control byte other than '\n', or a '>', which may start a header: the line code below takes that
 // line, from where this stopped) or when fewer than 64 bytes are left.
-__attribute__((target("avx512f,avx512bw,avx512vbmi2,bmi2,popcnt"))) const char *pack_chunks_avx512(Packer &pk, const char *p, const char *end)
+__attribute__((target("avx512f,avx512bw,avx512vbmi,avx512vbmi2,bmi2,popcnt"))) const char *pack_chunks_avx512(Packer &pk, const char *p, const char *end)
 {
     const __m512i exp_lut = _mm512_broadcast_i32x4(_mm_setr_epi8((char)0xFF, 'A', (char)0xFF, 'C', 'T', 'U', (char)0xFF, 'G', (char)0xFF,
                                                                  (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF, (char)0xFF,
@@ -440,18 +482,28 @@ __attribute__((target("avx512f,avx512bw,avx512vbmi2,bmi2,popcnt"))) const char *
         const __m512i up = _mm512_and_si512(v, _mm512_set1_epi8((char)0xDF));
         const __mmask64 ok = _mm512_cmpeq_epi8_mask(up, _mm512_shuffle_epi8(exp_lut, lo));
         const __mmask64 keep = ~nl;
-        const __m512i code = _mm512_maskz_compress_epi8(keep, _mm512_maskz_shuffle_epi8(ok, code_lut, lo));   // (zero behind the last base)
+        const uint64_t nlm = (uint64_t)nl;
+        const __m512i raw = _mm512_maskz_shuffle_epi8(ok, code_lut, lo);
+        __m512i code;
+        // r06: a chunk of a file with lines of 64 columns or more holds at most ONE line end, and taking one byte out of the vector is a
+        // byte permutation -- idx[i] = i + (i >= j), one vpermb -- where vpcompressb is microcoded on the Zen cores of the target host
+        if (nlm == 0) {
+            code = raw;
+        } else if ((nlm & (nlm - 1)) == 0) {
+            const __m512i iota = _mm512_set_epi8(63, 62, 61, 60, 59, 58, 57, 56, 55, 54, 53, 52, 51, 50, 49, 48, 47, 46, 45, 44, 43, 42, 41, 40, 39, 38, 37, 36, 35,
+                                                 34, 33, 32, 31, 30, 29, 28, 27, 26, 25, 24, 23, 22, 21, 20, 19, 18, 17, 16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6,
+                                                 5, 4, 3, 2, 1, 0);
+            const __m512i idx = _mm512_mask_add_epi8(iota, (__mmask64)~(nlm - 1), iota, _mm512_set1_epi8(1));   // + 1 from the line end on
+            code = _mm512_maskz_permutexvar_epi8((__mmask64)(~0ull >> 1), idx, raw);                             // (zero behind the last base)
+        } else {
+            code = _mm512_maskz_compress_epi8(keep, raw);   // (zero behind the last base)
+        }
         const unsigned nb = (unsigned)__builtin_popcountll((uint64_t)keep);
         const uint64_t valid = _pext_u64((uint64_t)ok, (uint64_t)keep);
         const __m512i t16 = _mm512_maddubs_epi16(code, _mm512_set1_epi16(0x0401));
         const __m512i t32 = _mm512_madd_epi16(t16, _mm512_set1_epi32(0x00100001));
         const __m128i packed = _mm512_cvtepi32_epi8(t32);   // byte j = the codes of bases 4 j .. 4 j + 3
-        if (nb >= 32) {
-            pk.push_block((uint64_t)_mm_extract_epi64(packed, 0), 32, (uint32_t)valid);
-            if (nb > 32) pk.push_block((uint64_t)_mm_extract_epi64(packed, 1), nb - 32, (uint32_t)(valid >> 32));
-        } else if (nb) {
-            pk.push_block((uint64_t)_mm_extract_epi64(packed, 0), nb, (uint32_t)valid);
-        }
+        pk.push_chunk((uint64_t)_mm_extract_epi64(packed, 0), (uint64_t)_mm_extract_epi64(packed, 1), nb, valid);
         p += 64;
     }
     return p;
@@ -459,8 +511,8 @@ __attribute__((target("avx512f,avx512bw,avx512vbmi2,bmi2,popcnt"))) const char *
 
 bool have_chunk_packer()
 {
-    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi2") &&
-                           __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt") && !SW_TEST_GETENV("SEQWIN_AMD_SCALAR_INGEST") &&
+    static const bool ok = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vbmi") &&
+                           __builtin_cpu_supports("avx512vbmi2") && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("popcnt") && !SW_TEST_GETENV("SEQWIN_AMD_SCALAR_INGEST") &&
                            !SW_TEST_GETENV("SEQWIN_AMD_NO_AVX512") && !SW_TEST_GETENV("SEQWIN_AMD_LINE_PACKER");
     return ok;
 }

@@ -164,6 +164,17 @@ def test_host_ingest_matches_oracle_reader(tmp_path):
     with gzip.open(gz, "wb") as f:
         f.write(b">g1\nACGTACGTAC\nGGGG\n>g2\nNNNN\n")
     files += [tricky, gz]
+    # fixed-width lines of 64 ... 129 columns: every 64-byte step of the chunk packer holds no or exactly one line end, at every
+    # position of the step as the file goes on (r06: one line end is taken out by a byte permutation, the step goes to the packer as
+    # one 64-base chunk); 1 % invalid bases and lower case around them, so that chunks with gaps take the 32-base blocks
+    rng = random.Random(17)
+    for width in (64, 65, 66, 79, 80, 81, 96, 100, 127, 128, 129):
+        seq = bytearray(rng.choice(b"ACGT") for _ in range(40_000 + width))
+        for _ in range(len(seq) // 100):
+            seq[rng.randrange(len(seq))] = rng.choice(b"NnRacgtu")
+        pth = tmp_path / f"w{width}.fa"
+        pth.write_bytes(b">w%d\n" % width + b"\n".join(bytes(seq[i:i + width]) for i in range(0, len(seq), width)) + b"\n>tail\nACGT")
+        files.append(pth)
     for n_cpu in (1, 3):
         offs, ids, seqs, bp = _host_ingest(files, n_cpu)
         exp_ids, exp_seqs, exp_offs = [], [], [0]
