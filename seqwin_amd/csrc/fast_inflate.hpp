@@ -281,7 +281,8 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
         // ---- the block's symbols: the fast loop, while a refill cannot reach the end of the real input and 320 bytes of output are
         // free (a refill's worth of literals, or the longest match + the overrun of its 8-byte copies): no other bounds to test ----
         bool block_done = false;
-        while (br.in + 8 <= br.in_end && (size_t)(out_cap - out) >= 320) {
+        // (a block without any distance code -- literals only -- stays out of the fast loop: its one test per match would be paid by all)
+        while (tb.d_usable && br.in + 8 <= br.in_end && (size_t)(out_cap - out) >= 320) {
             br.refill();
             uint32_t e = tb.ll[br.peek(LL_BITS)];
         have_entry:   // (r06: behind a match, the next symbol's entry is looked up BEFORE the match is copied -- see below)
@@ -303,32 +304,35 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
                 }
                 br.refill();   // a length / distance pair may need 48 bits (the bits `e` was found through stay where they are)
             }
-            if (e & K_SUB) {
-                br.drop(LL_BITS);
-                e = tb.ll[(e >> 16) + br.peek((e >> 8) & 0xFu)];
-                if (e & K_LIT) {
-                    br.drop(e & 0xFFu);
-                    *out++ = (uint8_t)(e >> 16);
-                    continue;
+            if (__builtin_expect(e & (K_SUB | K_EOB | K_BAD), 0)) {
+                if (e & K_SUB) {
+                    br.drop(LL_BITS);
+                    e = tb.ll[(e >> 16) + br.peek((e >> 8) & 0xFu)];
+                    if (e & K_LIT) {
+                        br.drop(e & 0xFFu);
+                        *out++ = (uint8_t)(e >> 16);
+                        continue;
+                    }
                 }
-            }
-            if (e & (K_EOB | K_BAD)) {
-                br.drop(e & 0xFFu);
-                if (e & K_BAD) return BAD;
-                block_done = true;
-                break;
+                if (e & (K_EOB | K_BAD)) {
+                    br.drop(e & 0xFFu);
+                    if (e & K_BAD) return BAD;
+                    block_done = true;
+                    break;
+                }
             }
             // length: code + extra bits in one step
             const unsigned lc = e & 0xFFu, lx = (e >> 8) & 0xFu;
             const unsigned len = (e >> 16) + ((uint32_t)(br.buf >> lc) & ((1u << lx) - 1u));
             br.drop(lc + lx);
-            if (!tb.d_usable) return BAD;
             uint32_t de = tb.d[br.peek(D_BITS)];
-            if (de & K_SUB) {
-                br.drop(D_BITS);
-                de = tb.d[(de >> 16) + br.peek((de >> 8) & 0xFu)];
+            if (__builtin_expect(de & (K_SUB | K_BAD), 0)) {
+                if (de & K_SUB) {
+                    br.drop(D_BITS);
+                    de = tb.d[(de >> 16) + br.peek((de >> 8) & 0xFu)];
+                }
+                if (de & K_BAD) return BAD;
             }
-            if (de & K_BAD) return BAD;
             const unsigned dc = de & 0xFFu, dx = (de >> 8) & 0xFu;
             const size_t dist = (de >> 16) + ((uint32_t)(br.buf >> dc) & ((1u << dx) - 1u));
             br.drop(dc + dx);
