@@ -584,7 +584,7 @@ def test_multi_device_host_side_under_thread_sanitizer(tmp_path):
     # unexplained GPU memory fault -- the upload stream writes a fresh block while the previous owner's kernels still do), must FAIL
     mk = subprocess.run(["make", "-C", str(ROOT / "tests" / "tools" / "hip_mock"), "-j6", "broken"], capture_output=True, text=True)
     assert mk.returncode == 0, mk.stderr[-3000:]
-    for exe, extra, jobs in (("tsan_multi_nosync", {"HIP_MOCK_DEVICES": "2"}, 60), ("tsan_multi_r04pool", {"HIP_MOCK_DEVICES": "1"}, 600)):
+    for exe, extra, jobs in (("tsan_multi_nosync", {"HIP_MOCK_DEVICES": "2"}, 120), ("tsan_multi_r04pool", {"HIP_MOCK_DEVICES": "1"}, 1200)):
         r = subprocess.run([str(out_dir / exe), str(jobs), "3"], capture_output=True, text=True, env=dict(env, **extra), timeout=600)
         assert r.returncode != 0 and ("ThreadSanitizer: data race" in r.stderr or "BAD DATA" in r.stderr), (exe, r.stdout[-500:], r.stderr[-1500:])
 
