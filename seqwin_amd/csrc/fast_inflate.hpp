@@ -186,9 +186,27 @@ inline const Tables &fixed_tables()
     return fixed;
 }
 
-// One DEFLATE stream: br at its first bit; out_begin..out_cap the output buffer, `out` the write position (history = [out_begin, out)).
-inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, uint8_t *out_cap, Tables &T)
+// One DEFLATE stream, resumable (r06): the bit reader at its current bit, out_begin..out_cap the output buffer, `out` the write position
+// (history = [out_begin, out)), the block that is open.  inflate_stream() below runs one stream from its first bit to its end;
+// inflate_pair() runs TWO streams in one loop -- the decoding of a symbol is a chain of dependent steps (refill -> table -> bits ->
+// table, ~25 cycles per length / distance pair) that leaves most of a core's issue width idle, and two independent chains fill it:
+// 1.4-1.5 x the bytes per second of one stream after the other (scripts: NOTES.md).
+struct Stream {
+    BitReader br;
+    uint8_t *out_begin = nullptr, *out = nullptr, *out_cap = nullptr;
+    Tables *T = nullptr;              // storage for the tables of a dynamic block
+    const Tables *tb = nullptr;       // the open block's tables
+    bool in_block = false, final_block = false, ended = false;
+};
+
+// Block headers from the reader's position on: stored blocks are copied out here; returns with a Huffman-coded block open
+// (s.in_block) or with the stream's last block behind it (s.ended).
+inline Result open_block(Stream &s)
 {
+    BitReader &br = s.br;
+    uint8_t *&out = s.out;
+    uint8_t *const out_cap = s.out_cap;
+    Tables &T = *s.T;
     // Every refill outside the fast loop is followed by an overrun() test before the next one: a refill moves `in` by at most 7
     // bytes and leaves >= 56 bits, so "not overrun" means in <= in_end + 7 and the NEXT refill's 8-byte load ends at or before
     // in_end + 15 < in_end + IN_PAD (the block header and the code-length-code loop refilled without that test, and a
@@ -213,7 +231,10 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
             br.in = p + len;
             br.buf = 0;
             br.cnt = 0;
-            if (final_block) return OK;
+            if (final_block) {
+                s.ended = true;
+                return OK;
+            }
             continue;
         } else if (type == 1) {
             tp = &fixed_tables();
@@ -277,10 +298,21 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
         } else {
             return BAD;
         }
-        const Tables &tb = *tp;
-        // ---- the block's symbols: the fast loop, while a refill cannot reach the end of the real input and 320 bytes of output are
-        // free (a refill's worth of literals, or the longest match + the overrun of its 8-byte copies): no other bounds to test ----
-        bool block_done = false;
+        s.tb = tp;
+        s.final_block = final_block != 0;
+        s.in_block = true;
+        return OK;
+    }
+}
+
+// The open block's symbols while a refill cannot reach the end of the real input and 320 bytes of output are free
+inline Result fast_loop(Stream &s, bool &block_done)
+{
+    BitReader &br = s.br;
+    uint8_t *&out = s.out;
+    uint8_t *const out_begin = s.out_begin, *const out_cap = s.out_cap;
+    const Tables &tb = *s.tb;
+    {
         // (a block without any distance code -- literals only -- stays out of the fast loop: its one test per match would be paid by all)
         while (tb.d_usable && br.in + 8 <= br.in_end && (size_t)(out_cap - out) >= 320) {
             br.refill();
@@ -371,6 +403,19 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
             }
             if (ahead) goto have_entry;
         }
+    }
+    return OK;
+}
+
+// ... and the careful loop for the ends of the buffers: until the block's end
+inline Result careful_loop(Stream &s)
+{
+    BitReader &br = s.br;
+    uint8_t *&out = s.out;
+    uint8_t *const out_begin = s.out_begin, *const out_cap = s.out_cap;
+    const Tables &tb = *s.tb;
+    const bool block_done = false;
+    {
         // ---- ... and the careful loop for the ends of the buffers ----
         while (!block_done) {
             br.refill();
@@ -442,9 +487,224 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
                 do *dst++ = *src++; while (dst < out);
             }
         }
-        if (br.overrun()) return BAD;
-        if (final_block) return OK;
     }
+    return OK;
+}
+
+inline Result close_block(Stream &s)
+{
+    if (s.br.overrun()) return BAD;
+    s.in_block = false;
+    if (s.final_block) s.ended = true;
+    return OK;
+}
+
+// from wherever the stream stands to its end
+inline Result run_stream(Stream &s)
+{
+    for (;;) {
+        if (!s.in_block) {
+            if (s.ended) return OK;
+            const Result r = open_block(s);
+            if (r != OK) return r;
+            if (s.ended) return OK;
+        }
+        bool block_done = false;
+        Result r = fast_loop(s, block_done);
+        if (r != OK) return r;
+        if (!block_done) {
+            r = careful_loop(s);
+            if (r != OK) return r;
+        }
+        r = close_block(s);
+        if (r != OK) return r;
+    }
+}
+
+// One DEFLATE stream: br at its first bit; out_begin..out_cap the output buffer, `out` the write position (history = [out_begin, out)).
+inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, uint8_t *out_cap, Tables &T)
+{
+    Stream s;
+    s.br = br;
+    s.out_begin = out_begin;
+    s.out = out;
+    s.out_cap = out_cap;
+    s.T = &T;
+    const Result r = run_stream(s);
+    br = s.br;
+    out = s.out;
+    return r;
+}
+
+// ---- two streams in one loop -------------------------------------------------------------------------------------------------------
+// The state of one stream inside the pair loop: plain locals of inflate_pair (their address never leaves it), so both streams'
+// bit buffers, cursors and table bases stay in registers.
+struct PairRegs {
+    uint64_t buf;
+    unsigned cnt;
+    const uint8_t *in, *in_end;
+    uint8_t *out, *out_begin, *out_cap;
+    const uint32_t *ll, *dt;
+};
+// One symbol of a stream (or up to three literals) -- the body of fast_loop without the look-ahead (the other stream's step is what
+// fills the wait): 0 go on, 1 end of block, 2 bad.  Needs what fast_loop needs: 8 readable bytes at `in`, 320 free bytes at `out`.
+__attribute__((always_inline)) inline int pair_step(PairRegs &r)
+{
+    uint64_t w;
+    memcpy(&w, r.in, 8);
+    r.buf |= w << r.cnt;
+    r.in += (63u - r.cnt) >> 3;
+    r.cnt |= 56u;
+    uint32_t e = r.ll[r.buf & ((1u << LL_BITS) - 1u)];
+    if (e & K_LIT) {
+        r.buf >>= (e & 0xFFu);
+        r.cnt -= (e & 0xFFu);
+        *r.out++ = (uint8_t)(e >> 16);
+        e = r.ll[r.buf & ((1u << LL_BITS) - 1u)];
+        if (e & K_LIT) {
+            r.buf >>= (e & 0xFFu);
+            r.cnt -= (e & 0xFFu);
+            *r.out++ = (uint8_t)(e >> 16);
+            e = r.ll[r.buf & ((1u << LL_BITS) - 1u)];
+            if (e & K_LIT) {
+                r.buf >>= (e & 0xFFu);
+                r.cnt -= (e & 0xFFu);
+                *r.out++ = (uint8_t)(e >> 16);
+                return 0;
+            }
+        }
+        memcpy(&w, r.in, 8);   // a length / distance pair may need 48 bits
+        r.buf |= w << r.cnt;
+        r.in += (63u - r.cnt) >> 3;
+        r.cnt |= 56u;
+    }
+    if (__builtin_expect(e & (K_SUB | K_EOB | K_BAD), 0)) {
+        if (e & K_SUB) {
+            r.buf >>= LL_BITS;
+            r.cnt -= LL_BITS;
+            e = r.ll[(e >> 16) + (uint32_t)(r.buf & ((1ull << ((e >> 8) & 0xFu)) - 1ull))];
+            if (e & K_LIT) {
+                r.buf >>= (e & 0xFFu);
+                r.cnt -= (e & 0xFFu);
+                *r.out++ = (uint8_t)(e >> 16);
+                return 0;
+            }
+        }
+        if (e & (K_EOB | K_BAD)) {
+            r.buf >>= (e & 0xFFu);
+            r.cnt -= (e & 0xFFu);
+            return (e & K_BAD) ? 2 : 1;
+        }
+    }
+    const unsigned lc = e & 0xFFu, lx = (e >> 8) & 0xFu;
+    const unsigned len = (e >> 16) + ((uint32_t)(r.buf >> lc) & ((1u << lx) - 1u));
+    r.buf >>= (lc + lx);
+    r.cnt -= (lc + lx);
+    uint32_t de = r.dt[r.buf & ((1u << D_BITS) - 1u)];
+    if (__builtin_expect(de & (K_SUB | K_BAD), 0)) {
+        if (de & K_SUB) {
+            r.buf >>= D_BITS;
+            r.cnt -= D_BITS;
+            de = r.dt[(de >> 16) + (uint32_t)(r.buf & ((1ull << ((de >> 8) & 0xFu)) - 1ull))];
+        }
+        if (de & K_BAD) return 2;
+    }
+    const unsigned dc = de & 0xFFu, dx = (de >> 8) & 0xFu;
+    const size_t dist = (de >> 16) + ((uint32_t)(r.buf >> dc) & ((1u << dx) - 1u));
+    r.buf >>= (dc + dx);
+    r.cnt -= (dc + dx);
+    if (dist > (size_t)(r.out - r.out_begin)) return 2;
+    const uint8_t *src = r.out - dist;
+    uint8_t *dst = r.out;
+    r.out += len;
+    if (dist >= 8) {
+        memcpy(&w, src, 8);
+        memcpy(dst, &w, 8);
+        memcpy(&w, src + 8, 8);
+        memcpy(dst + 8, &w, 8);
+        if (len > 16) {
+            src += 16;
+            dst += 16;
+            do {
+                memcpy(&w, src, 8);
+                memcpy(dst, &w, 8);
+                src += 8;
+                dst += 8;
+            } while (dst < r.out);
+        }
+    } else if (dist == 1) {
+        memset(dst, *src, len);
+    } else {
+        do *dst++ = *src++; while (dst < r.out);
+    }
+    return 0;
+}
+inline bool pair_ready(const Stream &s)   // a Huffman block with a distance code is open and the fast region's margins hold
+{
+    return s.in_block && s.tb->d_usable && s.br.in + 8 <= s.br.in_end && (size_t)(s.out_cap - s.out) >= 320;
+}
+
+// Two independent DEFLATE streams to their ends; *ra / *rb = what inflate_stream would have returned for each.  A stream that
+// fails, ends, or leaves the fast region is finished (or brought back) on its own; the other is not held up by it.
+inline void inflate_pair(Stream &a, Stream &b, Result *ra, Result *rb)
+{
+    Result res[2] = {OK, OK};
+    bool over[2] = {false, false};   // ended or failed: out of the pair loop for good
+    Stream *st[2] = {&a, &b};
+    for (;;) {
+        for (int x = 0; x < 2; ++x) {   // bring each stream to an open block inside the fast region (headers, stored blocks, buffer ends)
+            Stream &s = *st[x];
+            while (!over[x] && !pair_ready(s)) {
+                Result r = OK;
+                if (!s.in_block) {
+                    if (!s.ended) r = open_block(s);
+                } else {
+                    r = careful_loop(s);          // (a literal-only block, or the ends of the buffers: to the block's end)
+                    if (r == OK) r = close_block(s);
+                }
+                if (r != OK) {
+                    res[x] = r;
+                    over[x] = true;
+                } else if (s.ended) {
+                    over[x] = true;
+                }
+            }
+        }
+        if (over[0] || over[1]) break;
+        PairRegs p, q;
+        p.buf = a.br.buf; p.cnt = a.br.cnt; p.in = a.br.in; p.in_end = a.br.in_end; p.out = a.out; p.out_begin = a.out_begin; p.out_cap = a.out_cap;
+        p.ll = a.tb->ll; p.dt = a.tb->d;
+        q.buf = b.br.buf; q.cnt = b.br.cnt; q.in = b.br.in; q.in_end = b.br.in_end; q.out = b.out; q.out_begin = b.out_begin; q.out_cap = b.out_cap;
+        q.ll = b.tb->ll; q.dt = b.tb->d;
+        int sa = 0, sb = 0;
+        while (p.in + 8 <= p.in_end && (size_t)(p.out_cap - p.out) >= 320 && q.in + 8 <= q.in_end && (size_t)(q.out_cap - q.out) >= 320) {
+            sa = pair_step(p);
+            sb = pair_step(q);
+            if (sa | sb) break;
+        }
+        a.br.buf = p.buf; a.br.cnt = p.cnt; a.br.in = p.in; a.out = p.out;
+        b.br.buf = q.buf; b.br.cnt = q.cnt; b.br.in = q.in; b.out = q.out;
+        const int stp[2] = {sa, sb};
+        for (int x = 0; x < 2; ++x) {
+            if (stp[x] == 2) {
+                res[x] = BAD;
+                over[x] = true;
+            } else if (stp[x] == 1) {
+                const Result r = close_block(*st[x]);
+                if (r != OK) {
+                    res[x] = r;
+                    over[x] = true;
+                } else if (st[x]->ended) {
+                    over[x] = true;
+                }
+            }
+        }
+        if (over[0] && over[1]) break;
+    }
+    for (int x = 0; x < 2; ++x)   // what is left of the stream that outlasted its partner
+        if (res[x] == OK && !st[x]->ended) res[x] = run_stream(*st[x]);
+    *ra = res[0];
+    *rb = res[1];
 }
 
 // ---- CRC-32 (IEEE, reflected: the gzip trailer's) ---------------------------------------------------------------------------------
@@ -582,33 +842,51 @@ inline uint32_t crc32(const uint8_t *p, size_t n)   // the gzip trailer's CRC-32
     return ~crc32_slice8(crc, p, n);
 }
 
+// A gzip member's header at p (RFC 1952): the position of its DEFLATE stream, or nullptr for what is left to zlib
+inline const uint8_t *gzip_header(const uint8_t *p, const uint8_t *end)
+{
+    if (end - p < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8) return nullptr;
+    const unsigned flg = p[3];
+    if (flg & 0xE0u) return nullptr;      // reserved bits
+    p += 10;
+    if (flg & 4u) {                       // FEXTRA
+        if (end - p < 2) return nullptr;
+        const unsigned xl = p[0] | (p[1] << 8);
+        p += 2;
+        if ((size_t)(end - p) < xl) return nullptr;
+        p += xl;
+    }
+    for (unsigned bit : {8u, 16u})        // FNAME, FCOMMENT: zero-terminated
+        if (flg & bit) {
+            const uint8_t *z = (const uint8_t *)memchr(p, 0, (size_t)(end - p));
+            if (!z) return nullptr;
+            p = z + 1;
+        }
+    if (flg & 2u) return nullptr;         // FHCRC: zlib checks the header CRC -- rare enough to leave to it
+    if (end - p < 8) return nullptr;
+    return p;
+}
+// ... and its trailer at p behind the stream: CRC-32 and ISIZE of member_begin[0, n_out)
+inline bool gzip_trailer_ok(const uint8_t *p, const uint8_t *end, const uint8_t *member_begin, size_t n_out)
+{
+    if (end - p < 8) return false;
+    const uint32_t want_crc = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
+    const uint32_t isize = p[4] | (p[5] << 8) | (p[6] << 16) | ((uint32_t)p[7] << 24);
+    return (uint32_t)n_out == isize && crc32(member_begin, n_out) == want_crc;
+}
+
 // One or more gzip members in in[0, n) (followed by IN_PAD readable zero bytes) -> out[0, *out_len), at most out_cap bytes.
 // OK: every member well-formed, its CRC-32 and ISIZE right, nothing behind the last one.  NEED_OUT: out_cap is too small.
-inline Result gunzip_members(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len, Tables &T)
+// (o_start: output already produced by earlier members of the same file -- gunzip_pair hands its streams' rests over.)
+inline Result gunzip_members(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len, Tables &T, const uint8_t *p_start = nullptr,
+                             size_t o_start = 0)
 {
-    const uint8_t *p = in, *end = in + n;
-    uint8_t *o = out;
+    const uint8_t *p = p_start ? p_start : in, *end = in + n;
+    uint8_t *o = out + o_start;
     if (n < 18) return BAD;
     while (p < end) {
-        if (end - p < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8) return BAD;
-        const unsigned flg = p[3];
-        if (flg & 0xE0u) return BAD;          // reserved bits
-        p += 10;
-        if (flg & 4u) {                       // FEXTRA
-            if (end - p < 2) return BAD;
-            const unsigned xl = p[0] | (p[1] << 8);
-            p += 2;
-            if ((size_t)(end - p) < xl) return BAD;
-            p += xl;
-        }
-        for (unsigned bit : {8u, 16u})        // FNAME, FCOMMENT: zero-terminated
-            if (flg & bit) {
-                const uint8_t *z = (const uint8_t *)memchr(p, 0, (size_t)(end - p));
-                if (!z) return BAD;
-                p = z + 1;
-            }
-        if (flg & 2u) return BAD;             // FHCRC: zlib checks the header CRC -- rare enough to leave to it
-        if (end - p < 8) return BAD;
+        p = gzip_header(p, end);
+        if (!p) return BAD;
         BitReader br;
         br.in = p;
         br.in_end = end;
@@ -616,15 +894,43 @@ inline Result gunzip_members(const uint8_t *in, size_t n, uint8_t *out, size_t o
         const Result r = inflate_stream(br, member_begin, o, out + out_cap, T);
         if (r != OK) return r;
         p = br.position();
-        if (end - p < 8) return BAD;
-        const uint32_t want_crc = p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24);
-        const uint32_t isize = p[4] | (p[5] << 8) | (p[6] << 16) | ((uint32_t)p[7] << 24);
+        if (!gzip_trailer_ok(p, end, member_begin, (size_t)(o - member_begin))) return BAD;
         p += 8;
-        if ((uint32_t)(size_t)(o - member_begin) != isize) return BAD;
-        if (crc32(member_begin, (size_t)(o - member_begin)) != want_crc) return BAD;
     }
     *out_len = (size_t)(o - out);
     return OK;
+}
+
+// Two files at once (r06): the FIRST members of both are inflated in one loop (inflate_pair), further members -- rare -- one file
+// after the other.  The results are those of two gunzip_members calls.
+inline void gunzip_pair(const uint8_t *in_a, size_t n_a, uint8_t *out_a, size_t cap_a, size_t *len_a, Tables &T_a, Result *r_a, const uint8_t *in_b,
+                        size_t n_b, uint8_t *out_b, size_t cap_b, size_t *len_b, Tables &T_b, Result *r_b)
+{
+    const uint8_t *pa = n_a >= 18 ? gzip_header(in_a, in_a + n_a) : nullptr, *pb = n_b >= 18 ? gzip_header(in_b, in_b + n_b) : nullptr;
+    if (!pa || !pb) {   // (nothing to pair)
+        *r_a = gunzip_members(in_a, n_a, out_a, cap_a, len_a, T_a);
+        *r_b = gunzip_members(in_b, n_b, out_b, cap_b, len_b, T_b);
+        return;
+    }
+    Stream a, b;
+    a.br.in = pa; a.br.in_end = in_a + n_a; a.out_begin = a.out = out_a; a.out_cap = out_a + cap_a; a.T = &T_a;
+    b.br.in = pb; b.br.in_end = in_b + n_b; b.out_begin = b.out = out_b; b.out_cap = out_b + cap_b; b.T = &T_b;
+    inflate_pair(a, b, r_a, r_b);
+    struct Side {
+        Stream *s; const uint8_t *in; size_t n; uint8_t *out; size_t cap; size_t *len; Tables *T; Result *r;
+    } sides[2] = {{&a, in_a, n_a, out_a, cap_a, len_a, &T_a, r_a}, {&b, in_b, n_b, out_b, cap_b, len_b, &T_b, r_b}};
+    for (Side &d : sides) {
+        if (*d.r != OK) continue;
+        const uint8_t *p = d.s->br.position(), *end = d.in + d.n;
+        const size_t n_out = (size_t)(d.s->out - d.out);
+        if (!gzip_trailer_ok(p, end, d.out, n_out)) {
+            *d.r = BAD;
+            continue;
+        }
+        p += 8;
+        if (p < end) *d.r = gunzip_members(d.in, d.n, d.out, d.cap, d.len, *d.T, p, n_out);   // further members
+        else *d.len = n_out;
+    }
 }
 
 }  // namespace finf

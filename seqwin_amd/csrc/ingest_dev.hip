@@ -179,6 +179,10 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     }
     size_t free_b = 0, total_b = 0;
     SW_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (coff[n_paths] * 8 > free_b) {   // (r06: blocks the pool has cached for earlier builds are not "free" to hipMemGetInfo: give them back, ask again)
+        dev_pool_trim();
+        SW_HIP(hipMemGetInfo(&free_b, &total_b));
+    }
     if (coff[n_paths] * 8 > free_b) return decline("not enough free HBM", 0, free_b);          // (text ~4x the compressed bytes, + packed words + tables: the host route streams)
     DevArray<uint8_t> d_comp(coff[n_paths] + 16);
     std::vector<uint64_t> dstart(n_paths), dend(n_paths);
@@ -256,6 +260,10 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     std::vector<uint64_t> toff(n_paths + 1, 0);
     for (size_t i = 0; i < n_paths; ++i) toff[i + 1] = toff[i] + (((uint64_t)isize[i] + 15) & ~15ull);
     SW_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (toff[n_paths] + toff[n_paths] / 2 > free_b) {
+        dev_pool_trim();
+        SW_HIP(hipMemGetInfo(&free_b, &total_b));
+    }
     if (toff[n_paths] + toff[n_paths] / 2 > free_b) return decline("not enough free HBM for the text", 0, toff[n_paths]);
     const uint32_t nf = (uint32_t)n_paths;
     DevArray<uint8_t> d_text(toff[n_paths] + 16);
