@@ -372,6 +372,14 @@ def golden_checksums(workload, k, w):
     return None, None
 
 
+def distinct_gpus(ranks):
+    """How many different GPUs the ranks' records name.  One GPU = (host, UUID, PCI bus id) and, where a rank sees several devices, its
+    device index: two ranks on ONE card agree in all of them; two cards whose runtime reports no or equal UUIDs still differ in bus id
+    or index (a false "shared" would refuse a good node)."""
+    return len({(r.get("host"), r.get("uuid") or None, r.get("pci_bus_id"), r.get("device") if (r.get("visible_devices") or 0) > 1 else None)
+                for r in ranks})
+
+
 def preflight(world, rank, local_rank, dev):
     """Before anything is timed at N > 1: the N ranks must drive N DISTINCT GPUs, every ordered pair of them
     must have peer access (a pair without it would be staged through host memory: a different, slower experiment), and the
@@ -385,18 +393,18 @@ def preflight(world, rank, local_rank, dev):
 
     from seqwin_amd import dist as swdist
     force = os.environ.get("SEQWIN_BENCH_PREFLIGHT_FORCE", "")
+    me = {"rank": rank, "local_rank": local_rank, "host": os.uname().nodename, "pid": os.getpid()}
     try:
-        prop = torch.cuda.get_device_properties(local_rank)
-        me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": prop.name,
-              "uuid": str(getattr(prop, "uuid", "")), "pci_bus_id": getattr(prop, "pci_bus_id", None), "host": os.uname().nodename,
-              "pid": os.getpid(), "visible_devices": torch.cuda.device_count()}
-    except Exception as e:
-        me = {"rank": rank, "error": str(e)}
+        me.update(device=torch.cuda.current_device(), visible_devices=torch.cuda.device_count())
+        prop = torch.cuda.get_device_properties(me["device"])
+        me.update(name=prop.name, uuid=str(getattr(prop, "uuid", "") or ""), pci_bus_id=getattr(prop, "pci_bus_id", None))
+    except Exception as e:          # (what could be read stays in the line; the device index alone still tells two cards of a host apart)
+        me["error"] = str(e)
     ranks = [me]
     if world > 1:
         ranks = [None] * world
         dist.all_gather_object(ranks, me)
-    distinct = len({(r.get("host"), r.get("uuid") or r.get("pci_bus_id") or r.get("device")) for r in ranks})
+    distinct = distinct_gpus(ranks)
     if force == "distinct":
         distinct = 1
     info = {"ranks": ranks, "distinct_gpus": distinct}

@@ -541,3 +541,22 @@ def test_adjacency_key_width_and_bounds():
         assert len(rb) == world - 1 and list(rb) == sorted(rb) and all(0 <= x <= 1_000_003 for x in rb)
     parts = swdist.partition_assemblies(10, 4)                  # build.cpp:350-356: the remainder goes to the first workers
     assert parts == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def test_bench_preflight_counts_distinct_gpus():
+    """bench.py's pre-flight (refuses to time N ranks that are not on N GPUs): the count of distinct GPUs from the ranks' records.  Two
+    ranks on one card are one GPU however they see it; cards whose runtime reports equal or no UUIDs still count apart by bus id or
+    device index -- a good 8-GPU node must not be refused."""
+    import sys
+    sys.path.insert(0, str(GOLDEN.parent.parent))
+    from bench import distinct_gpus
+    node = [{"host": "h", "uuid": f"u{i}", "pci_bus_id": 0x10 + i, "device": i, "visible_devices": 8} for i in range(8)]
+    assert distinct_gpus(node) == 8
+    assert distinct_gpus([dict(r, uuid="") for r in node]) == 8                       # no UUIDs: bus ids / indices
+    assert distinct_gpus([dict(r, uuid="same", pci_bus_id=None) for r in node]) == 8  # equal UUIDs, no bus id: indices
+    masked = [dict(r, device=0, visible_devices=1) for r in node]                    # one visible device per rank (HIP_VISIBLE_DEVICES)
+    assert distinct_gpus(masked) == 8
+    assert distinct_gpus([node[0], dict(node[0], rank=1)]) == 1                       # two ranks on one card
+    assert distinct_gpus([masked[3], dict(masked[3], pid=2)]) == 1
+    assert distinct_gpus(node + [dict(node[0], host="other")]) == 9                   # the same numbering on another host
+    assert distinct_gpus([{"rank": 0, "host": "h", "error": "x"}, {"rank": 1, "host": "h", "error": "x"}]) == 1   # nothing known: refuse
