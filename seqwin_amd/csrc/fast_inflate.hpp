@@ -43,9 +43,21 @@ constexpr size_t IN_PAD = 16;                          // zero bytes the caller 
 // remaining bits), [11:8] extra bits, [15:12] kind, [31:16] base value / literal / index of the second-level table
 enum : uint32_t { K_LIT = 0x8000u, K_EOB = 0x4000u, K_SUB = 0x2000u, K_BAD = 0x1000u };
 
+// r06b: the SUPER table -- what the next LL_BITS bits of the stream decode to when they hold MORE than one symbol: up to two literals
+// and / or a whole match (length code + its extra bits + distance code; the distance's extra bits are read from the stream behind).
+// Level-6 DNA text is three matches in four symbols, a match is a length code of 2-3 bits + a distance code of 2-5 bits + ~10 extra
+// bits, a literal 4 bits: "literal, match" and "match" fit the 11 index bits in ~9 of 10 cases, and one table load decodes what took
+// two or three dependent ones (refill -> ll -> d: ~19 cycles per match; the loop is that chain).  Layout of an entry:
+//   [5:0] ALL the bits the entry consumes (literal codes + length code + length extra + distance code + distance extra bits: the
+//   shift count of the bit buffer, the one field on the loop's dependency chain -- a 64-bit shift takes its low six bits as they are),
+//   [9:6] the code bits among them (= where the distance's extra bits start), [11:10] literals (0-2), [12] a match follows them,
+//   [21:13] match length, [36:22] distance base, [44:37] [52:45] the literals.
+// 0 = nothing to gain here (end of block, long codes, a length whose distance code is not inside the index): the generic path.
+constexpr uint64_t S_ANY = 0x1C00u, S_MATCH = 0x1000u;
 struct Tables {
     uint32_t ll[LL_TABLE];
     uint32_t d[D_TABLE];
+    uint64_t sup[1u << LL_BITS];
     bool d_usable;   // false: the block declared no distance code at all (a block of literals only): any match is an error
 };
 
@@ -148,6 +160,38 @@ inline uint32_t d_entry(unsigned s)
     return ((uint32_t)kDistBase[s] << 16) | ((uint32_t)kDistExtra[s] << 8);
 }
 
+// The super table of a block's two tables (built per dynamic block: 2 048 entries, ~2 % of a 16 K-symbol block's decoding time).
+// Index bits are consumed from the low end; behind `used` consumed bits only LL_BITS - used bits are known, so a symbol counts
+// only if its first-level entry is a plain one (no second level, not invalid) whose code is no longer than that.
+inline void build_super(Tables &t)
+{
+    if (!t.d_usable) return;   // (a block of literals only never enters the fast loop)
+    constexpr unsigned N = 1u << LL_BITS;
+    for (unsigned i = 0; i < N; ++i) {
+        unsigned used = 0, nlit = 0;
+        uint64_t lits = 0, s = 0;
+        uint32_t e = t.ll[i];
+        while (nlit < 2 && (e & K_LIT) && (e & 0xFFu) <= LL_BITS - used) {
+            lits |= (uint64_t)((e >> 16) & 0xFFu) << (8 * nlit);
+            ++nlit;
+            used += e & 0xFFu;
+            e = t.ll[i >> used];
+        }
+        if (!(e & (K_LIT | K_EOB | K_SUB | K_BAD))) {   // a length code
+            const unsigned lc = e & 0xFFu, lx = (e >> 8) & 0xFu;
+            if (lc + lx <= LL_BITS - used) {
+                const unsigned len = (e >> 16) + ((i >> (used + lc)) & ((1u << lx) - 1u)), u2 = used + lc + lx;
+                const uint32_t de = t.d[(i >> u2) & ((1u << D_BITS) - 1u)];
+                if (!(de & (K_SUB | K_BAD)) && (de & 0xFFu) <= LL_BITS - u2)
+                    s = (uint64_t)(u2 + (de & 0xFFu) + ((de >> 8) & 0xFu)) | (uint64_t)(u2 + (de & 0xFFu)) << 6 | S_MATCH | (uint64_t)len << 13 |
+                        (uint64_t)(de >> 16) << 22;
+            }
+        }
+        if (!s) s = used | (uint64_t)used << 6;   // (literals only -- or nothing: 0, since no literal means used = 0)
+        t.sup[i] = s | (uint64_t)nlit << 10 | lits << 37;
+    }
+}
+
 struct BitReader {
     const uint8_t *in, *in_end;   // in_end: end of the REAL data; IN_PAD zero bytes follow it
     uint64_t buf = 0;
@@ -181,6 +225,7 @@ inline const Tables &fixed_tables()
         (void)build_table(lens, 288, LL_BITS, t.ll, LL_TABLE, ll_entry, false);
         (void)build_table(dl, 32, D_BITS, t.d, D_TABLE, d_entry, false);
         t.d_usable = true;
+        build_super(t);
         return t;
     }();
     return fixed;
@@ -295,6 +340,7 @@ inline Result open_block(Stream &s)
             for (unsigned s = 0; s < hdist; ++s) any = any || lens[hlit + s];
             T.d_usable = any;
             if (any && !build_table(lens + hlit, hdist, D_BITS, T.d, D_TABLE, d_entry, true)) return BAD;
+            build_super(T);
         } else {
             return BAD;
         }
@@ -305,106 +351,183 @@ inline Result open_block(Stream &s)
     }
 }
 
-// The open block's symbols while a refill cannot reach the end of the real input and 320 bytes of output are free
+// The open block's symbols while a refill cannot reach the end of the real input and 320 bytes of output are free.
+// The stream's state lives in locals (a byte store may alias anything behind a reference), and the loop is COUNTED: an iteration
+// consumes < 9 bytes of input (at most two literals + a length / distance pair with all extra bits: 70 bits; `in` runs at most 8 bytes
+// ahead of what is consumed) and writes <= 260 bytes (+ 16 of copy overshoot), so K iterations are safe when K is derived from what
+// is left of both buffers -- one decrement per symbol instead of two pointer comparisons, and K is recomputed when it runs out.
 inline Result fast_loop(Stream &s, bool &block_done)
 {
-    BitReader &br = s.br;
-    uint8_t *&out = s.out;
-    uint8_t *const out_begin = s.out_begin, *const out_cap = s.out_cap;
     const Tables &tb = *s.tb;
-    {
-        // (a block without any distance code -- literals only -- stays out of the fast loop: its one test per match would be paid by all)
-        while (tb.d_usable && br.in + 8 <= br.in_end && (size_t)(out_cap - out) >= 320) {
-            br.refill();
-            uint32_t e = tb.ll[br.peek(LL_BITS)];
-        have_entry:   // (r06: behind a match, the next symbol's entry is looked up BEFORE the match is copied -- see below)
-            if (e & K_LIT) {
-                // up to three literals straight from the first-level table (3 x 11 bits of the >= 56 in the buffer: every entry is
-                // found through valid bits, and a non-literal entry behind them is still good after the refill below)
-                br.drop(e & 0xFFu);
-                *out++ = (uint8_t)(e >> 16);
-                e = tb.ll[br.peek(LL_BITS)];
+    if (!tb.d_usable) return OK;   // (a block of literals only stays out of the fast loop: its one test per match would be paid by all)
+    uint64_t buf = s.br.buf;
+    unsigned cnt = s.br.cnt;
+    const uint8_t *in = s.br.in, *const in_end = s.br.in_end;
+    uint8_t *out = s.out, *const out_begin = s.out_begin, *const out_cap = s.out_cap;
+    Result res = OK;
+    constexpr uint32_t IDX = (1u << LL_BITS) - 1u;
+#define SW_FINF_REFILL()                 \
+    do {                                 \
+        uint64_t w_;                     \
+        memcpy(&w_, in, 8);              \
+        buf |= w_ << cnt;                \
+        in += (63u - cnt) >> 3;          \
+        cnt |= 56u;                      \
+    } while (0)
+    for (;;) {
+        const ptrdiff_t in_left = in_end - in;   // (signed: `in` may stand up to 8 bytes behind the end of the real input, inside the pad)
+        const size_t out_left = (size_t)(out_cap - out);
+        if (in_left < 64 || out_left < 320) break;
+        size_t k = (size_t)in_left / 16;   // 9 (k + 1) + 16 <= 16 k from k = 4 on: every refill of k iterations and of the look-ahead behind them reads real input
+        {
+            const size_t k_out = (out_left - 320) / 260 + 1;
+            if (k_out < k) k = k_out;
+        }
+        const bool far = (size_t)(out - out_begin) >= 32768;   // no distance reaches the start of the output any more
+        SW_FINF_REFILL();
+        uint64_t se = tb.sup[buf & IDX];
+        for (; k; --k) {
+            unsigned len;
+            size_t dist;
+            uint64_t se_next;
+            if (__builtin_expect((se & S_ANY) != 0, 1)) {
+                // the super entry: up to two literals (both bytes are stored whatever their number: what is not a literal is
+                // overwritten by the next symbol) and / or a whole match, from ONE table load
+                const uint16_t two = (uint16_t)(se >> 37);
+                memcpy(out, &two, 2);
+                out += (se >> 10) & 3u;
+                const unsigned all = (unsigned)se & 63u, code = (unsigned)(se >> 6) & 0xFu;   // (all <= 11 + 13 of the >= 56 bits)
+                const uint32_t extra = (uint32_t)(buf >> code) & ((1u << (all - code)) - 1u);
+                buf >>= all;
+                cnt -= all;
+                // The next iteration's entry: looked up BEFORE the refill (>= 32 valid bits are left, 11 are needed), so that the loop's
+                // dependency chain is table load -> shift -> mask -> table load, without the refill's shift and or; and before the
+                // match is copied: the entry does not depend on the bytes a match copies, its load overlaps the copy.
+                se_next = tb.sup[buf & IDX];
+                SW_FINF_REFILL();
+                if (!(se & S_MATCH)) {
+                    se = se_next;
+                    continue;
+                }
+                len = (unsigned)(se >> 13) & 0x1FFu;
+                dist = ((size_t)(se >> 22) & 0x7FFFu) + extra;
+            } else {
+                uint32_t e = tb.ll[buf & IDX];
                 if (e & K_LIT) {
-                    br.drop(e & 0xFFu);
+                    // up to three literals straight from the first-level table (3 x 11 bits of the >= 56 in the buffer: every entry is
+                    // found through valid bits, and a non-literal entry behind them is still good after the refill below)
+                    buf >>= (e & 0xFFu);
+                    cnt -= (e & 0xFFu);
                     *out++ = (uint8_t)(e >> 16);
-                    e = tb.ll[br.peek(LL_BITS)];
+                    e = tb.ll[buf & IDX];
                     if (e & K_LIT) {
-                        br.drop(e & 0xFFu);
+                        buf >>= (e & 0xFFu);
+                        cnt -= (e & 0xFFu);
                         *out++ = (uint8_t)(e >> 16);
-                        continue;
+                        e = tb.ll[buf & IDX];
+                        if (e & K_LIT) {
+                            buf >>= (e & 0xFFu);
+                            cnt -= (e & 0xFFu);
+                            *out++ = (uint8_t)(e >> 16);
+                            goto next_entry;
+                        }
+                    }
+                    SW_FINF_REFILL();   // a length / distance pair may need 48 bits (the bits `e` was found through stay where they are)
+                }
+                if (__builtin_expect(e & (K_SUB | K_EOB | K_BAD), 0)) {
+                    if (e & K_SUB) {
+                        buf >>= LL_BITS;
+                        cnt -= LL_BITS;
+                        e = tb.ll[(e >> 16) + (uint32_t)(buf & ((1u << ((e >> 8) & 0xFu)) - 1u))];
+                        if (e & K_LIT) {
+                            buf >>= (e & 0xFFu);
+                            cnt -= (e & 0xFFu);
+                            *out++ = (uint8_t)(e >> 16);
+                            goto next_entry;
+                        }
+                    }
+                    if (e & (K_EOB | K_BAD)) {
+                        buf >>= (e & 0xFFu);
+                        cnt -= (e & 0xFFu);
+                        if (e & K_BAD) res = BAD;
+                        else block_done = true;
+                        goto done;
                     }
                 }
-                br.refill();   // a length / distance pair may need 48 bits (the bits `e` was found through stay where they are)
-            }
-            if (__builtin_expect(e & (K_SUB | K_EOB | K_BAD), 0)) {
-                if (e & K_SUB) {
-                    br.drop(LL_BITS);
-                    e = tb.ll[(e >> 16) + br.peek((e >> 8) & 0xFu)];
-                    if (e & K_LIT) {
-                        br.drop(e & 0xFFu);
-                        *out++ = (uint8_t)(e >> 16);
-                        continue;
+                {
+                    // length: code + extra bits in one step
+                    const unsigned lc = e & 0xFFu, lx = (e >> 8) & 0xFu;
+                    len = (e >> 16) + ((uint32_t)(buf >> lc) & ((1u << lx) - 1u));
+                    buf >>= (lc + lx);
+                    cnt -= (lc + lx);
+                    uint32_t de = tb.d[buf & ((1u << D_BITS) - 1u)];
+                    if (__builtin_expect(de & (K_SUB | K_BAD), 0)) {
+                        if (de & K_SUB) {
+                            buf >>= D_BITS;
+                            cnt -= D_BITS;
+                            de = tb.d[(de >> 16) + (uint32_t)(buf & ((1u << ((de >> 8) & 0xFu)) - 1u))];
+                        }
+                        if (de & K_BAD) {
+                            res = BAD;
+                            goto done;
+                        }
                     }
+                    const unsigned dc = de & 0xFFu, dx = (de >> 8) & 0xFu;
+                    dist = (de >> 16) + ((uint32_t)(buf >> dc) & ((1u << dx) - 1u));
+                    buf >>= (dc + dx);
+                    cnt -= (dc + dx);
                 }
-                if (e & (K_EOB | K_BAD)) {
-                    br.drop(e & 0xFFu);
-                    if (e & K_BAD) return BAD;
-                    block_done = true;
-                    break;
-                }
+                SW_FINF_REFILL();
+                se_next = tb.sup[buf & IDX];
             }
-            // length: code + extra bits in one step
-            const unsigned lc = e & 0xFFu, lx = (e >> 8) & 0xFu;
-            const unsigned len = (e >> 16) + ((uint32_t)(br.buf >> lc) & ((1u << lx) - 1u));
-            br.drop(lc + lx);
-            uint32_t de = tb.d[br.peek(D_BITS)];
-            if (__builtin_expect(de & (K_SUB | K_BAD), 0)) {
-                if (de & K_SUB) {
-                    br.drop(D_BITS);
-                    de = tb.d[(de >> 16) + br.peek((de >> 8) & 0xFu)];
-                }
-                if (de & K_BAD) return BAD;
+            if (__builtin_expect(!far && dist > (size_t)(out - out_begin), 0)) {   // ("invalid distance too far back")
+                res = BAD;
+                goto done;
             }
-            const unsigned dc = de & 0xFFu, dx = (de >> 8) & 0xFu;
-            const size_t dist = (de >> 16) + ((uint32_t)(br.buf >> dc) & ((1u << dx) - 1u));
-            br.drop(dc + dx);
-            if (dist > (size_t)(out - out_begin)) return BAD;
-            const uint8_t *src = out - dist;
-            uint8_t *dst = out;
-            out += len;
-            // The loop is one dependent chain -- refill -> table -> bits -> table -- of ~23 cycles per length / distance pair, and three of
-            // four symbols of level-6 DNA text are such pairs.  The next symbol's table entry does not depend on the bytes the match copies:
-            // refill and look it up now (while the loop's conditions still hold), so that its load overlaps the copy.
-            const bool ahead = br.in + 8 <= br.in_end && (size_t)(out_cap - out) >= 320;
-            if (ahead) {
-                br.refill();
-                e = tb.ll[br.peek(LL_BITS)];
-            }
-            if (dist >= 8) {
-                uint64_t w;   // (most matches of DNA text are 3 ... 16 bytes: two moves without a loop; 320 spare bytes behind `out`)
-                memcpy(&w, src, 8);
-                memcpy(dst, &w, 8);
-                memcpy(&w, src + 8, 8);
-                memcpy(dst + 8, &w, 8);
-                if (len > 16) {
-                    src += 16;
-                    dst += 16;
+            {
+                const uint8_t *src = out - dist;
+                uint8_t *dst = out;
+                out += len;
+                if (__builtin_expect(dist >= 16, 1)) {
+                    struct W16 { uint64_t a, b; } w;   // (most matches of DNA text are 3 ... 16 bytes: one 16-byte move; spare bytes behind `out`)
+                    memcpy(&w, src, 16);
+                    memcpy(dst, &w, 16);
+                    if (__builtin_expect(len > 16, 0)) {
+                        do {
+                            src += 16;
+                            dst += 16;
+                            memcpy(&w, src, 16);
+                            memcpy(dst, &w, 16);
+                        } while (dst + 16 < out);
+                    }
+                } else if (dist >= 8) {
+                    uint64_t w;
                     do {
                         memcpy(&w, src, 8);
                         memcpy(dst, &w, 8);
                         src += 8;
                         dst += 8;
                     } while (dst < out);
+                } else if (dist == 1) {
+                    memset(dst, *src, len);
+                } else {
+                    do *dst++ = *src++; while (dst < out);
                 }
-            } else if (dist == 1) {
-                memset(dst, *src, len);
-            } else {
-                do *dst++ = *src++; while (dst < out);
             }
-            if (ahead) goto have_entry;
+            se = se_next;
+            continue;
+        next_entry:
+            SW_FINF_REFILL();
+            se = tb.sup[buf & IDX];
         }
     }
-    return OK;
+done:
+#undef SW_FINF_REFILL
+    s.br.buf = buf;
+    s.br.cnt = cnt;
+    s.br.in = in;
+    s.out = out;
+    return res;
 }
 
 // ... and the careful loop for the ends of the buffers: until the block's end
