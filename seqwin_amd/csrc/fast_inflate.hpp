@@ -160,35 +160,73 @@ inline uint32_t d_entry(unsigned s)
     return ((uint32_t)kDistBase[s] << 16) | ((uint32_t)kDistExtra[s] << 8);
 }
 
-// The super table of a block's two tables (built per dynamic block: 2 048 entries, ~2 % of a 16 K-symbol block's decoding time).
-// Index bits are consumed from the low end; behind `used` consumed bits only LL_BITS - used bits are known, so a symbol counts
-// only if its first-level entry is a plain one (no second level, not invalid) whose code is no longer than that.
+// One entry of the super table, decoded straight from the block's two tables.  Index bits are consumed from the low end; behind
+// `used` consumed bits only LL_BITS - used bits are known, so a symbol counts only if its first-level entry is a plain one (no
+// second level, not invalid) whose code is no longer than that.  (The definition: build_super below must agree with it entry for
+// entry -- tests/tools/finf_san_driver.cpp compares them on every case's last dynamic block.)
+inline uint64_t super_entry(const Tables &t, unsigned i)
+{
+    unsigned used = 0, nlit = 0;
+    uint64_t lits = 0, s = 0;
+    uint32_t e = t.ll[i];
+    while (nlit < 2 && (e & K_LIT) && (e & 0xFFu) <= LL_BITS - used) {
+        lits |= (uint64_t)((e >> 16) & 0xFFu) << (8 * nlit);
+        ++nlit;
+        used += e & 0xFFu;
+        e = t.ll[i >> used];
+    }
+    if (!(e & (K_LIT | K_EOB | K_SUB | K_BAD))) {   // a length code
+        const unsigned lc = e & 0xFFu, lx = (e >> 8) & 0xFu;
+        if (lc + lx <= LL_BITS - used) {
+            const unsigned len = (e >> 16) + ((i >> (used + lc)) & ((1u << lx) - 1u)), u2 = used + lc + lx;
+            const uint32_t de = t.d[(i >> u2) & ((1u << D_BITS) - 1u)];
+            if (!(de & (K_SUB | K_BAD)) && (de & 0xFFu) <= LL_BITS - u2)
+                s = (uint64_t)(u2 + (de & 0xFFu) + ((de >> 8) & 0xFu)) | (uint64_t)(u2 + (de & 0xFFu)) << 6 | S_MATCH | (uint64_t)len << 13 |
+                    (uint64_t)(de >> 16) << 22;
+        }
+    }
+    if (!s) s = used | (uint64_t)used << 6;   // (literals only -- or nothing: 0, since no literal means used = 0)
+    return s | (uint64_t)nlit << 10 | lits << 37;
+}
+
+// The super table of a block (built per dynamic block, 2 048 entries).  An entry that starts with a literal of l bits is that
+// literal in front of what the remaining bits decode to -- entry [i >> l], already built (i >> l < i), valid here if it holds at
+// most one literal and depends on no more index bits than are left: one table load per entry instead of a chain of up to four.
 inline void build_super(Tables &t)
 {
     if (!t.d_usable) return;   // (a block of literals only never enters the fast loop)
     constexpr unsigned N = 1u << LL_BITS;
-    for (unsigned i = 0; i < N; ++i) {
-        unsigned used = 0, nlit = 0;
-        uint64_t lits = 0, s = 0;
-        uint32_t e = t.ll[i];
-        while (nlit < 2 && (e & K_LIT) && (e & 0xFFu) <= LL_BITS - used) {
-            lits |= (uint64_t)((e >> 16) & 0xFFu) << (8 * nlit);
-            ++nlit;
-            used += e & 0xFFu;
-            e = t.ll[i >> used];
-        }
-        if (!(e & (K_LIT | K_EOB | K_SUB | K_BAD))) {   // a length code
+    t.sup[0] = super_entry(t, 0);   // (refers to itself in the recurrence)
+    for (unsigned i = 1; i < N; ++i) {
+        const uint32_t e = t.ll[i];
+        uint64_t s = 0;
+        if (e & K_LIT) {
+            const unsigned l0 = e & 0xFFu, left = LL_BITS - l0;
+            const uint64_t lit0 = (e >> 16) & 0xFFu, sj = t.sup[i >> l0];
+            const unsigned cj = (unsigned)(sj >> 6) & 0xFu, nj = (unsigned)(sj >> 10) & 3u;
+            if ((sj & S_ANY) && nj <= 1 && cj <= left) {
+                s = (sj & (S_MATCH | 0x1FFull << 13 | 0x7FFFull << 22)) | (uint64_t)((sj & 63u) + l0) | (uint64_t)(cj + l0) << 6 |
+                    (uint64_t)(nj + 1) << 10 | (lit0 | ((sj >> 37) & 0xFFu) << 8) << 37;
+            } else {
+                const uint32_t e1 = t.ll[i >> l0];   // a second literal?
+                if ((e1 & K_LIT) && (e1 & 0xFFu) <= left) {
+                    const unsigned used = l0 + (e1 & 0xFFu);
+                    s = used | (uint64_t)used << 6 | 2u << 10 | (lit0 | (uint64_t)((e1 >> 16) & 0xFFu) << 8) << 37;
+                } else {
+                    s = l0 | (uint64_t)l0 << 6 | 1u << 10 | lit0 << 37;
+                }
+            }
+        } else if (!(e & (K_EOB | K_SUB | K_BAD))) {   // a length code: the match, if its distance code lies inside the index
             const unsigned lc = e & 0xFFu, lx = (e >> 8) & 0xFu;
-            if (lc + lx <= LL_BITS - used) {
-                const unsigned len = (e >> 16) + ((i >> (used + lc)) & ((1u << lx) - 1u)), u2 = used + lc + lx;
+            if (lc + lx <= LL_BITS) {
+                const unsigned len = (e >> 16) + ((i >> lc) & ((1u << lx) - 1u)), u2 = lc + lx;
                 const uint32_t de = t.d[(i >> u2) & ((1u << D_BITS) - 1u)];
                 if (!(de & (K_SUB | K_BAD)) && (de & 0xFFu) <= LL_BITS - u2)
                     s = (uint64_t)(u2 + (de & 0xFFu) + ((de >> 8) & 0xFu)) | (uint64_t)(u2 + (de & 0xFFu)) << 6 | S_MATCH | (uint64_t)len << 13 |
                         (uint64_t)(de >> 16) << 22;
             }
         }
-        if (!s) s = used | (uint64_t)used << 6;   // (literals only -- or nothing: 0, since no literal means used = 0)
-        t.sup[i] = s | (uint64_t)nlit << 10 | lits << 37;
+        t.sup[i] = s;
     }
 }
 
@@ -231,11 +269,10 @@ inline const Tables &fixed_tables()
     return fixed;
 }
 
-// One DEFLATE stream, resumable (r06): the bit reader at its current bit, out_begin..out_cap the output buffer, `out` the write position
-// (history = [out_begin, out)), the block that is open.  inflate_stream() below runs one stream from its first bit to its end;
-// inflate_pair() runs TWO streams in one loop -- the decoding of a symbol is a chain of dependent steps (refill -> table -> bits ->
-// table, ~25 cycles per length / distance pair) that leaves most of a core's issue width idle, and two independent chains fill it:
-// 1.4-1.5 x the bytes per second of one stream after the other (scripts: NOTES.md).
+// One DEFLATE stream: the bit reader at its current bit, out_begin..out_cap the output buffer, `out` the write position (history =
+// [out_begin, out)), the block that is open.  inflate_stream() below runs one stream from its first bit to its end.  (r06 also had
+// TWO streams advancing in one loop, 1.2 x on the loop as it was then; the super table made the one-stream loop twice as fast as
+// that pair loop, which is gone: NOTES.md.)
 struct Stream {
     BitReader br;
     uint8_t *out_begin = nullptr, *out = nullptr, *out_cap = nullptr;
@@ -659,177 +696,6 @@ inline Result inflate_stream(BitReader &br, uint8_t *out_begin, uint8_t *&out, u
     return r;
 }
 
-// ---- two streams in one loop -------------------------------------------------------------------------------------------------------
-// The state of one stream inside the pair loop: plain locals of inflate_pair (their address never leaves it), so both streams'
-// bit buffers, cursors and table bases stay in registers.
-struct PairRegs {
-    uint64_t buf;
-    unsigned cnt;
-    const uint8_t *in, *in_end;
-    uint8_t *out, *out_begin, *out_cap;
-    const uint32_t *ll, *dt;
-};
-// One symbol of a stream (or up to three literals) -- the body of fast_loop without the look-ahead (the other stream's step is what
-// fills the wait): 0 go on, 1 end of block, 2 bad.  Needs what fast_loop needs: 8 readable bytes at `in`, 320 free bytes at `out`.
-__attribute__((always_inline)) inline int pair_step(PairRegs &r)
-{
-    uint64_t w;
-    memcpy(&w, r.in, 8);
-    r.buf |= w << r.cnt;
-    r.in += (63u - r.cnt) >> 3;
-    r.cnt |= 56u;
-    uint32_t e = r.ll[r.buf & ((1u << LL_BITS) - 1u)];
-    if (e & K_LIT) {
-        r.buf >>= (e & 0xFFu);
-        r.cnt -= (e & 0xFFu);
-        *r.out++ = (uint8_t)(e >> 16);
-        e = r.ll[r.buf & ((1u << LL_BITS) - 1u)];
-        if (e & K_LIT) {
-            r.buf >>= (e & 0xFFu);
-            r.cnt -= (e & 0xFFu);
-            *r.out++ = (uint8_t)(e >> 16);
-            e = r.ll[r.buf & ((1u << LL_BITS) - 1u)];
-            if (e & K_LIT) {
-                r.buf >>= (e & 0xFFu);
-                r.cnt -= (e & 0xFFu);
-                *r.out++ = (uint8_t)(e >> 16);
-                return 0;
-            }
-        }
-        memcpy(&w, r.in, 8);   // a length / distance pair may need 48 bits
-        r.buf |= w << r.cnt;
-        r.in += (63u - r.cnt) >> 3;
-        r.cnt |= 56u;
-    }
-    if (__builtin_expect(e & (K_SUB | K_EOB | K_BAD), 0)) {
-        if (e & K_SUB) {
-            r.buf >>= LL_BITS;
-            r.cnt -= LL_BITS;
-            e = r.ll[(e >> 16) + (uint32_t)(r.buf & ((1ull << ((e >> 8) & 0xFu)) - 1ull))];
-            if (e & K_LIT) {
-                r.buf >>= (e & 0xFFu);
-                r.cnt -= (e & 0xFFu);
-                *r.out++ = (uint8_t)(e >> 16);
-                return 0;
-            }
-        }
-        if (e & (K_EOB | K_BAD)) {
-            r.buf >>= (e & 0xFFu);
-            r.cnt -= (e & 0xFFu);
-            return (e & K_BAD) ? 2 : 1;
-        }
-    }
-    const unsigned lc = e & 0xFFu, lx = (e >> 8) & 0xFu;
-    const unsigned len = (e >> 16) + ((uint32_t)(r.buf >> lc) & ((1u << lx) - 1u));
-    r.buf >>= (lc + lx);
-    r.cnt -= (lc + lx);
-    uint32_t de = r.dt[r.buf & ((1u << D_BITS) - 1u)];
-    if (__builtin_expect(de & (K_SUB | K_BAD), 0)) {
-        if (de & K_SUB) {
-            r.buf >>= D_BITS;
-            r.cnt -= D_BITS;
-            de = r.dt[(de >> 16) + (uint32_t)(r.buf & ((1ull << ((de >> 8) & 0xFu)) - 1ull))];
-        }
-        if (de & K_BAD) return 2;
-    }
-    const unsigned dc = de & 0xFFu, dx = (de >> 8) & 0xFu;
-    const size_t dist = (de >> 16) + ((uint32_t)(r.buf >> dc) & ((1u << dx) - 1u));
-    r.buf >>= (dc + dx);
-    r.cnt -= (dc + dx);
-    if (dist > (size_t)(r.out - r.out_begin)) return 2;
-    const uint8_t *src = r.out - dist;
-    uint8_t *dst = r.out;
-    r.out += len;
-    if (dist >= 8) {
-        memcpy(&w, src, 8);
-        memcpy(dst, &w, 8);
-        memcpy(&w, src + 8, 8);
-        memcpy(dst + 8, &w, 8);
-        if (len > 16) {
-            src += 16;
-            dst += 16;
-            do {
-                memcpy(&w, src, 8);
-                memcpy(dst, &w, 8);
-                src += 8;
-                dst += 8;
-            } while (dst < r.out);
-        }
-    } else if (dist == 1) {
-        memset(dst, *src, len);
-    } else {
-        do *dst++ = *src++; while (dst < r.out);
-    }
-    return 0;
-}
-inline bool pair_ready(const Stream &s)   // a Huffman block with a distance code is open and the fast region's margins hold
-{
-    return s.in_block && s.tb->d_usable && s.br.in + 8 <= s.br.in_end && (size_t)(s.out_cap - s.out) >= 320;
-}
-
-// Two independent DEFLATE streams to their ends; *ra / *rb = what inflate_stream would have returned for each.  A stream that
-// fails, ends, or leaves the fast region is finished (or brought back) on its own; the other is not held up by it.
-inline void inflate_pair(Stream &a, Stream &b, Result *ra, Result *rb)
-{
-    Result res[2] = {OK, OK};
-    bool over[2] = {false, false};   // ended or failed: out of the pair loop for good
-    Stream *st[2] = {&a, &b};
-    for (;;) {
-        for (int x = 0; x < 2; ++x) {   // bring each stream to an open block inside the fast region (headers, stored blocks, buffer ends)
-            Stream &s = *st[x];
-            while (!over[x] && !pair_ready(s)) {
-                Result r = OK;
-                if (!s.in_block) {
-                    if (!s.ended) r = open_block(s);
-                } else {
-                    r = careful_loop(s);          // (a literal-only block, or the ends of the buffers: to the block's end)
-                    if (r == OK) r = close_block(s);
-                }
-                if (r != OK) {
-                    res[x] = r;
-                    over[x] = true;
-                } else if (s.ended) {
-                    over[x] = true;
-                }
-            }
-        }
-        if (over[0] || over[1]) break;
-        PairRegs p, q;
-        p.buf = a.br.buf; p.cnt = a.br.cnt; p.in = a.br.in; p.in_end = a.br.in_end; p.out = a.out; p.out_begin = a.out_begin; p.out_cap = a.out_cap;
-        p.ll = a.tb->ll; p.dt = a.tb->d;
-        q.buf = b.br.buf; q.cnt = b.br.cnt; q.in = b.br.in; q.in_end = b.br.in_end; q.out = b.out; q.out_begin = b.out_begin; q.out_cap = b.out_cap;
-        q.ll = b.tb->ll; q.dt = b.tb->d;
-        int sa = 0, sb = 0;
-        while (p.in + 8 <= p.in_end && (size_t)(p.out_cap - p.out) >= 320 && q.in + 8 <= q.in_end && (size_t)(q.out_cap - q.out) >= 320) {
-            sa = pair_step(p);
-            sb = pair_step(q);
-            if (sa | sb) break;
-        }
-        a.br.buf = p.buf; a.br.cnt = p.cnt; a.br.in = p.in; a.out = p.out;
-        b.br.buf = q.buf; b.br.cnt = q.cnt; b.br.in = q.in; b.out = q.out;
-        const int stp[2] = {sa, sb};
-        for (int x = 0; x < 2; ++x) {
-            if (stp[x] == 2) {
-                res[x] = BAD;
-                over[x] = true;
-            } else if (stp[x] == 1) {
-                const Result r = close_block(*st[x]);
-                if (r != OK) {
-                    res[x] = r;
-                    over[x] = true;
-                } else if (st[x]->ended) {
-                    over[x] = true;
-                }
-            }
-        }
-        if (over[0] && over[1]) break;
-    }
-    for (int x = 0; x < 2; ++x)   // what is left of the stream that outlasted its partner
-        if (res[x] == OK && !st[x]->ended) res[x] = run_stream(*st[x]);
-    *ra = res[0];
-    *rb = res[1];
-}
-
 // ---- CRC-32 (IEEE, reflected: the gzip trailer's) ---------------------------------------------------------------------------------
 // Slicing-by-8 tables built at first use; with PCLMULQDQ the bulk is folded 64 bytes at a time (Gopal et al., "Fast CRC
 // Computation for Generic Polynomials Using PCLMULQDQ Instruction"; constants for the reflected polynomial 0xEDB88320).  Both are
@@ -1000,12 +866,10 @@ inline bool gzip_trailer_ok(const uint8_t *p, const uint8_t *end, const uint8_t 
 
 // One or more gzip members in in[0, n) (followed by IN_PAD readable zero bytes) -> out[0, *out_len), at most out_cap bytes.
 // OK: every member well-formed, its CRC-32 and ISIZE right, nothing behind the last one.  NEED_OUT: out_cap is too small.
-// (o_start: output already produced by earlier members of the same file -- gunzip_pair hands its streams' rests over.)
-inline Result gunzip_members(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len, Tables &T, const uint8_t *p_start = nullptr,
-                             size_t o_start = 0)
+inline Result gunzip_members(const uint8_t *in, size_t n, uint8_t *out, size_t out_cap, size_t *out_len, Tables &T)
 {
-    const uint8_t *p = p_start ? p_start : in, *end = in + n;
-    uint8_t *o = out + o_start;
+    const uint8_t *p = in, *end = in + n;
+    uint8_t *o = out;
     if (n < 18) return BAD;
     while (p < end) {
         p = gzip_header(p, end);
@@ -1022,38 +886,6 @@ inline Result gunzip_members(const uint8_t *in, size_t n, uint8_t *out, size_t o
     }
     *out_len = (size_t)(o - out);
     return OK;
-}
-
-// Two files at once (r06): the FIRST members of both are inflated in one loop (inflate_pair), further members -- rare -- one file
-// after the other.  The results are those of two gunzip_members calls.
-inline void gunzip_pair(const uint8_t *in_a, size_t n_a, uint8_t *out_a, size_t cap_a, size_t *len_a, Tables &T_a, Result *r_a, const uint8_t *in_b,
-                        size_t n_b, uint8_t *out_b, size_t cap_b, size_t *len_b, Tables &T_b, Result *r_b)
-{
-    const uint8_t *pa = n_a >= 18 ? gzip_header(in_a, in_a + n_a) : nullptr, *pb = n_b >= 18 ? gzip_header(in_b, in_b + n_b) : nullptr;
-    if (!pa || !pb) {   // (nothing to pair)
-        *r_a = gunzip_members(in_a, n_a, out_a, cap_a, len_a, T_a);
-        *r_b = gunzip_members(in_b, n_b, out_b, cap_b, len_b, T_b);
-        return;
-    }
-    Stream a, b;
-    a.br.in = pa; a.br.in_end = in_a + n_a; a.out_begin = a.out = out_a; a.out_cap = out_a + cap_a; a.T = &T_a;
-    b.br.in = pb; b.br.in_end = in_b + n_b; b.out_begin = b.out = out_b; b.out_cap = out_b + cap_b; b.T = &T_b;
-    inflate_pair(a, b, r_a, r_b);
-    struct Side {
-        Stream *s; const uint8_t *in; size_t n; uint8_t *out; size_t cap; size_t *len; Tables *T; Result *r;
-    } sides[2] = {{&a, in_a, n_a, out_a, cap_a, len_a, &T_a, r_a}, {&b, in_b, n_b, out_b, cap_b, len_b, &T_b, r_b}};
-    for (Side &d : sides) {
-        if (*d.r != OK) continue;
-        const uint8_t *p = d.s->br.position(), *end = d.in + d.n;
-        const size_t n_out = (size_t)(d.s->out - d.out);
-        if (!gzip_trailer_ok(p, end, d.out, n_out)) {
-            *d.r = BAD;
-            continue;
-        }
-        p += 8;
-        if (p < end) *d.r = gunzip_members(d.in, d.n, d.out, d.cap, d.len, *d.T, p, n_out);   // further members
-        else *d.len = n_out;
-    }
 }
 
 }  // namespace finf

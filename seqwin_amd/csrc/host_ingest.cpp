@@ -176,42 +176,6 @@ bool slurp_gz_fast(const std::string &path, RawBuf &buf)
     return false;
 }
 
-// r06 (SEQWIN_AMD_GZ_PAIRS=1): TWO .gz files at once -- their first gzip members are inflated in one loop (finf::gunzip_pair: two
-// independent dependency chains share the core; 1.2 x the bytes per second on two different files, see ingest_files).  One attempt per file, sized from ISIZE; whatever
-// does not come out right (a buffer too small, anything fast_inflate declines, an unreadable file) is left to slurp() below, which
-// grows, falls back to zlib and raises what the reference raises.  ok_a / ok_b: buf_a / buf_b hold the file's text.
-void slurp_gz_fast_pair(const std::string &path_a, RawBuf &buf_a, bool &ok_a, const std::string &path_b, RawBuf &buf_b, bool &ok_b)
-{
-    ok_a = ok_b = false;
-    static thread_local RawBuf raw_a, raw_b;
-    static thread_local finf::Tables tables_a, tables_b;
-    if (!read_raw(path_a, raw_a) || raw_a.len < 18 || !read_raw(path_b, raw_b) || raw_b.len < 18) return;
-    auto cap_of = [](const RawBuf &raw) {
-        const uint8_t *in = (const uint8_t *)raw.p;
-        const uint32_t isize = in[raw.len - 4] | (in[raw.len - 3] << 8) | (in[raw.len - 2] << 16) | ((uint32_t)in[raw.len - 1] << 24);
-        return std::min<size_t>(std::max<size_t>((size_t)isize, raw.len), raw.len * 8 + 4096) + 64;
-    };
-    const size_t cap_a = cap_of(raw_a), cap_b = cap_of(raw_b);
-    try {
-        buf_a.reserve(cap_a);
-        buf_b.reserve(cap_b);
-    } catch (...) {
-        return;
-    }
-    size_t got_a = 0, got_b = 0;
-    finf::Result r_a = finf::BAD, r_b = finf::BAD;
-    finf::gunzip_pair((const uint8_t *)raw_a.p, raw_a.len, (uint8_t *)buf_a.p, cap_a, &got_a, tables_a, &r_a, (const uint8_t *)raw_b.p, raw_b.len,
-                      (uint8_t *)buf_b.p, cap_b, &got_b, tables_b, &r_b);
-    if (r_a == finf::OK) {
-        buf_a.len = got_a;
-        ok_a = true;
-    }
-    if (r_b == finf::OK) {
-        buf_b.len = got_b;
-        ok_b = true;
-    }
-}
-
 void slurp(const std::string &path, RawBuf &buf)
 {
     buf.len = 0;
@@ -742,15 +706,6 @@ void parse_assembly(const std::string &path, RawBuf &buf, int use_mmap, WordBuf 
     tp.finish();
 }
 
-// ... from the file's text, already in memory (the pair route of the .gz files)
-void parse_assembly_text(const std::string &path, const RawBuf &text, WordBuf &&storage, Assembly &a)
-{
-    TextParser tp(path, a, std::move(storage));
-    tp.expect_bytes(text.len);
-    tp.feed(text.p, text.p + text.len);
-    tp.finish();
-}
-
 // Recycles the packed-word buffers of assemblies that have been handed to the sink, so that a streaming ingest
 // keeps only ~n_workers buffers alive (and does not unmap / fault in fresh memory for every file).
 struct BufferPool {
@@ -851,20 +806,17 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
     std::condition_variable sunk_cv;
     size_t window = n_workers + n_workers / 2 + 4;
     if (const char *e = SW_TEST_GETENV("SEQWIN_AMD_INGEST_WINDOW")) window = (size_t)std::max(1, atoi(e));
-    // r06, SEQWIN_AMD_GZ_PAIRS=1 and every input a .gz file: a worker takes TWO files at a time and inflates them in one loop
-    // (slurp_gz_fast_pair).  Opt-in: the decoder gains 1.2 x on two different files (one thread, an idle core), the whole ingest 1.06-1.1 x
-    // on 2-4 threads of the build container, and on the GPU box -- 64 workers on a 16-CPU quota of an SMT host, where the second
-    // hardware thread already fills the slots one stream leaves idle -- it LOSES 8 % (profiles/r06_gz_pairs_ab.txt).
-    const char *pairs_env = getenv("SEQWIN_AMD_GZ_PAIRS");
-    bool pair_gz = n_paths >= 2 && pairs_env && strcmp(pairs_env, "0") != 0 && !getenv("SEQWIN_AMD_ZLIB_INFLATE");
-    for (size_t i = 0; pair_gz && i < n_paths; ++i) pair_gz = ends_with(paths[i], ".gz");
-    if (pair_gz) window = std::max<size_t>(window, 2);
     auto worker = [&]() {
-        RawBuf buf, buf2;
-        auto one = [&](size_t i, const RawBuf *text, RawBuf &scratch) {
+        RawBuf buf;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n_paths) break;
+            if (sink) {
+                std::unique_lock<std::mutex> lock(done_mu);
+                sunk_cv.wait(lock, [&] { return i < sunk + window; });
+            }
             try {
-                if (text) parse_assembly_text(paths[i], *text, pool.get(), asms[i]);
-                else parse_assembly(paths[i], scratch, use_mmap, pool.get(), asms[i]);
+                parse_assembly(paths[i], buf, use_mmap, pool.get(), asms[i]);
             } catch (const Error &e) {
                 errors[i].reset(new Error(e));
             } catch (const std::exception &e) {
@@ -877,27 +829,6 @@ void ingest_fasta(const char *const *paths, size_t n_paths, uint64_t n_cpu, Host
                     done[i] = 1;
                 }
                 done_cv.notify_all();
-            }
-        };
-        for (;;) {
-            const size_t i = next.fetch_add(pair_gz ? 2 : 1);
-            if (i >= n_paths) break;
-            const size_t cnt = (pair_gz && i + 1 < n_paths) ? 2 : 1;
-            if (sink) {
-                std::unique_lock<std::mutex> lock(done_mu);
-                sunk_cv.wait(lock, [&] { return i + cnt - 1 < sunk + window; });
-            }
-            if (cnt == 2) {
-                bool ok0 = false, ok1 = false;
-                try {
-                    slurp_gz_fast_pair(paths[i], buf, ok0, paths[i + 1], buf2, ok1);
-                } catch (...) {
-                    ok0 = ok1 = false;   // (each file's own route raises what there is to raise)
-                }
-                one(i, ok0 ? &buf : nullptr, buf);
-                one(i + 1, ok1 ? &buf2 : nullptr, buf2);
-            } else {
-                one(i, nullptr, buf);
             }
         }
     };
