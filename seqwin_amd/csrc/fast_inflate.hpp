@@ -189,18 +189,24 @@ inline uint64_t super_entry(const Tables &t, unsigned i)
     return s | (uint64_t)nlit << 10 | lits << 37;
 }
 
-// The super table of a block (built per dynamic block, 2 048 entries).  An entry that starts with a literal of l bits is that
-// literal in front of what the remaining bits decode to -- entry [i >> l], already built (i >> l < i), valid here if it holds at
-// most one literal and depends on no more index bits than are left: one table load per entry instead of a chain of up to four.
+// The super table of a block (built per dynamic block, 2 048 entries), in ascending index order with two short cuts:
+//   * an entry that ends in a match depends on its `code` low index bits only (decoding stopped there), so it is the entry of
+//     every index with those low bits: computed once, at the smallest such index, and copied to the others;
+//   * an entry that starts with a literal of l bits is that literal in front of what the remaining bits decode to -- entry
+//     [i >> l], already there (i >> l < i), valid here if it holds at most one literal and depends on no more index bits than are
+//     left: one table load instead of a chain of up to four.
 inline void build_super(Tables &t)
 {
     if (!t.d_usable) return;   // (a block of literals only never enters the fast loop)
     constexpr unsigned N = 1u << LL_BITS;
-    t.sup[0] = super_entry(t, 0);   // (refers to itself in the recurrence)
-    for (unsigned i = 1; i < N; ++i) {
+    memset(t.sup, 0, sizeof t.sup);
+    for (unsigned i = 0; i < N; ++i) {
+        if (t.sup[i]) continue;   // (a copy of a smaller index's match entry)
         const uint32_t e = t.ll[i];
         uint64_t s = 0;
-        if (e & K_LIT) {
+        if (i == 0) {
+            s = super_entry(t, 0);   // (refers to itself in the recurrence)
+        } else if (e & K_LIT) {
             const unsigned l0 = e & 0xFFu, left = LL_BITS - l0;
             const uint64_t lit0 = (e >> 16) & 0xFFu, sj = t.sup[i >> l0];
             const unsigned cj = (unsigned)(sj >> 6) & 0xFu, nj = (unsigned)(sj >> 10) & 3u;
@@ -227,6 +233,10 @@ inline void build_super(Tables &t)
             }
         }
         t.sup[i] = s;
+        if (s & S_MATCH) {
+            const unsigned step = 1u << ((unsigned)(s >> 6) & 0xFu);
+            for (unsigned j = i + step; j < N; j += step) t.sup[j] = s;
+        }
     }
 }
 
