@@ -30,6 +30,34 @@ static std::string make_text(size_t n, int kind)
     case 2: for (auto &c : s) c = (char)rnd(); break;                                           // noise
     case 3: for (size_t i = 0; i < n; ++i) s[i] = "ACGGTCA"[i % 7]; break;                      // tandem repeat: long matches
     case 4: for (auto &c : s) c = 'A'; break;                                                   // run: distance 1
+    case 6: {                                                                                   // words: many literal codes of many lengths, second-level tables
+        static const char *words[] = {"contig", "scaffold", "Escherichia", "coli", "plasmid", "whole", "genome", "shotgun", "sequence", "NZ_", "strain", "K-12", "\n>", "length=", " "};
+        size_t i = 0;
+        while (i < n) {
+            const char *w = words[rnd() % 15];
+            for (; *w && i < n; ++w) s[i++] = *w;
+            if (rnd() % 4 == 0 && i < n) s[i++] = (char)('0' + rnd() % 10);
+        }
+        break;
+    }
+    case 7: {                                                                                   // soft-masked FASTA: headers, 60-column lines, lower-case stretches, N runs
+        size_t i = 0, col = 0;
+        bool lower = false;
+        while (i < n) {
+            if (rnd() % 5000 == 0) {
+                const char *h = "\n>seq description text\n";
+                for (; *h && i < n; ++h) s[i++] = *h;
+                col = 0;
+                continue;
+            }
+            if (rnd() % 300 == 0) lower = !lower;
+            if (col == 60) { s[i++] = '\n'; col = 0; continue; }
+            const char c = rnd() % 400 == 0 ? 'N' : "ACGT"[rnd() & 3];
+            s[i++] = lower ? (char)(c | 0x20) : c;
+            ++col;
+        }
+        break;
+    }
     default: {                                                                                  // mixture with far matches
         for (auto &c : s) c = "ACGT"[rnd() & 3];
         for (int r = 0; r < 20 && n > 100; ++r) {
@@ -187,7 +215,7 @@ int main(int argc, char **argv)
         printf("%ld streams ending inside a dynamic block header: all declined, no access outside the buffers\n", n_hdr);
     }
     for (long c = 0; c < cases; ++c) {
-        const int kind = (int)(rnd() % 6);
+        const int kind = (int)(rnd() % 8);
         static const size_t sizes[] = {0, 1, 2, 17, 300, 5000, 70000, 300000};
         const size_t n = sizes[rnd() % 8] + (rnd() % 7);
         std::vector<uint8_t> gz;
