@@ -145,6 +145,9 @@ def e2e_build(paths, k, w, n_cpu, tar):
         ro = np.empty(na + 1, np.uint32)
         blob = ctypes.create_string_buffer(max(nb, 1))
         check(lib.sw_graph_export(g, _core._ptr(kmers), _core._ptr(nodes), _core._ptr(edges), _core._ptr(ro), blob))
+        t_ids = time.perf_counter()
+        ids = _core._split_ids(blob.raw[:nb], ro)   # (ids_by_assembly, the fifth element of _build_native's tuple: inside the timed call)
+        ids_ms = (time.perf_counter() - t_ids) * 1e3
         t2, c2 = time.perf_counter(), time.process_time()
         st = (ctypes.c_double * 8)()
         check(lib.sw_graph_stats(g, st))
@@ -158,7 +161,7 @@ def e2e_build(paths, k, w, n_cpu, tar):
     # CPU seconds of this process (all threads) over the call, and how long the container's CPU quota held its threads back
     split.update(cpu_s=round(c4 - c0, 3), cpu_s_build_export_penalty=[round(c1 - c0, 3), round(c2 - c1, 3), round(c4 - c2, 3)], quota_throttled_ms=None if thr0 is None or thr4 is None else round(thr4 - thr0, 1))
     split.update(sw_build_wall_ms=round((t1 - t0) * 1e3, 2), alloc_and_export_wall_ms=round((t2 - t1) * 1e3, 2),
-                 get_penalty_wall_ms=round((t4 - t3) * 1e3, 2), total_wall_ms=round((t4 - t0) * 1e3, 2),
+                 ids_list_ms=round(ids_ms, 2), get_penalty_wall_ms=round((t4 - t3) * 1e3, 2), total_wall_ms=round((t4 - t0) * 1e3, 2),
                  output_MB=round((kmers.nbytes + nodes.nbytes + edges.nbytes) / 1e6, 1))
     return (kmers, nodes, edges, ro), t4 - t0, split
 

@@ -8,6 +8,7 @@ foreign call, as the reference does with py::gil_scoped_release (:59,117,151).
 from __future__ import annotations
 
 import ctypes
+import gc
 import logging
 import operator
 import os
@@ -49,13 +50,18 @@ def _noconvert(a, dtype: np.dtype, name: str) -> np.ndarray:
 
 
 def _split_ids(blob: bytes, record_offsets: np.ndarray) -> list[tuple[str, ...]]:
-    names = blob.split(b"\0")[:-1] if blob else []
-    out, i = [], 0
-    for a in range(len(record_offsets) - 1):
-        n = int(record_offsets[a + 1]) - int(record_offsets[a])
-        out.append(tuple(s.decode("utf-8") for s in names[i:i + n]))
-        i += n
-    return out
+    """ids_by_assembly of python_bindings.cpp:73-80 from the exported blob (every id followed by a NUL) and the record offsets.
+    One decode and one split for the whole blob, and no cyclic-GC passes while the tuples are made (15 000 assemblies x 50 contigs:
+    0.05 s instead of 0.2 s of a 1.7 s call); an id that is not UTF-8 raises UnicodeDecodeError, as pybind11's cast does."""
+    names = blob.decode("utf-8").split("\0") if blob else []   # (one empty string behind the last NUL: no offset reaches it)
+    offs = record_offsets.tolist()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        return [tuple(names[offs[a]:offs[a + 1]]) for a in range(len(offs) - 1)]
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 # Native log lines go to Python's root logger, as log_python does in the reference (cpp/src/utils/logging.cpp:9-29).
@@ -106,6 +112,26 @@ def _build_native(assembly_paths, kmerlen, windowsize, n_cpu=1, low_memory=False
     return kmers, nodes, edges, record_offsets, _split_ids(blob.raw[:nb], record_offsets)
 
 
+def _hashes_array(used_hashes) -> np.ndarray:
+    """std::vector<uint64_t> from any iterable of ints, as pybind11's caster fills it (python_bindings.cpp:137-150).  In practice a
+    frozenset[np.uint64] of up to millions of node hashes (kmers.py:312): NumPy converts a list of unsigned or non-negative integers
+    in one go (0.15 s per million instead of 0.43 s element by element); anything else -- floats, negatives, objects -- goes through
+    the per-element check, which raises what the caster raises."""
+    items = list(used_hashes)
+    if not items:
+        return np.empty(0, np.uint64)
+    try:
+        a = np.asarray(items)
+    except Exception:
+        a = None
+    if a is not None and a.ndim == 1 and a.shape[0] == len(items):
+        if a.dtype == np.uint64:
+            return np.ascontiguousarray(a)
+        if a.dtype.kind == "i" and int(a.min()) >= 0:
+            return a.astype(np.uint64)
+    return np.fromiter((_size_t(h, "used_hashes") for h in items), dtype=np.uint64, count=len(items))
+
+
 def _get_penalty_native(kmers, nodes, record_offsets, is_targets, n_cpu=1):
     """seqwin::get_penalty on the GPU, in place on ``nodes`` (python_bindings.cpp:92-135)."""
     kmers = _noconvert(kmers, KMER_DTYPE, "kmers")
@@ -129,10 +155,7 @@ def _filter_kmers_native(kmers, nodes, used_hashes):
     nodes = _noconvert(nodes, NODE_DTYPE, "nodes")
     if isinstance(used_hashes, (str, bytes)):
         raise TypeError("used_hashes: expected an iterable of int")
-    try:
-        used = np.fromiter((_size_t(h, "used_hashes") for h in used_hashes), dtype=np.uint64)
-    except TypeError:
-        raise
+    used = _hashes_array(used_hashes)
     nk, nn = c_u64(), c_u64()
     args = (_ptr(kmers), c_u64(len(kmers)), _ptr(nodes), c_u64(len(nodes)), _ptr(used), c_u64(len(used)))
     check(lib.sw_filter_kmers(*args, None, None, ctypes.byref(nk), ctypes.byref(nn)))

@@ -98,6 +98,72 @@ def test_argument_validation_happens_without_a_device(smoke_paths):
         _get_penalty(kmers, nodes, offs, np.array([[True, False, True]]))    # shape[0] != len(offsets) - 1
 
 
+def test_used_hashes_reach_the_library_as_the_pybind_caster_fills_them():
+    """_core._hashes_array (the std::vector<uint64_t> of python_bindings.cpp:137-150): the one-go NumPy conversion gives what the
+    per-element check gives -- for sets of np.uint64 (what kmers.py:312 passes), Python ints up to 2^64 - 1, mixed integer types,
+    bools, empty iterables, generators -- and floats, negatives, too large values and non-integers raise what the per-element check
+    raises (the caster's errors)."""
+    def per_element(items):
+        return np.fromiter((_core._size_t(h, "used_hashes") for h in items), dtype=np.uint64, count=len(items))
+
+    rng = np.random.default_rng(9)
+    good = [
+        frozenset(np.uint64(x) for x in rng.integers(0, 2**63, 500, dtype=np.uint64) * 2 + 1),
+        [int(x) for x in rng.integers(0, 2**62, 300)],
+        [2**64 - 1, 0, 5],
+        [np.uint32(7), np.int64(9), 11],
+        (np.uint64(1),),
+        [True, False, 3],
+        [],
+        set(),
+    ]
+    for items in good:
+        lst = list(items)
+        got = _core._hashes_array(iter(lst))      # (an iterator: consumed once)
+        assert got.dtype == np.uint64 and got.flags.c_contiguous and np.array_equal(got, per_element(lst))
+    for bad in ([1.5, 2], [-1, 2], [2**64, 1], ["7"], [None], [np.float32(2)], [[1, 2], [3, 4]], [np.int64(-5)]):
+        with pytest.raises(Exception) as want:
+            per_element(bad)
+        with pytest.raises(type(want.value)):
+            _core._hashes_array(bad)
+    with pytest.raises(TypeError):
+        _core._hashes_array(5)
+
+
+def test_ids_by_assembly_from_the_exported_blob():
+    """_core._split_ids: the fifth element of _build_native's tuple (python_bindings.cpp:73-80: a list with one tuple of str per
+    assembly) from the NUL-terminated id blob and the record offsets sw_graph_export fills -- against the plain per-id loop, with
+    assemblies without records, no assembly at all, ids that are not ASCII; an id that is not UTF-8 raises UnicodeDecodeError as
+    pybind11's str cast does; the cyclic GC is left as it was found."""
+    import gc
+
+    def plain(blob, offs):
+        names = blob.split(b"\0")[:-1] if blob else []
+        return [tuple(s.decode("utf-8") for s in names[int(offs[a]):int(offs[a + 1])]) for a in range(len(offs) - 1)]
+
+    rng = random.Random(5)
+    for case in range(40):
+        n_asm = rng.choice([0, 1, 2, 7, 300])
+        counts = [rng.choice([0, 0, 1, 2, 5, 60]) for _ in range(n_asm)]
+        ids = [("".join(rng.choice("abcXYZ_.|0189é糖") for _ in range(rng.randint(1, 12)))).encode("utf-8") for _ in range(sum(counts))]
+        blob = b"".join(i + b"\0" for i in ids)
+        offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint32)
+        got = _core._split_ids(blob, offs)
+        assert got == plain(blob, offs) and len(got) == n_asm
+        assert all(type(t) is tuple and all(type(s) is str for s in t) for t in got)
+    assert _core._split_ids(b"", np.zeros(1, np.uint32)) == []
+    for enabled in (True, False):
+        (gc.enable if enabled else gc.disable)()
+        try:
+            _core._split_ids(b"a\0b\0", np.array([0, 1, 2], np.uint32))
+            assert gc.isenabled() == enabled
+            with pytest.raises(UnicodeDecodeError):
+                _core._split_ids(b"ok\0\xff\xfe\0", np.array([0, 2], np.uint32))
+            assert gc.isenabled() == enabled
+        finally:
+            gc.enable()
+
+
 @pytest.mark.skipif(not NO_GPU, reason="only meaningful on a box without a GPU")
 def test_no_cpu_fallback(smoke_paths):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
