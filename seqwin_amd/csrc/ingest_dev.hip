@@ -148,11 +148,11 @@ bool device_gz_ingest(const char *const *paths, size_t n_paths, uint64_t n_cpu, 
     // host); the rule is now made from the files' sizes below: device time ~ text of the LARGEST file / 1.27 MB/s (512 files of
     // 5 Mbp: 3.98 s), host time ~ all text / (0.65 GB/s x CPUs).  15 000 genomes of 5 Mbp on 16 CPUs: 4 s against 7 s -> device;
     // 512: 4 s against 0.25 s -> host.
-    // End of r06: the host decoder's super table (fast_inflate.hpp) made sw_host_ingest of .gz files 1.5 (8 threads) to 1.74 x (one
-    // thread) faster in the build container; the GPU box could not be measured any more, so the host rate below is the r05 figure
-    // times the smaller of the two factors: 1.0 GB/s per CPU -- and the device has to win by a quarter of its own estimate, since
-    // its figure at that scale is an extrapolation (15 000 genomes of 5 Mbp: 4.0 s, never measured end to end) while the host's is
-    // conservative: 15 000 genomes on 16 CPUs, 4.0 x 1.25 against 4.8 s -> host; on 8 CPUs, against 9.6 s -> device.
+    // End of r06: the host decoder's super table (fast_inflate.hpp) halved the host's CPU time: 1 024 .fa.gz genomes (5.2 GB of text)
+    // -> numpy on the GPU box cost 6.7-6.9 CPU-seconds before and 3.4-4.2 after (profiles/r06_e2e_gz_decoder_ab.txt), i.e. 1.2-1.5 GB/s
+    // of text per CPU-second for the whole call; the rule takes 1.0 -- and the device has to win by a quarter of its own estimate,
+    // since its figure at full size is an extrapolation (15 000 genomes of 5 Mbp: 4.0 s, never measured end to end): 15 000 genomes
+    // on 16 CPUs, 4.0 x 1.25 against 4.8 s -> host; on 8 CPUs, against 9.6 s -> device.
     if (n_paths == 0 || n_paths >= 0xFFFFFFFFull) return false;
     for (size_t i = 0; i < n_paths; ++i)
         if (!ends_with_gz(paths[i])) return false;
